@@ -1,0 +1,215 @@
+/*
+ * hrbf_mi355.h — C-ABI of libhrbf_mi355.so, the MI355X-native per-frame hot path of
+ * HRBF-Fusion (reference: YabinXuTUD/HRBFFusion3D, cited as path:line under /root/reference).
+ *
+ * Boundary replaced: `HRBFFusion::processFrame` (Core/src/HRBFFusion.h:110-113,
+ * Core/src/HRBFFusion.cpp:991-1241), the `GlobalModel` surfel map
+ * (Core/src/GlobalModel.h:44-175) and the operator seams underneath it
+ * (Core/src/Cuda/cudafuncs.cuh:64-241, Core/src/IndexMap.h:43-68).
+ *
+ * Conventions
+ *  - every function returns HRBF_OK (0) or a negative hrbf_status; nothing calls exit()
+ *    (the reference exit(0)s on CUDA errors, Core/src/Cuda/convenience.cuh:64-71).
+ *  - images are row-major, pixel (x,y) at index y*width+x; "f4" images are 4 floats/pixel
+ *    (the reference's RGBA32F textures); poses are 4x4 float, COLUMN-major (Eigen default),
+ *    camera-to-world, like `HRBFFusion::getCurrPose()` (Core/src/HRBFFusion.h).
+ *  - a surfel is 20 floats, the reference's interleaved layout (Core/src/Shaders/Vertex.cpp:21-44):
+ *      [x y z conf] [rgb24-as-float submapIdx initTime lastTime] [nx ny nz radius]
+ *      [k1dir.xyz k1] [k2dir.xyz k2]
+ *    Internally the map is five float4 planes (SoA) in HBM; the AoS form exists only at
+ *    hrbf_download_map / hrbf_upload_map.
+ *  - one context = one GPU = one thread at a time (the reference is single-threaded and
+ *    non-reentrant on this path).
+ */
+#ifndef HRBF_MI355_H_
+#define HRBF_MI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum hrbf_status {
+    HRBF_OK = 0,
+    HRBF_ERR_INVALID = -1,   /* bad argument / unsupported parameter combination */
+    HRBF_ERR_DEVICE = -2,    /* HIP runtime error, see hrbf_last_error() */
+    HRBF_ERR_CAPACITY = -3,  /* surfel map capacity exceeded */
+    HRBF_ERR_NODEVICE = -4,  /* no gfx950 device visible */
+    HRBF_ERR_COMM = -5       /* RCCL error */
+} hrbf_status;
+
+/* Parameters = HRBFFusion ctor arguments (Core/src/HRBFFusion.h:87-94) + the GlobalStateParam
+ * fields the path reads (Core/src/Utils/GlobalStateParams.h:12-63, defaults GUI/GlobalStateParam.txt). */
+typedef struct hrbf_params {
+    int32_t width, height;          /* Resolution singleton */
+    float fx, fy, cx, cy;           /* Intrinsics singleton */
+    float depth_scale;              /* metres per raw depth unit = 1/DepthMapFactor (HRBFFusion.cpp:772-780) */
+    /* ctor */
+    float confidence_threshold;     /* `confidence`, GUI passes 5.0 (GUI/src/HRBF_fusion.cpp:87-96) */
+    float depth_cutoff;             /* `depthCut`, GUI passes globalDepthCutoff = 3.5 */
+    float icp_weight;               /* `icpThresh` = 10 */
+    int32_t fast_odom;              /* false */
+    int32_t so3;                    /* true  */
+    int32_t frame_to_frame_rgb;     /* false */
+    int32_t rgb_only;               /* false (HRBFFusion.cpp:38) */
+    int32_t pyramid;                /* true  (HRBFFusion.cpp:40) */
+    float max_depth_processed;      /* 20.0  (HRBFFusion.cpp:37) */
+    /* preprocessing */
+    int32_t use_bilateral;          /* preprocessingUsebilateralFilter = true */
+    float init_radius_multiplier;   /* 4.0 */
+    float curv_estimation_window;   /* 3.0 */
+    float curv_valid_threshold;     /* 300 */
+    float normal_estimation_pca;    /* 1.0 */
+    int32_t use_conf_eval;          /* 0 */
+    float conf_eval_epsilon;        /* 1000 */
+    /* registration */
+    int32_t icp_use_corr_search;    /* false */
+    int32_t icp_search_radius;      /* 2 */
+    int32_t icp_use_weighted;       /* true */
+    float icp_curv_weight_lambda;   /* registrationICPCurvWeightImpactControl = 10 */
+    int32_t rgb_use_grad_weight;    /* registrationColorUseRGBGrad = false */
+    int32_t use_sparse_icp;         /* registrationICPUseSparseICP = false; true is rejected */
+    /* prediction */
+    float predict_window_multiplier;/* 3.0 */
+    int32_t predict_min_neighbors;  /* 6 */
+    int32_t predict_max_neighbors;  /* 10 */
+    float predict_conf_threshold;   /* 3.0 */
+    /* fusion */
+    float clean_window_multiplier;  /* fusionCleanWindowMultiplier = 2.0 */
+    float dense_enough_thresh;      /* globalDenseEnoughThresh = 0.75 */
+    /* build-specific */
+    int32_t max_surfels;            /* map capacity; reference: 4596^2 (GlobalModel.cpp:21-22) */
+    int32_t load_trajectory;        /* globalInputLoadTrajectory: poses supplied via hrbf_set_pose before each frame */
+} hrbf_params;
+
+typedef struct hrbf_context *hrbf_handle;
+
+void hrbf_default_params(hrbf_params *p, int width, int height, float fx, float fy, float cx, float cy,
+                         float depth_scale);
+
+/* lifecycle -------------------------------------------------------------------------------- */
+int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out);
+void hrbf_destroy(hrbf_handle h);
+const char *hrbf_last_error(void);
+const char *hrbf_version(void);
+
+/* primary entry: HRBFFusion::processFrame (Core/src/HRBFFusion.h:110-113).
+ * rgb: W*H*3 uint8 (R,G,B), depth: W*H uint16 raw units; host pointers borrowed for the call. */
+int hrbf_process_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth, int64_t timestamp,
+                       float weight_multiplier);
+/* same, inputs already resident in HBM (device pointers) — what bench.py times */
+int hrbf_process_frame_device(hrbf_handle h, const void *d_rgb, const void *d_depth, int64_t timestamp,
+                              float weight_multiplier);
+/* block until all work queued on the context's stream is complete */
+int hrbf_synchronize(hrbf_handle h);
+
+/* getters the reference's caller uses (GUI/src/HRBF_fusion.cpp:235-497) ---------------------- */
+int hrbf_get_pose(hrbf_handle h, float out16[16]);          /* getCurrPose(), column-major T_wc */
+int hrbf_set_pose(hrbf_handle h, const float in16[16]);     /* trajectory replay (HRBFFusion.cpp:1105-1108) */
+int hrbf_get_tick(hrbf_handle h);                           /* getTick() */
+uint32_t hrbf_surfel_count(hrbf_handle h);                  /* getGlobalModel().lastCount() */
+int hrbf_download_map(hrbf_handle h, float *out, size_t cap_surfels); /* GlobalModel::downloadMap (GlobalModel.cpp:775-804) */
+int hrbf_upload_map(hrbf_handle h, const float *in, size_t n_surfels); /* build-specific: seed the map (bench inflation) */
+int hrbf_last_icp(hrbf_handle h, float *error, float *count); /* getFrameToModel().lastICPError/lastICPCount */
+int hrbf_last_weighting(hrbf_handle h, float *w);
+/* live-tunable setters applied every GUI frame (GUI/src/HRBF_fusion.cpp:448-456) */
+int hrbf_set_rgb_only(hrbf_handle h, int v);
+int hrbf_set_icp_weight(hrbf_handle h, float v);
+int hrbf_set_pyramid(hrbf_handle h, int v);
+int hrbf_set_fast_odom(hrbf_handle h, int v);
+int hrbf_set_so3(hrbf_handle h, int v);
+int hrbf_set_frame_to_frame_rgb(hrbf_handle h, int v);
+int hrbf_set_confidence_threshold(hrbf_handle h, float v);
+int hrbf_set_depth_cutoff(hrbf_handle h, float v);
+
+/* named images = the reference's GPUTexture map (Core/src/GPUTexture.cpp:21-38) + IndexMap /
+ * FillIn texture getters (Core/src/IndexMap.h, Core/src/Shaders/FillIn.h) */
+typedef enum hrbf_image {
+    HRBF_IMG_DEPTH_FILTERED = 0,      /* f1, raw units */
+    HRBF_IMG_DEPTH_METRIC,            /* f1 */
+    HRBF_IMG_DEPTH_METRIC_FILTERED,   /* f1 */
+    HRBF_IMG_VERTEX_RAW,              /* f4 */
+    HRBF_IMG_VERTEX_FILTERED,         /* f4 */
+    HRBF_IMG_NORMAL,                  /* f4 (after updateNormalRad: NORMAL_OPT) */
+    HRBF_IMG_NORMAL_PCA,              /* f4 build-specific: PCA normal + radius consumed by fuse (data.vert:87-96) */
+    HRBF_IMG_RADIUS,                  /* f1 */
+    HRBF_IMG_CURV1,                   /* f4 */
+    HRBF_IMG_CURV2,                   /* f4 */
+    HRBF_IMG_GRADIENT_MAG,            /* f1 */
+    HRBF_IMG_CONFIDENCE,              /* f1 */
+    HRBF_IMG_INDEX,                   /* u32 */
+    HRBF_IMG_INDEX_VERTCONF,          /* f4 */
+    HRBF_IMG_INDEX_COLORTIME,         /* f4 */
+    HRBF_IMG_INDEX_NORMRAD,           /* f4 */
+    HRBF_IMG_INDEX_CURVMAX,           /* f4 */
+    HRBF_IMG_INDEX_CURVMIN,           /* f4 */
+    HRBF_IMG_PRED_IMAGE,              /* u8x4 */
+    HRBF_IMG_PRED_VERTEX,             /* f4 */
+    HRBF_IMG_PRED_NORMAL,             /* f4 */
+    HRBF_IMG_PRED_CURV1,              /* f4 */
+    HRBF_IMG_PRED_CURV2,              /* f4 */
+    HRBF_IMG_PRED_TIME,               /* u32 (reference: R16UI) */
+    HRBF_IMG_PRED_ICPWEIGHT,          /* f1 */
+    HRBF_IMG_FILL_IMAGE,              /* u8x4 */
+    HRBF_IMG_FILL_VERTEX,             /* f4 */
+    HRBF_IMG_FILL_NORMAL,             /* f4 */
+    HRBF_IMG_FILL_CURV1,              /* f4 */
+    HRBF_IMG_FILL_CURV2,              /* f4 */
+    HRBF_IMG_FILL_ICPWEIGHT,          /* f1 */
+    HRBF_IMG_COUNT
+} hrbf_image;
+size_t hrbf_image_bytes(hrbf_handle h, int which);
+int hrbf_get_image(hrbf_handle h, int which, void *out, size_t bytes);   /* device -> host */
+int hrbf_set_image(hrbf_handle h, int which, const void *in, size_t bytes); /* host -> device (tests) */
+
+/* per-region timings of the last frame in ms, named as the reference's Stopwatch regions
+ * (Core/src/HRBFFusion.cpp:1016,1063,1196,1248): 0 Initialization 1 Registration 2 Integration 3 Prediction;
+ * 4 = the fuse (clean+compact+append) streaming kernel alone.  Requires hrbf_enable_timing(h,1). */
+int hrbf_enable_timing(hrbf_handle h, int on);
+int hrbf_get_timings(hrbf_handle h, float out_ms[8]);
+/* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
+int hrbf_get_fuse_stats(hrbf_handle h, uint32_t out[4]);
+
+/* operator-level seams on the context's own images (isolated parity) ------------ */
+typedef enum hrbf_stage {
+    HRBF_STAGE_FILTER_DEPTH = 0,      /* filterDepth        HRBFFusion.cpp:1272-1280 */
+    HRBF_STAGE_METRICISE,             /* metriciseDepth     :1263-1270 */
+    HRBF_STAGE_VERTEX_NORMAL_RADIUS,  /* computeVertexNormalRadius :1329-1345 */
+    HRBF_STAGE_CURVATURE,             /* computeCurvatureGradient + updateNormalRad :1282-1310 */
+    HRBF_STAGE_CONFIDENCE,            /* VertexConfidence   :1311-1327 (uses last weighting) */
+    HRBF_STAGE_INITIALISE,            /* GlobalModel::initialise GlobalModel.cpp:214-288 */
+    HRBF_STAGE_PREDICT_INDICES,       /* IndexMap::predictIndices IndexMap.cpp:193-267 */
+    HRBF_STAGE_FUSE,                  /* GlobalModel::fuse  GlobalModel.cpp:355-548 */
+    HRBF_STAGE_CLEAN,                 /* GlobalModel::clean GlobalModel.cpp:551-688 */
+    HRBF_STAGE_PREDICT_HRBF,          /* IndexMap::predictHRBF IndexMap.cpp:413-518 */
+    HRBF_STAGE_FILLIN,                /* FillIn::vertex/normal/curvature/image FillIn.cpp:93-297 */
+    HRBF_STAGE_ODOMETRY,              /* initICP*.. + getIncrementalTransformation RGBDOdometry.cpp:183-247,660-1249 */
+    HRBF_STAGE_COUNT
+} hrbf_stage;
+int hrbf_upload_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth);
+int hrbf_run_stage(hrbf_handle h, int stage);
+int hrbf_set_tick(hrbf_handle h, int tick);
+int hrbf_set_weighting(hrbf_handle h, float w);
+
+/* icpStep seam (Core/src/Cuda/cudafuncs.cuh icpStep / reduce.cu:580-693) on caller-provided DEVICE
+ * planar maps: each map is 4 planes of rows*cols floats (x,y,z,w), NaN in plane 0 = invalid.
+ * A_out: 36 doubles row-major, b_out: 6 doubles, residual_out: {sum r^2 (weighted), inliers}. */
+int hrbf_icp_step(hrbf_handle h, const float Rcurr[9], const float tcurr[3],
+                  const float *vmap_curr, const float *nmap_curr, const float *ck1_curr, const float *ck2_curr,
+                  const float Rprev_inv[9], const float tprev[3], float fx, float fy, float cx, float cy,
+                  const float *vmap_g_prev, const float *nmap_g_prev, const float *ck1_g_prev,
+                  const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
+                  float dist_thresh, float angle_thresh, int use_weight,
+                  double A_out[36], double b_out[6], double residual_out[2]);
+
+/* multi-GPU: join an RCCL communicator; afterwards the odometry reductions are
+ * row-sharded over ranks and all-reduced (exact int64 limbs) every Gauss-Newton iteration. */
+int hrbf_comm_unique_id(uint8_t out128[128]);
+int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRBF_MI355_H_ */

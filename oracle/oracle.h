@@ -1,0 +1,132 @@
+/*
+ * oracle.h — CPU restatement ("oracle") of the HRBF-Fusion per-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under hrbffusion3d_amd/ or include/ may call into this
+ * library; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY UNPINNED: the reference (YabinXuTUD/HRBFFusion3D) has no tests, no golden vectors and
+ * cannot be built here (Pangolin/CUDA/Eigen/OpenCV/GL absent).  This oracle is a
+ * line-by-line restatement of the reference's GLSL/CUDA/host semantics (each function cites the
+ * file:line it follows); it is pinned only by analytic known-answer tests (tests/test_oracle_*.py).
+ *
+ * Plain C99, scalar, single-thread (OpenMP over pixels/surfels when built with -fopenmp; results
+ * are identical because every reduction goes through the exact accumulator of hrbf_detmath.h).
+ */
+#ifndef HRBF_ORACLE_H_
+#define HRBF_ORACLE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+#include "../include/hrbf_mi355.h"   /* hrbf_params, hrbf_image, hrbf_stage enums (types only) */
+#include "../include/hrbf_detmath.h"
+
+typedef struct { float x, y, z, w; } f4;
+typedef struct { float x, y, z; } f3;
+
+#define ORC_NUM_PYRS 3
+
+typedef struct orc_planar {   /* DeviceArray2D<float>(rows*4, cols), planar SoA (RGBDOdometry.cpp:128-136) */
+    int rows, cols;
+    float *p;                 /* 4*rows*cols */
+} orc_planar;
+
+typedef struct orc_ctx {
+    hrbf_params prm;
+    int W, H, P;
+    int tick;
+    float pose[16];           /* column-major T_wc */
+    float prev_pose[16];      /* pose at the end of the previous frame (lastPose, HRBFFusion.cpp:1064) */
+    float weighting;
+    float last_icp_error, last_icp_count;
+    int index_submap;
+    /* inputs */
+    uint8_t *rgb;             /* P*3 */
+    uint16_t *depth_raw;      /* P */
+    /* preprocessing images */
+    float *depth_filtered, *depth_metric, *depth_metric_filtered;
+    f4 *vertex_raw, *vertex_filtered, *normal, *normal_pca, *normal_opt, *curv1, *curv2;
+    float *radius, *gradmag, *confidence;
+    /* index map */
+    uint32_t *idx;
+    f4 *im_vertconf, *im_colortime, *im_normrad, *im_curvmax, *im_curvmin;
+    /* prediction */
+    uint8_t *pr_image;        /* P*4 */
+    f4 *pr_vertex, *pr_normal, *pr_curv1, *pr_curv2;
+    uint32_t *pr_time;
+    float *pr_icpw;
+    /* fill-in */
+    uint8_t *fi_image;
+    f4 *fi_vertex, *fi_normal, *fi_curv1, *fi_curv2;
+    float *fi_icpw;
+    /* surfel map: AoS 5 x f4, two ping-pong buffers */
+    f4 *map[2];
+    int target;
+    uint32_t count, cap;
+    /* fuse records: one per quarter-grid pixel, column-major order */
+    f4 *rec;                  /* Q*5 */
+    int32_t *rec_flag;        /* 0 none, 1 merge, 2 new */
+    uint32_t *rec_best;
+    int Q;
+    uint32_t fuse_stats[4];   /* in, merged, appended, out */
+    /* odometry state (RGBDOdometry members) */
+    orc_planar vmap_g[ORC_NUM_PYRS], nmap_g[ORC_NUM_PYRS], ck1_g[ORC_NUM_PYRS], ck2_g[ORC_NUM_PYRS];
+    orc_planar vmap_c[ORC_NUM_PYRS], nmap_c[ORC_NUM_PYRS], ck1_c[ORC_NUM_PYRS], ck2_c[ORC_NUM_PYRS];
+    float *icpw[ORC_NUM_PYRS];
+    float *last_depth[ORC_NUM_PYRS], *next_depth[ORC_NUM_PYRS];
+    uint8_t *last_image[ORC_NUM_PYRS], *next_image[ORC_NUM_PYRS], *last_next_image[ORC_NUM_PYRS];
+    int16_t *dIdx[ORC_NUM_PYRS], *dIdy[ORC_NUM_PYRS];
+    f3 *cloud[ORC_NUM_PYRS];
+    int16_t *corres;          /* P * 6 : zero.x zero.y one.x one.y valid pad ; diff in corres_diff */
+    float *corres_diff;
+    double timings_ms[8];
+} orc_ctx;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+orc_ctx *orc_create(const hrbf_params *p);
+void orc_destroy(orc_ctx *c);
+int orc_process_frame(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth, int64_t ts, float wmul);
+int orc_upload_frame(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth);
+int orc_run_stage(orc_ctx *c, int stage);
+void orc_get_pose(orc_ctx *c, float out16[16]);
+void orc_set_pose(orc_ctx *c, const float in16[16]);
+int orc_get_tick(orc_ctx *c);
+void orc_set_tick(orc_ctx *c, int t);
+void orc_set_weighting(orc_ctx *c, float w);
+float orc_get_weighting(orc_ctx *c);
+uint32_t orc_surfel_count(orc_ctx *c);
+int orc_download_map(orc_ctx *c, float *out, size_t cap);
+int orc_upload_map(orc_ctx *c, const float *in, size_t n);
+size_t orc_image_bytes(orc_ctx *c, int which);
+int orc_get_image(orc_ctx *c, int which, void *out, size_t bytes);
+int orc_set_image(orc_ctx *c, int which, const void *in, size_t bytes);
+void orc_last_icp(orc_ctx *c, float *err, float *cnt);
+void orc_get_fuse_stats(orc_ctx *c, uint32_t out[4]);
+void orc_get_timings(orc_ctx *c, double out[8]);
+
+/* standalone operators */
+int orc_icp_step(const float Rcurr[9], const float tcurr[3],
+                 const float *vmap_curr, const float *nmap_curr, const float *ck1_curr, const float *ck2_curr,
+                 const float Rprev_inv[9], const float tprev[3], float fx, float fy, float cx, float cy,
+                 const float *vmap_g_prev, const float *nmap_g_prev, const float *ck1_g_prev,
+                 const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
+                 float dist_thresh, float angle_thresh, int use_weight,
+                 double A_out[36], double b_out[6], double residual_out[2]);
+/* HRBF primitives for known-answer tests (hrbfbase.glsl:126-195) */
+float orc_hrbf_value(const float p[3], const f4 *vc, const f4 *nr, int n, int *nsupport);
+void orc_hrbf_gradient(const float p[3], const f4 *vc, const f4 *nr, int n, float out[3]);
+void orc_hrbf_hessian(const float p[3], const f4 *vc, const f4 *nr, int n, float out[9]);
+/* detmath exports for tests */
+float orc_expf(float x); float orc_acosf(float x); float orc_atan2f(float y, float x);
+void orc_sincosf(float x, float *s, float *c); void orc_sincos(double x, double *s, double *c);
+double orc_acos(double x);
+void orc_acc_test(const float *v, int n, double *out);
+/* 6x6 solve and SE3 update used by the GN loop (RGBDOdometry.cpp:1162-1204) */
+void orc_solve6(const double A[36], const double b[6], double x[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

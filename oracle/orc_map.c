@@ -1,0 +1,283 @@
+/*
+ * orc_map.c — surfel-map operations (oracle; test infrastructure only).
+ * Follows GlobalModel::{initialise,fuse,clean} (Core/src/GlobalModel.cpp:214-288,355-688),
+ * IndexMap::predictIndices (Core/src/IndexMap.cpp:193-267) and their shaders.
+ *
+ * GL rasterisation semantics fixed by this restatement:
+ *  - a 1-px GL point at window coordinate (u,v) lands on pixel (floor(u), floor(v)) and is clipped
+ *    unless 0 <= u < W, 0 <= v < H;
+ *  - GL_LESS z-test: smallest camera-space z wins, ties go to the lower surfel index (draw order);
+ *    the reference's 24-bit depth quantisation is not modelled;
+ *  - the 4596^2 scatter target of fuse stage 1 is "first primitive in draw order wins"
+ *    (all fragments z = 0, GL_LESS; GUI/src/Tools/GUI.h:69-71), draw order is column-major over
+ *    pixels (GlobalModel.cpp:89-96);
+ *  - transform feedback is an order-preserving compaction.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+#include "orc_vec.h"
+
+float orc_get_radius(float depth, float norm_z, float camz, float camw);
+float orc_radial_confidence(float x, float y, float cx, float cy, float max_dist, float weighting);
+
+#define SURF(buf, i, k) ((buf)[(size_t)(i) * 5 + (k)])
+
+/* ---- F4: init_unstableTex.vert:51-98 + .geom ---------------------------------------------- */
+void orc_initialise(orc_ctx *c)
+{
+    const int W = c->W, H = c->H;
+    const float cx = c->prm.cx, cy = c->prm.cy, thr = c->prm.curv_valid_threshold;
+    const float max_dist = sqrtf(((float)H * 0.5f) * ((float)H * 0.5f) + ((float)W * 0.5f) * ((float)W * 0.5f));
+    f4 *out = c->map[c->target];
+    uint32_t n = 0;
+    for (int px = 0; px < W; ++px)          /* column-major draw order */
+        for (int py = 0; py < H; ++py) {
+            int i = py * W + px;
+            f4 vl = c->vertex_raw[i];
+            f3 pg = xform(c->pose, xyz(vl));
+            float conf = orc_radial_confidence((float)px + 0.5f, (float)py + 0.5f, cx, cy, max_dist, 1.0f);
+            if (c->prm.use_conf_eval > 0) conf = conf * hd_expf(-c->prm.conf_eval_epsilon / sqrtf(c->gradmag[i]));
+            f4 nl = c->normal[i];
+            f3 ng = rot_mul(c->pose, xyz(nl));
+            f4 k1 = c->curv1[i], k2 = c->curv2[i];
+            if (len3(ng) > 0.5f && k1.w > -thr && k1.w < thr && k2.w > -thr && k2.w < thr) {
+                if (n >= c->cap) continue;
+                const uint8_t *rgb = &c->rgb[i * 3];
+                SURF(out, n, 0) = v4(pg.x, pg.y, pg.z, conf);
+                SURF(out, n, 1) = v4(encode_color_bytes(rgb[0], rgb[1], rgb[2]), 0.0f, 1.0f, 1.0f);
+                SURF(out, n, 2) = v4(ng.x, ng.y, ng.z, nl.w);
+                SURF(out, n, 3) = k1;
+                SURF(out, n, 4) = k2;
+                n++;
+            }
+        }
+    c->count = n;
+}
+
+/* ---- M1: index_map.vert:34-66, index_map.frag:35-43 --------------------------------------- */
+void orc_predict_indices(orc_ctx *c)
+{
+    const int W = c->W, H = c->H, P = c->P;
+    const float fx = c->prm.fx, fy = c->prm.fy, cx = c->prm.cx, cy = c->prm.cy;
+    const float maxDepth = c->prm.max_depth_processed;
+    float tinv[16];
+    rigid_inverse(c->pose, tinv);
+    const f4 *m = c->map[c->target];
+    float *zbuf = (float *)malloc(sizeof(float) * P);
+    int64_t *win = (int64_t *)malloc(sizeof(int64_t) * P);
+    for (int i = 0; i < P; ++i) { zbuf[i] = 0.0f; win[i] = -1; }
+    for (uint32_t s = 0; s < c->count; ++s) {
+        f4 p = SURF(m, s, 0);
+        f3 h = xform(tinv, xyz(p));
+        /* active-submap mask: only submap ids <= index_submap exist without the sparse back-end and
+           all of them are active (IndexMap.cpp:222-237 with lActiveKFID = {0..}) */
+        if (h.z > maxDepth || h.z < 0.0f) continue;
+        float u = ((fx * h.x) / h.z) + cx;
+        float v = ((fy * h.y) / h.z) + cy;
+        if (!(u >= 0.0f && u < (float)W && v >= 0.0f && v < (float)H)) continue;
+        int ix = (int)floorf(u), iy = (int)floorf(v);
+        int pi = iy * W + ix;
+        if (win[pi] < 0 || h.z < zbuf[pi]) { zbuf[pi] = h.z; win[pi] = s; }
+    }
+    for (int i = 0; i < P; ++i) {
+        if (win[i] < 0) {
+            c->idx[i] = 0;
+            c->im_vertconf[i] = c->im_colortime[i] = c->im_normrad[i] = c->im_curvmax[i] = c->im_curvmin[i] =
+                v4(0, 0, 0, 0);
+            continue;
+        }
+        uint32_t s = (uint32_t)win[i];
+        f4 p = SURF(m, s, 0), nr = SURF(m, s, 2);
+        f3 h = xform(tinv, xyz(p));
+        f3 n = normalize3(rot_mul(tinv, xyz(nr)));
+        c->idx[i] = s;
+        c->im_vertconf[i] = v4(h.x, h.y, h.z, p.w);
+        c->im_colortime[i] = SURF(m, s, 1);
+        c->im_normrad[i] = v4(n.x, n.y, n.z, nr.w);
+        c->im_curvmax[i] = SURF(m, s, 3);
+        c->im_curvmin[i] = SURF(m, s, 4);
+    }
+    free(zbuf); free(win);
+}
+
+/* ---- F1: data.vert:63-198 (association) + F2: update.vert:51-115 (merge) ------------------- */
+void orc_fuse(orc_ctx *c)
+{
+    const int W = c->W, H = c->H;
+    const float cx = c->prm.cx, cy = c->prm.cy;
+    const float camz = (float)(1.0 / (double)c->prm.fx), camw = (float)(1.0 / (double)c->prm.fy);
+    const float maxDepth = c->prm.max_depth_processed;
+    const float timef = (float)c->tick;
+    const int tpar = c->tick % 2;
+    const int QH = H / 2;
+    f4 *m = c->map[c->target];
+    memset(c->rec_flag, 0, sizeof(int32_t) * c->Q);
+    uint32_t merged = 0;
+    /* first-primitive-wins table */
+    uint32_t *slot = (uint32_t *)malloc(sizeof(uint32_t) * (c->count ? c->count : 1));
+    for (uint32_t i = 0; i < c->count; ++i) slot[i] = 0xFFFFFFFFu;
+
+    for (int px = 0; px < W; ++px)
+        for (int py = 0; py < H; ++py) {
+            if (!(px % 2 == tpar && py % 2 == tpar)) continue;
+            int i = py * W + px;
+            int q = (px / 2) * QH + (py / 2);
+            float x = (float)px + 0.5f, y = (float)py + 0.5f;
+            float zr = c->depth_metric[i];
+            f3 vl = v3((x - cx) * zr * camz, (y - cy) * zr * camw, zr);
+            f4 npca = c->normal_pca[i];
+            f3 nl = xyz(npca);
+            f4 k1 = c->curv1[i], k2 = c->curv2[i];
+            if (!(len3(nl) > 0.8f && vl.z > 0.3f && vl.z <= maxDepth && k1.w > -300.0f && k1.w < 300.0f &&
+                  k2.w > -300.0f && k2.w < 300.0f))
+                continue;
+            float bestDist = 1000.0f;
+            uint32_t best = 0;
+            int counter = 0;
+            float xl = (x - cx) * camz, yl = (y - cy) * camw;
+            float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+            f3 ray = v3(xl, yl, 1.0f);
+            float lray = len3(ray);
+            static const int offs[4] = {-1, 0, 0, 1};   /* half-pixel steps under exact floor() */
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    int sx = clampi(px + offs[a], 0, W - 1), sy = clampi(py + offs[b], 0, H - 1);
+                    int si = sy * W + sx;
+                    uint32_t current = c->idx[si];
+                    if (current > 0u) {
+                        f4 vcf = c->im_vertconf[si];
+                        if (fabsf((vcf.z * lambda) - (vl.z * lambda)) < 0.05f) {
+                            float dist = len3(cross3(ray, xyz(vcf))) / lray;
+                            f4 nr = c->im_normrad[si];
+                            int ok = fabsf(nr.z) < 0.75f;
+                            if (!ok) {
+                                float ang = hd_acosf(dot3(xyz(nr), nl) / (len3(xyz(nr)) * len3(nl)));
+                                ok = fabsf(ang) < 0.5f;
+                            }
+                            if (dist < bestDist && ok) { counter++; bestDist = dist; best = current; }
+                        }
+                    }
+                }
+            f3 pg = xform(c->pose, vl);
+            f3 ng = rot_mul(c->pose, nl);
+            const uint8_t *rgb = &c->rgb[i * 3];
+            f4 *r = &c->rec[(size_t)q * 5];
+            r[0] = v4(pg.x, pg.y, pg.z, c->confidence[i]);
+            r[1] = v4(encode_color_bytes(rgb[0], rgb[1], rgb[2]), (float)c->index_submap, timef,
+                      counter > 0 ? -1.0f : -2.0f);
+            r[2] = v4(ng.x, ng.y, ng.z, npca.w);
+            r[3] = k1; r[4] = k2;
+            c->rec_flag[q] = counter > 0 ? 1 : 2;
+            c->rec_best[q] = best;
+            if (counter > 0 && slot[best] == 0xFFFFFFFFu) slot[best] = (uint32_t)q;
+        }
+
+    /* F2: update.vert — only surfels holding a winning record change */
+    for (uint32_t s = 0; s < c->count; ++s) {
+        if (slot[s] == 0xFFFFFFFFu) continue;
+        const f4 *r = &c->rec[(size_t)slot[s] * 5];
+        f4 vp = SURF(m, s, 0), vc = SURF(m, s, 1), vn = SURF(m, s, 2), c1 = SURF(m, s, 3), c2 = SURF(m, s, 4);
+        float c_k = vp.w, a = r[0].w, sum = c_k + a;
+        if (r[2].w < (1.0f + 0.5f) * vn.w) {
+            SURF(m, s, 0) = v4(((c_k * vp.x) + (a * r[0].x)) / sum, ((c_k * vp.y) + (a * r[0].y)) / sum,
+                               ((c_k * vp.z) + (a * r[0].z)) / sum, sum);
+            f3 oc = decode_color(vc.x), nc = decode_color(r[1].x);
+            f3 avg = v3(((c_k * oc.x) + (a * nc.x)) / sum, ((c_k * oc.y) + (a * nc.y)) / sum,
+                        ((c_k * oc.z) + (a * nc.z)) / sum);
+            SURF(m, s, 1) = v4(encode_color(avg), vc.y, vc.z, (float)c->tick);
+            f3 nn = normalize3(v3(((c_k * vn.x) + (a * r[2].x)) / sum, ((c_k * vn.y) + (a * r[2].y)) / sum,
+                                  ((c_k * vn.z) + (a * r[2].z)) / sum));
+            SURF(m, s, 2) = v4(nn.x, nn.y, nn.z, ((c_k * vn.w) + (a * r[2].w)) / sum);
+            SURF(m, s, 3) = v4(((c_k * c1.x) + (a * r[3].x)) / sum, ((c_k * c1.y) + (a * r[3].y)) / sum,
+                               ((c_k * c1.z) + (a * r[3].z)) / sum, ((c_k * c1.w) + (a * r[3].w)) / sum);
+            SURF(m, s, 4) = v4(((c_k * c2.x) + (a * r[4].x)) / sum, ((c_k * c2.y) + (a * r[4].y)) / sum,
+                               ((c_k * c2.z) + (a * r[4].z)) / sum, ((c_k * c2.w) + (a * r[4].w)) / sum);
+        } else {
+            SURF(m, s, 0) = v4(vp.x, vp.y, vp.z, sum);
+            SURF(m, s, 1) = v4(vc.x, vc.y, vc.z, (float)c->tick);
+        }
+        merged++;
+    }
+    free(slot);
+    c->fuse_stats[1] = merged;
+}
+
+/* ---- F3: copy_unstable.vert:62-166 + .geom ------------------------------------------------ */
+static int clean_test(const orc_ctx *c, const float *tinv, f4 vp, f4 *vcol, f4 vn, f4 k1, f4 k2)
+{
+    const int W = c->W, H = c->H;
+    const float fx = c->prm.fx, fy = c->prm.fy, cx = c->prm.cx, cy = c->prm.cy;
+    const float maxDepth = c->prm.max_depth_processed, confThr = c->prm.confidence_threshold;
+    const float thr = c->prm.curv_valid_threshold;
+    const int time = c->tick;
+    int test = 1;
+    f3 lp = xform(tinv, xyz(vp));
+    float x = ((fx * lp.x) / lp.z) + cx;
+    float y = ((fy * lp.y) / lp.z) + cy;
+    f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
+    int count = 0, zCount = 0;
+    const float active = 1.0f;   /* all existing submaps active without the sparse back-end */
+    if (lp.z < maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)W && y < (float)H) {
+        /* half-pixel steps over [x - w/2, x + w/2) px (copy_unstable.vert:84-108 with FACTOR = 1):
+           samples at x + (k - w)*0.5, k = 0 .. 2w-1 */
+        int nw = (int)(2.0f * c->prm.clean_window_multiplier);
+        float w0 = c->prm.clean_window_multiplier * 0.5f;
+        for (int a = 0; a < nw; ++a) {
+            int sx = clampi((int)floorf(x + ((float)a * 0.5f - w0)), 0, W - 1);
+            for (int b = 0; b < nw; ++b) {
+                int sy = clampi((int)floorf(y + ((float)b * 0.5f - w0)), 0, H - 1);
+                int si = sy * W + sx;
+                uint32_t current = c->idx[si];
+                if (current > 0u) {
+                    f4 vcf = c->im_vertconf[si], ct = c->im_colortime[si];
+                    float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
+                    if (ct.z < vcol->z && vcf.w > confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
+                        sqrtf(dx * dx + dy * dy) < vn.w * 1.4f)
+                        count++;
+                    if (ct.w == (float)time && vcf.w > confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f &&
+                        fabsf(ln.z) > 0.85f && active > 0.0f)
+                        zCount++;
+                }
+            }
+        }
+    }
+    if (k1.w < -thr || k1.w > thr || k2.w < -thr || k2.w > thr) test = 0;
+    if (count > 8 || zCount > 4) test = 0;
+    if (vcol->w == -2.0f) vcol->w = (float)time;
+    if (vcol->w == -1.0f || (((float)time - vcol->w) > 200.0f && vp.w < confThr)) test = 0;
+    return test;
+}
+
+void orc_clean(orc_ctx *c)
+{
+    float tinv[16];
+    rigid_inverse(c->pose, tinv);
+    const f4 *m = c->map[c->target];
+    f4 *out = c->map[1 - c->target];
+    uint32_t n = 0, appended = 0;
+    c->fuse_stats[0] = c->count;
+    for (uint32_t s = 0; s < c->count; ++s) {
+        f4 vp = SURF(m, s, 0), vc = SURF(m, s, 1), vn = SURF(m, s, 2), k1 = SURF(m, s, 3), k2 = SURF(m, s, 4);
+        if (clean_test(c, tinv, vp, &vc, vn, k1, k2)) {
+            SURF(out, n, 0) = vp; SURF(out, n, 1) = vc; SURF(out, n, 2) = vn; SURF(out, n, 3) = k1; SURF(out, n, 4) = k2;
+            n++;
+        }
+    }
+    for (int q = 0; q < c->Q; ++q) {
+        if (c->rec_flag[q] == 0) continue;
+        const f4 *r = &c->rec[(size_t)q * 5];
+        f4 vc = r[1];
+        if (clean_test(c, tinv, r[0], &vc, r[2], r[3], r[4])) {
+            if (n >= c->cap) continue;
+            SURF(out, n, 0) = r[0]; SURF(out, n, 1) = vc; SURF(out, n, 2) = r[2]; SURF(out, n, 3) = r[3]; SURF(out, n, 4) = r[4];
+            n++; appended++;
+        }
+    }
+    c->count = n;
+    c->target = 1 - c->target;
+    c->fuse_stats[2] = appended;
+    c->fuse_stats[3] = n;
+    /* records are consumed: a second clean without a fuse must not re-append them */
+    memset(c->rec_flag, 0, sizeof(int32_t) * c->Q);
+}

@@ -1,0 +1,156 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle*.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from hrbffusion3d_amd.params import HrbfParams, IMAGES, STAGES
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ODIR = os.path.join(_ROOT, "oracle")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ODIR], stdout=subprocess.DEVNULL)
+
+
+def load(omp=False):
+    name = "liboracle_omp.so" if omp else "liboracle.so"
+    path = os.path.join(_ODIR, "_build", name)
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    lib.orc_create.restype = C.c_void_p
+    lib.orc_create.argtypes = [C.POINTER(HrbfParams)]
+    for fn in ("orc_destroy",):
+        getattr(lib, fn).argtypes = [C.c_void_p]
+    lib.orc_process_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
+    lib.orc_upload_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_run_stage.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_get_pose.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_set_pose.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_get_tick.argtypes = [C.c_void_p]
+    lib.orc_set_tick.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_set_weighting.argtypes = [C.c_void_p, C.c_float]
+    lib.orc_get_weighting.argtypes = [C.c_void_p]
+    lib.orc_get_weighting.restype = C.c_float
+    lib.orc_surfel_count.argtypes = [C.c_void_p]
+    lib.orc_surfel_count.restype = C.c_uint32
+    lib.orc_download_map.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.orc_upload_map.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.orc_image_bytes.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_image_bytes.restype = C.c_size_t
+    lib.orc_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.orc_set_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.orc_last_icp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_get_fuse_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_get_timings.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_hrbf_value.restype = C.c_float
+    lib.orc_hrbf_value.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_hrbf_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_hrbf_hessian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_expf.restype = C.c_float; lib.orc_expf.argtypes = [C.c_float]
+    lib.orc_acosf.restype = C.c_float; lib.orc_acosf.argtypes = [C.c_float]
+    lib.orc_atan2f.restype = C.c_float; lib.orc_atan2f.argtypes = [C.c_float, C.c_float]
+    lib.orc_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    lib.orc_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+    lib.orc_acos.restype = C.c_double; lib.orc_acos.argtypes = [C.c_double]
+    lib.orc_acc_test.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_solve6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_icp_step.argtypes = [C.c_void_p] * 6 + [C.c_void_p] * 2 + [C.c_float] * 4 + [C.c_void_p] * 5 + \
+        [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Same method names as hrbffusion3d_amd.api.HRBFFusion so parity tests read symmetrically."""
+
+    def __init__(self, params, omp=False):
+        self.lib = load(omp)
+        self.params = params
+        self.W, self.H = params.width, params.height
+        self.h = self.lib.orc_create(C.byref(params))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_frame(self, rgb, depth, ts=0, weight_multiplier=1.0):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        assert rgb.size == self.W * self.H * 3 and depth.size == self.W * self.H
+        return self.lib.orc_process_frame(self.h, _p(rgb), _p(depth), ts, weight_multiplier)
+
+    def upload_frame(self, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        return self.lib.orc_upload_frame(self.h, _p(rgb), _p(depth))
+
+    def run_stage(self, name):
+        r = self.lib.orc_run_stage(self.h, STAGES[name])
+        assert r == 0
+        return r
+
+    def get_pose(self):
+        o = np.zeros(16, np.float32); self.lib.orc_get_pose(self.h, _p(o)); return o.reshape(4, 4).T.copy()
+
+    def set_pose(self, T):
+        a = np.ascontiguousarray(np.asarray(T, np.float32).T); self.lib.orc_set_pose(self.h, _p(a))
+
+    @property
+    def tick(self):
+        return self.lib.orc_get_tick(self.h)
+
+    def set_tick(self, t):
+        self.lib.orc_set_tick(self.h, t)
+
+    def set_weighting(self, w):
+        self.lib.orc_set_weighting(self.h, w)
+
+    def get_weighting(self):
+        return self.lib.orc_get_weighting(self.h)
+
+    def surfel_count(self):
+        return int(self.lib.orc_surfel_count(self.h))
+
+    def download_map(self):
+        n = self.surfel_count()
+        o = np.zeros((n, 20), np.float32)
+        if n:
+            assert self.lib.orc_download_map(self.h, _p(o), n) == 0
+        return o
+
+    def upload_map(self, m):
+        m = np.ascontiguousarray(m, np.float32)
+        assert self.lib.orc_upload_map(self.h, _p(m), m.shape[0]) == 0
+
+    def get_image(self, name):
+        i, dt, ch = IMAGES[name]
+        shape = (self.H, self.W, ch) if ch > 1 else (self.H, self.W)
+        o = np.zeros(shape, np.dtype(dt))
+        assert self.lib.orc_get_image(self.h, i, _p(o), o.nbytes) == 0
+        return o
+
+    def set_image(self, name, a):
+        i, dt, ch = IMAGES[name]
+        a = np.ascontiguousarray(a, np.dtype(dt))
+        assert self.lib.orc_set_image(self.h, i, _p(a), a.nbytes) == 0
+
+    def last_icp(self):
+        e = C.c_float(); n = C.c_float()
+        self.lib.orc_last_icp(self.h, C.byref(e), C.byref(n)); return e.value, n.value
+
+    def fuse_stats(self):
+        o = np.zeros(4, np.uint32); self.lib.orc_get_fuse_stats(self.h, _p(o)); return o
+
+    def timings(self):
+        o = np.zeros(8, np.float64); self.lib.orc_get_timings(self.h, _p(o)); return o
