@@ -1,0 +1,203 @@
+"""Host-side Python mirror of the reference's `HRBFFusion` interface over the C-ABI of
+libhrbf_mi355.so (include/hrbf_mi355.h).
+
+Method names follow Core/src/HRBFFusion.h:82-534 (processFrame, getCurrPose, getTick, ...) in
+snake_case.  There is NO CPU fallback: importing is free, but constructing HRBFFusion without the
+HIP library or without a gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import HrbfParams, IMAGES, STAGES, default_params  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhrbf_mi355.so")
+_lib = None
+
+EXPORTS = [
+    "hrbf_default_params", "hrbf_create", "hrbf_destroy", "hrbf_last_error", "hrbf_version",
+    "hrbf_process_frame", "hrbf_process_frame_device", "hrbf_synchronize", "hrbf_get_pose", "hrbf_set_pose",
+    "hrbf_get_tick", "hrbf_surfel_count", "hrbf_download_map", "hrbf_upload_map", "hrbf_last_icp",
+    "hrbf_last_weighting", "hrbf_set_rgb_only", "hrbf_set_icp_weight", "hrbf_set_pyramid", "hrbf_set_fast_odom",
+    "hrbf_set_so3", "hrbf_set_frame_to_frame_rgb", "hrbf_set_confidence_threshold", "hrbf_set_depth_cutoff",
+    "hrbf_image_bytes", "hrbf_get_image", "hrbf_set_image", "hrbf_enable_timing", "hrbf_get_timings",
+    "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
+    "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init",
+]
+
+
+class HrbfError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libhrbf_mi355.so (built by hrbffusion3d_amd.build); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HrbfError("%s not found: run `python -m hrbffusion3d_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    lib.hrbf_last_error.restype = C.c_char_p
+    lib.hrbf_version.restype = C.c_char_p
+    lib.hrbf_default_params.argtypes = [C.POINTER(HrbfParams), i32, i32, f32, f32, f32, f32, f32]
+    lib.hrbf_default_params.restype = None
+    lib.hrbf_create.argtypes = [C.POINTER(HrbfParams), i32, C.POINTER(vp)]
+    lib.hrbf_destroy.argtypes = [vp]; lib.hrbf_destroy.restype = None
+    lib.hrbf_process_frame.argtypes = [vp, vp, vp, C.c_int64, f32]
+    lib.hrbf_process_frame_device.argtypes = [vp, vp, vp, C.c_int64, f32]
+    lib.hrbf_synchronize.argtypes = [vp]
+    lib.hrbf_get_pose.argtypes = [vp, vp]; lib.hrbf_set_pose.argtypes = [vp, vp]
+    lib.hrbf_get_tick.argtypes = [vp]; lib.hrbf_set_tick.argtypes = [vp, i32]
+    lib.hrbf_surfel_count.argtypes = [vp]; lib.hrbf_surfel_count.restype = C.c_uint32
+    lib.hrbf_download_map.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_upload_map.argtypes = [vp, vp, C.c_size_t]
+    lib.hrbf_last_icp.argtypes = [vp, vp, vp]; lib.hrbf_last_weighting.argtypes = [vp, vp]
+    for n in ("rgb_only", "pyramid", "fast_odom", "so3", "frame_to_frame_rgb"):
+        getattr(lib, "hrbf_set_" + n).argtypes = [vp, i32]
+    for n in ("icp_weight", "confidence_threshold", "depth_cutoff", "weighting"):
+        getattr(lib, "hrbf_set_" + n).argtypes = [vp, f32]
+    lib.hrbf_image_bytes.argtypes = [vp, i32]; lib.hrbf_image_bytes.restype = C.c_size_t
+    lib.hrbf_get_image.argtypes = [vp, i32, vp, C.c_size_t]; lib.hrbf_set_image.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.hrbf_enable_timing.argtypes = [vp, i32]; lib.hrbf_get_timings.argtypes = [vp, vp]
+    lib.hrbf_get_fuse_stats.argtypes = [vp, vp]
+    lib.hrbf_upload_frame.argtypes = [vp, vp, vp]; lib.hrbf_run_stage.argtypes = [vp, i32]
+    lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
+    lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HRBFFusion:
+    """`HRBFFusion` (Core/src/HRBFFusion.h:82-534) on one MI355X."""
+
+    def __init__(self, params=None, device=0):
+        self.lib = load_library()
+        self.params = params if params is not None else default_params()
+        self.W, self.H = self.params.width, self.params.height
+        h = C.c_void_p()
+        self._check(self.lib.hrbf_create(C.byref(self.params), device, C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HrbfError("hrbf status %d: %s" % (rc, self.lib.hrbf_last_error().decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hrbf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- primary entry (HRBFFusion.h:110-113)
+    def process_frame(self, rgb, depth, ts=0, weight_multiplier=1.0):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        if rgb.size != self.W * self.H * 3 or depth.size != self.W * self.H:
+            raise ValueError("frame size does not match the context resolution")
+        return self._check(self.lib.hrbf_process_frame(self.h, _p(rgb), _p(depth), ts, weight_multiplier))
+
+    def process_frame_device(self, d_rgb_ptr, d_depth_ptr, ts=0, weight_multiplier=1.0):
+        return self._check(self.lib.hrbf_process_frame_device(self.h, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr),
+                                                              ts, weight_multiplier))
+
+    def synchronize(self):
+        return self._check(self.lib.hrbf_synchronize(self.h))
+
+    def upload_frame(self, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        return self._check(self.lib.hrbf_upload_frame(self.h, _p(rgb), _p(depth)))
+
+    def run_stage(self, name):
+        return self._check(self.lib.hrbf_run_stage(self.h, STAGES[name]))
+
+    # -- getters (GUI/src/HRBF_fusion.cpp:235-497)
+    def get_pose(self):
+        o = np.zeros(16, np.float32)
+        self._check(self.lib.hrbf_get_pose(self.h, _p(o)))
+        return o.reshape(4, 4).T.copy()
+
+    def set_pose(self, T):
+        a = np.ascontiguousarray(np.asarray(T, np.float32).T)
+        self._check(self.lib.hrbf_set_pose(self.h, _p(a)))
+
+    @property
+    def tick(self):
+        return self.lib.hrbf_get_tick(self.h)
+
+    def set_tick(self, t):
+        self._check(self.lib.hrbf_set_tick(self.h, t))
+
+    def set_weighting(self, w):
+        self._check(self.lib.hrbf_set_weighting(self.h, w))
+
+    def get_weighting(self):
+        w = C.c_float()
+        self._check(self.lib.hrbf_last_weighting(self.h, C.byref(w)))
+        return w.value
+
+    def surfel_count(self):
+        return int(self.lib.hrbf_surfel_count(self.h))
+
+    def download_map(self):
+        n = self.surfel_count()
+        o = np.zeros((n, 20), np.float32)
+        if n:
+            self._check(self.lib.hrbf_download_map(self.h, _p(o), n))
+        return o
+
+    def upload_map(self, m):
+        m = np.ascontiguousarray(m, np.float32)
+        self._check(self.lib.hrbf_upload_map(self.h, _p(m), m.shape[0]))
+
+    def get_image(self, name):
+        i, dt, ch = IMAGES[name]
+        shape = (self.H, self.W, ch) if ch > 1 else (self.H, self.W)
+        o = np.zeros(shape, np.dtype(dt))
+        self._check(self.lib.hrbf_get_image(self.h, i, _p(o), o.nbytes))
+        return o
+
+    def set_image(self, name, a):
+        i, dt, ch = IMAGES[name]
+        a = np.ascontiguousarray(a, np.dtype(dt))
+        self._check(self.lib.hrbf_set_image(self.h, i, _p(a), a.nbytes))
+
+    def last_icp(self):
+        e = C.c_float(); n = C.c_float()
+        self._check(self.lib.hrbf_last_icp(self.h, C.byref(e), C.byref(n)))
+        return e.value, n.value
+
+    def fuse_stats(self):
+        o = np.zeros(4, np.uint32)
+        self._check(self.lib.hrbf_get_fuse_stats(self.h, _p(o)))
+        return o
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.hrbf_enable_timing(self.h, 1 if on else 0))
+
+    def timings(self):
+        o = np.zeros(8, np.float32)
+        self._check(self.lib.hrbf_get_timings(self.h, _p(o)))
+        return o
+
+    # live-tunable setters (GUI/src/HRBF_fusion.cpp:448-456)
+    def set_rgb_only(self, v): self._check(self.lib.hrbf_set_rgb_only(self.h, int(v)))
+    def set_icp_weight(self, v): self._check(self.lib.hrbf_set_icp_weight(self.h, float(v)))
+    def set_pyramid(self, v): self._check(self.lib.hrbf_set_pyramid(self.h, int(v)))
+    def set_fast_odom(self, v): self._check(self.lib.hrbf_set_fast_odom(self.h, int(v)))
+    def set_so3(self, v): self._check(self.lib.hrbf_set_so3(self.h, int(v)))
+    def set_frame_to_frame_rgb(self, v): self._check(self.lib.hrbf_set_frame_to_frame_rgb(self.h, int(v)))
+    def set_confidence_threshold(self, v): self._check(self.lib.hrbf_set_confidence_threshold(self.h, float(v)))
+    def set_depth_cutoff(self, v): self._check(self.lib.hrbf_set_depth_cutoff(self.h, float(v)))

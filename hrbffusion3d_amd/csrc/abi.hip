@@ -1,0 +1,657 @@
+// abi.hip — C-ABI of libhrbf_mi355 (include/hrbf_mi355.h): context, per-frame orchestration
+// (HRBFFusion::processFrame / predict, Core/src/HRBFFusion.cpp:991-1260) and the operator seams.
+//
+// One context owns one HIP stream; a frame is a fixed sequence of kernel launches on that stream
+// with no host synchronisation inside (pose, weighting, should-fill-in and surfel count all live in
+// device memory).  The reference ends every GL pass with glFinish() and every CUDA step with
+// cudaDeviceSynchronize().
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+const char *hrbf_set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return g_err;
+}
+extern "C" const char *hrbf_last_error(void) { return g_err; }
+extern "C" const char *hrbf_version(void) { return "hrbf-mi355 0.1 (gfx950)"; }
+
+extern "C" void hrbf_default_params(hrbf_params *p, int width, int height, float fx, float fy, float cx, float cy,
+                                    float depth_scale)
+{
+    memset(p, 0, sizeof(*p));
+    p->width = width; p->height = height; p->fx = fx; p->fy = fy; p->cx = cx; p->cy = cy; p->depth_scale = depth_scale;
+    p->confidence_threshold = 5.0f; p->depth_cutoff = 3.5f; p->icp_weight = 10.0f;
+    p->fast_odom = 0; p->so3 = 1; p->frame_to_frame_rgb = 0; p->rgb_only = 0; p->pyramid = 1;
+    p->max_depth_processed = 20.0f;
+    p->use_bilateral = 1; p->init_radius_multiplier = 4.0f; p->curv_estimation_window = 3.0f;
+    p->curv_valid_threshold = 300.0f; p->normal_estimation_pca = 1.0f; p->use_conf_eval = 0;
+    p->conf_eval_epsilon = 1000.0f;
+    p->icp_use_corr_search = 0; p->icp_search_radius = 2; p->icp_use_weighted = 1; p->icp_curv_weight_lambda = 10.0f;
+    p->rgb_use_grad_weight = 0; p->use_sparse_icp = 0;
+    p->predict_window_multiplier = 3.0f; p->predict_min_neighbors = 6; p->predict_max_neighbors = 10;
+    p->predict_conf_threshold = 3.0f;
+    p->clean_window_multiplier = 2.0f; p->dense_enough_thresh = 0.75f;
+    p->max_surfels = 4 * 1024 * 1024; p->load_trajectory = 0;
+}
+
+struct hrbf_context {
+    hrbf_params prm;
+    int device;
+    hipStream_t stream;
+    Cam cam;
+    int W, H, P, Q;
+    int tick;
+    // inputs
+    uint8_t *d_rgb; uint16_t *d_depth;
+    // images
+    float *d_depth_filtered, *d_depth_metric, *d_depth_metric_f, *d_radius, *d_gradmag, *d_confidence;
+    float4 *d_vertex_raw, *d_vertex_filtered, *d_normal, *d_normal_opt, *d_normal_pca, *d_curv1, *d_curv2;
+    uint32_t *d_idx; unsigned long long *d_zbuf;
+    float4 *d_im_vertconf, *d_im_colortime, *d_im_normrad, *d_im_curvmax, *d_im_curvmin;
+    uint8_t *d_pr_image, *d_fi_image;
+    float4 *d_pr_vertex, *d_pr_normal, *d_pr_curv1, *d_pr_curv2, *d_fi_vertex, *d_fi_normal, *d_fi_curv1, *d_fi_curv2;
+    uint32_t *d_pr_time; float *d_pr_icpw, *d_fi_icpw;
+    // map
+    MapPlanes map[2];
+    int target;
+    uint32_t cap;
+    uint32_t *d_count;          // [2], ping-pong with the map
+    uint32_t count_ub;          // host upper bound of the surfel count
+    uint32_t *h_count_pinned;   // async read-back (1-frame lag)
+    hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
+    RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best; uint32_t *d_slot;
+    uint32_t *d_stats; uint32_t *d_init_flags, *d_init_offs;
+    unsigned long long *d_tile_status; uint32_t max_tiles; uint32_t *d_ticket;
+    DevPose *d_pose;
+    OdoBuffers odo;
+    // timing
+    int timing; hipEvent_t ev[12]; float timings[8];
+};
+
+template <typename T>
+static int dalloc(T **p, size_t n)
+{
+    hipError_t e = hipMalloc((void **)p, sizeof(T) * (n ? n : 1));
+    if (e != hipSuccess) { hrbf_set_error("hipMalloc(%zu): %s", sizeof(T) * n, hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    e = hipMemset(*p, 0, sizeof(T) * (n ? n : 1));
+    if (e != hipSuccess) { hrbf_set_error("hipMemset: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    return HRBF_OK;
+}
+#define DA(ptr, n) do { int _r = dalloc(&(ptr), (n)); if (_r) { hrbf_destroy(c); return _r; } } while (0)
+
+static int alloc_planes(hrbf_context *c, MapPlanes &m, size_t n)
+{
+    int r;
+    if ((r = dalloc(&m.p0, n)) || (r = dalloc(&m.p1, n)) || (r = dalloc(&m.p2, n)) || (r = dalloc(&m.p3, n)) ||
+        (r = dalloc(&m.p4, n)))
+        return r;
+    (void)c;
+    return HRBF_OK;
+}
+
+extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
+{
+    if (!p || !out) { hrbf_set_error("null argument"); return HRBF_ERR_INVALID; }
+    *out = nullptr;
+    if (p->width <= 0 || p->height <= 0 || p->width % 8 || p->height % 8) {
+        hrbf_set_error("width/height must be positive multiples of 8 (3-level pyramid + quarter grid)");
+        return HRBF_ERR_INVALID;
+    }
+    if (p->use_sparse_icp) { hrbf_set_error("registrationICPUseSparseICP is not supported (SURVEY §8f-4)"); return HRBF_ERR_INVALID; }
+    if (p->curv_estimation_window > 3.0f || p->predict_window_multiplier > 3.0f || p->clean_window_multiplier > 8.0f) {
+        hrbf_set_error("window multipliers above the reference defaults (3/3/8) are not supported");
+        return HRBF_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        hrbf_set_error("no HIP device visible: libhrbf_mi355 has no CPU fallback");
+        return HRBF_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) { hrbf_set_error("device %d out of range (%d visible)", device, ndev); return HRBF_ERR_INVALID; }
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        hrbf_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return HRBF_ERR_NODEVICE;
+    }
+    hrbf_context *c = (hrbf_context *)calloc(1, sizeof(hrbf_context));
+    c->prm = *p; c->device = device;
+    c->W = p->width; c->H = p->height; c->P = c->W * c->H; c->Q = (c->W / 2) * (c->H / 2);
+    c->tick = 1;
+    c->cam.W = c->W; c->cam.H = c->H; c->cam.fx = p->fx; c->cam.fy = p->fy; c->cam.cx = p->cx; c->cam.cy = p->cy;
+    c->cam.camz = (float)(1.0 / (double)p->fx); c->cam.camw = (float)(1.0 / (double)p->fy);
+    c->cam.max_dist = sqrtf(((float)c->H * 0.5f) * ((float)c->H * 0.5f) + ((float)c->W * 0.5f) * ((float)c->W * 0.5f));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { hrbf_set_error("hipStreamCreate: %s", hipGetErrorString(e)); free(c); return HRBF_ERR_DEVICE; }
+    const size_t P = c->P;
+    DA(c->d_rgb, P * 3); DA(c->d_depth, P);
+    DA(c->d_depth_filtered, P); DA(c->d_depth_metric, P); DA(c->d_depth_metric_f, P); DA(c->d_radius, P);
+    DA(c->d_gradmag, P); DA(c->d_confidence, P);
+    DA(c->d_vertex_raw, P); DA(c->d_vertex_filtered, P); DA(c->d_normal, P); DA(c->d_normal_opt, P); DA(c->d_normal_pca, P);
+    DA(c->d_curv1, P); DA(c->d_curv2, P);
+    DA(c->d_idx, P); DA(c->d_zbuf, P);
+    DA(c->d_im_vertconf, P); DA(c->d_im_colortime, P); DA(c->d_im_normrad, P); DA(c->d_im_curvmax, P); DA(c->d_im_curvmin, P);
+    DA(c->d_pr_image, P * 4); DA(c->d_fi_image, P * 4);
+    DA(c->d_pr_vertex, P); DA(c->d_pr_normal, P); DA(c->d_pr_curv1, P); DA(c->d_pr_curv2, P);
+    DA(c->d_fi_vertex, P); DA(c->d_fi_normal, P); DA(c->d_fi_curv1, P); DA(c->d_fi_curv2, P);
+    DA(c->d_pr_time, P); DA(c->d_pr_icpw, P); DA(c->d_fi_icpw, P);
+    c->cap = (uint32_t)p->max_surfels;
+    { int r; if ((r = alloc_planes(c, c->map[0], c->cap)) || (r = alloc_planes(c, c->map[1], c->cap)) ||
+                 (r = alloc_planes(c, c->rec, c->Q))) { hrbf_destroy(c); return r; } }
+    DA(c->d_count, 2);
+    DA(c->d_rec_flag, c->Q); DA(c->d_rec_best, c->Q); DA(c->d_slot, c->cap);
+    DA(c->d_stats, 4); DA(c->d_init_flags, P); DA(c->d_init_offs, P);
+    c->max_tiles = (c->cap + c->Q) / fuse_tile_items() + 2;
+    DA(c->d_tile_status, c->max_tiles); DA(c->d_ticket, 1);
+    DA(c->d_pose, 1);
+    e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * 2, hipHostMallocDefault);
+    if (e != hipSuccess) { hrbf_set_error("hipHostMalloc: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
+    c->h_count_pinned[0] = 0;
+    hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming);
+    for (int i = 0; i < 12; ++i) hipEventCreate(&c->ev[i]);
+    // odometry buffers
+    for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
+        OdoLevel &L = c->odo.lv[i];
+        L.rows = c->H >> i; L.cols = c->W >> i;
+        const size_t n = (size_t)L.rows * L.cols;
+        DA(L.vmap_g, 4 * n); DA(L.nmap_g, 4 * n); DA(L.ck1_g, 4 * n); DA(L.ck2_g, 4 * n);
+        DA(L.vmap_c, 4 * n); DA(L.nmap_c, 4 * n); DA(L.ck1_c, 4 * n); DA(L.ck2_c, 4 * n);
+        DA(L.icpw, n); DA(L.last_depth, n); DA(L.next_depth, n);
+        DA(L.last_image, n); DA(L.next_image, n); DA(L.last_next_image, n);
+        DA(L.dIdx, n); DA(L.dIdy, n); DA(L.cloud, 3 * n);
+    }
+    { uint8_t *st; DA(st, odo_state_bytes()); c->odo.state = (OdoState *)st; }
+    DA(c->odo.corres, P * 6); DA(c->odo.corres_diff, P);
+    c->odo.max_blocks = (int)((P + 255) / 256);
+    DA(c->odo.icp_part, (size_t)c->odo.max_blocks * 87); DA(c->odo.rgb_part, (size_t)c->odo.max_blocks * 87);
+    DA(c->odo.res_part, (size_t)c->odo.max_blocks * 2); DA(c->odo.so3_part, (size_t)c->odo.max_blocks * 33);
+    DA(c->odo.totals, 256);
+    if (predict_upload_tables() != 0) { hrbf_set_error("constant upload failed"); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
+    launch_fill_u32(c->stream, c->d_slot, c->cap, 0xFFFFFFFFu);
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    launch_pose_set(c->stream, c->d_pose, I, 1);
+    { float one = 1.0f; hipMemcpyAsync(&c->d_pose->weighting, &one, sizeof(float), hipMemcpyHostToDevice, c->stream); }
+    e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hrbf_set_error("init sync: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
+    *out = c;
+    return HRBF_OK;
+}
+
+static void free_planes(MapPlanes &m) { hipFree(m.p0); hipFree(m.p1); hipFree(m.p2); hipFree(m.p3); hipFree(m.p4); }
+
+extern "C" void hrbf_destroy(hrbf_handle c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_rgb, c->d_depth, c->d_depth_filtered, c->d_depth_metric, c->d_depth_metric_f, c->d_radius,
+                    c->d_gradmag, c->d_confidence, c->d_vertex_raw, c->d_vertex_filtered, c->d_normal, c->d_normal_opt,
+                    c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_idx, c->d_zbuf, c->d_im_vertconf, c->d_im_colortime,
+                    c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, c->d_pr_image, c->d_fi_image, c->d_pr_vertex,
+                    c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_fi_vertex, c->d_fi_normal, c->d_fi_curv1,
+                    c->d_fi_curv2, c->d_pr_time, c->d_pr_icpw, c->d_fi_icpw, c->d_count, c->d_rec_flag, c->d_rec_best,
+                    c->d_slot, c->d_stats, c->d_init_flags, c->d_init_offs, c->d_tile_status, c->d_ticket, c->d_pose,
+                    c->odo.state, c->odo.corres, c->odo.corres_diff, c->odo.icp_part, c->odo.rgb_part, c->odo.res_part,
+                    c->odo.so3_part, c->odo.totals};
+    for (void *p : ptrs) if (p) hipFree(p);
+    free_planes(c->map[0]); free_planes(c->map[1]); free_planes(c->rec);
+    for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
+        OdoLevel &L = c->odo.lv[i];
+        void *q[] = {L.vmap_g, L.nmap_g, L.ck1_g, L.ck2_g, L.vmap_c, L.nmap_c, L.ck1_c, L.ck2_c, L.icpw, L.last_depth,
+                     L.next_depth, L.last_image, L.next_image, L.last_next_image, L.dIdx, L.dIdy, L.cloud};
+        for (void *p : q) if (p) hipFree(p);
+    }
+    if (c->h_count_pinned) hipHostFree(c->h_count_pinned);
+    if (c->ev_count) hipEventDestroy(c->ev_count);
+    for (int i = 0; i < 12; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    free(c);
+}
+
+// ------------------------------------------------------------------------------------------ stages
+static OdoSources make_sources(hrbf_context *c)
+{
+    OdoSources s;
+    s.pr_vertex = c->d_pr_vertex; s.pr_normal = c->d_pr_normal; s.pr_curv1 = c->d_pr_curv1; s.pr_curv2 = c->d_pr_curv2;
+    s.pr_icpw = c->d_pr_icpw; s.pr_image = c->d_pr_image;
+    s.fi_vertex = c->d_fi_vertex; s.fi_normal = c->d_fi_normal; s.fi_curv1 = c->d_fi_curv1; s.fi_curv2 = c->d_fi_curv2;
+    s.fi_icpw = c->d_fi_icpw; s.fi_image = c->d_fi_image;
+    s.vertex_filtered = c->d_vertex_filtered; s.normal = c->d_normal; s.curv1 = c->d_curv1; s.curv2 = c->d_curv2;
+    s.rgb = c->d_rgb;
+    return s;
+}
+static OdoConfig make_cfg(hrbf_context *c)
+{
+    OdoConfig g;
+    const hrbf_params &p = c->prm;
+    g.fx = p.fx; g.fy = p.fy; g.cx = p.cx; g.cy = p.cy;
+    g.rgb_only = p.rgb_only; g.icp_weight = p.icp_weight; g.pyramid = p.pyramid; g.fast_odom = p.fast_odom; g.so3 = p.so3;
+    g.frame_to_frame_rgb = p.frame_to_frame_rgb;
+    g.use_search = p.icp_use_corr_search; g.search_radius = p.icp_search_radius; g.use_weighted = p.icp_use_weighted;
+    g.rgb_use_grad = p.rgb_use_grad_weight; g.curv_thr = p.curv_valid_threshold;
+    return g;
+}
+
+static void st_filter(hrbf_context *c)
+{
+    launch_filter_metric(c->stream, c->cam, c->d_depth, c->d_depth_filtered, c->d_depth_metric, c->d_depth_metric_f,
+                         c->prm.depth_scale, c->prm.depth_cutoff, c->prm.use_bilateral);
+}
+static void st_vnr(hrbf_context *c)
+{
+    launch_vertex_normal_radius(c->stream, c->cam, c->d_depth_metric, c->d_depth_metric_f, c->d_vertex_raw,
+                                c->d_vertex_filtered, c->d_normal, c->d_normal_pca, c->d_radius,
+                                c->prm.init_radius_multiplier, c->prm.normal_estimation_pca > 0.0f);
+}
+static void st_curv(hrbf_context *c)
+{
+    launch_curvature(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
+                     c->d_normal_opt, (int)c->prm.curv_estimation_window);
+    hipMemcpyAsync(c->d_normal, c->d_normal_opt, sizeof(float4) * (size_t)c->P, hipMemcpyDeviceToDevice, c->stream);
+}
+static void st_conf(hrbf_context *c)
+{
+    launch_confidence(c->stream, c->cam, c->d_gradmag, c->d_confidence, &c->d_pose->weighting, c->prm.use_conf_eval,
+                      c->prm.conf_eval_epsilon);
+}
+static void refresh_count_ub(hrbf_context *c)
+{
+    // 1-frame-lag read-back of the surfel count; never blocks in steady state
+    if (c->ev_pending && hipEventQuery(c->ev_count) == hipSuccess) {
+        c->ev_pending = false;
+        uint32_t known = c->h_count_pinned[0];
+        uint32_t ub = known + c->ub_growth_since;
+        if (ub < c->count_ub) c->count_ub = ub;
+    }
+}
+static void request_count(hrbf_context *c)
+{
+    if (c->ev_pending) return;
+    hipMemcpyAsync(c->h_count_pinned, &c->d_count[c->target], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipEventRecord(c->ev_count, c->stream);
+    c->ev_pending = true;
+    c->ub_growth_since = 0;
+}
+static void st_init(hrbf_context *c)
+{
+    launch_initialise(c->stream, c->cam, c->d_pose, c->d_vertex_raw, c->d_normal, c->d_rgb, c->d_curv1, c->d_curv2,
+                      c->d_gradmag, c->prm.use_conf_eval, c->prm.conf_eval_epsilon, c->prm.curv_valid_threshold,
+                      c->d_init_flags, c->d_init_offs, c->map[c->target], c->cap, &c->d_count[c->target]);
+    c->count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
+    launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
+}
+static void st_indices(hrbf_context *c)
+{
+    launch_predict_indices(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->map[c->target],
+                           &c->d_count[c->target], c->count_ub, c->d_zbuf, c->d_idx, c->d_im_vertconf,
+                           c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin);
+}
+static void st_fuse(hrbf_context *c)
+{
+    launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, 0, c->d_depth_metric, c->d_normal_pca,
+                c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf, c->d_im_normrad, c->rec,
+                c->d_rec_flag, c->d_rec_best, c->d_slot, c->map[c->target], c->d_stats);
+}
+static void st_clean(hrbf_context *c)
+{
+    launch_clean(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->prm.confidence_threshold,
+                 c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier, c->map[c->target],
+                 c->map[1 - c->target], c->rec, c->d_rec_flag, &c->d_count[c->target], &c->d_count[1 - c->target],
+                 c->count_ub, c->d_stats, c->cap, c->d_idx, c->d_im_vertconf, c->d_im_colortime, c->d_tile_status,
+                 c->max_tiles, c->d_ticket);
+    c->target = 1 - c->target;
+    uint64_t ub = (uint64_t)c->count_ub + (uint64_t)c->Q;
+    c->count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
+    c->ub_growth_since += (uint32_t)c->Q;
+}
+static void st_predict(hrbf_context *c)
+{
+    launch_predict_hrbf(c->stream, c->cam, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax,
+                        c->d_im_curvmin, (int)c->prm.predict_window_multiplier, c->prm.predict_min_neighbors,
+                        c->prm.predict_max_neighbors, c->prm.predict_conf_threshold, c->prm.icp_curv_weight_lambda,
+                        c->d_pr_image, c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_time,
+                        c->d_pr_icpw);
+}
+static void st_fillin(hrbf_context *c)
+{
+    launch_fillin(c->stream, c->P, c->prm.curv_valid_threshold, c->prm.icp_curv_weight_lambda, c->prm.frame_to_frame_rgb,
+                  c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_icpw, c->d_pr_image,
+                  c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_fi_vertex,
+                  c->d_fi_normal, c->d_fi_curv1, c->d_fi_curv2, c->d_fi_icpw, c->d_fi_image);
+}
+static void st_odometry(hrbf_context *c)
+{
+    launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
+    OdoSources src = make_sources(c);
+    OdoConfig cfg = make_cfg(c);
+    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, nullptr, 0, 1);
+}
+
+#define TIMER(i) do { if (c->timing) hipEventRecord(c->ev[i], c->stream); } while (0)
+
+static int process_frame_resident(hrbf_context *c, float wmul)
+{
+    hipSetDevice(c->device);
+    refresh_count_ub(c);
+    TIMER(0);
+    st_filter(c); st_vnr(c); st_curv(c);
+    TIMER(1);
+    if (c->tick == 1) {
+        st_init(c);
+        TIMER(2); TIMER(3); TIMER(4); TIMER(5); TIMER(6);
+    } else {
+        if (!c->prm.load_trajectory) st_odometry(c);
+        TIMER(2);
+        launch_frame_epilogue(c->stream, c->d_pose, wmul, 1);
+        st_conf(c);
+        if (!c->prm.rgb_only) {
+            st_indices(c);
+            TIMER(3);
+            st_fuse(c);
+            TIMER(4);
+            st_indices(c);
+            TIMER(5);
+            st_clean(c);
+            TIMER(6);
+        } else { TIMER(3); TIMER(4); TIMER(5); TIMER(6); }
+    }
+    st_indices(c);
+    TIMER(7);
+    st_predict(c);
+    TIMER(8);
+    st_fillin(c);
+    launch_pose_commit_prev(c->stream, c->d_pose);
+    TIMER(9);
+    request_count(c);
+    c->tick++;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hrbf_set_error("launch: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    return HRBF_OK;
+}
+
+extern "C" int hrbf_upload_frame(hrbf_handle c, const uint8_t *rgb, const uint16_t *depth)
+{
+    if (!c || !rgb || !depth) { hrbf_set_error("null argument"); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));   // host buffers are borrowed only for the call
+    return HRBF_OK;
+}
+
+extern "C" int hrbf_process_frame(hrbf_handle c, const uint8_t *rgb, const uint16_t *depth, int64_t ts, float wmul)
+{
+    (void)ts;
+    int r = hrbf_upload_frame(c, rgb, depth);
+    if (r) return r;
+    return process_frame_resident(c, wmul);
+}
+
+extern "C" int hrbf_process_frame_device(hrbf_handle c, const void *d_rgb, const void *d_depth, int64_t ts, float wmul)
+{
+    (void)ts;
+    if (!c || !d_rgb || !d_depth) { hrbf_set_error("null argument"); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(c->d_rgb, d_rgb, (size_t)c->P * 3, hipMemcpyDeviceToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->d_depth, d_depth, (size_t)c->P * 2, hipMemcpyDeviceToDevice, c->stream));
+    return process_frame_resident(c, wmul);
+}
+
+extern "C" int hrbf_synchronize(hrbf_handle c)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+
+extern "C" int hrbf_run_stage(hrbf_handle c, int stage)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    switch (stage) {
+        case HRBF_STAGE_FILTER_DEPTH: st_filter(c); break;    // also writes both metric images
+        case HRBF_STAGE_METRICISE: st_filter(c); break;
+        case HRBF_STAGE_VERTEX_NORMAL_RADIUS: st_vnr(c); break;
+        case HRBF_STAGE_CURVATURE: st_curv(c); break;
+        case HRBF_STAGE_CONFIDENCE: st_conf(c); break;
+        case HRBF_STAGE_INITIALISE: st_init(c); break;
+        case HRBF_STAGE_PREDICT_INDICES: st_indices(c); break;
+        case HRBF_STAGE_FUSE: st_fuse(c); break;
+        case HRBF_STAGE_CLEAN: st_clean(c); break;
+        case HRBF_STAGE_PREDICT_HRBF: st_predict(c); break;
+        case HRBF_STAGE_FILLIN: st_fillin(c); break;
+        case HRBF_STAGE_ODOMETRY: st_odometry(c); break;
+        default: hrbf_set_error("unknown stage %d", stage); return HRBF_ERR_INVALID;
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ getters / setters
+extern "C" int hrbf_get_pose(hrbf_handle c, float out[16])
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    Rigid r;
+    HIP_CHECK(hipMemcpyAsync(&r, &c->d_pose->pose, sizeof(Rigid), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; ++i) { for (int k = 0; k < 3; ++k) out[k * 4 + i] = r.r[i * 3 + k]; out[12 + i] = r.t[i]; out[i * 4 + 3] = 0.0f; }
+    out[15] = 1.0f;
+    return HRBF_OK;
+}
+extern "C" int hrbf_set_pose(hrbf_handle c, const float in[16])
+{
+    if (!c || !in) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    launch_pose_set(c->stream, c->d_pose, in, c->tick == 1 ? 1 : 0);
+    return HRBF_OK;
+}
+extern "C" int hrbf_get_tick(hrbf_handle c) { return c ? c->tick : -1; }
+extern "C" int hrbf_set_tick(hrbf_handle c, int t) { if (!c) return HRBF_ERR_INVALID; c->tick = t; return HRBF_OK; }
+extern "C" int hrbf_set_weighting(hrbf_handle c, float w)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(&c->d_pose->weighting, &w, sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+extern "C" int hrbf_last_weighting(hrbf_handle c, float *w)
+{
+    if (!c || !w) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(w, &c->d_pose->weighting, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+extern "C" uint32_t hrbf_surfel_count(hrbf_handle c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    uint32_t n = 0;
+    if (hipMemcpyAsync(&n, &c->d_count[c->target], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
+    hipStreamSynchronize(c->stream);
+    if (n < c->count_ub) c->count_ub = n;   // exact knowledge tightens the launch bound
+    return n;
+}
+extern "C" int hrbf_last_icp(hrbf_handle c, float *err, float *cnt)
+{
+    if (!c || !err || !cnt) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    float v[2];
+    HIP_CHECK(hipMemcpyAsync(v, &c->d_pose->last_icp_error, sizeof(float) * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    *err = v[0]; *cnt = v[1];
+    return HRBF_OK;
+}
+
+// AoS <-> SoA transposes for the map boundary
+__global__ void k_map_to_aos(MapPlanes m, uint32_t n, float4 *__restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[(size_t)i * 5] = m.p0[i]; out[(size_t)i * 5 + 1] = m.p1[i]; out[(size_t)i * 5 + 2] = m.p2[i];
+    out[(size_t)i * 5 + 3] = m.p3[i]; out[(size_t)i * 5 + 4] = m.p4[i];
+}
+__global__ void k_map_from_aos(MapPlanes m, uint32_t n, const float4 *__restrict__ in)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    m.p0[i] = in[(size_t)i * 5]; m.p1[i] = in[(size_t)i * 5 + 1]; m.p2[i] = in[(size_t)i * 5 + 2];
+    m.p3[i] = in[(size_t)i * 5 + 3]; m.p4[i] = in[(size_t)i * 5 + 4];
+}
+
+extern "C" int hrbf_download_map(hrbf_handle c, float *out, size_t cap_surfels)
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    uint32_t n = hrbf_surfel_count(c);
+    if (cap_surfels < n) { hrbf_set_error("download_map: buffer holds %zu surfels, map has %u", cap_surfels, n); return HRBF_ERR_CAPACITY; }
+    if (n == 0) return HRBF_OK;
+    float4 *tmp = nullptr;
+    HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * (size_t)n));
+    hipLaunchKernelGGL(k_map_to_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->map[c->target], n, tmp);
+    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(float4) * 5 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) { hrbf_set_error("download_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    return HRBF_OK;
+}
+extern "C" int hrbf_upload_map(hrbf_handle c, const float *in, size_t n)
+{
+    if (!c || (!in && n)) return HRBF_ERR_INVALID;
+    if (n > c->cap) { hrbf_set_error("upload_map: %zu surfels exceed capacity %u", n, c->cap); return HRBF_ERR_CAPACITY; }
+    hipSetDevice(c->device);
+    uint32_t n32 = (uint32_t)n;
+    if (n) {
+        float4 *tmp = nullptr;
+        HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * n));
+        hipError_t e = hipMemcpyAsync(tmp, in, sizeof(float4) * 5 * n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_map_from_aos, dim3((n32 + 255) / 256), dim3(256), 0, c->stream, c->map[c->target], n32, tmp);
+            e = hipStreamSynchronize(c->stream);
+        }
+        hipFree(tmp);
+        if (e != hipSuccess) { hrbf_set_error("upload_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    }
+    HIP_CHECK(hipMemcpyAsync(&c->d_count[c->target], &n32, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->count_ub = n32;
+    return HRBF_OK;
+}
+
+#define SETTER(name, field, type)                                                         \
+    extern "C" int name(hrbf_handle c, type v) { if (!c) return HRBF_ERR_INVALID; c->prm.field = v; return HRBF_OK; }
+SETTER(hrbf_set_rgb_only, rgb_only, int)
+SETTER(hrbf_set_icp_weight, icp_weight, float)
+SETTER(hrbf_set_pyramid, pyramid, int)
+SETTER(hrbf_set_fast_odom, fast_odom, int)
+SETTER(hrbf_set_so3, so3, int)
+SETTER(hrbf_set_frame_to_frame_rgb, frame_to_frame_rgb, int)
+SETTER(hrbf_set_confidence_threshold, confidence_threshold, float)
+SETTER(hrbf_set_depth_cutoff, depth_cutoff, float)
+
+static void *img_ptr(hrbf_context *c, int which, size_t *bytes)
+{
+    const size_t P = (size_t)c->P;
+    switch (which) {
+#define I1(ID, F) case ID: *bytes = P * 4; return c->F;
+#define I4(ID, F) case ID: *bytes = P * 16; return c->F;
+        I1(HRBF_IMG_DEPTH_FILTERED, d_depth_filtered) I1(HRBF_IMG_DEPTH_METRIC, d_depth_metric)
+        I1(HRBF_IMG_DEPTH_METRIC_FILTERED, d_depth_metric_f)
+        I4(HRBF_IMG_VERTEX_RAW, d_vertex_raw) I4(HRBF_IMG_VERTEX_FILTERED, d_vertex_filtered)
+        I4(HRBF_IMG_NORMAL, d_normal) I4(HRBF_IMG_NORMAL_PCA, d_normal_pca) I1(HRBF_IMG_RADIUS, d_radius)
+        I4(HRBF_IMG_CURV1, d_curv1) I4(HRBF_IMG_CURV2, d_curv2) I1(HRBF_IMG_GRADIENT_MAG, d_gradmag)
+        I1(HRBF_IMG_CONFIDENCE, d_confidence) I1(HRBF_IMG_INDEX, d_idx)
+        I4(HRBF_IMG_INDEX_VERTCONF, d_im_vertconf) I4(HRBF_IMG_INDEX_COLORTIME, d_im_colortime)
+        I4(HRBF_IMG_INDEX_NORMRAD, d_im_normrad) I4(HRBF_IMG_INDEX_CURVMAX, d_im_curvmax)
+        I4(HRBF_IMG_INDEX_CURVMIN, d_im_curvmin)
+        I1(HRBF_IMG_PRED_IMAGE, d_pr_image) I4(HRBF_IMG_PRED_VERTEX, d_pr_vertex) I4(HRBF_IMG_PRED_NORMAL, d_pr_normal)
+        I4(HRBF_IMG_PRED_CURV1, d_pr_curv1) I4(HRBF_IMG_PRED_CURV2, d_pr_curv2) I1(HRBF_IMG_PRED_TIME, d_pr_time)
+        I1(HRBF_IMG_PRED_ICPWEIGHT, d_pr_icpw)
+        I1(HRBF_IMG_FILL_IMAGE, d_fi_image) I4(HRBF_IMG_FILL_VERTEX, d_fi_vertex) I4(HRBF_IMG_FILL_NORMAL, d_fi_normal)
+        I4(HRBF_IMG_FILL_CURV1, d_fi_curv1) I4(HRBF_IMG_FILL_CURV2, d_fi_curv2) I1(HRBF_IMG_FILL_ICPWEIGHT, d_fi_icpw)
+#undef I1
+#undef I4
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t hrbf_image_bytes(hrbf_handle c, int which) { size_t b = 0; if (c) img_ptr(c, which, &b); return b; }
+extern "C" int hrbf_get_image(hrbf_handle c, int which, void *out, size_t bytes)
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    size_t b; void *p = img_ptr(c, which, &b);
+    if (!p || bytes < b) { hrbf_set_error("get_image(%d): bad id or buffer too small", which); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(out, p, b, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+extern "C" int hrbf_set_image(hrbf_handle c, int which, const void *in, size_t bytes)
+{
+    if (!c || !in) return HRBF_ERR_INVALID;
+    size_t b; void *p = img_ptr(c, which, &b);
+    if (!p || bytes < b) { hrbf_set_error("set_image(%d): bad id or buffer too small", which); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(p, in, b, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+
+extern "C" int hrbf_enable_timing(hrbf_handle c, int on) { if (!c) return HRBF_ERR_INVALID; c->timing = on; return HRBF_OK; }
+extern "C" int hrbf_get_timings(hrbf_handle c, float out[8])
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) out[i] = 0.0f;
+    if (!c->timing) return HRBF_OK;
+    float ms;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) out[0] = ms;   // Initialization
+    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) out[1] = ms;   // Registration
+    if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) out[2] = ms;   // Integration (fuse)
+    if (hipEventElapsedTime(&ms, c->ev[7], c->ev[8]) == hipSuccess) out[3] = ms;   // Prediction
+    if (hipEventElapsedTime(&ms, c->ev[5], c->ev[6]) == hipSuccess) out[4] = ms;   // clean/compact/append stream pass
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[9]) == hipSuccess) out[5] = ms;   // whole frame
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) out[6] = ms;   // first projection (+confidence)
+    return HRBF_OK;
+}
+extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipMemcpyAsync(out, c->d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+
+extern "C" int hrbf_icp_step(hrbf_handle c, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                             const float *nmap_curr, const float *ck1_curr, const float *ck2_curr,
+                             const float Rprev_inv[9], const float tprev[3], float fx, float fy, float cx, float cy,
+                             const float *vmap_g_prev, const float *nmap_g_prev, const float *ck1_g_prev,
+                             const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
+                             float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
+                             double residual_out[2])
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    return run_icp_step(c->stream, Rcurr, tcurr, vmap_curr, nmap_curr, ck1_curr, ck2_curr, Rprev_inv, tprev, fx, fy, cx,
+                        cy, vmap_g_prev, nmap_g_prev, ck1_g_prev, ck2_g_prev, icp_weight_prev, rows, cols, dist_thresh,
+                        angle_thresh, use_weight, A_out, b_out, residual_out);
+}
+
+extern "C" int hrbf_comm_unique_id(uint8_t out128[128]) { (void)out128; hrbf_set_error("multi-GPU sharding: not built in this round"); return HRBF_ERR_COMM; }
+extern "C" int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
+{
+    (void)h; (void)rank; (void)world; (void)id128;
+    hrbf_set_error("multi-GPU sharding: not built in this round");
+    return HRBF_ERR_COMM;
+}

@@ -1,0 +1,540 @@
+// k_map.hip — surfel-map kernels for gfx950: seeding, index-map projection, data association,
+// sparse merge and the streaming clean + stable-compaction + append pass ("the fuse kernel").
+//
+// Replaces GlobalModel::{initialise,fuse,clean} (Core/src/GlobalModel.cpp:214-288,355-688) and
+// IndexMap::predictIndices (Core/src/IndexMap.cpp:193-267) with their GLSL programs
+// (init_unstableTex.*, index_map.*, data.*, update.vert, copy_unstable.*).
+//
+// Map layout in HBM: five float4 planes of `cap` entries (pos_conf, color_time, norm_rad, curv1,
+// curv2), two ping-pong copies.  A wavefront reading plane p touches 64 x 16 B = 1 KiB contiguous.
+//
+// Design notes (MI355X-first, not a translation of the GL pipeline):
+//  * the reference re-writes the whole map in fuse stage 2 (update.vert, 160 B/surfel) and clears a
+//    1.69 GB scatter target every frame; here only the <= W*H/4 merged surfels are touched, in place
+//    (k_apply_merges), winner per surfel = lowest draw-order record via atomicMin on a per-surfel slot.
+//  * projection = u64 atomicMin z-buffer (depth bits << 32 | id) + winner gather.
+//  * clean + append = ONE streaming pass with a decoupled look-back scan (single read + single write
+//    of every surviving surfel = 160 B/surfel), order preserving like GL transform feedback.
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// F4: seeding (init_unstableTex.vert:51-98).  Column-major order like the reference's draw;
+// compaction by a single-block-per-column-chunk scan is overkill for a once-per-run pass:
+// flags -> exclusive scan (k_scan_small) -> scatter.
+__global__ void k_init_flags(Cam cam, const DevPose *__restrict__ dp, const float4 *__restrict__ normal,
+                             const float4 *__restrict__ curv1, const float4 *__restrict__ curv2, float thr,
+                             uint32_t *__restrict__ flags)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;   // column-major order index
+    int P = cam.W * cam.H;
+    if (o >= P) return;
+    const Rigid pose = dp->pose;
+    int px = o / cam.H, py = o - px * cam.H;
+    int i = py * cam.W + px;
+    float4 nl = normal[i], k1 = curv1[i], k2 = curv2[i];
+    f3 ng = rot_mul(pose, xyz(nl));
+    flags[o] = (len3(ng) > 0.5f && k1.w > -thr && k1.w < thr && k2.w > -thr && k2.w < thr) ? 1u : 0u;
+}
+
+// generic exclusive scan of n uint32 (n <= a few 100k): one block, sequential chunks.
+__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                     int n, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < n ? in[i] : 0u;
+        uint32_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        uint32_t c = carry;
+        if (i < n) out[i] = c + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void k_init_scatter(Cam cam, const DevPose *__restrict__ dp, const float4 *__restrict__ vertex_raw,
+                               const float4 *__restrict__ normal, const uint8_t *__restrict__ rgb,
+                               const float4 *__restrict__ curv1, const float4 *__restrict__ curv2,
+                               const float *__restrict__ gradmag, int use_conf_eval, float eps,
+                               const uint32_t *__restrict__ flags, const uint32_t *__restrict__ offs, MapPlanes out,
+                               uint32_t cap)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    int P = cam.W * cam.H;
+    if (o >= P || !flags[o]) return;
+    const Rigid pose = dp->pose;
+    uint32_t n = offs[o];
+    if (n >= cap) return;
+    int px = o / cam.H, py = o - px * cam.H;
+    int i = py * cam.W + px;
+    float4 vl = vertex_raw[i], nl = normal[i];
+    f3 pg = xform(pose, xyz(vl));
+    float conf = radial_confidence((float)px + 0.5f, (float)py + 0.5f, cam.cx, cam.cy, cam.max_dist, 1.0f);
+    if (use_conf_eval > 0) conf = conf * hd_expf(-eps / hd_sqrtf(gradmag[i]));
+    f3 ng = rot_mul(pose, xyz(nl));
+    out.p0[n] = make_float4(pg.x, pg.y, pg.z, conf);
+    out.p1[n] = make_float4(encode_color_bytes(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]), 0.0f, 1.0f, 1.0f);
+    out.p2[n] = make_float4(ng.x, ng.y, ng.z, nl.w);
+    out.p3[n] = curv1[i];
+    out.p4[n] = curv2[i];
+}
+
+__global__ void k_clamp_count(uint32_t *count, uint32_t cap) { if (*count > cap) *count = cap; }
+
+// ------------------------------------------------------------------------------------------
+// M1: projection (index_map.vert:34-66 + GL point raster + GL_LESS z-test)
+#define ZB_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restrict__ dp, float maxDepth, const float4 *__restrict__ pos,
+                                                 const uint32_t *__restrict__ count,
+                                                 unsigned long long *__restrict__ zbuf)
+{
+    const uint32_t n = *count;
+    const Rigid tinv = dp->tinv;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        float4 p = pos[s];
+        f3 h = xform(tinv, xyz(p));
+        if (h.z > maxDepth || h.z < 0.0f) continue;
+        float u = ((cam.fx * h.x) / h.z) + cam.cx;
+        float v = ((cam.fy * h.y) / h.z) + cam.cy;
+        if (!(u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H)) continue;
+        int ix = (int)hd_floorf(u), iy = (int)hd_floorf(v);
+        unsigned long long key = ((unsigned long long)hd_f2u(h.z) << 32) | (unsigned long long)s;
+        unsigned long long *cell = &zbuf[iy * cam.W + ix];
+        // cheap pre-filter: keys only ever decrease, so a stale larger-or-equal read is conclusive
+        if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell, key);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m,
+                                                 const unsigned long long *__restrict__ zbuf,
+                                                 uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
+                                                 float4 *__restrict__ colortime, float4 *__restrict__ normrad,
+                                                 float4 *__restrict__ curvmax, float4 *__restrict__ curvmin)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cam.W * cam.H) return;
+    unsigned long long key = zbuf[i];
+    const Rigid tinv = dp->tinv;
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    if (key == ZB_EMPTY) {
+        idx[i] = 0; vertconf[i] = z4; colortime[i] = z4; normrad[i] = z4; curvmax[i] = z4; curvmin[i] = z4;
+        return;
+    }
+    uint32_t s = (uint32_t)(key & 0xFFFFFFFFull);
+    float4 p = m.p0[s], nr = m.p2[s];
+    f3 h = xform(tinv, xyz(p));
+    f3 n = normalize3(rot_mul(tinv, xyz(nr)));
+    idx[i] = s;
+    vertconf[i] = make_float4(h.x, h.y, h.z, p.w);
+    colortime[i] = m.p1[s];
+    normrad[i] = make_float4(n.x, n.y, n.z, nr.w);
+    curvmax[i] = m.p3[s];
+    curvmin[i] = m.p4[s];
+}
+
+// ------------------------------------------------------------------------------------------
+// F1: data association (data.vert:63-198) over the quarter grid; record q = (px/2)*(H/2) + py/2
+// preserves the reference's column-major draw order among active pixels.
+__global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__restrict__ dp, int tick, float maxDepth, int index_submap,
+                                                   const float *__restrict__ depth_metric,
+                                                   const float4 *__restrict__ normal_pca,
+                                                   const float4 *__restrict__ curv1, const float4 *__restrict__ curv2,
+                                                   const float *__restrict__ confidence,
+                                                   const uint8_t *__restrict__ rgb, const uint32_t *__restrict__ idx,
+                                                   const float4 *__restrict__ vertconf,
+                                                   const float4 *__restrict__ normrad, RecPlanes rec,
+                                                   int32_t *__restrict__ rec_flag, uint32_t *__restrict__ rec_best,
+                                                   uint32_t *__restrict__ slot)
+{
+    const int QW = cam.W / 2, QH = cam.H / 2;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= QW * QH) return;
+    const Rigid pose = dp->pose;
+    const int tpar = tick % 2;
+    const int px = (q / QH) * 2 + tpar, py = (q % QH) * 2 + tpar;
+    int flag = 0;
+    uint32_t best = 0;
+    if (px < cam.W && py < cam.H) {
+        const int i = py * cam.W + px;
+        const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+        const float zr = depth_metric[i];
+        f3 vl = mk3((x - cam.cx) * zr * cam.camz, (y - cam.cy) * zr * cam.camw, zr);
+        float4 npca = normal_pca[i];
+        f3 nl = xyz(npca);
+        float4 k1 = curv1[i], k2 = curv2[i];
+        if (len3(nl) > 0.8f && vl.z > 0.3f && vl.z <= maxDepth && k1.w > -300.0f && k1.w < 300.0f &&
+            k2.w > -300.0f && k2.w < 300.0f) {
+            float bestDist = 1000.0f;
+            int counter = 0;
+            float xl = (x - cam.cx) * cam.camz, yl = (y - cam.cy) * cam.camw;
+            float lambda = hd_sqrtf((xl * xl + yl * yl) + 1.0f);
+            f3 ray = mk3(xl, yl, 1.0f);
+            float lray = len3(ray);
+            float lnl = len3(nl);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int ox = (a == 0) ? -1 : (a == 3 ? 1 : 0);
+                const int sx = clampi(px + ox, 0, cam.W - 1);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int oy = (b == 0) ? -1 : (b == 3 ? 1 : 0);
+                    const int sy = clampi(py + oy, 0, cam.H - 1);
+                    const int si = sy * cam.W + sx;
+                    uint32_t current = idx[si];
+                    if (current > 0u) {
+                        float4 vcf = vertconf[si];
+                        if (hd_fabsf((vcf.z * lambda) - (vl.z * lambda)) < 0.05f) {
+                            float dist = len3(cross3(ray, xyz(vcf))) / lray;
+                            float4 nr = normrad[si];
+                            bool ok = hd_fabsf(nr.z) < 0.75f;
+                            if (!ok) {
+                                float ang = hd_acosf(dot3(xyz(nr), nl) / (len3(xyz(nr)) * lnl));
+                                ok = hd_fabsf(ang) < 0.5f;
+                            }
+                            if (dist < bestDist && ok) { counter++; bestDist = dist; best = current; }
+                        }
+                    }
+                }
+            }
+            f3 pg = xform(pose, vl);
+            f3 ng = rot_mul(pose, nl);
+            rec.p0[q] = make_float4(pg.x, pg.y, pg.z, confidence[i]);
+            rec.p1[q] = make_float4(encode_color_bytes(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]), (float)index_submap,
+                                    (float)tick, counter > 0 ? -1.0f : -2.0f);
+            rec.p2[q] = make_float4(ng.x, ng.y, ng.z, npca.w);
+            rec.p3[q] = k1;
+            rec.p4[q] = k2;
+            flag = counter > 0 ? 1 : 2;
+            if (counter > 0) atomicMin(&slot[best], (uint32_t)q);   // first primitive in draw order wins
+        }
+    }
+    rec_flag[q] = flag;
+    rec_best[q] = best;
+}
+
+// F2: sparse in-place merge (update.vert:51-115): only the winning record of each surfel applies.
+__global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes rec,
+                                                      const int32_t *__restrict__ rec_flag,
+                                                      const uint32_t *__restrict__ rec_best, uint32_t *__restrict__ slot,
+                                                      MapPlanes m, uint32_t *__restrict__ merged)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q || rec_flag[q] != 1) return;
+    const uint32_t s = rec_best[q];
+    if (slot[s] != (uint32_t)q) return;
+    slot[s] = 0xFFFFFFFFu;   // re-arm for the next frame (only touched entries are reset)
+    const float4 r0 = rec.p0[q], r1 = rec.p1[q], r2 = rec.p2[q], r3 = rec.p3[q], r4 = rec.p4[q];
+    const float4 vp = m.p0[s], vc = m.p1[s], vn = m.p2[s];
+    const float c_k = vp.w, a = r0.w, sum = c_k + a;
+    if (r2.w < (1.0f + 0.5f) * vn.w) {
+        const float4 c1 = m.p3[s], c2 = m.p4[s];
+        m.p0[s] = make_float4(((c_k * vp.x) + (a * r0.x)) / sum, ((c_k * vp.y) + (a * r0.y)) / sum,
+                              ((c_k * vp.z) + (a * r0.z)) / sum, sum);
+        f3 oc = decode_color(vc.x), nc = decode_color(r1.x);
+        f3 avg = mk3(((c_k * oc.x) + (a * nc.x)) / sum, ((c_k * oc.y) + (a * nc.y)) / sum,
+                     ((c_k * oc.z) + (a * nc.z)) / sum);
+        m.p1[s] = make_float4(encode_color(avg), vc.y, vc.z, (float)tick);
+        f3 nn = normalize3(mk3(((c_k * vn.x) + (a * r2.x)) / sum, ((c_k * vn.y) + (a * r2.y)) / sum,
+                               ((c_k * vn.z) + (a * r2.z)) / sum));
+        m.p2[s] = make_float4(nn.x, nn.y, nn.z, ((c_k * vn.w) + (a * r2.w)) / sum);
+        m.p3[s] = make_float4(((c_k * c1.x) + (a * r3.x)) / sum, ((c_k * c1.y) + (a * r3.y)) / sum,
+                              ((c_k * c1.z) + (a * r3.z)) / sum, ((c_k * c1.w) + (a * r3.w)) / sum);
+        m.p4[s] = make_float4(((c_k * c2.x) + (a * r4.x)) / sum, ((c_k * c2.y) + (a * r4.y)) / sum,
+                              ((c_k * c2.z) + (a * r4.z)) / sum, ((c_k * c2.w) + (a * r4.w)) / sum);
+    } else {
+        m.p0[s] = make_float4(vp.x, vp.y, vp.z, sum);
+        m.p1[s] = make_float4(vc.x, vc.y, vc.z, (float)tick);
+    }
+    atomicAdd(merged, 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+// F3: the fuse kernel — clean test (copy_unstable.vert:62-166) + order-preserving compaction of the
+// whole map + append of the new-surfel records, in one streaming pass.
+//
+// Items 0..N-1 are surfels, N..N+Q-1 are association records (draw order).  Tiles of
+// FUSE_TILE items are claimed through an atomic ticket so that a tile's predecessors have always
+// started (forward progress for the look-back).  Tile status words are single 8-byte granules
+// {flag:2 | value:32} written/read with relaxed agent-scope atomics (the datum is the flag, no fence).
+#define FUSE_THREADS 256
+#define FUSE_IPT 4
+#define FUSE_TILE (FUSE_THREADS * FUSE_IPT)
+#define ST_AGG (1ull << 62)
+#define ST_PREFIX (2ull << 62)
+#define ST_MASK (3ull << 62)
+
+struct CleanParams {
+    Cam cam;
+    const DevPose *dp;
+    float maxDepth, confThr, curvThr;
+    int time;
+    int nw;        // samples per axis = 2 * clean_window_multiplier
+    float w0;      // clean_window_multiplier * 0.5
+};
+
+__device__ __forceinline__ bool clean_test(const CleanParams &cp, const Rigid &tinv, float4 vp, float4 &vcol, float4 vn, float4 k1,
+                                           float4 k2, const uint32_t *__restrict__ idx,
+                                           const float4 *__restrict__ vertconf,
+                                           const float4 *__restrict__ colortime)
+{
+    const Cam &cam = cp.cam;
+    bool test = true;
+    f3 lp = xform(tinv, xyz(vp));
+    float x = ((cam.fx * lp.x) / lp.z) + cam.cx;
+    float y = ((cam.fy * lp.y) / lp.z) + cam.cy;
+    int count = 0, zCount = 0;
+    if (lp.z < cp.maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)cam.W && y < (float)cam.H) {
+        f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
+        const bool nz_ok = hd_fabsf(ln.z) > 0.85f;
+        const float rad14 = vn.w * 1.4f;
+        for (int a = 0; a < cp.nw; ++a) {
+            const int sx = clampi((int)hd_floorf(x + ((float)a * 0.5f - cp.w0)), 0, cam.W - 1);
+            for (int b = 0; b < cp.nw; ++b) {
+                const int sy = clampi((int)hd_floorf(y + ((float)b * 0.5f - cp.w0)), 0, cam.H - 1);
+                const int si = sy * cam.W + sx;
+                if (idx[si] > 0u) {
+                    float4 vcf = vertconf[si], ct = colortime[si];
+                    float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
+                    if (ct.z < vcol.z && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
+                        hd_sqrtf(dx * dx + dy * dy) < rad14)
+                        count++;
+                    if (ct.w == (float)cp.time && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f && nz_ok)
+                        zCount++;
+                }
+            }
+        }
+    }
+    if (k1.w < -cp.curvThr || k1.w > cp.curvThr || k2.w < -cp.curvThr || k2.w > cp.curvThr) test = false;
+    if (count > 8 || zCount > 4) test = false;
+    if (vcol.w == -2.0f) vcol.w = (float)cp.time;
+    if (vcol.w == -1.0f || (((float)cp.time - vcol.w) > 200.0f && vp.w < cp.confThr)) test = false;
+    return test;
+}
+
+__global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(CleanParams cp, MapPlanes in, MapPlanes out,
+                                                              RecPlanes rec, const int32_t *__restrict__ rec_flag, int Q,
+                                                              const uint32_t *__restrict__ count_in,
+                                                              uint32_t *__restrict__ count_out,
+                                                              uint32_t *__restrict__ stats, uint32_t cap,
+                                                              const uint32_t *__restrict__ idx,
+                                                              const float4 *__restrict__ vertconf,
+                                                              const float4 *__restrict__ colortime,
+                                                              unsigned long long *__restrict__ tile_status,
+                                                              uint32_t *__restrict__ ticket)
+{
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_wcnt[FUSE_IPT][FUSE_THREADS / 64];
+    __shared__ uint32_t s_prefix;
+    const uint32_t N = *count_in;
+    const Rigid tinv = cp.dp->tinv;
+    const uint32_t total = N + (uint32_t)Q;
+    const uint32_t num_tiles = (total + FUSE_TILE - 1) / FUSE_TILE;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= num_tiles) return;
+        const uint32_t base = tile * FUSE_TILE;
+
+        float4 v0[FUSE_IPT], v1[FUSE_IPT], v2[FUSE_IPT], v3[FUSE_IPT], v4[FUSE_IPT];
+        bool keep[FUSE_IPT];
+        uint32_t lrank[FUSE_IPT];   // rank within (k, wave)
+#pragma unroll
+        for (int k = 0; k < FUSE_IPT; ++k) {
+            const uint32_t it = base + k * FUSE_THREADS + threadIdx.x;
+            keep[k] = false;
+            if (it < N) {
+                v0[k] = in.p0[it]; v1[k] = in.p1[it]; v2[k] = in.p2[it]; v3[k] = in.p3[it]; v4[k] = in.p4[it];
+                keep[k] = clean_test(cp, tinv, v0[k], v1[k], v2[k], v3[k], v4[k], idx, vertconf, colortime);
+            } else if (it < total) {
+                const uint32_t q = it - N;
+                if (rec_flag[q] != 0) {
+                    v0[k] = rec.p0[q]; v1[k] = rec.p1[q]; v2[k] = rec.p2[q]; v3[k] = rec.p3[q]; v4[k] = rec.p4[q];
+                    keep[k] = clean_test(cp, tinv, v0[k], v1[k], v2[k], v3[k], v4[k], idx, vertconf, colortime);
+                }
+            }
+            const unsigned long long bal = __ballot(keep[k]);
+            lrank[k] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[k][wid] = (uint32_t)__popcll(bal);
+        }
+        __syncthreads();
+        // item order inside the tile is k-major then wave then lane
+        uint32_t tile_total = 0;
+        uint32_t off[FUSE_IPT];
+#pragma unroll
+        for (int k = 0; k < FUSE_IPT; ++k)
+#pragma unroll
+            for (int w = 0; w < FUSE_THREADS / 64; ++w) {
+                if (w == wid) off[k] = tile_total;
+                tile_total += s_wcnt[k][w];
+            }
+        // decoupled look-back by wave 0
+        if (wid == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&tile_status[tile], (tile == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long)tile_total,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t excl = 0;
+            if (tile > 0) {
+                int look = (int)tile - 1;
+                for (;;) {
+                    const int t = look - lane;
+                    unsigned long long st = ST_PREFIX;   // virtual tile -1: prefix 0
+                    if (t >= 0) {
+                        do {
+                            st = __hip_atomic_load(&tile_status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } while ((st & ST_MASK) == 0);
+                    }
+                    const unsigned long long pmask = __ballot((st & ST_MASK) == ST_PREFIX);
+                    // sum values of lanes up to and including the first (nearest) PREFIX lane
+                    const int first = pmask ? __ffsll((long long)pmask) - 1 : 64;
+                    uint32_t val = (lane <= first) ? (uint32_t)(st & 0xFFFFFFFFull) : 0u;
+                    for (int d = 32; d > 0; d >>= 1) val += __shfl_down(val, d);
+                    val = __shfl(val, 0);
+                    excl += val;
+                    if (pmask) break;
+                    look -= 64;
+                }
+                if (lane == 0)
+                    __hip_atomic_store(&tile_status[tile], ST_PREFIX | (unsigned long long)(excl + tile_total),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) {
+                s_prefix = excl;
+                if (tile == num_tiles - 1) {
+                    uint32_t tot = excl + tile_total;
+                    *count_out = tot > cap ? cap : tot;
+                    stats[0] = N; stats[3] = tot > cap ? cap : tot;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        uint32_t appended = 0;
+#pragma unroll
+        for (int k = 0; k < FUSE_IPT; ++k) {
+            if (keep[k]) {
+                const uint32_t o = prefix + off[k] + lrank[k];
+                if (o < cap) {
+                    out.p0[o] = v0[k]; out.p1[o] = v1[k]; out.p2[o] = v2[k]; out.p3[o] = v3[k]; out.p4[o] = v4[k];
+                    if (base + k * FUSE_THREADS + threadIdx.x >= N) appended++;
+                }
+            }
+        }
+        if (base + FUSE_TILE > N) {   // only tiles that contain records count appends
+            for (int d = 32; d > 0; d >>= 1) appended += __shfl_down(appended, d);
+            if (lane == 0 && appended) atomicAdd(&stats[2], appended);
+        }
+        __syncthreads();   // s_tile / s_wcnt reuse
+    }
+}
+
+__global__ void k_zero_u32(uint32_t *p, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+__global__ void k_zero_flags(int32_t *p, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+__global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const float4 *vertex_raw, const float4 *normal,
+                       const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
+                       int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
+                       uint32_t cap, uint32_t *count)
+{
+    int P = cam.W * cam.H;
+    hipLaunchKernelGGL(k_init_flags, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, normal, curv1, curv2, thr, flags);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, flags, offs, P, count);
+    hipLaunchKernelGGL(k_init_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, vertex_raw, normal, rgb, curv1,
+                       curv2, gradmag, use_conf_eval, eps, flags, offs, out, cap);
+    hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap);
+}
+
+void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
+                            const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
+                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin)
+{
+    int P = cam.W * cam.H;
+    hipLaunchKernelGGL(k_fill_u64, dim3((P + 255) / 256), dim3(256), 0, s, zbuf, P, ZB_EMPTY);
+    uint32_t blocks = (count_ub + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride the rest
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf);
+    hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, zbuf, idx, vertconf, colortime,
+                       normrad, curvmax, curvmin);
+}
+
+void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
+                 const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
+                 const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
+                 const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
+                 MapPlanes m, uint32_t *stats)
+{
+    int Q = (cam.W / 2) * (cam.H / 2);
+    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 4);
+    hipLaunchKernelGGL(k_associate, dim3((Q + 255) / 256), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
+                       depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
+                       rec_best, slot);
+    hipLaunchKernelGGL(k_apply_merges, dim3((Q + 255) / 256), dim3(256), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
+                       stats + 1);
+}
+
+void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
+                  int time, float clean_window_multiplier, MapPlanes in, MapPlanes out, RecPlanes rec, int32_t *rec_flag,
+                  const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
+                  const uint32_t *idx, const float4 *vertconf, const float4 *colortime,
+                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket)
+{
+    int Q = (cam.W / 2) * (cam.H / 2);
+    CleanParams cp;
+    cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
+    cp.nw = (int)(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f;
+    uint32_t tiles = (count_ub + (uint32_t)Q + FUSE_TILE - 1) / FUSE_TILE;
+    if (tiles > max_tiles) tiles = max_tiles;
+    hipMemsetAsync(tile_status, 0, sizeof(unsigned long long) * (size_t)tiles, s);
+    hipMemsetAsync(ticket, 0, sizeof(uint32_t), s);
+    uint32_t blocks = tiles < 256u * 4u ? tiles : 256u * 4u;   // persistent: <= 4 workgroups per CU
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), 0, s, cp, in, out, rec, rec_flag, Q, count_in,
+                       count_out, stats, cap, idx, vertconf, colortime, tile_status, ticket);
+    hipLaunchKernelGGL(k_zero_flags, dim3((Q + 255) / 256), dim3(256), 0, s, rec_flag, Q);
+}
+
+void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
+{
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+
+uint32_t fuse_tile_items() { return FUSE_TILE; }

@@ -1,0 +1,1098 @@
+// k_odo.hip — frame-to-model RGB-D odometry for gfx950, fully device resident.
+//
+// Replaces RGBDOdometry (Core/src/Utils/RGBDOdometry.cpp:183-247,660-1249), the CUDA kernels of
+// Core/src/Cuda/reduce.cu:253-1359 (icpStep / rgbStep / computeRgbResidual / so3Step) and
+// Core/src/Cuda/cudafuncs.cu:57-1028 (map pyramids, copies, Sobel, ...), and the host-side Eigen
+// Gauss-Newton loop (LDLT, rodrigues, SE3 update; Core/src/Utils/OdometryProvider.h:35-93).
+//
+// MI355X design:
+//  * the reference synchronises with the host ~70 times per frame (kernel + cudaDeviceSynchronize +
+//    29-float download per step).  Here the whole registration is a fixed launch sequence on one
+//    stream; the 6x6 / 3x3 solves and the SE3 update run in a one-workgroup kernel and every
+//    iteration's state (OdoState) stays in HBM/L2.  No host round trip.
+//  * reductions: one pixel per lane, 256-thread workgroups; every addend goes through the exact
+//    limb accumulator (hrbf_detmath.h) -> wave64 __shfl_down tree on int64 limbs -> LDS -> one
+//    partial row per workgroup -> summed by the solve kernel.  Integer sums make the result
+//    independent of wave/block shape and of the number of GPUs (RCCL all-reduce of int64).
+//  * warp-32 shuffle emulation through shared memory of the reference (reduce.cu:58-80) has no
+//    counterpart: gfx950 shuffles natively across 64 lanes.
+#include "common.h"
+#include "kernels.h"
+
+#define RB 256               // reduction workgroup = 4 wave64
+#define NLIMB(n) ((n) * 3)
+
+struct OdoState {
+    float Rprev[9], tprev[3], Rcurr[9], tcurr[3], Rprev_inv[9];
+    double Rt[16];                    // resultRt, row-major
+    double resultR[9], lastResultR[9];
+    float R_lr[9];
+    float so3_lastError, so3_lastCount;
+    int so3_done;
+    float basis[9], kinv[9], krlr[9]; // SO3 step operands
+    float krk[9], kt[3];              // RGB residual operands
+    float lastRGBError;
+    int gn_break;
+    float res_icp[2];
+    float last_icp_error, last_icp_count;
+    float sigmaVal;
+};
+
+size_t odo_state_bytes() { return sizeof(OdoState); }
+
+#define PLN(base, k, rows, cols, y, x) ((base)[((size_t)(k) * (rows) + (y)) * (cols) + (x)])
+
+// ------------------------------------------------------------------------------------------
+// exact workgroup reduction of N floats per lane -> part[blockIdx.x][3N]
+template <int N>
+__device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ part)
+{
+    __shared__ long long s_part[RB / 64][NLIMB(N)];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool any = __ballot(valid) != 0ull;
+    if (any) {
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+            hd_limbs l;
+            if (valid) l = hd_limbs_from_f32(vals[i]);
+            else { l.l0 = 0; l.l1 = 0; l.l2 = 0; }
+            long long a = l.l0, b = l.l1, c = l.l2;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                a += __shfl_down(a, d);
+                b += __shfl_down(b, d);
+                c += __shfl_down(c, d);
+            }
+            if (lane == 0) { s_part[wid][i * 3] = a; s_part[wid][i * 3 + 1] = b; s_part[wid][i * 3 + 2] = c; }
+        }
+    } else if (lane == 0) {
+        for (int i = 0; i < NLIMB(N); ++i) s_part[wid][i] = 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NLIMB(N); t += RB) {
+        long long s = 0;
+#pragma unroll
+        for (int w = 0; w < RB / 64; ++w) s += s_part[w][t];
+        part[(size_t)blockIdx.x * NLIMB(N) + t] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ O1: map building
+__device__ __forceinline__ uint8_t intensity_u8(int r, int g, int b)
+{
+    float v = (float)r * 0.114f;
+    v = v + (float)g * 0.299f;
+    v = v + (float)b * 0.587f;
+    return (uint8_t)(int)v;
+}
+
+// level 0 of every pyramid in one pass (copyMaps, copyCurvatureMap, copyicpWeightMap,
+// verticesToDepth, imageBGRToIntensity; cudafuncs.cu:344-470,874-911)
+__global__ void k_odo_level0(int P, OdoLevel L, OdoSources src, const DevPose *__restrict__ dp, int f2f, float curv_thr)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int fill = dp->should_fill_in;
+    const float4 *vtex = fill ? src.fi_vertex : src.pr_vertex;
+    const float4 *ntex = fill ? src.fi_normal : src.pr_normal;
+    const uint8_t *img = (fill || f2f) ? src.fi_image : src.pr_image;
+    const float4 *k1t = fill ? src.fi_curv1 : src.pr_curv1;
+    const float4 *k2t = fill ? src.fi_curv2 : src.pr_curv2;
+    const float *iwt = fill ? src.fi_icpw : src.pr_icpw;
+    const float qn = hd_nanf();
+    const size_t PP = (size_t)P;
+    // model
+    {
+        float4 v = vtex[i], n = ntex[i];
+        float4 vo = make_float4(qn, qn, qn, qn), no = vo;
+        if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
+        L.vmap_g[i] = vo.x; L.vmap_g[PP + i] = vo.y; L.vmap_g[2 * PP + i] = vo.z; L.vmap_g[3 * PP + i] = vo.w;
+        L.nmap_g[i] = no.x; L.nmap_g[PP + i] = no.y; L.nmap_g[2 * PP + i] = no.z; L.nmap_g[3 * PP + i] = no.w;
+        L.last_depth[i] = (v.z > 6.0f || v.z <= 0.0f) ? qn : v.z;
+        L.last_image[i] = intensity_u8(img[i * 4], img[i * 4 + 1], img[i * 4 + 2]);
+        float4 s = k1t[i], o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck1_g[i] = o.x; L.ck1_g[PP + i] = o.y; L.ck1_g[2 * PP + i] = o.z; L.ck1_g[3 * PP + i] = o.w;
+        s = k2t[i]; o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck2_g[i] = o.x; L.ck2_g[PP + i] = o.y; L.ck2_g[2 * PP + i] = o.z; L.ck2_g[3 * PP + i] = o.w;
+        float w = iwt[i];
+        L.icpw[i] = w > 0.0f ? w : qn;
+    }
+    // live frame
+    {
+        float4 v = src.vertex_filtered[i], n = src.normal[i];
+        float4 vo = make_float4(qn, qn, qn, qn), no = vo;
+        if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
+        L.vmap_c[i] = vo.x; L.vmap_c[PP + i] = vo.y; L.vmap_c[2 * PP + i] = vo.z; L.vmap_c[3 * PP + i] = vo.w;
+        L.nmap_c[i] = no.x; L.nmap_c[PP + i] = no.y; L.nmap_c[2 * PP + i] = no.z; L.nmap_c[3 * PP + i] = no.w;
+        L.next_depth[i] = (v.z > 6.0f || v.z <= 0.0f) ? qn : v.z;
+        L.next_image[i] = intensity_u8(src.rgb[i * 3], src.rgb[i * 3 + 1], src.rgb[i * 3 + 2]);
+        float4 s = src.curv1[i], o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck1_c[i] = o.x; L.ck1_c[PP + i] = o.y; L.ck1_c[2 * PP + i] = o.z; L.ck1_c[3 * PP + i] = o.w;
+        s = src.curv2[i]; o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck2_c[i] = o.x; L.ck2_c[PP + i] = o.y; L.ck2_c[2 * PP + i] = o.z; L.ck2_c[3 * PP + i] = o.w;
+    }
+}
+
+// resizeMapKernel / resizeCMapKernel (cudafuncs.cu:526-674): validity plane = 0 (maps) or 3 (curvature)
+__device__ __forceinline__ void resize_planar(const float *__restrict__ in, int irows, int icols, float *__restrict__ out,
+                                              int orows, int ocols, int x, int y, int valid_plane, bool normalize)
+{
+    const float qn = hd_nanf();
+    const int xs = x * 2, ys = y * 2;
+    float a = PLN(in, valid_plane, irows, icols, ys, xs), b = PLN(in, valid_plane, irows, icols, ys, xs + 1),
+          c = PLN(in, valid_plane, irows, icols, ys + 1, xs), d = PLN(in, valid_plane, irows, icols, ys + 1, xs + 1);
+    if (hd_isnanf(a) || hd_isnanf(b) || hd_isnanf(c) || hd_isnanf(d)) {
+        for (int k = 0; k < 4; ++k) PLN(out, k, orows, ocols, y, x) = qn;
+        return;
+    }
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = (((PLN(in, k, irows, icols, ys, xs) + PLN(in, k, irows, icols, ys, xs + 1)) +
+                 PLN(in, k, irows, icols, ys + 1, xs)) + PLN(in, k, irows, icols, ys + 1, xs + 1)) / 4.0f;
+    if (normalize) {
+        float inv = 1.0f / hd_sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+        r[0] *= inv; r[1] *= inv; r[2] *= inv;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) PLN(out, k, orows, ocols, y, x) = r[k];
+}
+
+__constant__ float c_gk[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+
+// pyrDownKernelGaussF / pyrDownKernelIntensityGauss (cudafuncs.cu:493-524,818-848) incl. border quirk
+__device__ __forceinline__ float pyrdown_f(const float *__restrict__ src, int srows, int scols, int x, int y)
+{
+    int tx = 2 * x + 3 < scols - 1 ? 2 * x + 3 : scols - 1;
+    int ty = 2 * y + 3 < srows - 1 ? 2 * y + 3 : srows - 1;
+    float sum = 0.0f; int count = 0;
+    for (int cy = (2 * y - 2 > 0 ? 2 * y - 2 : 0); cy < ty; ++cy)
+        for (int cx = (2 * x - 2 > 0 ? 2 * x - 2 : 0); cx < tx; ++cx) {
+            float s = src[cy * scols + cx];
+            if (!hd_isnanf(s)) {
+                float g = c_gk[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                sum += s * g;
+                count += (int)g;
+            }
+        }
+    return sum / (float)count;
+}
+__device__ __forceinline__ uint8_t pyrdown_u8(const uint8_t *__restrict__ src, int srows, int scols, int x, int y)
+{
+    int tx = 2 * x + 3 < scols - 1 ? 2 * x + 3 : scols - 1;
+    int ty = 2 * y + 3 < srows - 1 ? 2 * y + 3 : srows - 1;
+    float sum = 0.0f; int count = 0;
+    for (int cy = (2 * y - 2 > 0 ? 2 * y - 2 : 0); cy < ty; ++cy)
+        for (int cx = (2 * x - 2 > 0 ? 2 * x - 2 : 0); cx < tx; ++cx) {
+            uint8_t s = src[cy * scols + cx];
+            if (s > 0) {
+                float g = c_gk[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                sum += (float)s * g;
+                count += (int)g;
+            }
+        }
+    return count > 0 ? (uint8_t)(int)(sum / (float)count) : (uint8_t)0;
+}
+
+__global__ void k_odo_downsample(OdoLevel I, OdoLevel O)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= O.rows * O.cols) return;
+    int y = i / O.cols, x = i - y * O.cols;
+    resize_planar(I.vmap_g, I.rows, I.cols, O.vmap_g, O.rows, O.cols, x, y, 0, false);
+    resize_planar(I.nmap_g, I.rows, I.cols, O.nmap_g, O.rows, O.cols, x, y, 0, true);
+    resize_planar(I.ck1_g, I.rows, I.cols, O.ck1_g, O.rows, O.cols, x, y, 3, false);
+    resize_planar(I.ck2_g, I.rows, I.cols, O.ck2_g, O.rows, O.cols, x, y, 3, false);
+    resize_planar(I.vmap_c, I.rows, I.cols, O.vmap_c, O.rows, O.cols, x, y, 0, false);
+    resize_planar(I.nmap_c, I.rows, I.cols, O.nmap_c, O.rows, O.cols, x, y, 0, true);
+    resize_planar(I.ck1_c, I.rows, I.cols, O.ck1_c, O.rows, O.cols, x, y, 3, false);
+    resize_planar(I.ck2_c, I.rows, I.cols, O.ck2_c, O.rows, O.cols, x, y, 3, false);
+    {   // resizeicpWeightMapKernel cudafuncs.cu:694-726
+        const float qn = hd_nanf();
+        float a = I.icpw[(2 * y) * I.cols + 2 * x], b = I.icpw[(2 * y) * I.cols + 2 * x + 1],
+              c = I.icpw[(2 * y + 1) * I.cols + 2 * x], d = I.icpw[(2 * y + 1) * I.cols + 2 * x + 1];
+        O.icpw[i] = (hd_isnanf(a) || hd_isnanf(b) || hd_isnanf(c) || hd_isnanf(d)) ? qn : (((a + b) + c) + d) / 4.0f;
+    }
+    O.last_depth[i] = pyrdown_f(I.last_depth, I.rows, I.cols, x, y);
+    O.next_depth[i] = pyrdown_f(I.next_depth, I.rows, I.cols, x, y);
+    O.last_image[i] = pyrdown_u8(I.last_image, I.rows, I.cols, x, y);
+    O.next_image[i] = pyrdown_u8(I.next_image, I.rows, I.cols, x, y);
+}
+
+// tranformMapsKernel / tranformCurvMapsKernel (cudafuncs.cu:213-322), in place, one level
+__device__ __forceinline__ void transform_planar(float *m, int rows, int cols, int i, const Rigid &T, bool add_t)
+{
+    const size_t PP = (size_t)rows * cols;
+    float vx = m[i];
+    if (hd_isnanf(vx)) return;
+    f3 o = rot_mul(T, mk3(vx, m[PP + i], m[2 * PP + i]));
+    if (add_t) o = mk3(o.x + T.t[0], o.y + T.t[1], o.z + T.t[2]);
+    m[i] = o.x; m[PP + i] = o.y; m[2 * PP + i] = o.z;
+}
+__global__ void k_odo_transform(OdoLevel L, const DevPose *__restrict__ dp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.rows * L.cols) return;
+    const Rigid T = dp->pose;
+    transform_planar(L.vmap_g, L.rows, L.cols, i, T, true);
+    transform_planar(L.nmap_g, L.rows, L.cols, i, T, false);
+    transform_planar(L.ck1_g, L.rows, L.cols, i, T, false);
+    transform_planar(L.ck2_g, L.rows, L.cols, i, T, false);
+}
+
+// applyKernel (Sobel, cudafuncs.cu:927-954, running kernelIndex quirk) + projectPointsKernel (:995-1013)
+__global__ void k_odo_sobel_cloud(OdoLevel L, float fx, float fy, float cx, float cy, int do_rgb)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows = L.rows, cols = L.cols;
+    if (i >= rows * cols) return;
+    if (!do_rgb) return;
+    int y = i / cols, x = i - y * cols;
+    const float gx[9] = {1, 0, -1, 2, 0, -2, 1, 0, -1};
+    const float gy[9] = {1, 2, 1, 0, 0, 0, -1, -2, -1};
+    float dxv = 0.0f, dyv = 0.0f;
+    int ki = 8;
+    for (int j = (y - 1 > 0 ? y - 1 : 0); j <= (y + 1 < rows - 1 ? y + 1 : rows - 1); ++j)
+        for (int ii = (x - 1 > 0 ? x - 1 : 0); ii <= (x + 1 < cols - 1 ? x + 1 : cols - 1); ++ii) {
+            float s = (float)L.next_image[j * cols + ii];
+            dxv += s * gx[ki];
+            dyv += s * gy[ki];
+            --ki;
+        }
+    L.dIdx[i] = (int16_t)dxv;
+    L.dIdy[i] = (int16_t)dyv;
+    float invFx = 1.0f / fx, invFy = 1.0f / fy;
+    float z = L.last_depth[i];
+    L.cloud[i * 3] = ((float)x - cx) * z * invFx;
+    L.cloud[i * 3 + 1] = ((float)y - cy) * z * invFy;
+    L.cloud[i * 3 + 2] = z;
+}
+
+__global__ void k_first_rgb(int P, const uint8_t *__restrict__ rgb, uint8_t *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) out[i] = intensity_u8(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+}
+__global__ void k_pyrdown_u8(const uint8_t *__restrict__ src, int srows, int scols, uint8_t *__restrict__ dst)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int dcols = scols / 2, drows = srows / 2;
+    if (i >= dcols * drows) return;
+    int y = i / dcols, x = i - y * dcols;
+    dst[i] = pyrdown_u8(src, srows, scols, x, y);
+}
+
+// ------------------------------------------------------------------------------------------ small dense algebra
+template <typename T, int NMAX>
+__host__ __device__ inline void ldlt_solve(int n, const T *Ain, const T *b, T *x)
+{
+    T A[NMAX * NMAX]; int perm[NMAX]; T y[NMAX];
+    for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int piv = k; T best = A[k * n + k] < 0 ? -A[k * n + k] : A[k * n + k];
+        for (int i = k + 1; i < n; ++i) {
+            T v = A[i * n + i] < 0 ? -A[i * n + i] : A[i * n + i];
+            if (v > best) { best = v; piv = i; }
+        }
+        if (piv != k) {
+            for (int j = 0; j < n; ++j) { T t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            for (int j = 0; j < n; ++j) { T t = A[j * n + k]; A[j * n + k] = A[j * n + piv]; A[j * n + piv] = t; }
+            int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+        }
+        T d = A[k * n + k];
+        if (d == 0) continue;
+        for (int i = k + 1; i < n; ++i) A[i * n + k] = A[i * n + k] / d;
+        for (int i = k + 1; i < n; ++i)
+            for (int j = k + 1; j <= i; ++j) {
+                A[i * n + j] = A[i * n + j] - A[i * n + k] * d * A[j * n + k];
+                A[j * n + i] = A[i * n + j];
+            }
+    }
+    for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] = y[i] - A[i * n + j] * y[j];
+    for (int i = 0; i < n; ++i) y[i] = (A[i * n + i] == 0) ? 0 : y[i] / A[i * n + i];
+    for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] = y[i] - A[j * n + i] * y[j];
+    for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+}
+
+__host__ __device__ inline void inv3d(const double *m, double *o)
+{
+    double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    double c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    double det = (a * c00 + b * c01) + c * c02;
+    double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[3] = c01 * id; o[4] = (a * i - c * g) * id; o[5] = (c * d - a * f) * id;
+    o[6] = c02 * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
+}
+template <typename T>
+__host__ __device__ inline void mul3(const T *a, const T *b, T *o)
+{
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+        o[r * 3 + c] = (a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c]) + a[r * 3 + 2] * b[6 + c];
+}
+__host__ __device__ inline void rodrigues(const double *src, double *R)
+{
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    double rx = src[0], ry = src[1], rz = src[2];
+    double theta = hd_sqrt((rx * rx + ry * ry) + rz * rz);
+    if (theta >= 2.2204460492503131e-16) {
+        double s, cth; hd_sincos(theta, &s, &cth);
+        double c1 = 1.0 - cth, itheta = 1.0 / theta;
+        rx *= itheta; ry *= itheta; rz *= itheta;
+        double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        double rxm[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; ++k) R[k] = (cth * I[k] + c1 * rrt[k]) + s * rxm[k];
+    }
+}
+__host__ __device__ inline void inv3f_cof(const float *m, float *o)
+{
+    float a = m[0], b = m[1], cc = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    float det = (a * c00 + b * c01) + cc * c02, id = 1.0f / det;
+    o[0] = c00 * id; o[1] = (cc * h - b * i) * id; o[2] = (b * f - cc * e) * id;
+    o[3] = c01 * id; o[4] = (a * i - cc * g) * id; o[5] = (cc * d - a * f) * id;
+    o[6] = c02 * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
+}
+
+// sum partial rows: totals[t] = sum_b part[b][t]   (one workgroup)
+__device__ __forceinline__ void sum_partials(const long long *__restrict__ part, int nblocks, int width,
+                                             long long *__restrict__ totals)
+{
+    __shared__ long long s_acc[8][128];
+    // width <= 87 < 128; 8 row groups x 128 columns = 1024 threads
+    const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    long long s = 0;
+    if (col < width)
+        for (int b = grp; b < nblocks; b += 8) s += part[(size_t)b * width + col];
+    s_acc[grp][col] = s;
+    __syncthreads();
+    if (threadIdx.x < width) {
+        long long t = 0;
+        for (int g = 0; g < 8; ++g) t += s_acc[g][threadIdx.x];
+        totals[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double limbs_to_double(const long long *t, int i)
+{
+    return hd_acc_to_double(hd_limbs_combine(t[i * 3], t[i * 3 + 1], t[i * 3 + 2]));
+}
+
+// ------------------------------------------------------------------------------------------ O2: SO3 pre-alignment
+__global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, const OdoState *__restrict__ st,
+                                                   long long *__restrict__ part)
+{
+    const int rows = L.rows, cols = L.cols;
+    const int i = blockIdx.x * RB + threadIdx.x;
+    float row4[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
+    bool valid = false;
+    if (!st->so3_done && i < rows * cols) {
+        const int y = i / cols, x = i - y * cols;
+        const uint8_t *lastImage = L.last_next_image, *nextImage = L.next_image;
+        f3 un = mk3((float)x, (float)y, 1.0f);
+        f3 wp = m33_mul(st->basis, un);
+        float fu = wp.x / wp.z, fv = wp.y / wp.z;
+        if (fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f) {
+            int wx = (int)hd_rintf(fu), wy = (int)hd_rintf(fv);
+            if (wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 &&
+                y < rows - 1) {
+                valid = true;
+                float actu = (float)nextImage[wy * cols + wx];
+                float back = (float)nextImage[wy * cols + wx - 1], fore = (float)nextImage[wy * cols + wx + 1];
+                float gnx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+                back = (float)nextImage[(wy - 1) * cols + wx]; fore = (float)nextImage[(wy + 1) * cols + wx];
+                float gny = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+                actu = (float)lastImage[y * cols + x];
+                back = (float)lastImage[y * cols + x - 1]; fore = (float)lastImage[y * cols + x + 1];
+                float glx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+                back = (float)lastImage[(y - 1) * cols + x]; fore = (float)lastImage[(y + 1) * cols + x];
+                float gly = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+                float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+                f3 point = m33_mul(st->kinv, un);
+                float z2 = point.z * point.z;
+                const float *k = st->krlr;
+                float a = k[0], b = k[1], cc = k[2], d = k[3], e = k[4], f = k[5], g = k[6], h = k[7], i_ = k[8];
+                float fxp = (float)x, fyp = (float)y;
+                f3 lp = mk3((((point.z * (d * gy + a * gx)) - (gy * g * fyp)) - (gx * g * fxp)) / z2,
+                            (((point.z * (e * gy + b * gx)) - (gy * h * fyp)) - (gx * h * fxp)) / z2,
+                            (((point.z * (f * gy + cc * gx)) - (gy * i_ * fyp)) - (gx * i_ * fxp)) / z2);
+                f3 jr = cross3(lp, point);
+                float r[4] = {jr.x, jr.y, jr.z, -((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x])};
+                int q = 0;
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                    for (int jj = ii; jj < 4; ++jj) row4[q++] = r[ii] * r[jj];
+                row4[9] = r[3] * r[3];
+                row4[10] = 1.0f;
+            }
+        }
+    }
+    block_reduce_exact<11>(row4, valid, part);
+}
+
+__device__ inline void so3_set_operands(OdoState *st, float fx, float fy, float cx, float cy)
+{
+    double K[9] = {0}, Kinv[9], KR[9], Hm[9];
+    K[0] = fx / 4; K[4] = fy / 4; K[2] = cx / 4; K[5] = cy / 4; K[8] = 1;
+    inv3d(K, Kinv);
+    mul3<double>(K, st->resultR, KR);
+    mul3<double>(KR, Kinv, Hm);
+    for (int k = 0; k < 9; ++k) { st->basis[k] = (float)Hm[k]; st->kinv[k] = (float)Kinv[k]; st->krlr[k] = (float)KR[k]; }
+}
+
+// begin of registration: latch previous pose, reset SO3 / GN state
+__global__ void k_odo_begin(OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 9; ++k) { st->Rprev[k] = dp->pose.r[k]; st->Rcurr[k] = dp->pose.r[k]; }
+    for (int k = 0; k < 3; ++k) { st->tprev[k] = dp->pose.t[k]; st->tcurr[k] = dp->pose.t[k]; }
+    inv3f_cof(st->Rprev, st->Rprev_inv);
+    for (int k = 0; k < 9; ++k) { st->resultR[k] = st->lastResultR[k] = (k % 4 == 0) ? 1.0 : 0.0; st->R_lr[k] = (k % 4 == 0) ? 1.0f : 0.0f; }
+    st->so3_lastError = 3.402823466e+38f / 2.0f;
+    st->so3_lastCount = 3.402823466e+38f / 2.0f;
+    st->so3_done = cfg.so3 ? 0 : 1;
+    st->gn_break = 0;
+    st->res_icp[0] = st->res_icp[1] = 0.0f;
+    if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
+}
+
+__global__ __launch_bounds__(1024) void k_so3_solve(OdoState *st, const long long *__restrict__ part, int nblocks,
+                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg)
+{
+    if (do_reduce) sum_partials(part, nblocks, 33, totals);
+    if (threadIdx.x != 0) return;
+    if (st->so3_done) return;
+    double s[11];
+    for (int i = 0; i < 11; ++i) s[i] = limbs_to_double(totals, i);
+    float jtj[9], jtr[3];
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            float value = (float)s[shift++];
+            if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+        }
+    float res0 = (float)s[9], res1 = (float)s[10];
+    float so3err = hd_sqrtf(res0) / res1, so3cnt = res1;
+    if (so3err < st->so3_lastError && st->so3_lastCount == so3cnt) { st->so3_done = 1; return; }
+    else if (so3err > st->so3_lastError + 0.001f) {
+        for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
+        st->so3_done = 1;
+        return;
+    }
+    st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
+    for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
+    float delta[3];
+    ldlt_solve<float, 3>(3, jtj, jtr, delta);
+    double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
+    rodrigues(dd, rotU);
+    float rotUf[9], tmp[9];
+    for (int k = 0; k < 9; ++k) rotUf[k] = (float)rotU[k];
+    mul3<float>(rotUf, st->R_lr, tmp);
+    for (int k = 0; k < 9; ++k) { st->R_lr[k] = tmp[k]; st->resultR[k] = tmp[k]; }
+    so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
+}
+
+// ------------------------------------------------------------------------------------------ GN operands
+__device__ inline void gn_set_operands(OdoState *st, float fxl, float fyl, float cxl, float cyl)
+{
+    double K[9] = {0}, Kinv[9];
+    K[0] = fxl; K[4] = fyl; K[2] = cxl; K[5] = cyl; K[8] = 1;
+    inv3d(K, Kinv);
+    const double *Rt = st->Rt;
+    double L[9], Li[9], ti[3];
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) L[r * 3 + k] = Rt[r * 4 + k];
+    inv3d(L, Li);
+    for (int r = 0; r < 3; ++r) ti[r] = -((Li[r * 3] * Rt[3] + Li[r * 3 + 1] * Rt[7]) + Li[r * 3 + 2] * Rt[11]);
+    double KR[9], KRK[9];
+    mul3<double>(K, Li, KR); mul3<double>(KR, Kinv, KRK);
+    for (int k = 0; k < 9; ++k) st->krk[k] = (float)KRK[k];
+    for (int r = 0; r < 3; ++r)
+        st->kt[r] = (float)((K[r * 3] * ti[0] + K[r * 3 + 1] * ti[1]) + K[r * 3 + 2] * ti[2]);
+}
+
+__global__ void k_gn_begin(OdoState *st, OdoConfig cfg, int level)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 16; ++k) st->Rt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (cfg.so3) for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) st->Rt[r * 4 + k] = st->resultR[r * 3 + k];
+    const int div = 1 << level;
+    gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+    st->lastRGBError = 3.402823466e+38f;
+}
+
+// ------------------------------------------------------------------------------------------ O3 + O4 fused launch
+struct IcpArgs {
+    const float *vmap_c, *nmap_c, *ck1_c, *ck2_c, *vmap_g, *nmap_g, *ck1_g, *ck2_g, *icpw;
+    int rows, cols;
+    float fx, fy, cx, cy, distThres, angleThres;
+    int use_search, radius, use_weight;
+};
+
+__device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                          int x, int y, float *out)
+{
+    const int rows = A.rows, cols = A.cols;
+    f3 vcur = mk3(PLN(A.vmap_c, 0, rows, cols, y, x), PLN(A.vmap_c, 1, rows, cols, y, x), PLN(A.vmap_c, 2, rows, cols, y, x));
+    f3 ncur = mk3(PLN(A.nmap_c, 0, rows, cols, y, x), PLN(A.nmap_c, 1, rows, cols, y, x), PLN(A.nmap_c, 2, rows, cols, y, x));
+    float ck1 = PLN(A.ck1_c, 3, rows, cols, y, x), ck2 = PLN(A.ck2_c, 3, rows, cols, y, x);
+    if (hd_isnanf(vcur.x) || hd_isnanf(ncur.x) || hd_isnanf(ck1) || hd_isnanf(ck2)) return false;
+    f3 vg_ = add3(m33_mul(Rcurr, vcur), tcurr);
+    f3 vcp = m33_mul(Rpi, sub3(vg_, tprev));
+    float fu = vcp.x * A.fx / vcp.z + A.cx, fv = vcp.y * A.fy / vcp.z + A.cy;
+    if (hd_isnanf(fu) || hd_isnanf(fv)) return false;
+    if (!(fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f)) return false;
+    int ux = (int)hd_rintf(fu), uy = (int)hd_rintf(fv);
+    if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcp.z < 0.0f) return false;
+    f3 ncur_g = m33_mul(Rcurr, ncur);
+    const int R = A.use_search ? A.radius : 0;
+    bool found = false;
+    int bx = -1, by = -1;
+    f3 bv = mk3(0, 0, 0), bn = mk3(0, 0, 0);
+    float p_smallest = 1e8f, DpR = -1e8f;
+    if (A.use_search)
+        for (int cy_ = uy - R; cy_ < uy + R + 1; ++cy_)
+            for (int cx_ = ux - R; cx_ < ux + R + 1; ++cx_) {
+                if (cx_ < 0 || cy_ < 0 || cx_ >= cols || cy_ >= rows) continue;
+                f3 vp = mk3(PLN(A.vmap_g, 0, rows, cols, cy_, cx_), PLN(A.vmap_g, 1, rows, cols, cy_, cx_), PLN(A.vmap_g, 2, rows, cols, cy_, cx_));
+                f3 np = mk3(PLN(A.nmap_g, 0, rows, cols, cy_, cx_), PLN(A.nmap_g, 1, rows, cols, cy_, cx_), PLN(A.nmap_g, 2, rows, cols, cy_, cx_));
+                float c1 = PLN(A.ck1_g, 3, rows, cols, cy_, cx_), c2 = PLN(A.ck2_g, 3, rows, cols, cy_, cx_);
+                if (hd_isnanf(vp.x) || hd_isnanf(np.x) || hd_isnanf(c1) || hd_isnanf(c2)) continue;
+                float dist = len3(sub3(vp, vg_)), sine = len3(cross3(ncur_g, np));
+                if (sine > A.angleThres || dist > A.distThres) continue;
+                if (dist > DpR) DpR = dist;
+            }
+    for (int cy_ = uy - R; cy_ < uy + R + 1; ++cy_)
+        for (int cx_ = ux - R; cx_ < ux + R + 1; ++cx_) {
+            if (cx_ < 0 || cy_ < 0 || cx_ >= cols || cy_ >= rows) continue;
+            f3 vp = mk3(PLN(A.vmap_g, 0, rows, cols, cy_, cx_), PLN(A.vmap_g, 1, rows, cols, cy_, cx_), PLN(A.vmap_g, 2, rows, cols, cy_, cx_));
+            f3 np = mk3(PLN(A.nmap_g, 0, rows, cols, cy_, cx_), PLN(A.nmap_g, 1, rows, cols, cy_, cx_), PLN(A.nmap_g, 2, rows, cols, cy_, cx_));
+            float c1 = PLN(A.ck1_g, 3, rows, cols, cy_, cx_), c2 = PLN(A.ck2_g, 3, rows, cols, cy_, cx_);
+            if (hd_isnanf(vp.x) || hd_isnanf(np.x) || hd_isnanf(c1) || hd_isnanf(c2)) continue;
+            float dist = len3(sub3(vp, vg_)), sine = len3(cross3(ncur_g, np));
+            if (sine > A.angleThres || dist > A.distThres) continue;
+            float p = 1.0f;
+            if (A.use_search) {
+                float a1 = hd_fabsf(c1), a2 = hd_fabsf(c2);
+                float ckmax = a1 > a2 ? a1 : a2;
+                float D_p = dist / DpR;
+                float D_n = 1.0f - dot3(np, ncur_g);
+                float D_c = 1.0f - hd_expf(-hd_fabsf(c1 - ck1) / ckmax) * hd_expf(-hd_fabsf(c2 - ck2) / ckmax);
+                p = (0.333f * D_p + 0.333f * D_n) + 0.333f * D_c;
+            }
+            if (p < p_smallest) { bx = cx_; by = cy_; bv = vp; bn = np; p_smallest = p; }
+            found = true;
+        }
+    if (!found) return false;
+    f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
+    f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
+    f3 n_cp = m33_mul(Rpi, bn);
+    float weight = 1.0f;
+    if (A.use_weight) { float w = A.icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
+    float row[7];
+    f3 cr = cross3(s_cp, n_cp);
+    row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
+    row[6] = dot3(n_cp, sub3(s_cp, d_cp));
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 7; ++j) out[k++] = weight * row[i] * row[j];
+    out[27] = weight * row[6] * row[6];
+    out[28] = 1.0f;
+    return true;
+}
+
+// RGBResidual::getProducts (reduce.cu:981-1060)
+__device__ __forceinline__ void rgb_residual_pixel(const OdoLevel &L, const OdoState *st, float minScale, int k,
+                                                   int16_t *__restrict__ corres, float *__restrict__ corres_diff,
+                                                   long long &cnt, long long &sig)
+{
+    const int rows = L.rows, cols = L.cols;
+    const int i = k / cols, j0 = k - i * cols;
+    int16_t *co = &corres[(size_t)k * 6];
+    int16_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    float dout = 0.0f;
+    if (j0 < cols - 5 && i < rows - 1) {
+        bool valid = true;
+        for (int u = (i - 2 > 0 ? i - 2 : 0); u < (i + 2 < rows ? i + 2 : rows); ++u)
+            for (int v = (j0 - 2 > 0 ? j0 - 2 : 0); v < (j0 + 2 < cols ? j0 + 2 : cols); ++v)
+                valid = valid && (L.next_image[u * cols + v] > 0);
+        if (valid) {
+            int valx = L.dIdx[k], valy = L.dIdy[k];
+            float mTwo = (float)((valx * valx) + (valy * valy));
+            if (mTwo >= minScale) {
+                const int y = i, x = j0;
+                float d1 = L.next_depth[y * cols + x];
+                if (!hd_isnanf(d1)) {
+                    const float *krk = st->krk;
+                    float td1 = d1 * ((krk[6] * (float)x + krk[7] * (float)y) + krk[8]) + st->kt[2];
+                    float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + st->kt[0]) / td1;
+                    float fv = (d1 * ((krk[3] * (float)x + krk[4] * (float)y) + krk[5]) + st->kt[1]) / td1;
+                    if (fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f) {
+                        int u0 = (int)hd_rintf(fu), v0 = (int)hd_rintf(fv);
+                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                            float d0 = L.last_depth[v0 * cols + u0];
+                            if (d0 > 0.0f && hd_fabsf(td1 - d0) <= 0.07f && L.last_image[v0 * cols + u0] != 0) {
+                                float diff = (float)L.next_image[y * cols + x] - (float)L.last_image[v0 * cols + u0];
+                                c0 = (int16_t)u0; c1 = (int16_t)v0; c2 = (int16_t)x; c3 = (int16_t)y; c4 = 1;
+                                dout = diff;
+                                cnt += 1;
+                                sig += (long long)(diff * diff);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    co[0] = c0; co[1] = c1; co[2] = c2; co[3] = c3; co[4] = c4; co[5] = 0;
+    corres_diff[k] = dout;
+}
+
+// blocks [0, nb) : ICP products ; blocks [nb, 2nb) : RGB residual.  Both read the same OdoState.
+__global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, const OdoState *__restrict__ st, int nb,
+                                                       int do_icp, int do_rgb, float minScale,
+                                                       long long *__restrict__ icp_part, long long *__restrict__ res_part,
+                                                       int16_t *__restrict__ corres, float *__restrict__ corres_diff)
+{
+    if ((int)blockIdx.x < nb) {
+        float out[29];
+#pragma unroll
+        for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+        bool valid = false;
+        const int i = blockIdx.x * RB + threadIdx.x;
+        if (do_icp && !st->gn_break && i < A.rows * A.cols) {
+            const int y = i / A.cols, x = i - y * A.cols;
+            valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
+                              mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
+        }
+        // icp_part rows are indexed by blockIdx.x in [0, nb)
+        block_reduce_exact<29>(out, valid, icp_part);
+    } else {
+        __shared__ long long s_c[RB / 64], s_s[RB / 64];
+        const int b = blockIdx.x - nb;
+        const int k = b * RB + threadIdx.x;
+        long long cnt = 0, sig = 0;
+        if (do_rgb && !st->gn_break && k < L.rows * L.cols)
+            rgb_residual_pixel(L, st, minScale, k, corres, corres_diff, cnt, sig);
+        for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
+        if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long c = 0, s = 0;
+            for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
+            res_part[b * 2] = c; res_part[b * 2 + 1] = s;
+        }
+    }
+}
+
+// RGBReduction::getProducts (reduce.cu:717-808); every workgroup first folds the residual partials
+// into (count, sigma) and derives sigmaVal (RGBDOdometry.cpp:1017-1030)
+__global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__restrict__ st, int nb, float fx, float fy,
+                                                    int rgb_only, int use_grad, const long long *__restrict__ res_part,
+                                                    const int16_t *__restrict__ corres,
+                                                    const float *__restrict__ corres_diff, long long *__restrict__ rgb_part,
+                                                    long long *__restrict__ totals_res)
+{
+    __shared__ long long s_c[RB / 64], s_s[RB / 64];
+    __shared__ float s_sigma;
+    __shared__ int s_break;
+    long long cnt = 0, sig = 0;
+    for (int b = threadIdx.x; b < nb; b += RB) { cnt += res_part[b * 2]; sig += res_part[b * 2 + 1]; }
+    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c = 0, s = 0;
+        for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
+        float sigmaVal = hd_sqrtf((((float)s / (float)c) == 0.0f) ? 1.0f : (float)c);
+        float rgbError = (float)(hd_sqrt((double)s) / (double)(c == 0 ? 1 : c));
+        int brk = st->gn_break;
+        if (rgb_only && rgbError > st->lastRGBError) brk = 1;
+        if (rgb_only) sigmaVal = -1.0f;
+        s_sigma = sigmaVal; s_break = brk;
+        if (blockIdx.x == 0) { totals_res[0] = c; totals_res[1] = s; }
+    }
+    __syncthreads();
+    const float sigma = s_sigma;
+    const int brk = s_break;
+    float out[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+    bool valid = false;
+    const int k = blockIdx.x * RB + threadIdx.x;
+    const int cols = L.cols;
+    if (!brk && k < L.rows * cols) {
+        const int16_t *co = &corres[(size_t)k * 6];
+        if (co[4]) {
+            valid = true;
+            float diff = corres_diff[k];
+            float w = sigma + hd_fabsf(diff);
+            w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
+            if (sigma == -1.0f) w = 1.0f;
+            float row[7];
+            row[6] = -w * diff;
+            const float *cpp = &L.cloud[((size_t)co[1] * cols + co[0]) * 3];
+            const float cpx = cpp[0], cpy = cpp[1], cpz = cpp[2];
+            float invz = 1.0f / cpz;
+            float dIx = w * 0.125f * (float)L.dIdx[co[3] * cols + co[2]];
+            float dIy = w * 0.125f * (float)L.dIdy[co[3] * cols + co[2]];
+            float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
+            float v2 = -(v0 * cpx + v1 * cpy) * invz;
+            row[0] = v0; row[1] = v1; row[2] = v2;
+            row[3] = -cpz * v1 + cpy * v2;
+            row[4] = cpz * v0 - cpx * v2;
+            row[5] = -cpy * v0 + cpx * v1;
+            float rw = 1.0f;
+            if (use_grad) {
+                float gm = hd_sqrtf(dIx * dIx + dIy * dIy);
+                rw = hd_expf(-0.5f * (10.0f / gm) * (10.0f / gm));
+            }
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 7; ++j) out[q++] = rw * row[i] * row[j];
+            out[27] = rw * row[6] * row[6];
+            out[28] = 1.0f;
+        }
+    }
+    block_reduce_exact<29>(out, valid, rgb_part);
+}
+
+__device__ inline void unpack27(const double *s, float *A, float *b)
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            float value = (float)s[shift++];
+            if (j == 6) b[i] = value; else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+}
+
+// solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93); also prepares the
+// operands of the next iteration (possibly on the next pyramid level).
+__global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, const long long *__restrict__ icp_part,
+                                                   const long long *__restrict__ rgb_part, int nb,
+                                                   long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
+                                                   int next_level, int level_changes)
+{
+    if (do_reduce) {
+        sum_partials(icp_part, nb, 87, totals);
+        sum_partials(rgb_part, nb, 87, totals + 87);
+    }
+    if (threadIdx.x != 0) return;
+    const int rgbOnly = cfg.rgb_only;
+    const int icp = !rgbOnly && cfg.icp_weight > 0.0f;
+    const int rgb = rgbOnly || cfg.icp_weight < 100.0f;
+    const long long c = totals[174], sg = totals[175];
+    if (rgb) {
+        float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
+        if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
+        if (!st->gn_break) st->lastRGBError = rgbError;
+    }
+    if (!st->gn_break) {
+        float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+        for (int k = 0; k < 36; ++k) A_icp[k] = A_rgb[k] = 0.0f;
+        for (int k = 0; k < 6; ++k) b_icp[k] = b_rgb[k] = 0.0f;
+        double s[29];
+        if (icp) {
+            for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals, i);
+            unpack27(s, A_icp, b_icp);
+            st->res_icp[0] = (float)s[27]; st->res_icp[1] = (float)s[28];
+        }
+        st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
+        st->last_icp_count = st->res_icp[1];
+        if (rgb) {
+            for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals + 87, i);
+            unpack27(s, A_rgb, b_rgb);
+        }
+        double lastA[36], lastb[6], result[6];
+        if (icp && rgb) {
+            double w = cfg.icp_weight, ww = w * w;
+            for (int k = 0; k < 36; ++k) lastA[k] = (double)A_rgb[k] + ww * (double)A_icp[k];
+            for (int k = 0; k < 6; ++k) lastb[k] = (double)b_rgb[k] + w * (double)b_icp[k];
+        } else if (icp) {
+            for (int k = 0; k < 36; ++k) lastA[k] = A_icp[k];
+            for (int k = 0; k < 6; ++k) lastb[k] = b_icp[k];
+        } else {
+            for (int k = 0; k < 36; ++k) lastA[k] = A_rgb[k];
+            for (int k = 0; k < 6; ++k) lastb[k] = b_rgb[k];
+        }
+        ldlt_solve<double, 6>(6, lastA, lastb, result);
+        double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
+        rodrigues(rv, Ru);
+        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
+        U[12] = U[13] = U[14] = 0; U[15] = 1;
+        double *Rt = st->Rt;
+        for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k)
+            N[r * 4 + k] = ((U[r * 4] * Rt[k] + U[r * 4 + 1] * Rt[4 + k]) + U[r * 4 + 2] * Rt[8 + k]) + U[r * 4 + 3] * Rt[12 + k];
+        for (int k = 0; k < 16; ++k) Rt[k] = N[k];
+        float oR[9], ot[3];
+        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }
+        float iR[9], it_[3];
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[k * 3 + r];
+        for (int r = 0; r < 3; ++r) it_[r] = -((iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1]) + iR[r * 3 + 2] * ot[2]);
+        float Rc[9];
+        mul3<float>(st->Rprev, iR, Rc);
+        for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rc[k];
+        f3 rt = m33_mul(st->Rprev, mk3(it_[0], it_[1], it_[2]));
+        st->tcurr[0] = rt.x + st->tprev[0]; st->tcurr[1] = rt.y + st->tprev[1]; st->tcurr[2] = rt.z + st->tprev[2];
+    }
+    if (level_changes) { st->gn_break = 0; st->lastRGBError = 3.402823466e+38f; }
+    if (next_level >= 0) {
+        const int div = 1 << next_level;
+        gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+    }
+}
+
+// end of registration: 0.3 m guard (RGBDOdometry.cpp:1232-1236), publish the pose
+__global__ void k_odo_end(OdoState *st, DevPose *dp, OdoConfig cfg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
+    if (rgb) {
+        f3 d = mk3(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
+        if (len3(d) > 0.3f) {
+            for (int k = 0; k < 9; ++k) st->Rcurr[k] = st->Rprev[k];
+            for (int k = 0; k < 3; ++k) st->tcurr[k] = st->tprev[k];
+        }
+    }
+    for (int k = 0; k < 9; ++k) dp->pose.r[k] = st->Rcurr[k];
+    for (int k = 0; k < 3; ++k) dp->pose.t[k] = st->tcurr[k];
+    dp->tinv = rigid_inverse(dp->pose);
+    dp->last_icp_error = st->last_icp_error;
+    dp->last_icp_count = st->last_icp_count;
+}
+
+// ------------------------------------------------------------------------------------------ pose bookkeeping
+__global__ void k_pose_set(DevPose *dp, Rigid p, int also_prev)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    dp->pose = p;
+    dp->tinv = rigid_inverse(p);
+    if (also_prev) dp->prev = p;
+}
+__global__ void k_pose_commit_prev(DevPose *dp)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) dp->prev = dp->pose;
+}
+
+// HRBFFusion::rodrigues2 (HRBFFusion.cpp:2004-2050) without the JacobiSVD re-orthonormalisation
+__device__ inline f3 rodrigues2(const float *R)
+{
+    double rx = (double)R[7] - (double)R[5], ry = (double)R[2] - (double)R[6], rz = (double)R[3] - (double)R[1];
+    double s = hd_sqrt(((rx * rx + ry * ry) + rz * rz) * 0.25);
+    double cth = ((double)((R[0] + R[4]) + R[8]) - 1.0) * 0.5;
+    cth = cth > 1.0 ? 1.0 : (cth < -1.0 ? -1.0 : cth);
+    double theta = hd_acos(cth);
+    if (s < 1e-5) {
+        if (cth > 0) rx = ry = rz = 0;
+        else {
+            double t;
+            t = ((double)R[0] + 1.0) * 0.5; rx = hd_sqrt(t > 0.0 ? t : 0.0);
+            t = ((double)R[4] + 1.0) * 0.5; ry = hd_sqrt(t > 0.0 ? t : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
+            t = ((double)R[8] + 1.0) * 0.5; rz = hd_sqrt(t > 0.0 ? t : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
+            double arx = rx < 0 ? -rx : rx, ary = ry < 0 ? -ry : ry, arz = rz < 0 ? -rz : rz;
+            if (arx < ary && arx < arz && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= hd_sqrt((rx * rx + ry * ry) + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1.0 / (2.0 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    return mk3((float)rx, (float)ry, (float)rz);
+}
+
+// velocity weighting (HRBFFusion.cpp:1112-1123): diff = currPose^-1 * lastPose
+__global__ void k_frame_weighting(DevPose *dp, float weight_multiplier)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Rigid inv = dp->tinv, last = dp->prev;
+    float Rm[9];
+    mul3<float>(inv.r, last.r, Rm);
+    f3 lt = m33_mul(inv.r, mk3(last.t[0], last.t[1], last.t[2]));
+    f3 dt = mk3(lt.x + inv.t[0], lt.y + inv.t[1], lt.z + inv.t[2]);
+    float a = len3(dt), b = len3(rodrigues2(Rm));
+    float weighting = a > b ? a : b;
+    const float largest = 0.01f, minWeight = 0.5f;
+    if (weighting > largest) weighting = largest;
+    float wv = 1.0f - (weighting / largest);
+    dp->weighting = (wv > minWeight ? wv : minWeight) * weight_multiplier;
+}
+
+void launch_pose_set(hipStream_t s, DevPose *dp, const float p[16], int also_prev)
+{
+    Rigid r;
+    for (int i = 0; i < 3; ++i) { for (int k = 0; k < 3; ++k) r.r[i * 3 + k] = p[k * 4 + i]; r.t[i] = p[12 + i]; }
+    hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(1), 0, s, dp, r, also_prev);
+}
+void launch_frame_epilogue(hipStream_t s, DevPose *dp, float weight_multiplier, int tracked)
+{
+    (void)tracked;
+    hipLaunchKernelGGL(k_frame_weighting, dim3(1), dim3(1), 0, s, dp, weight_multiplier);
+}
+void launch_pose_commit_prev(hipStream_t s, DevPose *dp)
+{
+    hipLaunchKernelGGL(k_pose_commit_prev, dim3(1), dim3(1), 0, s, dp);
+}
+
+void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb)
+{
+    const OdoLevel &L0 = ob.lv[0];
+    int P = L0.rows * L0.cols;
+    hipLaunchKernelGGL(k_first_rgb, dim3((P + 255) / 256), dim3(256), 0, s, P, rgb, L0.last_next_image);
+    for (int i = 0; i + 1 < HRBF_NUM_PYRS; ++i) {
+        int n = ob.lv[i + 1].rows * ob.lv[i + 1].cols;
+        hipLaunchKernelGGL(k_pyrdown_u8, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i].last_next_image, ob.lv[i].rows,
+                           ob.lv[i].cols, ob.lv[i + 1].last_next_image);
+    }
+}
+
+static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
+{
+    IcpArgs A;
+    A.vmap_c = L.vmap_c; A.nmap_c = L.nmap_c; A.ck1_c = L.ck1_c; A.ck2_c = L.ck2_c;
+    A.vmap_g = L.vmap_g; A.nmap_g = L.nmap_g; A.ck1_g = L.ck1_g; A.ck2_g = L.ck2_g; A.icpw = L.icpw;
+    A.rows = L.rows; A.cols = L.cols;
+    const int div = 1 << level;
+    A.fx = cfg.fx / div; A.fy = cfg.fy / div; A.cx = cfg.cx / div; A.cy = cfg.cy / div;
+    A.distThres = 0.1f; A.angleThres = 0.3420201433f;   // sin(20 deg), RGBDOdometry.h:65-66
+    A.use_search = cfg.use_search; A.radius = cfg.search_radius; A.use_weight = cfg.use_weighted;
+    return A;
+}
+
+void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp, void *comm,
+                     int rank, int world)
+{
+    (void)rank;
+    const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
+    const int icp = !cfg.rgb_only && cfg.icp_weight > 0.0f;
+    const int P = ob.lv[0].rows * ob.lv[0].cols;
+    // O1: pyramids
+    hipLaunchKernelGGL(k_odo_level0, dim3((P + 255) / 256), dim3(256), 0, s, P, ob.lv[0], src, dp, cfg.frame_to_frame_rgb,
+                       cfg.curv_thr);
+    for (int i = 1; i < HRBF_NUM_PYRS; ++i) {
+        int n = ob.lv[i].rows * ob.lv[i].cols;
+        hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);
+    }
+    for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
+        int n = ob.lv[i].rows * ob.lv[i].cols, div = 1 << i;
+        hipLaunchKernelGGL(k_odo_transform, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i], dp);
+        hipLaunchKernelGGL(k_odo_sobel_cloud, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i], cfg.fx / div, cfg.fy / div,
+                           cfg.cx / div, cfg.cy / div, rgb);
+    }
+    hipLaunchKernelGGL(k_odo_begin, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
+    const bool multi = comm != nullptr && world > 1;
+    // O2: SO3 pre-alignment on level 2
+    if (cfg.so3) {
+        const OdoLevel &L = ob.lv[2];
+        const int nb = (L.rows * L.cols + RB - 1) / RB;
+        for (int it = 0; it < 10; ++it) {
+            hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part);
+            hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.so3_part, nb, ob.totals + 176, 1, cfg);
+        }
+    }
+    // O3-O6: coarse-to-fine Gauss-Newton
+    int iterations[3] = {cfg.fast_odom ? 3 : 10, cfg.pyramid ? 5 : 0, cfg.pyramid ? 4 : 0};
+    int first_level = -1;
+    for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) if (iterations[i] > 0) { first_level = i; break; }
+    hipLaunchKernelGGL(k_gn_begin, dim3(1), dim3(1), 0, s, ob.state, cfg, first_level < 0 ? 0 : first_level);
+    const float minGrad[3] = {5, 3, 1};
+    for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) {
+        const OdoLevel &L = ob.lv[i];
+        const int nb = (L.rows * L.cols + RB - 1) / RB;
+        const int div = 1 << i;
+        IcpArgs A = make_icp_args(L, cfg, i);
+        const float minScale = (float)(((double)minGrad[i] * (double)minGrad[i]) / (0.125 * 0.125));
+        for (int j = 0; j < iterations[i]; ++j) {
+            hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
+                               ob.icp_part, ob.res_part, ob.corres, ob.corres_diff);
+            hipLaunchKernelGGL(k_gn_rgb_step, dim3(nb), dim3(RB), 0, s, L, ob.state, nb, cfg.fx / div, cfg.fy / div,
+                               cfg.rgb_only, cfg.rgb_use_grad, ob.res_part, ob.corres, ob.corres_diff, ob.rgb_part,
+                               ob.totals + 174);
+            // operands for the next iteration: same level, or the next non-empty finer level
+            const bool last_of_level = (j == iterations[i] - 1);
+            int next_level = i;
+            if (last_of_level) {
+                next_level = -1;
+                for (int k = i - 1; k >= 0; --k) if (iterations[k] > 0) { next_level = k; break; }
+            }
+            (void)multi;
+            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, nb, ob.totals, 1,
+                               cfg, next_level, last_of_level ? 1 : 0);
+        }
+    }
+    hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
+    if (cfg.so3)   // swap NextImage <-> lastNextImage (RGBDOdometry.cpp:1239-1245): pointer swap, no copy
+        for (int i = 0; i < HRBF_NUM_PYRS; ++i) { uint8_t *t = ob.lv[i].last_next_image; ob.lv[i].last_next_image = ob.lv[i].next_image; ob.lv[i].next_image = t; }
+}
+
+// ------------------------------------------------------------------------------------------ icpStep seam
+__global__ __launch_bounds__(RB) void k_icp_only(IcpArgs A, Rigid cur, Rigid prevInv_and_tprev, long long *__restrict__ part)
+{
+    float out[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+    bool valid = false;
+    const int i = blockIdx.x * RB + threadIdx.x;
+    if (i < A.rows * A.cols) {
+        const int y = i / A.cols, x = i - y * A.cols;
+        valid = icp_pixel(A, cur.r, mk3(cur.t[0], cur.t[1], cur.t[2]), prevInv_and_tprev.r,
+                          mk3(prevInv_and_tprev.t[0], prevInv_and_tprev.t[1], prevInv_and_tprev.t[2]), x, y, out);
+    }
+    block_reduce_exact<29>(out, valid, part);
+}
+
+int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                 const float *nmap_curr, const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9],
+                 const float tprev[3], float fx, float fy, float cx, float cy, const float *vmap_g_prev,
+                 const float *nmap_g_prev, const float *ck1_g_prev, const float *ck2_g_prev, const float *icpw, int rows,
+                 int cols, float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
+                 double residual_out[2])
+{
+    IcpArgs A;
+    A.vmap_c = vmap_curr; A.nmap_c = nmap_curr; A.ck1_c = ck1_curr; A.ck2_c = ck2_curr;
+    A.vmap_g = vmap_g_prev; A.nmap_g = nmap_g_prev; A.ck1_g = ck1_g_prev; A.ck2_g = ck2_g_prev; A.icpw = icpw;
+    A.rows = rows; A.cols = cols; A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
+    A.distThres = dist_thresh; A.angleThres = angle_thresh; A.use_search = 0; A.radius = 0; A.use_weight = use_weight;
+    Rigid cur, prv;
+    for (int k = 0; k < 9; ++k) { cur.r[k] = Rcurr[k]; prv.r[k] = Rprev_inv[k]; }
+    for (int k = 0; k < 3; ++k) { cur.t[k] = tcurr[k]; prv.t[k] = tprev[k]; }
+    const int nb = (rows * cols + RB - 1) / RB;
+    long long *part = nullptr;
+    HIP_CHECK(hipMalloc(&part, sizeof(long long) * 87 * (size_t)nb));
+    hipLaunchKernelGGL(k_icp_only, dim3(nb), dim3(RB), 0, s, A, cur, prv, part);
+    long long *h = (long long *)malloc(sizeof(long long) * 87 * (size_t)nb);
+    hipError_t e = hipMemcpyAsync(h, part, sizeof(long long) * 87 * (size_t)nb, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(part);
+    if (e != hipSuccess) { free(h); hrbf_set_error("icp_step: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    long long tot[87];
+    for (int t = 0; t < 87; ++t) tot[t] = 0;
+    for (int b = 0; b < nb; ++b) for (int t = 0; t < 87; ++t) tot[t] += h[(size_t)b * 87 + t];
+    free(h);
+    double sums[29];
+    for (int i = 0; i < 29; ++i) sums[i] = hd_acc_to_double(hd_limbs_combine(tot[i * 3], tot[i * 3 + 1], tot[i * 3 + 2]));
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            double v = sums[shift++];
+            if (j == 6) b_out[i] = v; else A_out[j * 6 + i] = A_out[i * 6 + j] = v;
+        }
+    residual_out[0] = sums[27]; residual_out[1] = sums[28];
+    return HRBF_OK;
+}

@@ -1,0 +1,404 @@
+// k_pre.hip — per-frame pre-processing kernels for gfx950.
+//
+// Replaces the GLSL passes driven by HRBFFusion::filterDepth / metriciseDepth /
+// computeVertexNormalRadius / computeCurvatureGradient / updateNormalRad / VertexConfidence
+// (Core/src/HRBFFusion.cpp:1263-1345; shaders depth_bilateral.frag, depth_metric_*.frag,
+// depth_vertex_normal_radius.frag, depth_curvature_gradient.frag, depth_confidence_evaluation.frag).
+// Compute-bound window kernels: 16x16 pixel tiles (4 wavefronts), window halo staged in LDS.
+#include "common.h"
+#include "kernels.h"
+
+#define TB 16   // tile edge; 256 threads = 4 wave64
+
+// ---------------------------------------------------------------------------------------------
+// P1 + P2: bilateral (13x13) or gated Gaussian (9x9) on raw depth, plus both metric images.
+// LDS: (16+12)^2 raw depths as float-mm (value / adj precomputed once per texel).
+template <bool BILATERAL>
+__global__ __launch_bounds__(256) void k_filter_metric(Cam cam, const uint16_t *__restrict__ raw,
+                                                       float *__restrict__ filtered, float *__restrict__ metric,
+                                                       float *__restrict__ metric_f, float depthFactor, float maxD)
+{
+    constexpr int R = BILATERAL ? 6 : 4;
+    constexpr int TW = TB + 2 * R;
+    __shared__ float tile[TW * TW];
+    const int W = cam.W, H = cam.H;
+    const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
+    const float adj = 1.0f / (depthFactor * 1000.0f);
+    for (int i = threadIdx.y * TB + threadIdx.x; i < TW * TW; i += TB * TB) {
+        int tx = i % TW, ty = i / TW;
+        int gx = bx + tx - R, gy = by + ty - R;
+        float v = 0.0f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = (float)raw[gy * W + gx] / adj;
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int x = bx + threadIdx.x, y = by + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int lx = threadIdx.x + R, ly = threadIdx.y + R;
+    const float value = tile[ly * TW + lx];
+    float out;
+    if (value > maxD * 1000.0f || value < 300.0f) out = 0.0f;
+    else {
+        int x0 = x - R > 0 ? x - R : 0, x1 = x + R + 1 < W ? x + R + 1 : W;
+        int y0 = y - R > 0 ? y - R : 0, y1 = y + R + 1 < H ? y + R + 1 : H;
+        float sum1 = 0.0f, sum2 = 0.0f;
+        for (int cy = y0; cy < y1; ++cy) {
+            const float dy = (float)y - (float)cy;
+            const float *row = &tile[(cy - by + R) * TW + (R - bx)];
+            for (int cx = x0; cx < x1; ++cx) {
+                float tmp = row[cx];
+                float dx = (float)x - (float)cx;
+                if (BILATERAL) {
+                    float space2 = dx * dx + dy * dy;
+                    float dv = value - tmp;
+                    float color2 = dv * dv;
+                    float weight = hd_expf(-(space2 * 0.024691358f + color2 * 0.000555556f));
+                    sum1 += tmp * weight;
+                    sum2 += weight;
+                } else if (tmp > 300.0f && hd_fabsf(tmp - value) < 100.0f) {
+                    float weight = hd_expf(-((dx * dx + dy * dy) / (2.0f * 3.0f * 3.0f)));
+                    sum1 += tmp * weight;
+                    sum2 += weight;
+                }
+            }
+        }
+        out = (sum1 / sum2) * adj;
+    }
+    const int i = y * W + x;
+    filtered[i] = out;
+    // metriciseDepth (depth_metric_raw.frag:29-42, depth_metric_filtered.frag:29-41)
+    const uint32_t hi = (uint32_t)(maxD / depthFactor), lo = (uint32_t)(0.3f / depthFactor);
+    const float fhi = maxD / depthFactor, flo = 0.3f / depthFactor;
+    uint32_t v = raw[i];
+    metric[i] = (v > hi || v < lo) ? 0.0f : (float)v * depthFactor;
+    metric_f[i] = (out > fhi || out < flo) ? 0.0f : out * depthFactor;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P3: vertex / PCA normal / radius (depth_vertex_normal_radius.frag:23-68, geometry.glsl:63-244)
+__device__ __forceinline__ f3 roots2(float b, float cc)
+{
+    float d = b * b - 4.0f * cc;
+    if (d < 0.0f) d = 0.0f;
+    float sd = hd_sqrtf(d);
+    return mk3(0.0f, 0.5f * (b + sd), 0.5f * (b - sd));
+}
+
+__device__ __forceinline__ f3 compute_roots(float m00, float m10, float m20, float m11, float m21, float m22)
+{
+    float c0 = (((m00 * m11 * m22 + 2.0f * m10 * m20 * m21) - m00 * m21 * m21) - m11 * m20 * m20) - m22 * m10 * m10;
+    float c1 = ((((m00 * m11 - m10 * m10) + m00 * m22) - m20 * m20) + m11 * m22) - m21 * m21;
+    float c2 = (m00 + m11) + m22;
+    if (hd_fabsf(c0) < 0.000001f) return roots2(c2, c1);
+    const float s_inv3 = 1.0f / 3.0f;
+    const float s_sqrt3 = 1.7320508075688772f;
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    float rho = hd_sqrtf(-a_over_3);
+    float theta = hd_atan2f(hd_sqrtf(-q), half_b) * s_inv3;
+    float st, ct;
+    hd_sincosf(theta, &st, &ct);
+    f3 r;
+    r.x = c2_over_3 + 2.0f * rho * ct;
+    r.y = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    r.z = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    if (r.x >= r.y) { float t = r.x; r.x = r.y; r.y = t; }
+    if (r.y >= r.z) {
+        float t = r.y; r.y = r.z; r.z = t;
+        if (r.x >= r.y) { float t1 = r.x; r.x = r.y; r.y = t1; }
+    }
+    if (r.x <= 0.0f) return roots2(c2, c1);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_vertex_normal_radius(Cam cam, const float *__restrict__ depth_metric,
+                                                              const float *__restrict__ depth_metric_f,
+                                                              float4 *__restrict__ vertex_raw,
+                                                              float4 *__restrict__ vertex_filtered,
+                                                              float4 *__restrict__ normal,
+                                                              float4 *__restrict__ normal_pca,
+                                                              float *__restrict__ radius, float radius_mult,
+                                                              int use_pca)
+{
+    constexpr int R = 3, TW = TB + 2 * R;
+    __shared__ float tile[TW * TW];
+    const int W = cam.W, H = cam.H;
+    const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
+    for (int i = threadIdx.y * TB + threadIdx.x; i < TW * TW; i += TB * TB) {
+        int tx = i % TW, ty = i / TW;
+        int gx = clampi(bx + tx - R, 0, W - 1), gy = clampi(by + ty - R, 0, H - 1);
+        tile[i] = depth_metric_f[gy * W + gx];
+    }
+    __syncthreads();
+    const int px = bx + threadIdx.x, py = by + threadIdx.y;
+    if (px >= W || py >= H) return;
+    const int i = py * W + px;
+    const float cx = cam.cx, cy = cam.cy, camz = cam.camz, camw = cam.camw;
+    const float zr = depth_metric[i], zf = tile[(threadIdx.y + R) * TW + threadIdx.x + R];
+    f3 vr = mk3(((float)px - cx) * zr * camz, ((float)py - cy) * zr * camw, zr);
+    f3 vf = mk3(((float)px - cx) * zf * camz, ((float)py - cy) * zf * camw, zf);
+    f3 n = mk3(0.0f, 0.0f, 0.0f);
+    if (use_pca) {
+        int x0 = px - 3, x1 = px + 3, y0 = py - 3, y1 = py + 3;
+        float xoff = 0.5f, yoff = 0.5f;
+        if (x0 < 0) { x0 = 0; xoff = 0.0f; }
+        if (y0 < 0) { y0 = 0; yoff = 0.0f; }
+        if (x1 > W - 1) x1 = W - 1;
+        if (y1 > H - 1) y1 = H - 1;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+        int cnt = 0;
+        for (int ix = x0; ix <= x1; ++ix)
+            for (int iy = y0; iy <= y1; ++iy) {
+                float z = tile[(iy - by + R) * TW + (ix - bx + R)];
+                if (z > 0.3f && hd_fabsf(z - vf.z) < 0.05f) {
+                    float X = (((float)ix + xoff) - cx) * z * camz;
+                    float Y = (((float)iy + yoff) - cy) * z * camw;
+                    a0 += X * X; a1 += X * Y; a2 += X * z; a3 += Y * Y; a4 += Y * z; a5 += z * z;
+                    a6 += X; a7 += Y; a8 += z;
+                    cnt++;
+                }
+            }
+        if (cnt >= 8) {
+            float fn = (float)cnt;
+            a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
+            float m00 = a0 - a6 * a6, m10 = a1 - a6 * a7, m20 = a2 - a6 * a8;
+            float m11 = a3 - a7 * a7, m21 = a4 - a7 * a8, m22 = a5 - a8 * a8;
+            float s01 = m00 > m10 ? m00 : m10, s23 = m20 > m11 ? m20 : m11;
+            float s0123 = s01 > s23 ? s01 : s23;
+            float s45 = m21 > m22 ? m21 : m22;
+            float scale = s0123 > s45 ? s0123 : s45;
+            float n00 = m00 / scale, n10 = m10 / scale, n20 = m20 / scale, n11 = m11 / scale, n21 = m21 / scale,
+                  n22 = m22 / scale;
+            f3 ev = compute_roots(m00, m10, m20, m11, m21, m22);
+            float eigenvalue = ev.x * scale;
+            n00 -= eigenvalue; n11 -= eigenvalue; n22 -= eigenvalue;
+            f3 row0 = mk3(n00, n10, n20), row1 = mk3(n10, n11, n21), row2 = mk3(n20, n21, n22);
+            f3 v1 = cross3(row0, row1), v2 = cross3(row0, row2), v3 = cross3(row1, row2);
+            float l1 = len3(v1), l2 = len3(v2), l3 = len3(v3);
+            f3 nrm;
+            if (l1 >= l2 && l1 >= l3) nrm = v1;
+            else if (l2 >= l1 && l2 >= l3) nrm = v2;
+            else nrm = v3;
+            if (nrm.z < 0.0f) nrm = mk3(-nrm.x, -nrm.y, -nrm.z);
+            n = normalize3(nrm);
+        }
+    } else {
+        // central differences (geometry.glsl:36-51) gated by checkNeighbours on the RAW depth (utils.glsl:23-41)
+        bool ok = depth_metric[py * W + clampi(px - 1, 0, W - 1)] != 0.0f &&
+                  depth_metric[clampi(py - 1, 0, H - 1) * W + px] != 0.0f &&
+                  depth_metric[py * W + clampi(px + 1, 0, W - 1)] != 0.0f &&
+                  depth_metric[clampi(py + 1, 0, H - 1) * W + px] != 0.0f;
+        if (ok) {
+            const int lx = threadIdx.x + R, ly = threadIdx.y + R;
+            float z;
+            z = tile[ly * TW + lx + 1]; f3 vxf = mk3(((float)(px + 1) - cx) * z * camz, ((float)py - cy) * z * camw, z);
+            z = tile[ly * TW + lx - 1]; f3 vxb = mk3(((float)(px - 1) - cx) * z * camz, ((float)py - cy) * z * camw, z);
+            z = tile[(ly + 1) * TW + lx]; f3 vyf = mk3(((float)px - cx) * z * camz, ((float)(py + 1) - cy) * z * camw, z);
+            z = tile[(ly - 1) * TW + lx]; f3 vyb = mk3(((float)px - cx) * z * camz, ((float)(py - 1) - cy) * z * camw, z);
+            f3 del_x = sub3(scale3(add3(vxb, vf), 0.5f), scale3(add3(vxf, vf), 0.5f));
+            f3 del_y = sub3(scale3(add3(vyb, vf), 0.5f), scale3(add3(vyf, vf), 0.5f));
+            n = normalize3(cross3(del_x, del_y));
+        }
+    }
+    float radius_init = radius_mult * get_radius(vf.z, n.z, camz, camw);
+    normal_pca[i] = make_float4(n.x, n.y, n.z, radius_init);
+    if (len3(n) < 0.3f || vr.z < 0.3f || vf.z < 0.3f) {
+        vr = mk3(0, 0, 0); vf = mk3(0, 0, 0); n = mk3(0, 0, 0); radius_init = 0.0f;
+    }
+    vertex_raw[i] = make_float4(vr.x, vr.y, vr.z,
+                                radial_confidence((float)px + 0.5f, (float)py + 0.5f, cx, cy, cam.max_dist, 1.0f));
+    vertex_filtered[i] = make_float4(vf.x, vf.y, vf.z, 1.0f);
+    normal[i] = make_float4(n.x, n.y, n.z, radius_init);
+    radius[i] = radius_init;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P4 + P5: HRBF gradient / Hessian at the pixel's own vertex over its (2w+1)^2 window
+// (depth_curvature_gradient.frag:28-142 + hrbfbase.glsl:37-124,147-195).  The neighbour list of the
+// GLSL is never materialised: gradient and Hessian sums are accumulated in one pass in the same
+// visiting order (x outer, y inner).  LDS: vertex xyz + normal xyzw for tile + halo.
+struct NbTexel { float px, py, pz, nx, ny, nz, rad, valid; };
+
+__global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__restrict__ vertex_filtered,
+                                                   const float4 *__restrict__ normal_in,
+                                                   float4 *__restrict__ curv1, float4 *__restrict__ curv2,
+                                                   float *__restrict__ gradmag, float4 *__restrict__ normal_out,
+                                                   int win)
+{
+    constexpr int RMAX = 3, TW = TB + 2 * RMAX;
+    __shared__ NbTexel tile[TW * TW];
+    const int W = cam.W, H = cam.H;
+    const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
+    for (int i = threadIdx.y * TB + threadIdx.x; i < TW * TW; i += TB * TB) {
+        int tx = i % TW, ty = i / TW;
+        int gx = bx + tx - RMAX, gy = by + ty - RMAX;
+        NbTexel t;
+        t.px = t.py = t.pz = t.nx = t.ny = t.nz = t.rad = 0.0f; t.valid = 0.0f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            float4 v = vertex_filtered[gy * W + gx], n = normal_in[gy * W + gx];
+            t.px = v.x; t.py = v.y; t.pz = v.z; t.nx = n.x; t.ny = n.y; t.nz = n.z; t.rad = n.w;
+            t.valid = (v.z > 0.3f && len3(mk3(n.x, n.y, n.z)) > 0.8f) ? 1.0f : 0.0f;
+        }
+        tile[i] = t;
+    }
+    __syncthreads();
+    const int px = bx + threadIdx.x, py = by + threadIdx.y;
+    if (px >= W || py >= H) return;
+    const int i = py * W + px;
+    const NbTexel me = tile[(threadIdx.y + RMAX) * TW + threadIdx.x + RMAX];
+    float4 pcmax = make_float4(0, 0, 0, 1000.0f), pcmin = make_float4(0, 0, 0, 1000.0f), nopt = make_float4(0, 0, 0, 0);
+    float gmag = 0.0f;
+    if (me.pz > 0.3f && len3(mk3(me.nx, me.ny, me.nz)) > 0.5f) {
+        float k1 = 1000.0f, k2 = 1000.0f;
+        f3 pmax = mk3(0, 0, 0), pmin = mk3(0, 0, 0);
+        int x0 = px - win < 0 ? 0 : px - win, x1 = px + win > W - 1 ? W - 1 : px + win;
+        int y0 = py - win < 0 ? 0 : py - win, y1 = py + win > H - 1 ? H - 1 : py + win;
+        int n = 0;
+        float grx = 0.0f, gry = 0.0f, grz = 0.0f;
+        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g4 = 0.0f, g5 = 0.0f, g8 = 0.0f;
+        for (int ix = x0; ix <= x1; ++ix)
+            for (int iy = y0; iy <= y1; ++iy) {
+                const NbTexel nb = tile[(iy - by + RMAX) * TW + (ix - bx + RMAX)];
+                if (!(hd_fabsf(nb.pz - me.pz) < 0.10f && nb.valid > 0.0f)) continue;
+                n++;
+                const float sx = 10.0f * nb.nx, sy = 10.0f * nb.ny, sz = 10.0f * nb.nz;
+                const float vx = me.px - nb.px, vy = me.py - nb.py, vz = me.pz - nb.pz;
+                const float d2 = (vx * vx + vy * vy) + vz * vz;
+                const float T2 = nb.rad * nb.rad;
+                // getWeightH (hrbfbase.glsl:37-69)
+                float h0, h1, h2, h4, h5, h8;
+                if (d2 > T2) { h0 = h1 = h2 = h4 = h5 = h8 = 0.0f; }
+                else if (d2 == 0.0f) { h0 = h4 = h8 = -20.0f / T2; h1 = h2 = h5 = 0.0f; }
+                else {
+                    float r = hd_sqrtf(d2 / T2);
+                    float s = 1.0f - r;
+                    float s2 = s * s;
+                    float t1 = 20.0f * s2 / (T2 * T2 * r);
+                    float t2 = -r * s * T2;
+                    h0 = t1 * (3.0f * (vx * vx) + t2);
+                    h1 = t1 * 3.0f * vx * vy;
+                    h2 = t1 * 3.0f * vx * vz;
+                    h4 = t1 * (3.0f * (vy * vy) + t2);
+                    h5 = t1 * 3.0f * vy * vz;
+                    h8 = t1 * (3.0f * (vz * vz) + t2);
+                }
+                grx -= (sx * h0 + sy * h1) + sz * h2;
+                gry -= (sx * h1 + sy * h4) + sz * h5;
+                grz -= (sx * h2 + sy * h5) + sz * h8;
+                // getWeightT (hrbfbase.glsl:72-124), only the 18 entries the Hessian consumes
+                if (!(d2 > T2 || d2 == 0.0f)) {
+                    float r = hd_sqrtf(d2 / T2);
+                    float s = 1.0f - r;
+                    float s2 = r - 2.0f + 1.0f / r;
+                    float s3 = 60.0f / (T2 * T2);
+                    float s4 = 1.0f / (r * r);
+                    float prx = vx / (T2 * r), pry = vy / (T2 * r), prz = vz / (T2 * r);
+                    float qx = prx - s4 * prx, qy = pry - s4 * pry, qz = prz - s4 * prz;
+                    float tss = T2 * s * s;
+                    float t0 = s3 * (tss * prx + 2.0f * vx * s2 + vx * vx * qx);
+                    float t1_ = s3 * vy * (qx * vx + s2);
+                    float t2_ = s3 * vz * (qx * vx + s2);
+                    float t3 = s3 * (tss * pry + vx * vx * qy);
+                    float t4 = s3 * vx * (qy * vy + s2);
+                    float t5 = s3 * vx * vz * qy;
+                    float t6 = s3 * (tss * prz + vx * vx * qz);
+                    float t7 = s3 * vx * vy * qz;
+                    float t8 = s3 * vx * (qz * vz + s2);
+                    float t13 = s3 * (tss * pry + 2.0f * vy * s2 + vy * vy * qy);
+                    float t14 = s3 * vz * (qy * vy + s2);
+                    float t16 = s3 * (tss * prz + vy * vy * qz);
+                    float t17 = s3 * vy * (qz * vz + s2);
+                    float t26 = s3 * (tss * prz + 2.0f * vz * s2 + vz * vz * qz);
+                    g0 -= (sx * t0 + sy * t1_) + sz * t2_;
+                    g1 -= (sx * t3 + sy * t4) + sz * t5;
+                    g2 -= (sx * t6 + sy * t7) + sz * t8;
+                    g4 -= (sx * t4 + sy * t13) + sz * t14;      // hw[12] = t[4]
+                    g5 -= (sx * t7 + sy * t16) + sz * t17;      // hw[15] = t[7]
+                    g8 -= (sx * t8 + sy * t17) + sz * t26;      // hw[24] = t[8], hw[25] = t[17]
+                } else {
+                    // zero third derivatives still perform "g -= 0" in the oracle: a no-op in IEEE
+                }
+            }
+        if (n > 15) {
+            float4 vn = normal_in[i];
+            gmag = hd_fabsf((grx * vn.x + gry * vn.y) + grz * vn.z);
+            f3 gn = normalize3(mk3(grx, gry, grz));
+            nopt = make_float4(gn.x, gn.y, gn.z, vn.w);
+            const float ga = grx, gb = gry, gc = grz;
+            float g2c = gc * gc * gc;
+            float h_x = -ga / gc, h_y = -gb / gc;
+            float h_xx = (((2.0f * ga * gc * g2 - ga * ga * g8) - gc * gc * g0)) / g2c;
+            float h_xy = (((ga * gc * g5 + gb * gc * g2) - ga * gb * g8) - gc * gc * g1) / g2c;
+            float h_yy = (((2.0f * gb * gc * g5 - gb * gb * g8) - gc * gc * g4)) / g2c;
+            f3 r_u = mk3(1.0f, 0.0f, h_x), r_v = mk3(0.0f, 1.0f, h_y);
+            float E = 1.0f + h_x * h_x, F = h_x * h_y, G = 1.0f + h_y * h_y;
+            float length = hd_sqrtf((h_x * h_x + h_y * h_y) + 1.0f);
+            float L = h_xx / length, M = h_xy / length, N = h_yy / length;
+            float den = E * G - F * F;
+            float curvature_g = (L * N - M * M) / den;
+            float curvature_m = ((E * N + G * L) - 2.0f * F * M) / (2.0f * den);
+            if (!hd_isnanf(curvature_g) && !hd_isnanf(curvature_m)) {
+                float delta = curvature_m * curvature_m - curvature_g;
+                if (delta < 0.0f) delta = 0.0f;
+                float sd = hd_sqrtf(delta);
+                k1 = curvature_m + sd;
+                k2 = curvature_m - sd;
+                float lmax = -(M - k1 * F) / (N - k1 * G);
+                float lmin = -(M - k2 * F) / (N - k2 * G);
+                pmax = normalize3(add3(r_u, scale3(r_v, lmax)));
+                pmin = normalize3(add3(r_u, scale3(r_v, lmin)));
+            }
+        }
+        pcmax = make_float4(pmax.x, pmax.y, pmax.z, k1);
+        pcmin = make_float4(pmin.x, pmin.y, pmin.z, k2);
+    }
+    curv1[i] = pcmax; curv2[i] = pcmin; gradmag[i] = gmag;
+    normal_out[i] = nopt;   // updateNormalRad: NORMAL <- NORMAL_OPT (HRBFFusion.cpp:1301-1310)
+}
+
+// VertexConfidence (depth_confidence_evaluation.frag:37-50); weighting lives in device memory so
+// the frame needs no host round trip between registration and fusion.
+__global__ void k_confidence(Cam cam, const float *__restrict__ gradmag, float *__restrict__ confidence,
+                             const float *__restrict__ weighting, int use_conf_eval, float epsilon)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cam.W * cam.H) return;
+    int py = i / cam.W, px = i - py * cam.W;
+    float conf = radial_confidence((float)px + 0.5f, (float)py + 0.5f, cam.cx, cam.cy, cam.max_dist, *weighting);
+    if (use_conf_eval > 0) conf = conf * hd_expf(-epsilon / hd_sqrtf(gradmag[i]));
+    confidence[i] = conf;
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline dim3 grid2d(const Cam &c) { return dim3((c.W + TB - 1) / TB, (c.H + TB - 1) / TB); }
+
+void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, float *filtered, float *metric,
+                          float *metric_f, float depthFactor, float maxD, int bilateral)
+{
+    dim3 b(TB, TB);
+    if (bilateral)
+        hipLaunchKernelGGL(k_filter_metric<true>, grid2d(cam), b, 0, s, cam, raw, filtered, metric, metric_f, depthFactor, maxD);
+    else
+        hipLaunchKernelGGL(k_filter_metric<false>, grid2d(cam), b, 0, s, cam, raw, filtered, metric, metric_f, depthFactor, maxD);
+}
+void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm, const float *dmf, float4 *vr,
+                                 float4 *vf, float4 *n, float4 *npca, float *radius, float radius_mult, int use_pca)
+{
+    hipLaunchKernelGGL(k_vertex_normal_radius, grid2d(cam), dim3(TB, TB), 0, s, cam, dm, dmf, vr, vf, n, npca, radius,
+                       radius_mult, use_pca);
+}
+void launch_curvature(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
+                      float *gradmag, float4 *normal_out, int win)
+{
+    hipLaunchKernelGGL(k_curvature, grid2d(cam), dim3(TB, TB), 0, s, cam, vf, normal_in, c1, c2, gradmag, normal_out, win);
+}
+void launch_confidence(hipStream_t s, const Cam &cam, const float *gradmag, float *conf, const float *weighting,
+                       int use_conf_eval, float eps)
+{
+    int P = cam.W * cam.H;
+    hipLaunchKernelGGL(k_confidence, dim3((P + 255) / 256), dim3(256), 0, s, cam, gradmag, conf, weighting, use_conf_eval, eps);
+}

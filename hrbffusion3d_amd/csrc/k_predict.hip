@@ -1,0 +1,363 @@
+// k_predict.hip — HRBF ray-cast surface prediction + fill-in for gfx950.
+//
+// Replaces IndexMap::predictHRBF (Core/src/IndexMap.cpp:413-518 -> predict_hrbf.frag:40-311,
+// hrbfbase.glsl:20-34,126-166) and FillIn::{vertex,normal,curvature,image}
+// (Core/src/Shaders/FillIn.cpp:93-297 -> fill_*.frag), Resize::vertex + denseEnough
+// (HRBFFusion.cpp:974-988,1069-1070).
+//
+// One thread per pixel, 16x16 tiles.  The GLSL gathers up to 49 neighbours into five private
+// vec4[100] arrays; here the neighbour attributes the implicit needs (position, normal, support)
+// are staged ONCE per tile in LDS (tile + 3-texel halo, 22x22 x 32 B = 15.5 KB) and each thread
+// keeps only a 49-bit mask of accepted window slots in the shader's ring visiting order, so the
+// <= 46 implicit evaluations per pixel run entirely out of LDS + registers.
+#include "common.h"
+#include "kernels.h"
+
+#define TB 16
+#define PR 3
+#define PTW (TB + 2 * PR)
+
+struct PTexel { float px, py, pz, conf, nx, ny, nz, rad; };
+
+// ring visiting order of predict_hrbf.frag:75-80: rings i = 0..3, x offset outer, y offset inner,
+// ring-border texels only.  slot -> (dx,dy) packed as (dx+3) | (dy+3) << 3; ring end markers.
+struct RingTable { unsigned char off[49]; unsigned char col_start[49]; };
+__constant__ unsigned char c_ring_off[49];
+__constant__ unsigned char c_ring_newcol[49];   // 1 if this slot starts a new x-offset column (the `k` loop restarts)
+
+static void build_ring_table(unsigned char *off, unsigned char *newcol)
+{
+    int n = 0;
+    for (int i = 0; i <= 3; ++i)
+        for (int dj = -i; dj <= i; ++dj) {
+            bool first = true;
+            for (int dk = -i; dk <= i; ++dk) {
+                if (!(dj == -i || dk == -i || dj == i || dk == i)) continue;
+                off[n] = (unsigned char)((dj + 3) | ((dk + 3) << 3));
+                newcol[n] = first ? 1 : 0;
+                first = false;
+                n++;
+            }
+        }
+}
+
+int predict_upload_tables()
+{
+    unsigned char off[49], nc[49];
+    build_ring_table(off, nc);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ring_off), off, 49) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ring_newcol), nc, 49) != hipSuccess) return -1;
+    return 0;
+}
+
+// hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34) over the masked neighbour set
+__device__ __forceinline__ float hrbf_value(const PTexel *__restrict__ tile, int lbase, unsigned long long mask,
+                                            f3 p, int &nsup)
+{
+    float value = 0.0f;
+    int ns = 0;
+    while (mask) {
+        const int slot = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int o = c_ring_off[slot];
+        const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
+        const float sx = 10.0f * t.nx, sy = 10.0f * t.ny, sz = 10.0f * t.nz;
+        const float vx = p.x - t.px, vy = p.y - t.py, vz = p.z - t.pz;
+        const float d2 = (vx * vx + vy * vy) + vz * vz;
+        const float T2 = t.rad * t.rad;
+        if (T2 < d2) continue;
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        if (!(d2 > T2 || d2 == 0.0f)) {
+            float invT2 = 1.0f / T2;
+            float r = hd_sqrtf(d2 * invT2);
+            float s = 1.0f - r;
+            float s3 = s * s * s;
+            float tt = -20.0f * s3 * invT2;
+            gx = vx * tt; gy = vy * tt; gz = vz * tt;
+        }
+        value -= (gx * sx + gy * sy) + gz * sz;
+        ns++;
+    }
+    nsup = ns;
+    return value;
+}
+
+// hrbfgradient (hrbfbase.glsl:147-166) with getWeightH (:37-69)
+__device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, int lbase, unsigned long long mask, f3 p)
+{
+    float grx = 0.0f, gry = 0.0f, grz = 0.0f;
+    while (mask) {
+        const int slot = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int o = c_ring_off[slot];
+        const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
+        const float sx = 10.0f * t.nx, sy = 10.0f * t.ny, sz = 10.0f * t.nz;
+        const float vx = p.x - t.px, vy = p.y - t.py, vz = p.z - t.pz;
+        const float d2 = (vx * vx + vy * vy) + vz * vz;
+        const float T2 = t.rad * t.rad;
+        float h0, h1, h2, h4, h5, h8;
+        if (d2 > T2) { h0 = h1 = h2 = h4 = h5 = h8 = 0.0f; }
+        else if (d2 == 0.0f) { h0 = h4 = h8 = -20.0f / T2; h1 = h2 = h5 = 0.0f; }
+        else {
+            float r = hd_sqrtf(d2 / T2);
+            float s = 1.0f - r;
+            float s2 = s * s;
+            float t1 = 20.0f * s2 / (T2 * T2 * r);
+            float t2 = -r * s * T2;
+            h0 = t1 * (3.0f * (vx * vx) + t2);
+            h1 = t1 * 3.0f * vx * vy;
+            h2 = t1 * 3.0f * vx * vz;
+            h4 = t1 * (3.0f * (vy * vy) + t2);
+            h5 = t1 * 3.0f * vy * vz;
+            h8 = t1 * (3.0f * (vz * vz) + t2);
+        }
+        grx -= (sx * h0 + sy * h1) + sz * h2;
+        gry -= (sx * h1 + sy * h4) + sz * h5;
+        grz -= (sx * h2 + sy * h5) + sz * h8;
+    }
+    return mk3(grx, gry, grz);
+}
+
+__global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__restrict__ vertconf,
+                                                      const float4 *__restrict__ normrad,
+                                                      const float4 *__restrict__ colortime,
+                                                      const float4 *__restrict__ curvmax,
+                                                      const float4 *__restrict__ curvmin, int win, int minn, int maxn,
+                                                      float cthr, float lambda, uint8_t *__restrict__ pr_image,
+                                                      float4 *__restrict__ pr_vertex, float4 *__restrict__ pr_normal,
+                                                      float4 *__restrict__ pr_curv1, float4 *__restrict__ pr_curv2,
+                                                      uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw)
+{
+    __shared__ PTexel tile[PTW * PTW];
+    const int W = cam.W, H = cam.H;
+    const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
+    for (int i = threadIdx.y * TB + threadIdx.x; i < PTW * PTW; i += TB * TB) {
+        int tx = i % PTW, ty = i / PTW;
+        int gx = bx + tx - PR, gy = by + ty - PR;
+        PTexel t;
+        t.px = t.py = t.pz = t.conf = t.nx = t.ny = t.nz = t.rad = 0.0f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            float4 v = vertconf[gy * W + gx], n = normrad[gy * W + gx];
+            t.px = v.x; t.py = v.y; t.pz = v.z; t.conf = v.w; t.nx = n.x; t.ny = n.y; t.nz = n.z; t.rad = n.w;
+        } else t.pz = -1.0f;   // outside the image: rejected like `j < 0 || j > 1` (predict_hrbf.frag:85)
+        tile[i] = t;
+    }
+    __syncthreads();
+    const int px = bx + threadIdx.x, py = by + threadIdx.y;
+    if (px >= W || py >= H) return;
+    const int pi = py * W + px;
+    const int lbase = (threadIdx.y + PR) * PTW + threadIdx.x + PR;
+
+    // neighbour gathering with the reference's "break only the innermost loop" behaviour
+    unsigned long long mask = 0ull;
+    int n = 0;
+    {
+        const int nslots = (2 * win + 1) * (2 * win + 1);
+        bool skip_col = false;
+        for (int slot = 0; slot < nslots; ++slot) {
+            if (c_ring_newcol[slot]) skip_col = false;
+            if (skip_col) continue;
+            const int o = c_ring_off[slot];
+            const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
+            if (t.pz < 0.1f || len3(mk3(t.nx, t.ny, t.nz)) < 0.1f || t.conf < cthr || t.nz < 0.0f) continue;
+            mask |= 1ull << slot;
+            n++;
+            if (n > maxn) skip_col = true;
+        }
+    }
+
+    const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    const float xl = (x - cam.cx) * cam.camz, yl = (y - cam.cy) * cam.camw;
+    const f3 ray = normalize3(mk3(xl, yl, 1.0f));
+
+    f3 closest = mk3(0, 0, 0);
+    {
+        float pmin = 1000000.0f;
+        unsigned long long m = mask;
+        while (m) {
+            const int slot = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int o = c_ring_off[slot];
+            const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
+            float pj = hd_fabsf(dot3(mk3(t.px, t.py, t.pz), ray));
+            if (pj < pmin) { closest = scale3(ray, pj); pmin = pj; }
+        }
+    }
+    bool find_interval = false, found = false;
+    f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), p_temp = mk3(0, 0, 0), ntemp = mk3(0, 0, 0);
+    int nsup = 0;
+    if (n > minn) {
+        float v0 = hrbf_value(tile, lbase, mask, closest, nsup);
+        if (nsup > minn) {
+            if (v0 > 0.0f) {
+                ep = closest;
+                bool sfound = false;
+                for (int i = 0; i < 25; ++i) {
+                    f3 p1 = sub3(ep, scale3(ray, 0.004f * (float)i));
+                    float v1 = hrbf_value(tile, lbase, mask, p1, nsup);
+                    if (v1 < 0.0f) { sp = p1; sfound = true; break; }
+                }
+                if (sfound)
+                    for (int i = 1; i < 11; ++i) {
+                        f3 p2 = add3(sp, scale3(ray, 0.0004f * (float)i));
+                        float v2 = hrbf_value(tile, lbase, mask, p2, nsup);
+                        if (v2 > 0.0f) { ep = p2; find_interval = true; break; }
+                    }
+            } else {
+                sp = closest;
+                bool efound = false;
+                for (int i = 0; i < 25; ++i) {
+                    f3 p1 = add3(sp, scale3(ray, 0.004f * (float)i));
+                    float v1 = hrbf_value(tile, lbase, mask, p1, nsup);
+                    if (v1 > 0.0f) { ep = p1; efound = true; break; }
+                }
+                if (efound)
+                    for (int i = 1; i < 11; ++i) {
+                        f3 p2 = sub3(ep, scale3(ray, 0.0004f * (float)i));
+                        float v2 = hrbf_value(tile, lbase, mask, p2, nsup);
+                        if (v2 < 0.0f) { sp = p2; find_interval = true; break; }
+                    }
+            }
+        }
+    }
+    if (find_interval) {
+        for (int j = 0; j < 10; ++j) {
+            f3 step = sub3(ep, sp);
+            if (len3(step) < 0.00001f) { ntemp = hrbf_gradient(tile, lbase, mask, p_temp); found = true; break; }
+            p_temp = add3(sp, scale3(step, 0.5f));
+            float f_temp = hrbf_value(tile, lbase, mask, p_temp, nsup);
+            if (hd_fabsf(f_temp) < 0.00001f) { ntemp = hrbf_gradient(tile, lbase, mask, p_temp); found = true; break; }
+            if (f_temp < 0.0f) sp = p_temp; else ep = p_temp;
+        }
+    }
+
+    uchar4 img = make_uchar4(0, 0, 0, 0);
+    f3 p_surface = mk3(0, 0, 0), p_normal = mk3(0, 0, 0);
+    float4 cmx = make_float4(0, 0, 0, 1000.0f), cmn = make_float4(0, 0, 0, 1000.0f);
+    float icpw = 0.0f, confidence = 0.0f, radius = 0.0f;
+    uint32_t tm = 0;
+    if (found) {
+        p_surface = p_temp;
+        p_normal = normalize3(ntemp);
+        float dsm = 1000000.0f;
+        int best_o = -1;
+        unsigned long long m = mask;
+        while (m) {
+            const int slot = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int o = c_ring_off[slot];
+            const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
+            float dx = p_surface.x - t.px, dy = p_surface.y - t.py, dz = p_surface.z - t.pz;
+            float dist = hd_sqrtf((dx * dx + dy * dy) + dz * dz);
+            if (dist < dsm) { dsm = dist; best_o = o; confidence = t.conf; radius = t.rad; }
+        }
+        if (best_o >= 0) {
+            const int gi = (py + (best_o >> 3) - 3) * W + (px + (best_o & 7) - 3);
+            cmx = curvmax[gi]; cmn = curvmin[gi];
+            float4 ct = colortime[gi];
+            int ci = (int)ct.x;
+            img = make_uchar4((unsigned char)((ci >> 16) & 0xFF), (unsigned char)((ci >> 8) & 0xFF),
+                              (unsigned char)(ci & 0xFF), 255);
+            tm = (uint32_t)ct.z;
+        }
+        float a1 = hd_fabsf(cmx.w), a2 = hd_fabsf(cmn.w);
+        float cm = a1 > a2 ? a1 : a2;
+        icpw = (1.0f / (p_surface.z * p_surface.z)) *
+               (confidence / 256.0f + hd_expf(-0.5f * (lambda * lambda) / (cm * cm)));
+    }
+    reinterpret_cast<uchar4 *>(pr_image)[pi] = img;
+    pr_vertex[pi] = make_float4(p_surface.x, p_surface.y, p_surface.z, confidence);
+    pr_normal[pi] = make_float4(p_normal.x, p_normal.y, p_normal.z, radius);
+    pr_curv1[pi] = cmx; pr_curv2[pi] = cmn;
+    pr_time[pi] = tm;
+    pr_icpw[pi] = icpw;
+}
+
+// fill_vertex.frag:43-72, fill_normal.frag:36-49, fill_curvature.frag:35-51, fill_rgb.frag:29-37
+__global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb, const float4 *__restrict__ pr_vertex,
+                         const float4 *__restrict__ pr_normal, const float4 *__restrict__ pr_curv1,
+                         const float4 *__restrict__ pr_curv2, const float *__restrict__ pr_icpw,
+                         const uint8_t *__restrict__ pr_image, const float4 *__restrict__ vertex_filtered,
+                         const float4 *__restrict__ normal, const float4 *__restrict__ curv1,
+                         const float4 *__restrict__ curv2, const float *__restrict__ confidence,
+                         const uint8_t *__restrict__ rgb, float4 *__restrict__ fi_vertex,
+                         float4 *__restrict__ fi_normal, float4 *__restrict__ fi_curv1, float4 *__restrict__ fi_curv2,
+                         float *__restrict__ fi_icpw, uint8_t *__restrict__ fi_image)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float4 s = pr_vertex[i];
+    if (s.z == 0.0f) {
+        float4 fv = vertex_filtered[i], r1 = curv1[i], r2 = curv2[i];
+        float4 outv = make_float4(0, 0, 0, 0);
+        float outw = 0.0f;
+        if (r1.w > -thr && r1.w < thr && r2.w > -thr && r2.w < thr) {
+            float vConf = confidence[i];
+            float a1 = hd_fabsf(r1.w), a2 = hd_fabsf(r2.w);
+            float cm = a1 > a2 ? a1 : a2;
+            outw = (1.0f / (fv.z * fv.z)) * (vConf / 256.0f + hd_expf(-0.5f * (lambda * lambda) / (cm * cm)));
+            outv = make_float4(fv.x, fv.y, fv.z, vConf);
+        }
+        fi_vertex[i] = outv; fi_icpw[i] = outw;
+    } else { fi_vertex[i] = s; fi_icpw[i] = pr_icpw[i]; }
+    float4 n = pr_normal[i];
+    fi_normal[i] = (len3(xyz(n)) < 0.8f) ? normal[i] : n;
+    float4 k1 = pr_curv1[i], k2 = pr_curv2[i];
+    if (k1.w > 300.0f || k2.w > 300.0f) { fi_curv1[i] = curv1[i]; fi_curv2[i] = curv2[i]; }
+    else { fi_curv1[i] = k1; fi_curv2[i] = k2; }
+    uchar4 e = reinterpret_cast<const uchar4 *>(pr_image)[i];
+    if ((int)e.x + (int)e.y + (int)e.z == 0 || frame_to_frame_rgb)
+        e = make_uchar4(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], 255);
+    reinterpret_cast<uchar4 *>(fi_image)[i] = e;
+}
+
+// Resize::vertex + denseEnough: *flag = 1 when the 20x20-cell thumbnail of the predicted vertex map
+// is NOT dense enough (=> shouldFillIn, HRBFFusion.cpp:1069-1070).  Stays on the device.
+__global__ void k_should_fill_in(Cam cam, const float4 *__restrict__ pr_vertex, float thresh, int *flag)
+{
+    const int cs = 20;
+    const int w = cam.W / cs, h = cam.H / cs;
+    int sum = 0;
+    for (int c = threadIdx.x; c < w * h; c += blockDim.x) {
+        int i = c % w, j = c / w;
+        int sx = (int)hd_floorf(((float)i + 0.5f) * (float)cam.W / (float)w);
+        int sy = (int)hd_floorf(((float)j + 0.5f) * (float)cam.H / (float)h);
+        sum += pr_vertex[sy * cam.W + sx].z > 0.0f ? 1 : 0;
+    }
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+    __shared__ int ws[16];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += ws[k];
+        float per = (float)tot / (float)(w * h);
+        *flag = (per > thresh) ? 0 : 1;
+    }
+}
+
+void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, const float4 *normrad,
+                         const float4 *colortime, const float4 *curvmax, const float4 *curvmin, int win, int minn,
+                         int maxn, float cthr, float lambda, uint8_t *pr_image, float4 *pr_vertex, float4 *pr_normal,
+                         float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw)
+{
+    dim3 g((cam.W + TB - 1) / TB, (cam.H + TB - 1) / TB);
+    hipLaunchKernelGGL(k_predict_hrbf, g, dim3(TB, TB), 0, s, cam, vertconf, normrad, colortime, curvmax, curvmin, win,
+                       minn, maxn, cthr, lambda, pr_image, pr_vertex, pr_normal, pr_curv1, pr_curv2, pr_time, pr_icpw);
+}
+
+void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const float4 *pr_vertex,
+                   const float4 *pr_normal, const float4 *pr_curv1, const float4 *pr_curv2, const float *pr_icpw,
+                   const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
+                   const float4 *curv2, const float *confidence, const uint8_t *rgb, float4 *fi_vertex,
+                   float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image)
+{
+    hipLaunchKernelGGL(k_fillin, dim3((P + 255) / 256), dim3(256), 0, s, P, thr, lambda, f2f, pr_vertex, pr_normal,
+                       pr_curv1, pr_curv2, pr_icpw, pr_image, vertex_filtered, normal, curv1, curv2, confidence, rgb,
+                       fi_vertex, fi_normal, fi_curv1, fi_curv2, fi_icpw, fi_image);
+}
+
+void launch_should_fill_in(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float thresh, int *flag)
+{
+    hipLaunchKernelGGL(k_should_fill_in, dim3(1), dim3(256), 0, s, cam, pr_vertex, thresh, flag);
+}

@@ -1,0 +1,118 @@
+// kernels.h — host-callable launchers of the gfx950 kernels (internal to libhrbf_mi355).
+#pragma once
+#include "common.h"
+
+struct MapPlanes { float4 *p0, *p1, *p2, *p3, *p4; };
+typedef MapPlanes RecPlanes;
+
+// device-resident pose block: written by the odometry epilogue, read by every map kernel, so a
+// frame needs no host round trip (the reference syncs ~40x per frame)
+struct DevPose {
+    Rigid pose;        // T_wc
+    Rigid tinv;        // cofactor inverse
+    Rigid prev;        // pose at the end of the previous frame (lastPose)
+    float weighting;   // velocity weighting (HRBFFusion.cpp:1112-1123)
+    float last_icp_error, last_icp_count;
+    int should_fill_in;
+};
+
+// ---- k_pre.hip
+void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, float *filtered, float *metric,
+                          float *metric_f, float depthFactor, float maxD, int bilateral);
+void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm, const float *dmf, float4 *vr,
+                                 float4 *vf, float4 *n, float4 *npca, float *radius, float radius_mult, int use_pca);
+void launch_curvature(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
+                      float *gradmag, float4 *normal_out, int win);
+void launch_confidence(hipStream_t s, const Cam &cam, const float *gradmag, float *conf, const float *weighting,
+                       int use_conf_eval, float eps);
+
+// ---- k_map.hip
+void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const float4 *vertex_raw, const float4 *normal,
+                       const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
+                       int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
+                       uint32_t cap, uint32_t *count);
+void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
+                            const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
+                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin);
+void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
+                 const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
+                 const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
+                 const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
+                 MapPlanes m, uint32_t *stats);
+void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
+                  int time, float clean_window_multiplier, MapPlanes in, MapPlanes out, RecPlanes rec, int32_t *rec_flag,
+                  const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
+                  const uint32_t *idx, const float4 *vertconf, const float4 *colortime,
+                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket);
+void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
+uint32_t fuse_tile_items();
+
+// ---- k_predict.hip
+int predict_upload_tables();
+void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, const float4 *normrad,
+                         const float4 *colortime, const float4 *curvmax, const float4 *curvmin, int win, int minn,
+                         int maxn, float cthr, float lambda, uint8_t *pr_image, float4 *pr_vertex, float4 *pr_normal,
+                         float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw);
+void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const float4 *pr_vertex,
+                   const float4 *pr_normal, const float4 *pr_curv1, const float4 *pr_curv2, const float *pr_icpw,
+                   const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
+                   const float4 *curv2, const float *confidence, const uint8_t *rgb, float4 *fi_vertex,
+                   float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image);
+void launch_should_fill_in(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float thresh, int *flag);
+
+// ---- k_odo.hip
+struct OdoLevel {
+    int rows, cols;
+    float *vmap_g, *nmap_g, *ck1_g, *ck2_g;   // model maps, planar 4 x rows x cols, global frame
+    float *vmap_c, *nmap_c, *ck1_c, *ck2_c;   // live-frame maps
+    float *icpw;
+    float *last_depth, *next_depth;
+    uint8_t *last_image, *next_image, *last_next_image;
+    int16_t *dIdx, *dIdy;
+    float *cloud;                             // rows*cols*3 (x,y,z interleaved)
+};
+
+struct OdoState;   // device-resident Gauss-Newton state, defined in k_odo.hip
+
+struct OdoBuffers {
+    OdoLevel lv[HRBF_NUM_PYRS];
+    OdoState *state;
+    int16_t *corres;        // P*6
+    float *corres_diff;     // P
+    long long *icp_part;    // max_blocks * 87
+    long long *rgb_part;    // max_blocks * 87
+    long long *res_part;    // max_blocks * 2
+    long long *so3_part;    // max_blocks * 33
+    long long *totals;      // 87 + 87 + 2 + 33 (all-reduce buffer)
+    int max_blocks;
+};
+
+struct OdoSources {   // images the odometry is initialised from (selected on device by should_fill_in)
+    const float4 *pr_vertex, *pr_normal, *pr_curv1, *pr_curv2; const float *pr_icpw; const uint8_t *pr_image;
+    const float4 *fi_vertex, *fi_normal, *fi_curv1, *fi_curv2; const float *fi_icpw; const uint8_t *fi_image;
+    const float4 *vertex_filtered, *normal, *curv1, *curv2; const uint8_t *rgb;
+};
+
+struct OdoConfig {
+    float fx, fy, cx, cy;
+    int rgb_only; float icp_weight; int pyramid, fast_odom, so3, frame_to_frame_rgb;
+    int use_search, search_radius, use_weighted, rgb_use_grad;
+    float curv_thr;
+};
+
+size_t odo_state_bytes();
+void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
+// full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
+void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
+                     void *comm /* ncclComm_t or null */, int rank, int world);
+// pose bookkeeping
+void launch_pose_set(hipStream_t s, DevPose *dp, const float pose16_colmajor[16], int also_prev);
+void launch_frame_epilogue(hipStream_t s, DevPose *dp, float weight_multiplier, int tracked);
+void launch_pose_commit_prev(hipStream_t s, DevPose *dp);
+// standalone icpStep seam
+int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                 const float *nmap_curr, const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9],
+                 const float tprev[3], float fx, float fy, float cx, float cy, const float *vmap_g_prev,
+                 const float *nmap_g_prev, const float *ck1_g_prev, const float *ck2_g_prev, const float *icpw, int rows,
+                 int cols, float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
+                 double residual_out[2]);

@@ -315,4 +315,33 @@ HD_FN double hd_acc_to_double(hd_acc128 a)
     return neg ? -v : v;
 }
 
+/* ---------------------------------------------------------------- limb form (parallel-friendly)
+ * The same exact integer split into three 40-bit limbs, each carried in an int64:
+ *     Q = l0 + l1 * 2^40 + l2 * 2^80.
+ * Limbs of up to 2^23 addends can be summed independently with plain 64-bit adds (wave shuffles,
+ * LDS, atomics, RCCL int64 all-reduce) and recombined once at the end with hd_limbs_combine. */
+typedef struct { int64_t l0, l1, l2; } hd_limbs;
+
+HD_FN hd_limbs hd_limbs_from_f32(float p)
+{
+    hd_acc128 q = hd_acc_from_f32(p);
+    const uint64_t M40 = (1ull << 40) - 1ull;
+    hd_limbs r;
+    r.l0 = (int64_t)(q.lo & M40);
+    r.l1 = (int64_t)(((q.lo >> 40) | ((uint64_t)q.hi << 24)) & M40);
+    r.l2 = q.hi >> 16;
+    return r;
+}
+
+HD_FN hd_acc128 hd_limbs_combine(int64_t s0, int64_t s1, int64_t s2)
+{
+    hd_acc128 a, t;
+    a.lo = (uint64_t)s0; a.hi = s0 < 0 ? -1 : 0;
+    t.lo = (uint64_t)s1 << 40; t.hi = s1 >> 24;
+    hd_acc_add(&a, t);
+    t.lo = 0; t.hi = (int64_t)((uint64_t)s2 << 16);
+    hd_acc_add(&a, t);
+    return a;
+}
+
 #endif /* HRBF_DETMATH_H_ */
