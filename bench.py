@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the HRBF-Fusion per-frame hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one hrbf_process_frame over one synthetic 640x480 RGB-D frame (pre-processing, SO3 +
+3-level joint ICP/RGB registration, index-map projection x3, data association + merge, clean +
+compact + append, HRBF ray-cast prediction + fill-in) against a map pre-seeded to >= 1 M surfels.
+Inputs are resident in HBM before the timed region (torch tensors; PyTorch is plumbing only).
+
+N > 1: one process per GPU (torchrun), each an independent replica of the same sequence
+(SURVEY.md §8e last row: the per-frame path of one sequence does not shard below VGA); no data-path
+collective, "scaling": "weak", value = frames all ranks processed / max-over-ranks time.
+
+One JSON line on rank 0, with `roofline` (fuse streaming kernel, HIP events on the library's own
+stream) and `cpu_baseline` (the CPU oracle on a bounded sample; baseline, not target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--surfels", type=int, default=1_050_000)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--noise", action="store_true", help="Kinect-style depth noise + 3%% drop-outs")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seed, frames, poses):
+    """Oracle (OpenMP build) on the same workload, bounded sample: bootstrap + n frames."""
+    from oracle_lib import Oracle
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.params import default_params
+    n = args.cpu_frames
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, min(cores, 32))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    fx, fy, cx, cy = synth.intrinsics(args.width, args.height)
+    p = default_params(args.width, args.height, fx, fy, cx, cy, max_surfels=int(seed.shape[0] + 200_000 + 80_000 * (n + 1)))
+    o = Oracle(p, omp=True)
+    o.upload_map(seed)
+    o.set_pose(poses[0])
+    o.bootstrap(frames[0][0], frames[0][1])
+    t0 = time.perf_counter()
+    for k in range(1, n + 1):
+        o.process_frame(frames[k][0], frames[k][1])
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames of the same %dx%d stream against the same %d-surfel map (oracle, OpenMP)" %
+                      (n, args.width, args.height, seed.shape[0])}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion
+    from hrbffusion3d_amd.params import default_params
+
+    W, H = args.width, args.height
+    K, Wm = args.steps, args.warmup
+    nframes = 1 + Wm + K
+    t_gen = time.perf_counter()
+    frames, poses = [], []
+    for k in range(nframes):
+        rgb, depth, T = synth.frame(k, W, H, noise=args.noise)
+        frames.append((rgb, depth)); poses.append(T)
+    seed = synth.seed_map(args.surfels, t_now=1, width=W)
+    t_gen = time.perf_counter() - t_gen
+
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    cap = int(seed.shape[0] + 200_000 + (W // 2) * (H // 2) * 4)
+    cap += (W // 2) * (H // 2) * min(nframes, 64)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=cap)
+    fus = HRBFFusion(p, device=local_rank)
+    fus.upload_map(seed)
+    fus.set_pose(poses[0])
+    fus.bootstrap(frames[0][0], frames[0][1])
+
+    # inputs resident in HBM before timing
+    d_rgb = [torch.from_numpy(f[0]).cuda() for f in frames]
+    d_dep = [torch.from_numpy(f[1].view(np.int16)).cuda() for f in frames]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(1, 1 + Wm):
+        fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), k)
+    fus.synchronize()
+    count0 = fus.surfel_count()
+    fus.enable_timing(True)
+    fus.reset_fuse_ring()
+
+    barrier(); torch.cuda.synchronize(); fus.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + Wm, 1 + Wm + K):
+        fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), k)
+    fus.synchronize(); torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # roofline of the fuse streaming kernel from the event ring recorded during the timed region
+    ms, st = fus.fuse_ring(K)
+    ok = ms > 0
+    B = 80.0 * (st[:, 0].astype(np.float64) + st[:, 3] + st[:, 1] + st[:, 2])   # 80(N_in + N_out + M + A), SURVEY §8d
+    gbps = float((B[ok] / (ms[ok] * 1e-3)).mean() / 1e9) if ok.any() else 0.0
+    fuse_ms = float(ms[ok].mean()) if ok.any() else 0.0
+    count1 = fus.surfel_count()
+    P_end = fus.get_pose()
+    err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
+    tm = fus.timings()
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec at 640x480, 1M-surfel map, 1 MI355X",
+            "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d RGB-D stream (room+sphere+relief, Lissajous path, seed 12345), "
+                                   "map pre-seeded to %d surfels, full processFrame per step" % (W, H, seed.shape[0]),
+                       "surfels_start": int(count0), "surfels_end": int(count1),
+                       "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                       "final_translation_error_mm": err_mm,
+                       "last_frame_region_ms": {"Initialization": float(tm[0]), "Registration": float(tm[1]),
+                                                "Integration": float(tm[2]), "Prediction": float(tm[3]),
+                                                "fuse_stream_pass": float(tm[4])}},
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                         "traffic": None, "kernel": "k_fuse_stream", "avg_kernel_ms": fuse_ms,
+                         "bytes_per_launch": float(B[ok].mean()) if ok.any() else 0.0},
+        }
+        if args.cpu_frames > 0 and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, seed, frames, poses)
+            except Exception as e:  # the baseline leg must never take the bench line down
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
+                                   "sample": "skipped (rank 0 at N=1 only)"}
+        if args.verbose:
+            sys.stderr.write("gen %.1fs, timed %.3fs, fuse kernel %.4f ms, %s\n" % (t_gen, dt, fuse_ms, st[-1]))
+        print(json.dumps(out))
+    fus.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

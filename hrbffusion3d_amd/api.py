@@ -24,7 +24,7 @@ EXPORTS = [
     "hrbf_set_so3", "hrbf_set_frame_to_frame_rgb", "hrbf_set_confidence_threshold", "hrbf_set_depth_cutoff",
     "hrbf_image_bytes", "hrbf_get_image", "hrbf_set_image", "hrbf_enable_timing", "hrbf_get_timings",
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
-    "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init",
+    "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
 
 
@@ -65,6 +65,9 @@ def load_library():
     lib.hrbf_enable_timing.argtypes = [vp, i32]; lib.hrbf_get_timings.argtypes = [vp, vp]
     lib.hrbf_get_fuse_stats.argtypes = [vp, vp]
     lib.hrbf_upload_frame.argtypes = [vp, vp, vp]; lib.hrbf_run_stage.argtypes = [vp, i32]
+    lib.hrbf_bootstrap.argtypes = [vp, vp, vp]
+    lib.hrbf_get_fuse_ring.argtypes = [vp, i32, vp, vp]; lib.hrbf_reset_fuse_ring.argtypes = [vp]
+    lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
     _lib = lib
@@ -119,6 +122,10 @@ class HRBFFusion:
     def upload_frame(self, rgb, depth):
         rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
         return self._check(self.lib.hrbf_upload_frame(self.h, _p(rgb), _p(depth)))
+
+    def bootstrap(self, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        return self._check(self.lib.hrbf_bootstrap(self.h, _p(rgb), _p(depth)))
 
     def run_stage(self, name):
         return self._check(self.lib.hrbf_run_stage(self.h, STAGES[name]))
@@ -183,6 +190,19 @@ class HRBFFusion:
         o = np.zeros(4, np.uint32)
         self._check(self.lib.hrbf_get_fuse_stats(self.h, _p(o)))
         return o
+
+    def fuse_ring(self, max_frames=1024):
+        ms = np.zeros(max_frames, np.float32); st = np.zeros((max_frames, 4), np.uint32)
+        n = self.lib.hrbf_get_fuse_ring(self.h, max_frames, _p(ms), _p(st))
+        if n < 0:
+            raise HrbfError("hrbf_get_fuse_ring failed")
+        return ms[:n].copy(), st[:n].copy()
+
+    def reset_fuse_ring(self):
+        self.lib.hrbf_reset_fuse_ring(self.h)
+
+    def set_load_trajectory(self, v):
+        self._check(self.lib.hrbf_set_load_trajectory(self.h, int(v)))
 
     def enable_timing(self, on=True):
         self._check(self.lib.hrbf_enable_timing(self.h, 1 if on else 0))

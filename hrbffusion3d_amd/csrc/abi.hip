@@ -40,6 +40,8 @@ extern "C" void hrbf_default_params(hrbf_params *p, int width, int height, float
     p->max_surfels = 4 * 1024 * 1024; p->load_trajectory = 0;
 }
 
+#define HRBF_RING 1024
+
 struct hrbf_context {
     hrbf_params prm;
     int device;
@@ -72,6 +74,8 @@ struct hrbf_context {
     OdoBuffers odo;
     // timing
     int timing; hipEvent_t ev[12]; float timings[8];
+    // per-frame ring: HIP events bracketing ONLY the k_fuse_stream launch + its item statistics
+    hipEvent_t *ring_e0, *ring_e1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid;
 };
 
 template <typename T>
@@ -156,6 +160,9 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     c->h_count_pinned[0] = 0;
     hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming);
     for (int i = 0; i < 12; ++i) hipEventCreate(&c->ev[i]);
+    c->ring_e0 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t)); c->ring_e1 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t));
+    for (int i = 0; i < HRBF_RING; ++i) { hipEventCreate(&c->ring_e0[i]); hipEventCreate(&c->ring_e1[i]); }
+    DA(c->d_stats_ring, (size_t)HRBF_RING * 4);
     // odometry buffers
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         OdoLevel &L = c->odo.lv[i];
@@ -211,6 +218,9 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     if (c->h_count_pinned) hipHostFree(c->h_count_pinned);
     if (c->ev_count) hipEventDestroy(c->ev_count);
     for (int i = 0; i < 12; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->ring_e0) for (int i = 0; i < HRBF_RING; ++i) { if (c->ring_e0[i]) hipEventDestroy(c->ring_e0[i]); if (c->ring_e1[i]) hipEventDestroy(c->ring_e1[i]); }
+    free(c->ring_e0); free(c->ring_e1);
+    if (c->d_stats_ring) hipFree(c->d_stats_ring);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
 }
@@ -305,7 +315,14 @@ static void st_clean(hrbf_context *c)
                  c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier, c->map[c->target],
                  c->map[1 - c->target], c->rec, c->d_rec_flag, &c->d_count[c->target], &c->d_count[1 - c->target],
                  c->count_ub, c->d_stats, c->cap, c->d_idx, c->d_im_vertconf, c->d_im_colortime, c->d_tile_status,
-                 c->max_tiles, c->d_ticket);
+                 c->max_tiles, c->d_ticket, c->timing ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
+                 c->timing ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr);
+    if (c->timing) {
+        hipMemcpyAsync(c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4, c->d_stats, sizeof(uint32_t) * 4,
+                       hipMemcpyDeviceToDevice, c->stream);
+        c->ring_head++;
+        if (c->ring_valid < HRBF_RING) c->ring_valid++;
+    }
     c->target = 1 - c->target;
     uint64_t ub = (uint64_t)c->count_ub + (uint64_t)c->Q;
     c->count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
@@ -402,6 +419,20 @@ extern "C" int hrbf_process_frame_device(hrbf_handle c, const void *d_rgb, const
     HIP_CHECK(hipMemcpyAsync(c->d_rgb, d_rgb, (size_t)c->P * 3, hipMemcpyDeviceToDevice, c->stream));
     HIP_CHECK(hipMemcpyAsync(c->d_depth, d_depth, (size_t)c->P * 2, hipMemcpyDeviceToDevice, c->stream));
     return process_frame_resident(c, wmul);
+}
+
+extern "C" int hrbf_bootstrap(hrbf_handle c, const uint8_t *rgb, const uint16_t *depth)
+{
+    int r = hrbf_upload_frame(c, rgb, depth);
+    if (r) return r;
+    st_filter(c); st_vnr(c); st_curv(c);
+    launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
+    st_conf(c);
+    st_indices(c); st_predict(c); st_fillin(c);
+    launch_pose_commit_prev(c->stream, c->d_pose);
+    c->tick = 2;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
 }
 
 extern "C" int hrbf_synchronize(hrbf_handle c)
@@ -624,6 +655,27 @@ extern "C" int hrbf_get_timings(hrbf_handle c, float out[8])
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) out[6] = ms;   // first projection (+confidence)
     return HRBF_OK;
 }
+extern "C" int hrbf_get_fuse_ring(hrbf_handle c, int max_frames, float *kernel_ms, uint32_t *stats4)
+{
+    if (!c || !kernel_ms || !stats4) return -1;
+    hipSetDevice(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    int n = (int)c->ring_valid; if (n > max_frames) n = max_frames;
+    uint32_t *h = (uint32_t *)malloc(sizeof(uint32_t) * 4 * HRBF_RING);
+    if (hipMemcpy(h, c->d_stats_ring, sizeof(uint32_t) * 4 * HRBF_RING, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return -1; }
+    for (int i = 0; i < n; ++i) {   // oldest first among the last n
+        uint32_t slot = (c->ring_head - (uint32_t)n + (uint32_t)i) % HRBF_RING;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ring_e0[slot], c->ring_e1[slot]) != hipSuccess) ms = -1.0f;
+        kernel_ms[i] = ms;
+        memcpy(&stats4[i * 4], &h[slot * 4], sizeof(uint32_t) * 4);
+    }
+    free(h);
+    return n;
+}
+extern "C" int hrbf_reset_fuse_ring(hrbf_handle c) { if (!c) return -1; c->ring_head = 0; c->ring_valid = 0; return 0; }
+extern "C" int hrbf_set_load_trajectory(hrbf_handle c, int v) { if (!c) return HRBF_ERR_INVALID; c->prm.load_trajectory = v; return HRBF_OK; }
+
 extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
 {
     if (!c || !out) return HRBF_ERR_INVALID;

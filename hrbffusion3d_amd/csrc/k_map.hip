@@ -515,7 +515,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   int time, float clean_window_multiplier, MapPlanes in, MapPlanes out, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const uint32_t *idx, const float4 *vertconf, const float4 *colortime,
-                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket)
+                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket, hipEvent_t e0, hipEvent_t e1)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     CleanParams cp;
@@ -527,8 +527,10 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     hipMemsetAsync(ticket, 0, sizeof(uint32_t), s);
     uint32_t blocks = tiles < 256u * 4u ? tiles : 256u * 4u;   // persistent: <= 4 workgroups per CU
     if (blocks == 0) blocks = 1;
+    if (e0) hipEventRecord(e0, s);
     hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), 0, s, cp, in, out, rec, rec_flag, Q, count_in,
                        count_out, stats, cap, idx, vertconf, colortime, tile_status, ticket);
+    if (e1) hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_zero_flags, dim3((Q + 255) / 256), dim3(256), 0, s, rec_flag, Q);
 }
 

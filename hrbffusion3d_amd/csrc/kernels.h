@@ -43,7 +43,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   int time, float clean_window_multiplier, MapPlanes in, MapPlanes out, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const uint32_t *idx, const float4 *vertconf, const float4 *colortime,
-                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket);
+                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket, hipEvent_t e0, hipEvent_t e1);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 uint32_t fuse_tile_items();
 

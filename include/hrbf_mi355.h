@@ -169,6 +169,13 @@ int hrbf_set_image(hrbf_handle h, int which, const void *in, size_t bytes); /* h
  * 4 = the fuse (clean+compact+append) streaming kernel alone.  Requires hrbf_enable_timing(h,1). */
 int hrbf_enable_timing(hrbf_handle h, int on);
 int hrbf_get_timings(hrbf_handle h, float out_ms[8]);
+/* ring of the last <= 1024 frames (timing enabled): duration in ms of the fuse streaming kernel alone
+ * (HIP events on the context's stream bracketing only that launch) and its {in, merged, appended, out}
+ * surfel counts; returns the number of frames written, oldest first. */
+int hrbf_get_fuse_ring(hrbf_handle h, int max_frames, float *kernel_ms, uint32_t *stats4);
+int hrbf_reset_fuse_ring(hrbf_handle h);
+/* build-specific: toggle trajectory replay (globalInputLoadTrajectory) between frames */
+int hrbf_set_load_trajectory(hrbf_handle h, int v);
 /* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
 int hrbf_get_fuse_stats(hrbf_handle h, uint32_t out[4]);
 
@@ -189,6 +196,10 @@ typedef enum hrbf_stage {
     HRBF_STAGE_COUNT
 } hrbf_stage;
 int hrbf_upload_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth);
+/* build-specific: start tracking against an uploaded map (hrbf_upload_map + hrbf_set_pose): runs the
+ * pre-processing of the given frame, initFirstRGB and predict() (HRBFFusion.cpp:1244-1260), then sets
+ * tick = 2, i.e. the state the reference is in after its first processFrame. */
+int hrbf_bootstrap(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth);
 int hrbf_run_stage(hrbf_handle h, int stage);
 int hrbf_set_tick(hrbf_handle h, int tick);
 int hrbf_set_weighting(hrbf_handle h, float w);

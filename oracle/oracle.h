@@ -90,6 +90,7 @@ void orc_destroy(orc_ctx *c);
 int orc_process_frame(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth, int64_t ts, float wmul);
 int orc_upload_frame(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth);
 int orc_run_stage(orc_ctx *c, int stage);
+int orc_bootstrap(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth);
 void orc_get_pose(orc_ctx *c, float out16[16]);
 void orc_set_pose(orc_ctx *c, const float in16[16]);
 int orc_get_tick(orc_ctx *c);

@@ -204,6 +204,18 @@ int orc_process_frame(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth, int
     return 0;
 }
 
+int orc_bootstrap(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth)
+{
+    orc_upload_frame(c, rgb, depth);
+    orc_filter_depth(c); orc_metricise(c); orc_vertex_normal_radius(c); orc_curvature(c);
+    orc_odo_init_first_rgb(c);
+    orc_confidence(c);
+    orc_predict_indices(c); orc_predict_hrbf(c); orc_fillin(c);
+    memcpy(c->prev_pose, c->pose, sizeof(c->pose));
+    c->tick = 2;
+    return 0;
+}
+
 int orc_run_stage(orc_ctx *c, int stage)
 {
     switch (stage) {

@@ -27,6 +27,7 @@ def load(omp=False):
     lib.orc_process_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
     lib.orc_upload_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_run_stage.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_bootstrap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_get_pose.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_set_pose.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_get_tick.argtypes = [C.c_void_p]
@@ -94,6 +95,10 @@ class Oracle:
     def upload_frame(self, rgb, depth):
         rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
         return self.lib.orc_upload_frame(self.h, _p(rgb), _p(depth))
+
+    def bootstrap(self, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        return self.lib.orc_bootstrap(self.h, _p(rgb), _p(depth))
 
     def run_stage(self, name):
         r = self.lib.orc_run_stage(self.h, STAGES[name])
