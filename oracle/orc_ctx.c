@@ -312,3 +312,15 @@ void orc_acc_test(const float *v, int n, double *out)
     for (int i = 0; i < n; ++i) hd_acc_add_f32(&a, v[i]);
     *out = hd_acc_to_double(a);
 }
+
+/* color.glsl:19-34 round trip over all 2^24 colours; returns the number of failures */
+int orc_color_roundtrip_failures(void)
+{
+    int bad = 0;
+    for (int c = 0; c < (1 << 24); ++c) {
+        f3 d = decode_color((float)c);
+        if (encode_color(d) != (float)c) bad++;
+        if (encode_color_bytes((c >> 16) & 255, (c >> 8) & 255, c & 255) != (float)c) bad++;
+    }
+    return bad;
+}

@@ -1,0 +1,50 @@
+"""Generates tests/golden/gputest_pair_expected.npz from the CPU oracle on the reference's only
+real-data fixture (GPUTest/{1c,1d,2c,2d}.png, BASELINE config 1: two-frame pair, CPU-only path).
+
+The reference pins nothing (no tests, cannot be built here): these are the ORACLE's outputs, kept
+as a regression pin and as the committed expectation the GPU path is compared against.
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from hrbffusion3d_amd.params import default_params, IMAGES  # noqa: E402
+from oracle_lib import Oracle  # noqa: E402
+
+
+def digest(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def run(make):
+    f = lambda n: np.array(Image.open(os.path.join(HERE, n + ".png")))
+    o = make(default_params(max_surfels=1 << 20))
+    out = {}
+    for k, (c, d) in enumerate([("1c", "1d"), ("2c", "2d")]):
+        o.process_frame(f(c), f(d))
+        tag = "f%d_" % (k + 1)
+        out[tag + "pose"] = o.get_pose()
+        out[tag + "count"] = np.array([o.surfel_count()])
+        out[tag + "stats"] = o.fuse_stats()
+        out[tag + "icp"] = np.array(o.last_icp(), np.float32)
+        out[tag + "map_sha"] = digest(o.download_map())
+        for name in IMAGES:
+            out[tag + "sha_" + name] = digest(o.get_image(name))
+        out[tag + "crop_pred_vertex"] = o.get_image("PRED_VERTEX")[200:232, 300:332].copy()
+        out[tag + "crop_fill_vertex"] = o.get_image("FILL_VERTEX")[200:232, 300:332].copy()
+        out[tag + "crop_curv1"] = o.get_image("CURV1")[200:232, 300:332].copy()
+        out[tag + "crop_normal"] = o.get_image("NORMAL")[200:232, 300:332].copy()
+    return out
+
+
+if __name__ == "__main__":
+    out = run(lambda p: Oracle(p, omp=True))
+    np.savez_compressed(os.path.join(HERE, "gputest_pair_expected.npz"), **out)
+    print("wrote", len(out), "arrays; frame-2 pose:\n", out["f2_pose"])

@@ -1,0 +1,87 @@
+"""The C-ABI shared library: loads on a CPU-only host, exports every symbol include/hrbf_mi355.h
+declares, agrees with the Python parameter mirror, and fails LOUDLY without a GPU (no CPU fallback).
+No compute entry point is exercised here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from hrbffusion3d_amd import api
+from hrbffusion3d_amd.params import HrbfParams, default_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(api.LIB_PATH):
+        from hrbffusion3d_amd import build
+        build.build()
+    return api.load_library()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "hrbf_mi355.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hrbf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(api.EXPORTS) <= set(names)
+
+
+def test_default_params_match_python_mirror(lib):
+    p = HrbfParams()
+    lib.hrbf_default_params(C.byref(p), 640, 480, 528.0, 528.0, 320.0, 240.0, 1.0 / 5000.0)
+    q = default_params()
+    for name, _ in HrbfParams._fields_:
+        assert getattr(p, name) == getattr(q, name), name
+    # GUI/GlobalStateParam.txt defaults
+    assert (p.predict_min_neighbors, p.predict_max_neighbors, p.predict_window_multiplier) == (6, 10, 3.0)
+    assert p.icp_weight == 10.0 and p.confidence_threshold == 5.0 and p.depth_cutoff == 3.5
+
+
+def test_version_and_error_strings(lib):
+    assert b"gfx950" in lib.hrbf_version()
+    assert isinstance(lib.hrbf_last_error(), bytes)
+
+
+def test_create_fails_loudly_without_a_gpu(lib):
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is visible; the no-device path cannot be exercised")
+    with pytest.raises(api.HrbfError) as e:
+        api.HRBFFusion(default_params(max_surfels=1024))
+    assert "no HIP device" in str(e.value) or "status -4" in str(e.value)
+
+
+def test_invalid_parameters_are_rejected(lib):
+    h = C.c_void_p()
+    p = default_params(max_surfels=1024)
+    p.use_sparse_icp = 1
+    assert lib.hrbf_create(C.byref(p), 0, C.byref(h)) == -1
+    p = default_params(width=642, max_surfels=1024)
+    assert lib.hrbf_create(C.byref(p), 0, C.byref(h)) == -1
+    assert lib.hrbf_create(None, 0, C.byref(h)) == -1
+
+
+def test_product_path_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under hrbffusion3d_amd/ or include/ may reference it"""
+    bad = []
+    for base in ("hrbffusion3d_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"oracle_lib|liboracle|\borc_[a-z_]+\s*\(|#include\s*[\"<][^\">]*oracle|import\s+.*oracle", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

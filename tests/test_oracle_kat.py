@@ -1,0 +1,309 @@
+"""Analytic known-answer tests that pin the CPU oracle: the reference ships no
+tests or golden vectors, so these identities — derivable from the cited maths alone — are what the
+oracle answers to."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+from hrbffusion3d_amd.params import default_params
+
+
+def _f4(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def lib(oracle_lib_built):
+    return oracle_lib_built.load()
+
+
+def test_wendland_identities(lib):
+    """phi(0)=1 => value(centre)=0; grad phi(0)=0; Hess phi(0) = -20/rho^2 I (hrbfbase.glsl:45-50)."""
+    rho = 0.05
+    n = np.array([0.3, -0.2, 0.9]); n /= np.linalg.norm(n)
+    vc = _f4([[0.1, 0.2, 1.0, 1.0]]); nr = _f4([[*n, rho]])
+    p = _f4([0.1, 0.2, 1.0])
+    ns = C.c_int()
+    assert lib.orc_hrbf_value(_p(p), _p(vc), _p(nr), 1, C.byref(ns)) == 0.0 and ns.value == 1
+    g = np.zeros(3, np.float32)
+    lib.orc_hrbf_gradient(_p(p), _p(vc), _p(nr), 1, _p(g))
+    np.testing.assert_allclose(g, 200.0 * n / rho ** 2, rtol=1e-5)
+    # outside the support everything vanishes
+    p2 = _f4([0.1, 0.2, 1.0 + 1.01 * rho])
+    assert lib.orc_hrbf_value(_p(p2), _p(vc), _p(nr), 1, C.byref(ns)) == 0.0 and ns.value == 0
+
+
+def _plane_centres(n, d, spacing=0.01, half=0.06, rho=0.04):
+    n = np.asarray(n, np.float64); n /= np.linalg.norm(n)
+    a = np.cross(n, [1.0, 0, 0]); a /= np.linalg.norm(a); b = np.cross(n, a)
+    g = np.arange(-half, half + 1e-9, spacing)
+    uu, vv = np.meshgrid(g, g)
+    pts = d * n + uu[..., None] * a + vv[..., None] * b
+    pts = pts.reshape(-1, 3)
+    vc = np.concatenate([pts, np.ones((len(pts), 1))], 1)
+    nr = np.concatenate([np.tile(n, (len(pts), 1)), np.full((len(pts), 1), rho)], 1)
+    return _f4(vc), _f4(nr), n
+
+
+def test_plane_implicit_is_odd_and_gradient_parallel_to_normal(lib):
+    vc, nr, n = _plane_centres([0.2, -0.1, 1.0], 1.0)
+    ns = C.c_int()
+    on = _f4(1.0 * n)
+    f0 = lib.orc_hrbf_value(_p(on), _p(vc), _p(nr), len(vc), C.byref(ns))
+    assert ns.value > 6
+    for delta in (0.002, 0.005, 0.01):
+        fp = lib.orc_hrbf_value(_p(_f4((1.0 + delta) * n)), _p(vc), _p(nr), len(vc), C.byref(ns))
+        fm = lib.orc_hrbf_value(_p(_f4((1.0 - delta) * n)), _p(vc), _p(nr), len(vc), C.byref(ns))
+        assert fp > 0 > fm                     # positive behind the surface (normals point away from the camera)
+        slope = (fp - fm) / (2 * delta)
+        assert abs(f0 / slope) < 2e-6          # zero level set within 2 um of the plane (fp32 centres)
+        assert abs(fp + fm - 2 * f0) < 2e-3 * abs(fp)   # odd in the signed distance
+    g = np.zeros(3, np.float32)
+    lib.orc_hrbf_gradient(_p(on), _p(vc), _p(nr), len(vc), _p(g))
+    g = g / np.linalg.norm(g)
+    assert g @ n > 0.99999
+    h = np.zeros(9, np.float32)
+    lib.orc_hrbf_hessian(_p(on), _p(vc), _p(nr), len(vc), _p(h))
+    assert np.allclose(h.reshape(3, 3), h.reshape(3, 3).T)
+
+
+def _index_map_from_depth(o, z, n_cam, conf=10.0, color=0x808080):
+    """fill the oracle's index-map images as if one surfel sat behind every pixel"""
+    W, H = o.W, o.H
+    fx, fy, cx, cy = o.params.fx, o.params.fy, o.params.cx, o.params.cy
+    r = scenes.pixel_rays(W, H, fx, fy, cx, cy)
+    P = r * z[..., None]
+    vcf = np.concatenate([P, np.full((H, W, 1), conf)], -1)
+    rad = 4.0 * np.sqrt(2.0) * z / fx
+    nr = np.concatenate([np.broadcast_to(n_cam, (H, W, 3)), rad[..., None]], -1)
+    valid = z > 0
+    vcf[~valid] = 0; nr[~valid] = 0
+    o.set_image("INDEX_VERTCONF", vcf); o.set_image("INDEX_NORMRAD", nr)
+    ct = np.zeros((H, W, 4)); ct[..., 0] = color; ct[..., 2] = 1; ct[..., 3] = 1
+    o.set_image("INDEX_COLORTIME", ct)
+    k = np.zeros((H, W, 4)); k[..., 0] = 1.0
+    o.set_image("INDEX_CURVMAX", k); o.set_image("INDEX_CURVMIN", k)
+    o.set_image("INDEX", np.arange(1, W * H + 1, dtype=np.uint32).reshape(H, W))
+
+
+@pytest.mark.parametrize("normal", [(0.0, 0.0, 1.0), (0.25, -0.15, 1.0)])
+def test_prediction_lands_on_the_plane(oracle_lib_built, normal):
+    """HRBF ray cast of a dense planar surfel set returns the plane to < 1e-4 m, normal || n."""
+    W, H = 96, 72
+    p = default_params(W, H, 80.0, 80.0, 48.0, 36.0, max_surfels=1024)
+    o = oracle_lib_built.Oracle(p)
+    n = np.asarray(normal, np.float64); n /= np.linalg.norm(n)
+    z = scenes.plane_depth(W, H, p.fx, p.fy, p.cx, p.cy, n, 1.5)
+    _index_map_from_depth(o, z, n)
+    o.run_stage("PREDICT_HRBF")
+    pv = o.get_image("PRED_VERTEX"); pn = o.get_image("PRED_NORMAL")
+    inner = np.zeros((H, W), bool); inner[6:-6, 6:-6] = True
+    ok = pv[..., 2] > 0
+    assert ok[inner].mean() > 0.999
+    dist = np.abs(pv[..., :3] @ n - 1.5)
+    assert dist[inner & ok].max() < 1e-4
+    assert (pn[..., :3] @ n)[inner & ok].min() > 0.9999
+    assert np.all(pv[inner & ok][:, 3] == 10.0)           # nearest-neighbour confidence
+    assert np.all(o.get_image("PRED_IMAGE")[inner & ok][:, :3] == 0x80)
+    o.close()
+
+
+def _sphere_kappa(oracle_lib_built, R, zc):
+    W, H = 160, 120
+    p = default_params(W, H, 264.0, 264.0, 80.0, 60.0, max_surfels=1024)
+    o = oracle_lib_built.Oracle(p)
+    z = scenes.sphere_depth(W, H, p.fx, p.fy, p.cx, p.cy, (0, 0, zc), R)
+    r = scenes.pixel_rays(W, H, p.fx, p.fy, p.cx, p.cy)
+    P = r * z[..., None]
+    n = (np.array([0, 0, zc]) - P) / R          # towards the centre = away from the camera
+    rad = np.where(z > 0, 4.0 * np.sqrt(2.0) * z / p.fx, 0.0)
+    valid = z > 0
+    vf = np.concatenate([P, np.ones((H, W, 1))], -1); vf[~valid] = 0
+    nn = np.concatenate([n, rad[..., None]], -1); nn[~valid] = 0
+    o.set_image("VERTEX_FILTERED", vf); o.set_image("NORMAL", nn)
+    o.run_stage("CURVATURE")
+    k1 = o.get_image("CURV1")[..., 3]; k2 = o.get_image("CURV2")[..., 3]
+    core = valid & (n[..., 2] > 0.8) & (np.abs(k1) < 300)
+    no = o.get_image("NORMAL")[..., :3]
+    cosn = np.median((no[core] * n[core]).sum(-1))
+    o.close()
+    return k1[core], k2[core], cosn
+
+
+def test_sphere_curvature(oracle_lib_built):
+    """P4 on a sphere (depth_curvature_gradient.frag:95-137): the closed-form HRBF (coefficients
+    10 n_i, no solve) is a quasi-interpolant, so kappa carries a constant bias; what must hold is
+    isotropy (k1 ~ k2), one sign, the 1/R scaling and the right order of magnitude."""
+    k1a, k2a, cosa = _sphere_kappa(oracle_lib_built, 0.4, 1.3)
+    k1b, k2b, cosb = _sphere_kappa(oracle_lib_built, 0.8, 1.7)
+    assert len(k1a) > 500 and len(k1b) > 500
+    ma, mb = np.median(k1a), np.median(k1b)
+    assert np.sign(ma) == np.sign(mb) == np.sign(np.median(k2a))
+    assert abs(np.median(k1a) - np.median(k2a)) < 0.1 * abs(ma)      # umbilic
+    assert 0.6 / 0.4 < abs(ma) < 1.5 / 0.4 and 0.6 / 0.8 < abs(mb) < 1.5 / 0.8
+    assert abs(ma / mb - 2.0) < 0.3                                  # kappa ~ 1/R
+    assert cosa > 0.999 and cosb > 0.999                             # refined normal stays analytic
+
+
+def test_plane_curvature_is_zero(oracle_lib_built):
+    W, H = 96, 72
+    p = default_params(W, H, 160.0, 160.0, 48.0, 36.0, max_surfels=1024)
+    o = oracle_lib_built.Oracle(p)
+    n = np.array([0.1, 0.2, 1.0]); n /= np.linalg.norm(n)
+    z = scenes.plane_depth(W, H, p.fx, p.fy, p.cx, p.cy, n, 1.2)
+    r = scenes.pixel_rays(W, H, p.fx, p.fy, p.cx, p.cy)
+    P = r * z[..., None]
+    vf = np.concatenate([P, np.ones((H, W, 1))], -1)
+    nn = np.concatenate([np.broadcast_to(n, (H, W, 3)), (4 * np.sqrt(2) * z / p.fx)[..., None]], -1)
+    o.set_image("VERTEX_FILTERED", vf); o.set_image("NORMAL", nn)
+    o.run_stage("CURVATURE")
+    k1 = o.get_image("CURV1")[6:-6, 6:-6, 3]; k2 = o.get_image("CURV2")[6:-6, 6:-6, 3]
+    assert np.abs(k1).max() < 0.05 and np.abs(k2).max() < 0.05
+    o.close()
+
+
+def _planar_maps(z, fx, fy, cx, cy, n_img):
+    """planar (4,H,W) maps like RGBDOdometry's DeviceArray2D from a depth image and a normal image"""
+    H, W = z.shape
+    r = scenes.pixel_rays(W, H, fx, fy, cx, cy)
+    P = r * z[..., None]
+    v = np.stack([P[..., 0], P[..., 1], P[..., 2], np.ones_like(z)]).astype(np.float32)
+    n = np.stack([n_img[..., 0], n_img[..., 1], n_img[..., 2], np.ones_like(z)]).astype(np.float32)
+    bad = z <= 0
+    v[0][bad] = np.nan; n[0][bad] = np.nan
+    k = np.zeros_like(v); k[3] = 0.5
+    return np.ascontiguousarray(v), np.ascontiguousarray(n), np.ascontiguousarray(k)
+
+
+def _corner_normals(z, fx, fy, cx, cy):
+    r = scenes.pixel_rays(z.shape[1], z.shape[0], fx, fy, cx, cy)
+    P = r * z[..., None]
+    dx = np.zeros_like(P); dy = np.zeros_like(P)
+    dx[:, 1:-1] = P[:, 2:] - P[:, :-2]; dy[1:-1] = P[2:] - P[:-2]
+    n = np.cross(dx, dy); ln = np.linalg.norm(n, axis=-1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-12), 0)
+    n = np.where(n[..., 2:3] < 0, -n, n)
+    return n
+
+
+def _icp(lib, Rc, tc, cur, Rpi, tp, K, mod, use_weight=0, w=None):
+    v, n, k = cur; vg, ng, kg = mod
+    H, W = v.shape[1:]
+    A = np.zeros(36); b = np.zeros(6); res = np.zeros(2)
+    if w is None:
+        w = np.ones((H, W), np.float32)
+    lib.orc_icp_step(_p(_f4(Rc)), _p(_f4(tc)), _p(v), _p(n), _p(k), _p(k), _p(_f4(Rpi)), _p(_f4(tp)),
+                     K[0], K[1], K[2], K[3], _p(vg), _p(ng), _p(kg), _p(kg), _p(w), H, W, 0.1, 0.342, use_weight,
+                     _p(A), _p(b), _p(res))
+    return A.reshape(6, 6), b, res
+
+
+def test_icp_identity_gives_zero_rhs_and_spd_matrix(lib):
+    W, H = 160, 120
+    K = (132.0, 132.0, 80.0, 60.0)
+    z = scenes.corner_depth(W, H, *K)
+    m = _planar_maps(z, *K, _corner_normals(z, *K))
+    A, b, res = _icp(lib, np.eye(3), np.zeros(3), m, np.eye(3), np.zeros(3), K, m)
+    assert res[1] > 0.8 * W * H and res[0] == 0.0
+    assert np.all(b == 0.0)
+    assert np.allclose(A, A.T) and np.linalg.eigvalsh(A).min() > 0
+
+
+def test_icp_recovers_a_known_small_motion(lib):
+    W, H = 160, 120
+    K = (132.0, 132.0, 80.0, 60.0)
+    z = scenes.corner_depth(W, H, *K)
+    model = _planar_maps(z, *K, _corner_normals(z, *K))
+    # the live frame is the model seen from a slightly moved camera: points expressed in the new camera frame
+    rv = np.array([0.004, -0.006, 0.003]); t = np.array([0.004, -0.003, 0.005])
+    th = np.linalg.norm(rv); kx = rv / th
+    Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx     # T_wc of the live camera
+    r = scenes.pixel_rays(W, H, *K)
+    # analytic re-render: intersect live rays (world: R r, origin t) with the three planes again
+    A3 = np.array([[1.0, 1.0, 1.0], [-1.0, 1.0, 1.0], [0.0, -1.0, 1.0]]); A3 /= np.linalg.norm(A3, axis=1, keepdims=True)
+    q, _ = np.linalg.qr(A3.T); ns = np.array([n if n[2] > 0 else -n for n in q.T]); apex = np.array([0, 0, 2.2])
+    rw = r @ R.T
+    ts = [np.where(rw @ n > 1e-6, ((apex - t) @ n) / (rw @ n), np.inf) for n in ns]
+    zl = np.min(np.stack(ts), axis=0); zl = np.where(np.isfinite(zl), zl, 0)
+    nl_world = np.zeros((H, W, 3))
+    which = np.argmin(np.stack(ts), axis=0)
+    for i, n in enumerate(ns):
+        nl_world[which == i] = n
+    nl = nl_world @ R                                                  # into the live camera frame
+    nl = np.where(nl[..., 2:3] < 0, -nl, nl)
+    live = _planar_maps(zl, *K, nl)
+    Rc, tc = np.eye(3), np.zeros(3)
+    for _ in range(12):
+        A, b, res = _icp(lib, Rc, tc, live, np.eye(3), np.zeros(3), K, model)
+        x = np.zeros(6)
+        lib.orc_solve6(_p(np.ascontiguousarray(A)), _p(np.ascontiguousarray(b)), _p(x))
+        # incremental update of the MODEL->live transform, as in computeUpdateSE3 + T_prev * dT^-1
+        wv = x[3:]; th2 = np.linalg.norm(wv)
+        if th2 > 0:
+            k2 = wv / th2; K2 = np.array([[0, -k2[2], k2[1]], [k2[2], 0, -k2[0]], [-k2[1], k2[0], 0]])
+            dR = np.eye(3) + np.sin(th2) * K2 + (1 - np.cos(th2)) * K2 @ K2
+        else:
+            dR = np.eye(3)
+        T = np.eye(4); T[:3, :3] = dR; T[:3, 3] = x[:3]
+        Tc = np.eye(4); Tc[:3, :3] = Rc; Tc[:3, 3] = tc
+        Tc = Tc @ np.linalg.inv(T)
+        Rc, tc = Tc[:3, :3], Tc[:3, 3]
+    assert np.linalg.norm(tc - t) < 1e-4
+    assert np.linalg.norm(Rc - R) < 1e-4
+
+
+def test_solve6_matches_numpy(lib):
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((6, 6)); A = M @ M.T + 0.1 * np.eye(6); b = rng.standard_normal(6)
+    x = np.zeros(6)
+    lib.orc_solve6(_p(np.ascontiguousarray(A)), _p(b), _p(x))
+    np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-10)
+
+
+def test_colour_round_trip_all_2_pow_24(lib):
+    lib.orc_color_roundtrip_failures.restype = C.c_int
+    assert lib.orc_color_roundtrip_failures() == 0
+
+
+def test_merge_is_confidence_weighted_average(oracle_lib_built):
+    """update.vert:82-93: fusing the identical frame again at the same pose keeps positions and adds
+    the pixel confidence; a = c_k would give the midpoint — here v_g == v_k so the mean is v_k."""
+    W, H = 160, 120
+    fx = 132.0
+    p = default_params(W, H, fx, fx, 80.0, 60.0, max_surfels=1 << 16, load_trajectory=1)
+    o = oracle_lib_built.Oracle(p)
+    z = scenes.plane_depth(W, H, fx, fx, 80.0, 60.0, (0.0, 0.0, 1.0), 1.5)
+    d = scenes.to_u16(z); rgb = scenes.gray_rgb(W, H)
+    o.process_frame(rgb, d)
+    m0 = o.download_map()
+    assert len(m0) > 0.8 * W * H
+    o.process_frame(rgb, d)
+    st = o.fuse_stats(); m1 = o.download_map()
+    assert st[1] > 0.15 * W * H          # the quarter grid merged
+    removed = int(st[0]) + int(st[2]) - int(st[3])
+    # order-preserving compaction: survivors keep their relative order, so after dropping the removed
+    # surfels the first (n0 - removed) rows of m1 are the old surfels.  Match by init pixel (unchanged cols).
+    n0 = len(m0)
+    keep = n0 - removed
+    old = m1[:keep]
+    changed = old[:, 7] == 2.0
+    assert changed.sum() <= st[1]
+    if removed == 0:
+        assert changed.sum() == st[1]
+        # the reference seeds with integer pixel coordinates (depth_vertex_normal_radius.frag:38) but fuses
+        # with pixel centres (data.vert:66-72): x,y move by about half a pixel footprint, z stays
+        assert np.median(np.abs(old[changed, :2] - m0[changed, :2])) < 0.5 * 1.5 / fx
+        assert np.abs(old[changed, 2] - m0[changed, 2]).max() < 1e-4
+        assert np.all(old[changed, 3] > m0[changed, 3])                  # confidence accumulated
+        assert np.array_equal(old[~changed].view(np.uint32), m0[~changed].view(np.uint32))   # untouched: bit-identical
+    else:
+        assert np.all(old[changed, 3] > 1.0)
+    assert np.all(m1[keep:, 7] == 2.0) and np.all(m1[keep:, 6] == 2.0)   # appended this frame
+    o.close()

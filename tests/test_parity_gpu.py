@@ -1,0 +1,286 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle.  Everything here is BIT-EXACT:
+integer images, float images (compared as raw bits, NaN included), the surfel map and the pose.
+The arithmetic contract (include/hrbf_detmath.h) is what makes that possible; the only tolerance in
+this file is on the standalone icpStep seam against an independent fp64 numpy reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from hrbffusion3d_amd import synth
+from hrbffusion3d_amd.params import IMAGES, default_params
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gputest_pair_expected.npz")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def assert_same_state(o, g, tag="", images=None):
+    for name in (images or IMAGES):
+        a, b = o.get_image(name), g.get_image(name)
+        assert np.array_equal(bits(a), bits(b)), "%s image %s differs in %d values" % (
+            tag, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()) if a.dtype.itemsize == 4 else -1)
+    assert o.surfel_count() == g.surfel_count(), tag
+    assert np.array_equal(bits(o.download_map()), bits(g.download_map())), tag + " map"
+    assert np.array_equal(bits(o.get_pose()), bits(g.get_pose())), tag + " pose"
+
+
+@pytest.fixture()
+def pair(oracle_lib_built, gpu_available):
+    from hrbffusion3d_amd.api import HRBFFusion
+    made = []
+
+    def make(params, omp=True):
+        o = oracle_lib_built.Oracle(params, omp=omp); g = HRBFFusion(params)
+        made.append((o, g))
+        return o, g
+    yield make
+    for o, g in made:
+        o.close(); g.close()
+
+
+def test_native_library_is_the_one_running(gpu_available):
+    from hrbffusion3d_amd import api
+    api.load_library()
+    maps = open("/proc/self/maps").read()
+    assert "libhrbf_mi355.so" in maps
+
+
+def test_png_pair_matches_oracle_and_golden(pair, png_pair):
+    """GPUTest/{1c,1d,2c,2d}.png (the reference's only real-data fixture), 640x480, four frames."""
+    import hashlib
+    o, g = pair(default_params(max_surfels=1 << 20))
+    exp = np.load(GOLD)
+    seq = [png_pair[0], png_pair[1], png_pair[0], png_pair[1]]
+    for k, (rgb, d) in enumerate(seq):
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "frame %d" % (k + 1))
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+        assert o.last_icp() == g.last_icp() and o.get_weighting() == g.get_weighting()
+        if k < 2:   # committed golden fixture
+            tag = "f%d_" % (k + 1)
+            assert np.array_equal(bits(g.get_pose()), bits(exp[tag + "pose"]))
+            assert g.surfel_count() == int(exp[tag + "count"][0])
+            sha = np.frombuffer(hashlib.sha256(g.download_map().tobytes()).digest(), np.uint8)
+            assert np.array_equal(sha, exp[tag + "map_sha"])
+            for name in IMAGES:
+                sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(g.get_image(name)).tobytes()).digest(), np.uint8)
+                assert np.array_equal(sha, exp[tag + "sha_" + name]), name
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_tracked_synthetic_stream(pair, noise):
+    """QVGA synthetic stream against a pre-seeded map, tracking ON: 10 frames, every image, the map
+    (content AND order) and the trajectory bit-identical to the oracle."""
+    W, H = 320, 240
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    seed = synth.seed_map(150_000, width=W)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=seed.shape[0] + 400_000)
+    o, g = pair(p)
+    rgb, d, T = synth.frame(0, W, H, noise=noise)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
+    assert_same_state(o, g, "bootstrap")
+    for k in range(1, 11):
+        rgb, d, T = synth.frame(k, W, H, noise=noise)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "frame %d" % k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+    err = np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3])
+    assert err < 0.05
+
+
+@pytest.mark.parametrize("variant", ["gauss_filter", "central_diff_normals", "no_so3_no_pyramid", "conf_eval", "rgb_only",
+                                     "icp_only"])
+def test_parameter_variants(pair, variant):
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    kw = {"gauss_filter": dict(use_bilateral=0), "central_diff_normals": dict(normal_estimation_pca=0.0),
+          "no_so3_no_pyramid": dict(so3=0, pyramid=0, fast_odom=1), "conf_eval": dict(use_conf_eval=1),
+          "rgb_only": dict(rgb_only=1), "icp_only": dict(icp_weight=100.0)}[variant]
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17, **kw)
+    o, g = pair(p)
+    for k in range(4):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "%s frame %d" % (variant, k))
+
+
+def test_edge_cases_empty_and_invalid_depth(pair):
+    """all-zero depth (no valid pixel), depth beyond the cut-off, and a frame after an empty one"""
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 16)
+    o, g = pair(p)
+    rgb = scenes.gray_rgb(W, H)
+    zero = np.zeros((H, W), np.uint16)
+    far = np.full((H, W), 60000, np.uint16)
+    good = synth.frame(0, W, H)[1]
+    ragged = good.copy(); ragged[::3, ::2] = 0; ragged[:7] = 0; ragged[:, -5:] = 0
+    for k, d in enumerate([zero, far, good, ragged, zero, good]):
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "edge frame %d" % k)
+    assert g.surfel_count() > 0
+
+
+def test_stage_seams_in_isolation(pair):
+    """operator-level seams: each stage run alone on injected inputs"""
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    rgb, d, T = synth.frame(3, W, H, noise=True)
+    for x in (o, g):
+        x.upload_frame(rgb, d)
+        x.run_stage("FILTER_DEPTH"); x.run_stage("METRICISE")
+    assert_same_state(o, g, "filter", ["DEPTH_FILTERED", "DEPTH_METRIC", "DEPTH_METRIC_FILTERED"])
+    for x in (o, g):
+        x.run_stage("VERTEX_NORMAL_RADIUS")
+    assert_same_state(o, g, "vnr", ["VERTEX_RAW", "VERTEX_FILTERED", "NORMAL", "NORMAL_PCA", "RADIUS"])
+    for x in (o, g):
+        x.run_stage("CURVATURE")
+    assert_same_state(o, g, "curv", ["CURV1", "CURV2", "GRADIENT_MAG", "NORMAL"])
+    for x in (o, g):
+        x.set_weighting(0.75); x.run_stage("CONFIDENCE")
+    assert_same_state(o, g, "conf", ["CONFIDENCE"])
+    seed = synth.seed_map(60_000, width=W)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.set_tick(5); x.run_stage("PREDICT_INDICES")
+    assert_same_state(o, g, "indices", [n for n in IMAGES if n.startswith("INDEX")])
+    for x in (o, g):
+        x.run_stage("PREDICT_HRBF"); x.run_stage("FILLIN")
+    assert_same_state(o, g, "predict", [n for n in IMAGES if n.startswith(("PRED", "FILL"))])
+    for x in (o, g):
+        x.run_stage("FUSE")
+    assert np.array_equal(o.fuse_stats()[:2], g.fuse_stats()[:2])
+    assert_same_state(o, g, "fuse", ["INDEX"])
+    for x in (o, g):
+        x.run_stage("PREDICT_INDICES"); x.run_stage("CLEAN")
+    assert_same_state(o, g, "clean", ["INDEX"])
+    assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+    # idempotence: a second clean without a fuse appends nothing and keeps the map
+    before = g.download_map()
+    for x in (o, g):
+        x.run_stage("PREDICT_INDICES"); x.run_stage("CLEAN")
+    assert_same_state(o, g, "clean twice", ["INDEX"])
+    assert g.fuse_stats()[2] == 0 and len(g.download_map()) <= len(before)
+
+
+def test_icp_step_seam(oracle_lib_built, gpu_available):
+    """hrbf_icp_step on caller-owned device maps == oracle (bit-exact sums) ~= fp64 numpy (1e-5)."""
+    import torch
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    K = (132.0, 132.0, 80.0, 60.0)
+    z = scenes.corner_depth(W, H, *K)
+    r = scenes.pixel_rays(W, H, *K)
+    P = r * z[..., None]
+    dx = np.zeros_like(P); dy = np.zeros_like(P)
+    dx[:, 1:-1] = P[:, 2:] - P[:, :-2]; dy[1:-1] = P[2:] - P[:-2]
+    n = np.cross(dx, dy); ln = np.linalg.norm(n, axis=-1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-12), 0); n = np.where(n[..., 2:3] < 0, -n, n)
+    v = np.stack([P[..., 0], P[..., 1], P[..., 2], np.ones_like(z)]).astype(np.float32)
+    nn = np.stack([n[..., 0], n[..., 1], n[..., 2], np.ones_like(z)]).astype(np.float32)
+    v[0][z <= 0] = np.nan; nn[0][ln[..., 0] <= 0] = np.nan
+    kk = np.zeros_like(v); kk[3] = 0.5
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.1, 3.0, (H, W)).astype(np.float32); w[::7, ::5] = np.nan
+    Rc = np.eye(3, dtype=np.float32); Rc[0, 1] = -0.004; Rc[1, 0] = 0.004
+    tc = np.array([0.003, -0.002, 0.004], np.float32)
+    I3 = np.eye(3, dtype=np.float32); t0 = np.zeros(3, np.float32)
+    lib = oracle_lib_built.load()
+    A0 = np.zeros(36); b0 = np.zeros(6); r0 = np.zeros(2)
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.orc_icp_step(pp(Rc), pp(tc), pp(v), pp(nn), pp(kk), pp(kk), pp(I3), pp(t0), *K, pp(v), pp(nn), pp(kk), pp(kk),
+                     pp(w), H, W, 0.1, 0.342, 1, pp(A0), pp(b0), pp(r0))
+    g = HRBFFusion(default_params(W, H, *K, max_surfels=1024))
+    dv, dn, dk, dw = (torch.from_numpy(a).cuda() for a in (v, nn, kk, w))
+    A1 = np.zeros(36); b1 = np.zeros(6); r1 = np.zeros(2)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    rc = g.lib.hrbf_icp_step(g.h, pp(Rc), pp(tc), dp(dv), dp(dn), dp(dk), dp(dk), pp(I3), pp(t0), *K, dp(dv), dp(dn),
+                             dp(dk), dp(dk), dp(dw), H, W, 0.1, 0.342, 1, pp(A1), pp(b1), pp(r1))
+    assert rc == 0
+    assert np.array_equal(A0, A1) and np.array_equal(b0, b1) and np.array_equal(r0, r1)
+    assert r1[1] > 0.5 * W * H
+    # independent fp64 reference of the point-to-plane system (reduce.cu:494-545)
+    Pm = np.moveaxis(v[:3].astype(np.float64), 0, -1); Nm = np.moveaxis(nn[:3].astype(np.float64), 0, -1)
+    s = Pm @ Rc.astype(np.float64).T + tc
+    u = np.rint(s[..., 0] * K[0] / s[..., 2] + K[2]); vv = np.rint(s[..., 1] * K[1] / s[..., 2] + K[3])
+    ok = np.isfinite(u) & np.isfinite(vv) & (u >= 0) & (vv >= 0) & (u < W) & (vv < H)
+    ui = np.where(ok, u, 0).astype(int); vi = np.where(ok, vv, 0).astype(int)
+    dm = Pm[vi, ui]; nm = Nm[vi, ui]; wm = w[vi, ui].astype(np.float64)
+    ng = Nm @ Rc.astype(np.float64).T
+    ok &= np.isfinite(dm[..., 0]) & np.isfinite(nm[..., 0]) & np.isfinite(Pm[..., 0]) & np.isfinite(Nm[..., 0])
+    ok &= (np.linalg.norm(dm - s, axis=-1) <= 0.1) & (np.linalg.norm(np.cross(ng, nm), axis=-1) <= 0.342)
+    wm = np.where(np.isnan(wm), 0.0, wm)
+    J = np.concatenate([nm, np.cross(s, nm)], -1)[ok]; rr = ((s - dm) * nm).sum(-1)[ok]; ww = wm[ok]
+    A_ref = (J * ww[:, None]).T @ J; b_ref = (J * ww[:, None]).T @ rr
+    assert int(r1[1]) == int(ok.sum())
+    np.testing.assert_allclose(A1.reshape(6, 6), A_ref, rtol=1e-5, atol=1e-7 * np.abs(A_ref).max())
+    np.testing.assert_allclose(b1, b_ref, rtol=1e-5, atol=1e-6 * np.abs(b_ref).max())
+    g.close()
+
+
+def test_full_size_properties_1M(gpu_available):
+    """BASELINE sizes (640x480, > 1 M surfels): size-independent properties instead of the oracle:
+    count conservation, order preservation of the compaction, in-place invariance of untouched
+    surfels, z-buffer correctness of the index map, and run-to-run determinism."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 640, 480
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    seed = synth.seed_map(1_050_000)
+    seed[:, 6] = np.arange(len(seed)) % 16000 + 1      # initTime doubles as an order tag (kept < 2^24)
+    tag = (seed[:, 0].view(np.uint32).astype(np.uint64) << 32) | seed[:, 1].view(np.uint32)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=seed.shape[0] + 600_000)
+
+    def run():
+        g = HRBFFusion(p)
+        g.upload_map(seed); g.set_pose(synth.camera_pose(0))
+        rgb, d, _ = synth.frame(0, W, H); g.bootstrap(rgb, d)
+        maps, stats = [], []
+        for k in range(1, 4):
+            rgb, d, T = synth.frame(k, W, H)
+            g.process_frame(rgb, d)
+            maps.append(g.download_map()); stats.append(g.fuse_stats().astype(np.int64))
+        out = (maps, stats, g.get_pose(), g.get_image("INDEX"), g.get_image("INDEX_VERTCONF"), T)
+        g.close()
+        return out
+
+    maps, stats, pose, idx, vcf, T = run()
+    n_prev = len(seed)
+    for m, st in zip(maps, stats):
+        assert st[0] == n_prev and st[3] == len(m)
+        removed = st[0] + st[2] - st[3]
+        assert removed >= 0 and st[1] > 30000 and st[2] <= (W // 2) * (H // 2)
+        n_prev = len(m)
+    # order preservation: the seeded surfels that survive appear in their original relative order.
+    # Unmerged surfels keep (x,y) bit for bit -> their tags form a subsequence of the seed tags.
+    m = maps[-1]
+    old = m[m[:, 7] == 1.0]                      # never merged, never appended
+    t_old = (old[:, 0].view(np.uint32).astype(np.uint64) << 32) | old[:, 1].view(np.uint32)
+    pos = {int(t): i for i, t in enumerate(tag)}
+    where = np.array([pos[int(t)] for t in t_old[::97]])
+    assert np.all(np.diff(where) > 0)
+    assert np.array_equal(bits(old[::97]), bits(seed[where]))      # untouched surfels are bit-identical
+    # appended surfels carry this run's time stamps and sit at the tail
+    tail = m[len(seed) - int(sum(s[0] + s[2] - s[3] for s in stats)):]
+    assert np.all(tail[:, 6] >= 2.0)
+    # index map = z-buffer: each stored index points at a surfel that projects into that pixel with that depth
+    ys, xs = np.nonzero(idx)
+    sel = slice(None, None, 211)
+    Tinv = np.linalg.inv(pose.astype(np.float64))
+    P = maps[-1][idx[ys[sel], xs[sel]], :3].astype(np.float64) @ Tinv[:3, :3].T + Tinv[:3, 3]
+    assert np.abs(P[:, 2] - vcf[ys[sel], xs[sel], 2]).max() < 1e-5
+    u = np.floor(fx * P[:, 0] / P[:, 2] + cx); v = np.floor(fy * P[:, 1] / P[:, 2] + cy)
+    assert (np.abs(u - xs[sel]) <= 1).all() and (np.abs(v - ys[sel]) <= 1).all()
+    assert np.linalg.norm(pose[:3, 3] - T[:3, 3]) < 0.02
+    # determinism: atomics (z-buffer, slots, look-back) do not leak scheduling order into the result
+    maps2, stats2, pose2, idx2, _, _ = run()
+    assert np.array_equal(bits(maps[-1]), bits(maps2[-1])) and np.array_equal(bits(pose), bits(pose2))
+    assert np.array_equal(idx, idx2)
