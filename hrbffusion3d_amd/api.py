@@ -13,7 +13,7 @@ import numpy as np
 from .params import HrbfParams, IMAGES, STAGES, default_params  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhrbf_mi355.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("HRBF_LIB", "libhrbf_mi355.so"))   # HRBF_LIB: experiment builds
 _lib = None
 
 EXPORTS = [

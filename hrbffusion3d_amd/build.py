@@ -26,15 +26,23 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: experiment variants, e.g. build(True, defines=["-DFUSE_IPT=4"], out="libhrbf_v1.so")"""
+    global OUT
+    if out is not None:
+        return _build_to(os.path.join(HERE, out), list(defines), verbose, "_" + os.path.splitext(out)[0])
     if not force and not _stale():
         return OUT
+    return _build_to(OUT, [], verbose, "")
+
+
+def _build_to(OUT, defines, verbose, suffix):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS
+        obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
+        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS + defines
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

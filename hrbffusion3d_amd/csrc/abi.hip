@@ -60,8 +60,10 @@ struct hrbf_context {
     float4 *d_pr_vertex, *d_pr_normal, *d_pr_curv1, *d_pr_curv2, *d_fi_vertex, *d_fi_normal, *d_fi_curv1, *d_fi_curv2;
     uint32_t *d_pr_time; float *d_pr_icpw, *d_fi_icpw;
     // map
-    MapPlanes map[2];
-    int target;
+    MapPlanes map;              // single copy: the fuse pass compacts in place
+    int target;                 // index of the live surfel-count word (d_count ping-pongs)
+    int map_dirty;              // map uploaded from outside since the last fuse pass -> full curvature re-check
+    int fuse_tick;              // tick of the last association/merge (a clean at another tick re-checks everything)
     uint32_t cap;
     uint32_t *d_count;          // [2], ping-pong with the map
     uint32_t count_ub;          // host upper bound of the surfel count
@@ -69,7 +71,9 @@ struct hrbf_context {
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best; uint32_t *d_slot;
     uint32_t *d_stats; uint32_t *d_init_flags, *d_init_offs;
-    unsigned long long *d_tile_status; uint32_t max_tiles; uint32_t *d_ticket;
+    uint32_t *d_tile_count; uint32_t *d_tile_done; uint32_t max_tiles;
+    uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
+    float4 *d_clean_tex;        // 2 x float4 per pixel: packed index-map texels for the clean test
     DevPose *d_pose;
     OdoBuffers odo;
     // timing
@@ -147,14 +151,15 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     DA(c->d_fi_vertex, P); DA(c->d_fi_normal, P); DA(c->d_fi_curv1, P); DA(c->d_fi_curv2, P);
     DA(c->d_pr_time, P); DA(c->d_pr_icpw, P); DA(c->d_fi_icpw, P);
     c->cap = (uint32_t)p->max_surfels;
-    { int r; if ((r = alloc_planes(c, c->map[0], c->cap)) || (r = alloc_planes(c, c->map[1], c->cap)) ||
-                 (r = alloc_planes(c, c->rec, c->Q))) { hrbf_destroy(c); return r; } }
+    { int r; if ((r = alloc_planes(c, c->map, c->cap)) || (r = alloc_planes(c, c->rec, c->Q))) { hrbf_destroy(c); return r; } }
     DA(c->d_count, 2);
     DA(c->d_rec_flag, c->Q); DA(c->d_rec_best, c->Q); DA(c->d_slot, c->cap);
     DA(c->d_stats, 4); DA(c->d_init_flags, P); DA(c->d_init_offs, P);
     c->max_tiles = (c->cap + c->Q) / fuse_tile_items() + 2;
-    DA(c->d_tile_status, c->max_tiles); DA(c->d_ticket, 1);
+    DA(c->d_tile_count, (size_t)c->max_tiles * fuse_tile_count_stride()); DA(c->d_tile_done, c->max_tiles);
     DA(c->d_pose, 1);
+    DA(c->d_keep_flags, (size_t)c->cap + (size_t)c->Q + 64);
+    DA(c->d_clean_tex, 2 * P);
     e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * 2, hipHostMallocDefault);
     if (e != hipSuccess) { hrbf_set_error("hipHostMalloc: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     c->h_count_pinned[0] = 0;
@@ -177,8 +182,9 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     { uint8_t *st; DA(st, odo_state_bytes()); c->odo.state = (OdoState *)st; }
     DA(c->odo.corres, P * 6); DA(c->odo.corres_diff, P);
     c->odo.max_blocks = (int)((P + 255) / 256);
-    DA(c->odo.icp_part, (size_t)c->odo.max_blocks * 87); DA(c->odo.rgb_part, (size_t)c->odo.max_blocks * 87);
-    DA(c->odo.res_part, (size_t)c->odo.max_blocks * 2); DA(c->odo.so3_part, (size_t)c->odo.max_blocks * 33);
+    { uint8_t *blk; DA(blk, odo_slot_bytes());
+      c->odo.icp_part = (long long *)blk; c->odo.rgb_part = c->odo.icp_part + 32 * 87;
+      c->odo.res_part = c->odo.rgb_part + 32 * 87; c->odo.so3_part = c->odo.res_part + 64 * 2; }
     DA(c->odo.totals, 256);
     if (predict_upload_tables() != 0) { hrbf_set_error("constant upload failed"); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     launch_fill_u32(c->stream, c->d_slot, c->cap, 0xFFFFFFFFu);
@@ -204,11 +210,10 @@ extern "C" void hrbf_destroy(hrbf_handle c)
                     c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, c->d_pr_image, c->d_fi_image, c->d_pr_vertex,
                     c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_fi_vertex, c->d_fi_normal, c->d_fi_curv1,
                     c->d_fi_curv2, c->d_pr_time, c->d_pr_icpw, c->d_fi_icpw, c->d_count, c->d_rec_flag, c->d_rec_best,
-                    c->d_slot, c->d_stats, c->d_init_flags, c->d_init_offs, c->d_tile_status, c->d_ticket, c->d_pose,
-                    c->odo.state, c->odo.corres, c->odo.corres_diff, c->odo.icp_part, c->odo.rgb_part, c->odo.res_part,
-                    c->odo.so3_part, c->odo.totals};
+                    c->d_slot, c->d_stats, c->d_init_flags, c->d_init_offs, c->d_tile_count, c->d_tile_done, c->d_pose, c->d_keep_flags, c->d_clean_tex,
+                    c->odo.state, c->odo.corres, c->odo.corres_diff, c->odo.icp_part, c->odo.totals};
     for (void *p : ptrs) if (p) hipFree(p);
-    free_planes(c->map[0]); free_planes(c->map[1]); free_planes(c->rec);
+    free_planes(c->map); free_planes(c->rec);
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         OdoLevel &L = c->odo.lv[i];
         void *q[] = {L.vmap_g, L.nmap_g, L.ck1_g, L.ck2_g, L.vmap_c, L.nmap_c, L.ck1_c, L.ck2_c, L.icpw, L.last_depth,
@@ -293,29 +298,31 @@ static void st_init(hrbf_context *c)
 {
     launch_initialise(c->stream, c->cam, c->d_pose, c->d_vertex_raw, c->d_normal, c->d_rgb, c->d_curv1, c->d_curv2,
                       c->d_gradmag, c->prm.use_conf_eval, c->prm.conf_eval_epsilon, c->prm.curv_valid_threshold,
-                      c->d_init_flags, c->d_init_offs, c->map[c->target], c->cap, &c->d_count[c->target]);
+                      c->d_init_flags, c->d_init_offs, c->map, c->cap, &c->d_count[c->target]);
     c->count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
     launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
 }
-static void st_indices(hrbf_context *c)
+static void st_indices(hrbf_context *c, bool for_clean = true)
 {
-    launch_predict_indices(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->map[c->target],
+    launch_predict_indices(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->map,
                            &c->d_count[c->target], c->count_ub, c->d_zbuf, c->d_idx, c->d_im_vertconf,
-                           c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin);
+                           c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin,
+                           for_clean ? c->d_clean_tex : nullptr);
 }
 static void st_fuse(hrbf_context *c)
 {
     launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, 0, c->d_depth_metric, c->d_normal_pca,
                 c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf, c->d_im_normrad, c->rec,
-                c->d_rec_flag, c->d_rec_best, c->d_slot, c->map[c->target], c->d_stats);
+                c->d_rec_flag, c->d_rec_best, c->d_slot, c->map, c->d_stats);
+    c->fuse_tick = c->tick;
 }
 static void st_clean(hrbf_context *c)
 {
     launch_clean(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->prm.confidence_threshold,
-                 c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier, c->map[c->target],
-                 c->map[1 - c->target], c->rec, c->d_rec_flag, &c->d_count[c->target], &c->d_count[1 - c->target],
-                 c->count_ub, c->d_stats, c->cap, c->d_idx, c->d_im_vertconf, c->d_im_colortime, c->d_tile_status,
-                 c->max_tiles, c->d_ticket, c->timing ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
+                 c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier, (c->map_dirty || c->fuse_tick != c->tick) ? 1 : 0, c->map,
+                 c->rec, c->d_rec_flag, &c->d_count[c->target], &c->d_count[1 - c->target],
+                 c->count_ub, c->d_stats, c->cap, c->d_clean_tex, c->d_keep_flags,
+                 c->d_tile_count, c->d_tile_done, c->max_tiles, c->timing ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
                  c->timing ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr);
     if (c->timing) {
         hipMemcpyAsync(c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4, c->d_stats, sizeof(uint32_t) * 4,
@@ -324,6 +331,7 @@ static void st_clean(hrbf_context *c)
         if (c->ring_valid < HRBF_RING) c->ring_valid++;
     }
     c->target = 1 - c->target;
+    c->map_dirty = 0;
     uint64_t ub = (uint64_t)c->count_ub + (uint64_t)c->Q;
     c->count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
     c->ub_growth_since += (uint32_t)c->Q;
@@ -369,17 +377,17 @@ static int process_frame_resident(hrbf_context *c, float wmul)
         launch_frame_epilogue(c->stream, c->d_pose, wmul, 1);
         st_conf(c);
         if (!c->prm.rgb_only) {
-            st_indices(c);
+            st_indices(c, false);
             TIMER(3);
             st_fuse(c);
             TIMER(4);
-            st_indices(c);
+            st_indices(c, true);
             TIMER(5);
             st_clean(c);
             TIMER(6);
         } else { TIMER(3); TIMER(4); TIMER(5); TIMER(6); }
     }
-    st_indices(c);
+    st_indices(c, false);
     TIMER(7);
     st_predict(c);
     TIMER(8);
@@ -549,7 +557,7 @@ extern "C" int hrbf_download_map(hrbf_handle c, float *out, size_t cap_surfels)
     if (n == 0) return HRBF_OK;
     float4 *tmp = nullptr;
     HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * (size_t)n));
-    hipLaunchKernelGGL(k_map_to_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->map[c->target], n, tmp);
+    hipLaunchKernelGGL(k_map_to_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->map, n, tmp);
     hipError_t e = hipMemcpyAsync(out, tmp, sizeof(float4) * 5 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(tmp);
@@ -567,7 +575,7 @@ extern "C" int hrbf_upload_map(hrbf_handle c, const float *in, size_t n)
         HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * n));
         hipError_t e = hipMemcpyAsync(tmp, in, sizeof(float4) * 5 * n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_map_from_aos, dim3((n32 + 255) / 256), dim3(256), 0, c->stream, c->map[c->target], n32, tmp);
+            hipLaunchKernelGGL(k_map_from_aos, dim3((n32 + 255) / 256), dim3(256), 0, c->stream, c->map, n32, tmp);
             e = hipStreamSynchronize(c->stream);
         }
         hipFree(tmp);
@@ -576,6 +584,7 @@ extern "C" int hrbf_upload_map(hrbf_handle c, const float *in, size_t n)
     HIP_CHECK(hipMemcpyAsync(&c->d_count[c->target], &n32, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->count_ub = n32;
+    c->map_dirty = 1;
     return HRBF_OK;
 }
 

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
                                                  const unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
-                                                 float4 *__restrict__ curvmax, float4 *__restrict__ curvmin)
+                                                 float4 *__restrict__ curvmax, float4 *__restrict__ curvmin,
+                                                 float4 *__restrict__ clean_tex)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cam.W * cam.H) return;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
     const float4 z4 = make_float4(0, 0, 0, 0);
     if (key == ZB_EMPTY) {
         idx[i] = 0; vertconf[i] = z4; colortime[i] = z4; normrad[i] = z4; curvmax[i] = z4; curvmin[i] = z4;
+        if (clean_tex) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
         return;
     }
     uint32_t s = (uint32_t)(key & 0xFFFFFFFFull);
@@ -148,7 +150,11 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
     f3 n = normalize3(rot_mul(tinv, xyz(nr)));
     idx[i] = s;
     vertconf[i] = make_float4(h.x, h.y, h.z, p.w);
-    colortime[i] = m.p1[s];
+    const float4 ct = m.p1[s];
+    colortime[i] = ct;
+    // packed texel for the clean test (pass A of the fuse): 32 contiguous bytes instead of three gathers;
+    // .w of the second half = the reference's `current > 0U` gate (copy_unstable.vert:111)
+    if (clean_tex) { clean_tex[2 * i] = make_float4(h.x, h.y, h.z, p.w); clean_tex[2 * i + 1] = make_float4(ct.z, ct.w, s > 0u ? 1.0f : 0.0f, 0.0f); }
     normrad[i] = make_float4(n.x, n.y, n.z, nr.w);
     curvmax[i] = m.p3[s];
     curvmin[i] = m.p4[s];
@@ -272,18 +278,35 @@ __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes
 
 // ------------------------------------------------------------------------------------------
 // F3: the fuse kernel — clean test (copy_unstable.vert:62-166) + order-preserving compaction of the
-// whole map + append of the new-surfel records, in one streaming pass.
+// whole map + append of the new-surfel records, in ONE streaming pass, IN PLACE.
 //
-// Items 0..N-1 are surfels, N..N+Q-1 are association records (draw order).  Tiles of
-// FUSE_TILE items are claimed through an atomic ticket so that a tile's predecessors have always
-// started (forward progress for the look-back).  Tile status words are single 8-byte granules
-// {flag:2 | value:32} written/read with relaxed agent-scope atomics (the datum is the flag, no fence).
-#define FUSE_THREADS 256
-#define FUSE_IPT 4
+// Items 0..N-1 are surfels, N..N+Q-1 are association records (draw order).  Tiles of FUSE_TILE
+// items are claimed through an atomic ticket so that a tile's predecessors have always started
+// (forward progress for the decoupled look-back).  Tile status words are single 8-byte granules
+// {flag:2 | value:32} written/read with relaxed agent-scope atomics (the datum is the flag).
+//
+// Traffic design (the reference streams 400 B/surfel through update.vert + copy_unstable.vert):
+//  * the test of a surfel that is out of view needs only pos_conf + color_time (32 B); norm_rad is
+//    fetched for in-view surfels only; the curvature validity of a surfel that was not merged this
+//    frame was established when it last passed this kernel, so curv planes are read only for
+//    surfels merged this frame (lastTime == time) or after an external map upload (full_check);
+//  * compaction is stable and leftwards (out <= in), so it is done in place: a surfel whose
+//    output slot equals its input slot is not moved at all.  Until the first removal of a frame
+//    nothing is written; after it, survivors are re-read (all 5 planes) and written `shift` slots
+//    to the left.  Worst case (removal at index 0) = 80 B read + 80 B written per surfel, the
+//    classic out-of-place cost.
+//  * in-place safety: tile t writes into the source range of tiles t' <= t only.  Every tile raises
+//    tile_done[t'] once all the loads it will ever issue have returned (s_waitcnt vmcnt(0)); a
+//    writer polls tile_done of the tiles its output range overlaps.  tile_done never waits on
+//    another tile's writes, so there is no serial chain.
+#ifndef FUSE_THREADS
+#ifndef FUSE_THREADS
+#define FUSE_THREADS 512
+#endif
+#endif
+#define FUSE_IPT 4   // the move path below is written out for exactly 4 items per thread
 #define FUSE_TILE (FUSE_THREADS * FUSE_IPT)
-#define ST_AGG (1ull << 62)
-#define ST_PREFIX (2ull << 62)
-#define ST_MASK (3ull << 62)
+#define TC_STRIDE 32   // one tile counter per 128-byte line: wave atomics of different tiles never share a line
 
 struct CleanParams {
     Cam cam;
@@ -292,163 +315,220 @@ struct CleanParams {
     int time;
     int nw;        // samples per axis = 2 * clean_window_multiplier
     float w0;      // clean_window_multiplier * 0.5
+    int full_check;
 };
 
-__device__ __forceinline__ bool clean_test(const CleanParams &cp, const Rigid &tinv, float4 vp, float4 &vcol, float4 vn, float4 k1,
-                                           float4 k2, const uint32_t *__restrict__ idx,
-                                           const float4 *__restrict__ vertconf,
-                                           const float4 *__restrict__ colortime)
+// window part of the test; returns false when the surfel must be dropped.
+// The reference walks a 4x4 half-pixel grid (copy_unstable.vert:104-141) = 2..3 DISTINCT texels per axis,
+// some visited twice.  Each distinct texel is fetched once from the packed clean texture (2 x float4,
+// written by k_resolve) and its two predicates are counted with the multiplicity of the visit pattern.
+__device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid &tinv, f3 lp, float x, float y,
+                                             float init_time, float4 vn, const float4 *__restrict__ clean_tex)
 {
     const Cam &cam = cp.cam;
-    bool test = true;
-    f3 lp = xform(tinv, xyz(vp));
-    float x = ((cam.fx * lp.x) / lp.z) + cam.cx;
-    float y = ((cam.fy * lp.y) / lp.z) + cam.cy;
     int count = 0, zCount = 0;
-    if (lp.z < cp.maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)cam.W && y < (float)cam.H) {
-        f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
-        const bool nz_ok = hd_fabsf(ln.z) > 0.85f;
-        const float rad14 = vn.w * 1.4f;
-        for (int a = 0; a < cp.nw; ++a) {
-            const int sx = clampi((int)hd_floorf(x + ((float)a * 0.5f - cp.w0)), 0, cam.W - 1);
+    f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
+    const bool nz_ok = hd_fabsf(ln.z) > 0.85f;
+    const float rad14 = vn.w * 1.4f;
+    const float ftime = (float)cp.time;
+    int prev_sx = -1, colc = 0, colz = 0;
+    for (int a = 0; a < cp.nw; ++a) {
+        const int sx = clampi((int)hd_floorf(x + ((float)a * 0.5f - cp.w0)), 0, cam.W - 1);
+        if (sx != prev_sx) {
+            prev_sx = sx; colc = 0; colz = 0;
+            int prev_sy = -1, c1 = 0, z1 = 0;
             for (int b = 0; b < cp.nw; ++b) {
                 const int sy = clampi((int)hd_floorf(y + ((float)b * 0.5f - cp.w0)), 0, cam.H - 1);
-                const int si = sy * cam.W + sx;
-                if (idx[si] > 0u) {
-                    float4 vcf = vertconf[si], ct = colortime[si];
-                    float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
-                    if (ct.z < vcol.z && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
-                        hd_sqrtf(dx * dx + dy * dy) < rad14)
-                        count++;
-                    if (ct.w == (float)cp.time && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f && nz_ok)
-                        zCount++;
+                if (sy != prev_sy) {
+                    prev_sy = sy; c1 = 0; z1 = 0;
+                    const int si = sy * cam.W + sx;
+                    const float4 vcf = clean_tex[2 * si], tt = clean_tex[2 * si + 1];
+                    if (tt.z > 0.0f) {
+                        float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
+                        if (tt.x < init_time && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
+                            hd_sqrtf(dx * dx + dy * dy) < rad14)
+                            c1 = 1;
+                        if (tt.y == ftime && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f && nz_ok) z1 = 1;
+                    }
                 }
+                colc += c1; colz += z1;
             }
         }
+        count += colc; zCount += colz;
     }
-    if (k1.w < -cp.curvThr || k1.w > cp.curvThr || k2.w < -cp.curvThr || k2.w > cp.curvThr) test = false;
-    if (count > 8 || zCount > 4) test = false;
-    if (vcol.w == -2.0f) vcol.w = (float)cp.time;
-    if (vcol.w == -1.0f || (((float)cp.time - vcol.w) > 200.0f && vp.w < cp.confThr)) test = false;
-    return test;
+    return !(count > 8 || zCount > 4);
 }
 
-__global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(CleanParams cp, MapPlanes in, MapPlanes out,
-                                                              RecPlanes rec, const int32_t *__restrict__ rec_flag, int Q,
+__device__ __forceinline__ bool in_view(const CleanParams &cp, const Rigid &tinv, float4 vp, f3 &lp, float &x, float &y)
+{
+    const Cam &cam = cp.cam;
+    lp = xform(tinv, xyz(vp));
+    x = ((cam.fx * lp.x) / lp.z) + cam.cx;
+    y = ((cam.fy * lp.y) / lp.z) + cam.cy;
+    return lp.z < cp.maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)cam.W && y < (float)cam.H;
+}
+
+// Pass A: the clean test of every surfel and record -> one keep byte per item.  Embarrassingly
+// parallel, so the in-view minority (16 index-map samples each) is spread over the whole chip by the
+// hardware scheduler instead of stalling the scan tiles that happen to contain it.
+__global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m, RecPlanes rec,
+                                                     const int32_t *__restrict__ rec_flag, int Q,
+                                                     const uint32_t *__restrict__ count_in,
+                                                     const float4 *__restrict__ clean_tex,
+                                                     uint8_t *__restrict__ keep_flags,
+                                                     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ stats)
+{
+    const uint32_t N = *count_in;
+    const uint32_t total = N + (uint32_t)Q;
+    const Rigid tinv = cp.dp->tinv;
+    const float ftime = (float)cp.time;
+    const uint32_t total64 = (total + 63u) & ~63u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[2] = 0;   // appended counter, accumulated by pass B
+    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < total64; it += gridDim.x * blockDim.x) {
+        const bool is_surf = it < N;
+        const uint32_t q = it - N;
+        bool keep = false;
+        if (it < total && (is_surf || rec_flag[q] != 0)) {
+            const float4 vp = is_surf ? m.p0[it] : rec.p0[q];
+            const float4 vc = is_surf ? m.p1[it] : rec.p1[q];
+            keep = true;
+            f3 lp; float x, y;
+            if (in_view(cp, tinv, vp, lp, x, y)) {
+                const float4 vn = is_surf ? m.p2[it] : rec.p2[q];
+                keep = clean_window(cp, tinv, lp, x, y, vc.z, vn, clean_tex);
+            }
+            if (!is_surf || cp.full_check || vc.w == ftime) {
+                const float k1 = is_surf ? m.p3[it].w : rec.p3[q].w;
+                const float k2 = is_surf ? m.p4[it].w : rec.p4[q].w;
+                if (k1 < -cp.curvThr || k1 > cp.curvThr || k2 < -cp.curvThr || k2 > cp.curvThr) keep = false;
+            }
+            float lastw = vc.w;
+            if (lastw == -2.0f) lastw = ftime;
+            if (lastw == -1.0f || ((ftime - lastw) > 200.0f && vp.w < cp.confThr)) keep = false;
+        }
+        if (it < total) keep_flags[it] = keep ? 1 : 0;
+        // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
+        const unsigned long long bal = __ballot(keep);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&tile_count[(size_t)(it / FUSE_TILE) * TC_STRIDE], (uint32_t)__popcll(bal));
+    }
+}
+
+// Pass B: in-place leftward move of the survivors + append of the records (see header comment).
+// A tile's output offset = sum of the keep counts of all earlier tiles, summed directly by the tile
+// (<= a few thousand L2-resident words): no scan kernel, no look-back chain.
+// The grid is sized to be fully co-resident (<= 1 workgroup of 512 threads per CU) and every workgroup walks its
+// tiles in increasing order, so a writer only ever waits for tile_done of a tile that is finished or
+// owned by a running workgroup; raising tile_done needs no wait -> placement-independent, no deadlock.
+struct MoveSlot { float4 a, b, c, d, e; uint32_t it, o; bool keep; };
+
+__device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, const RecPlanes &rec, uint32_t N, float ftime)
+{
+    if (!sl.keep) return;
+    if (sl.it < N) { sl.a = m.p0[sl.it]; sl.b = m.p1[sl.it]; sl.c = m.p2[sl.it]; sl.d = m.p3[sl.it]; sl.e = m.p4[sl.it]; }
+    else {
+        const uint32_t q = sl.it - N;
+        sl.a = rec.p0[q]; sl.b = rec.p1[q]; sl.c = rec.p2[q]; sl.d = rec.p3[q]; sl.e = rec.p4[q];
+        if (sl.b.w == -2.0f) sl.b.w = ftime;     // copy_unstable.vert:155-158
+    }
+}
+__device__ __forceinline__ uint32_t move_store(const MoveSlot &sl, const MapPlanes &m, uint32_t N, uint32_t cap)
+{
+    if (!sl.keep || sl.o >= cap) return 0u;
+    if (sl.o != sl.it || sl.it >= N) { m.p0[sl.o] = sl.a; m.p1[sl.o] = sl.b; m.p2[sl.o] = sl.c; m.p3[sl.o] = sl.d; m.p4[sl.o] = sl.e; }
+    return sl.it >= N ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlanes m, RecPlanes rec, int Q,
+                                                              const uint8_t *__restrict__ keep_flags,
+                                                              const uint32_t *__restrict__ tile_count,
                                                               const uint32_t *__restrict__ count_in,
                                                               uint32_t *__restrict__ count_out,
                                                               uint32_t *__restrict__ stats, uint32_t cap,
-                                                              const uint32_t *__restrict__ idx,
-                                                              const float4 *__restrict__ vertconf,
-                                                              const float4 *__restrict__ colortime,
-                                                              unsigned long long *__restrict__ tile_status,
-                                                              uint32_t *__restrict__ ticket)
+                                                              uint32_t *__restrict__ tile_done)
 {
-    __shared__ uint32_t s_tile;
-    __shared__ uint32_t s_wcnt[FUSE_IPT][FUSE_THREADS / 64];
-    __shared__ uint32_t s_prefix;
+    constexpr int NWAVE = FUSE_THREADS / 64;
+    __shared__ uint32_t s_wcnt[FUSE_IPT][NWAVE];
+    __shared__ uint32_t s_psum[NWAVE];
     const uint32_t N = *count_in;
-    const Rigid tinv = cp.dp->tinv;
     const uint32_t total = N + (uint32_t)Q;
     const uint32_t num_tiles = (total + FUSE_TILE - 1) / FUSE_TILE;
+    const uint32_t surfel_tiles = (N + FUSE_TILE - 1) / FUSE_TILE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float ftime = (float)time;
 
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= num_tiles) return;
+    for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const uint32_t base = tile * FUSE_TILE;
-
-        float4 v0[FUSE_IPT], v1[FUSE_IPT], v2[FUSE_IPT], v3[FUSE_IPT], v4[FUSE_IPT];
-        bool keep[FUSE_IPT];
-        uint32_t lrank[FUSE_IPT];   // rank within (k, wave)
+        uint32_t psum = 0;
+        for (uint32_t t = threadIdx.x; t < tile; t += FUSE_THREADS) psum += tile_count[(size_t)t * TC_STRIDE];
+        for (int d = 32; d > 0; d >>= 1) psum += __shfl_down(psum, d);
+        if (lane == 0) s_psum[wid] = psum;
+        __syncthreads();
+        uint32_t prefix = 0;
 #pragma unroll
-        for (int k = 0; k < FUSE_IPT; ++k) {
-            const uint32_t it = base + k * FUSE_THREADS + threadIdx.x;
-            keep[k] = false;
-            if (it < N) {
-                v0[k] = in.p0[it]; v1[k] = in.p1[it]; v2[k] = in.p2[it]; v3[k] = in.p3[it]; v4[k] = in.p4[it];
-                keep[k] = clean_test(cp, tinv, v0[k], v1[k], v2[k], v3[k], v4[k], idx, vertconf, colortime);
-            } else if (it < total) {
-                const uint32_t q = it - N;
-                if (rec_flag[q] != 0) {
-                    v0[k] = rec.p0[q]; v1[k] = rec.p1[q]; v2[k] = rec.p2[q]; v3[k] = rec.p3[q]; v4[k] = rec.p4[q];
-                    keep[k] = clean_test(cp, tinv, v0[k], v1[k], v2[k], v3[k], v4[k], idx, vertconf, colortime);
-                }
-            }
-            const unsigned long long bal = __ballot(keep[k]);
-            lrank[k] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wcnt[k][wid] = (uint32_t)__popcll(bal);
+        for (int w = 0; w < NWAVE; ++w) prefix += s_psum[w];
+        const uint32_t tile_total = tile_count[(size_t)tile * TC_STRIDE];
+        if (tile == num_tiles - 1 && threadIdx.x == 0) {
+            const uint32_t tot = prefix + tile_total;
+            *count_out = tot > cap ? cap : tot;
+            stats[0] = N; stats[3] = tot > cap ? cap : tot;
+        }
+        const bool tile_has_surfels = base < N;
+        const uint32_t n_surf_here = N > base ? (N - base < FUSE_TILE ? N - base : FUSE_TILE) : 0u;
+        const bool moves = (prefix != base) || (tile_total != n_surf_here) || (base + FUSE_TILE > N);
+        if (!moves) {   // nothing in this tile changes place: no load, no store
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            continue;
+        }
+        MoveSlot s0, s1, s2, s3;
+        s0.it = base + threadIdx.x; s1.it = s0.it + FUSE_THREADS; s2.it = s1.it + FUSE_THREADS; s3.it = s2.it + FUSE_THREADS;
+        s0.keep = s0.it < total && keep_flags[s0.it] != 0; s1.keep = s1.it < total && keep_flags[s1.it] != 0;
+        s2.keep = s2.it < total && keep_flags[s2.it] != 0; s3.keep = s3.it < total && keep_flags[s3.it] != 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned long long b0 = __ballot(s0.keep), b1 = __ballot(s1.keep), b2 = __ballot(s2.keep), b3 = __ballot(s3.keep);
+        if (lane == 0) {
+            s_wcnt[0][wid] = (uint32_t)__popcll(b0); s_wcnt[1][wid] = (uint32_t)__popcll(b1);
+            s_wcnt[2][wid] = (uint32_t)__popcll(b2); s_wcnt[3][wid] = (uint32_t)__popcll(b3);
         }
         __syncthreads();
-        // item order inside the tile is k-major then wave then lane
-        uint32_t tile_total = 0;
-        uint32_t off[FUSE_IPT];
+        {   // item order inside the tile: k-major, then wave, then lane
+            uint32_t run = prefix, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
 #pragma unroll
-        for (int k = 0; k < FUSE_IPT; ++k)
+            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o0 = run; run += s_wcnt[0][w]; }
 #pragma unroll
-            for (int w = 0; w < FUSE_THREADS / 64; ++w) {
-                if (w == wid) off[k] = tile_total;
-                tile_total += s_wcnt[k][w];
-            }
-        // decoupled look-back by wave 0
-        if (wid == 0) {
-            if (lane == 0)
-                __hip_atomic_store(&tile_status[tile], (tile == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long)tile_total,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t excl = 0;
-            if (tile > 0) {
-                int look = (int)tile - 1;
-                for (;;) {
-                    const int t = look - lane;
-                    unsigned long long st = ST_PREFIX;   // virtual tile -1: prefix 0
-                    if (t >= 0) {
-                        do {
-                            st = __hip_atomic_load(&tile_status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } while ((st & ST_MASK) == 0);
-                    }
-                    const unsigned long long pmask = __ballot((st & ST_MASK) == ST_PREFIX);
-                    // sum values of lanes up to and including the first (nearest) PREFIX lane
-                    const int first = pmask ? __ffsll((long long)pmask) - 1 : 64;
-                    uint32_t val = (lane <= first) ? (uint32_t)(st & 0xFFFFFFFFull) : 0u;
-                    for (int d = 32; d > 0; d >>= 1) val += __shfl_down(val, d);
-                    val = __shfl(val, 0);
-                    excl += val;
-                    if (pmask) break;
-                    look -= 64;
-                }
-                if (lane == 0)
-                    __hip_atomic_store(&tile_status[tile], ST_PREFIX | (unsigned long long)(excl + tile_total),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane == 0) {
-                s_prefix = excl;
-                if (tile == num_tiles - 1) {
-                    uint32_t tot = excl + tile_total;
-                    *count_out = tot > cap ? cap : tot;
-                    stats[0] = N; stats[3] = tot > cap ? cap : tot;
-                }
-            }
+            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o1 = run; run += s_wcnt[1][w]; }
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o2 = run; run += s_wcnt[2][w]; }
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o3 = run; run += s_wcnt[3][w]; }
+            s0.o = o0 + (uint32_t)__popcll(b0 & lt); s1.o = o1 + (uint32_t)__popcll(b1 & lt);
+            s2.o = o2 + (uint32_t)__popcll(b2 & lt); s3.o = o3 + (uint32_t)__popcll(b3 & lt);
+        }
+        move_load(s0, m, rec, N, ftime); move_load(s1, m, rec, N, ftime);
+        move_load(s2, m, rec, N, ftime); move_load(s3, m, rec, N, ftime);
+        // every load this tile will ever issue on the map has returned -> publish tile_done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile_has_surfels && threadIdx.x == 0)
+            __hip_atomic_store(&tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // wait until the source tiles our output range overlaps have finished reading
+        if (tile_total > 0 && threadIdx.x < 64) {
+            const uint32_t t_lo = prefix / FUSE_TILE;
+            const uint32_t t_hi = (prefix + tile_total - 1) / FUSE_TILE;
+            for (uint32_t t = t_lo + (uint32_t)lane; t <= t_hi && t < surfel_tiles; t += 64)
+                if (t != tile)
+                    while (__hip_atomic_load(&tile_done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                        __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
-        const uint32_t prefix = s_prefix;
-        uint32_t appended = 0;
-#pragma unroll
-        for (int k = 0; k < FUSE_IPT; ++k) {
-            if (keep[k]) {
-                const uint32_t o = prefix + off[k] + lrank[k];
-                if (o < cap) {
-                    out.p0[o] = v0[k]; out.p1[o] = v1[k]; out.p2[o] = v2[k]; out.p3[o] = v3[k]; out.p4[o] = v4[k];
-                    if (base + k * FUSE_THREADS + threadIdx.x >= N) appended++;
-                }
-            }
-        }
+        uint32_t appended = move_store(s0, m, N, cap) + move_store(s1, m, N, cap) + move_store(s2, m, N, cap) +
+                            move_store(s3, m, N, cap);
         if (base + FUSE_TILE > N) {   // only tiles that contain records count appends
             for (int d = 32; d > 0; d >>= 1) appended += __shfl_down(appended, d);
             if (lane == 0 && appended) atomicAdd(&stats[2], appended);
         }
-        __syncthreads();   // s_tile / s_wcnt reuse
+        __syncthreads();   // s_wcnt / s_psum reuse
     }
 }
 
@@ -457,10 +537,12 @@ __global__ void k_zero_u32(uint32_t *p, int n)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
-__global__ void k_zero_flags(int32_t *p, int n)
+// end of the fuse pass: re-arm the record flags, the tile counters and tile_done for the next frame
+__global__ void k_zero_flags(int32_t *p, int n, uint32_t *tile_count, uint32_t *tile_done, int ntiles)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
+    if (i < ntiles) { tile_count[(size_t)i * TC_STRIDE] = 0; tile_done[i] = 0; }
 }
 __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
@@ -484,7 +566,8 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
 
 void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
                             const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
-                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin)
+                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
+                            float4 *clean_tex)
 {
     int P = cam.W * cam.H;
     hipLaunchKernelGGL(k_fill_u64, dim3((P + 255) / 256), dim3(256), 0, s, zbuf, P, ZB_EMPTY);
@@ -493,7 +576,7 @@ void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, fl
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf);
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, zbuf, idx, vertconf, colortime,
-                       normrad, curvmax, curvmin);
+                       normrad, curvmax, curvmin, clean_tex);
 }
 
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
@@ -512,26 +595,31 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
 }
 
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
-                  int time, float clean_window_multiplier, MapPlanes in, MapPlanes out, RecPlanes rec, int32_t *rec_flag,
+                  int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
-                  const uint32_t *idx, const float4 *vertconf, const float4 *colortime,
-                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket, hipEvent_t e0, hipEvent_t e1)
+                  const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
+                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     CleanParams cp;
     cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
-    cp.nw = (int)(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f;
-    uint32_t tiles = (count_ub + (uint32_t)Q + FUSE_TILE - 1) / FUSE_TILE;
+    cp.nw = (int)(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
+    const uint32_t items_ub = count_ub + (uint32_t)Q;
+    uint32_t tiles = (items_ub + FUSE_TILE - 1) / FUSE_TILE;
     if (tiles > max_tiles) tiles = max_tiles;
-    hipMemsetAsync(tile_status, 0, sizeof(unsigned long long) * (size_t)tiles, s);
-    hipMemsetAsync(ticket, 0, sizeof(uint32_t), s);
-    uint32_t blocks = tiles < 256u * 4u ? tiles : 256u * 4u;   // persistent: <= 4 workgroups per CU
-    if (blocks == 0) blocks = 1;
     if (e0) hipEventRecord(e0, s);
-    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), 0, s, cp, in, out, rec, rec_flag, Q, count_in,
-                       count_out, stats, cap, idx, vertconf, colortime, tile_status, ticket);
+    uint32_t fblocks = (items_ub + 255) / 256;
+    if (fblocks > 256u * 16u) fblocks = 256u * 16u;
+    if (fblocks == 0) fblocks = 1;
+    hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
+                       keep_flags, tile_count, stats);
+    uint32_t blocks = tiles < 256u ? tiles : 256u;   // co-resident: ONE 512-thread workgroup per CU (132 VGPR -> 12 waves/CU)
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), 0, s, time, m, rec, Q, keep_flags, tile_count,
+                       count_in, count_out, stats, cap, tile_done);
     if (e1) hipEventRecord(e1, s);
-    hipLaunchKernelGGL(k_zero_flags, dim3((Q + 255) / 256), dim3(256), 0, s, rec_flag, Q);
+    int nz = Q > (int)tiles ? Q : (int)tiles;
+    hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, Q, tile_count, tile_done, (int)tiles);
 }
 
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
@@ -540,3 +628,4 @@ void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
 }
 
 uint32_t fuse_tile_items() { return FUSE_TILE; }
+uint32_t fuse_tile_count_stride() { return TC_STRIDE; }

@@ -39,13 +39,38 @@ struct OdoState {
 };
 
 size_t odo_state_bytes() { return sizeof(OdoState); }
+size_t odo_slot_bytes() { return sizeof(long long) * (32 * 87 * 2 + 64 * 2 + 32 * 33); }
 
 #define PLN(base, k, rows, cols, y, x) ((base)[((size_t)(k) * (rows) + (y)) * (cols) + (x)])
 
 // ------------------------------------------------------------------------------------------
-// exact workgroup reduction of N floats per lane -> part[blockIdx.x][3N]
+// exact workgroup reduction of N floats per lane.
+//   lane: float -> five 26-bit limbs (hd_limbs26)            [exact, integer]
+//   wave: 32-bit DPP add tree (quad_perm, row_ror, row_bcast) [64 x 26 bits fits 32 bits: no carries]
+//   block: the 4 wave totals are folded to int64 limbs in LDS
+//   grid: one 64-bit atomicAdd per limb into slot (blockIdx % ODO_SLOTS) — integer adds commute, so the
+//         result does not depend on arrival order.  The consumer sums the ODO_SLOTS rows and re-zeroes them.
+#define ODO_SLOTS 32
+#define RES_SLOTS 64
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)   // total in lane 63
+{
+    v += dpp_u32<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_u32<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_u32<0x124, 0xf>(v);   // row_ror:4
+    v += dpp_u32<0x128, 0xf>(v);   // row_ror:8
+    v += dpp_u32<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v += dpp_u32<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 template <int N>
-__device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ part)
+__device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ slots)
 {
     __shared__ long long s_part[RB / 64][NLIMB(N)];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -53,27 +78,27 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
     if (any) {
 #pragma unroll 1
         for (int i = 0; i < N; ++i) {
-            hd_limbs l;
-            if (valid) l = hd_limbs_from_f32(vals[i]);
-            else { l.l0 = 0; l.l1 = 0; l.l2 = 0; }
-            long long a = l.l0, b = l.l1, c = l.l2;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                a += __shfl_down(a, d);
-                b += __shfl_down(b, d);
-                c += __shfl_down(c, d);
+            hd_limbs26 l;
+            if (valid) l = hd_limbs26_from_f32(vals[i]);
+            else { l.d0 = l.d1 = l.d2 = l.d3 = 0u; l.d4 = 0; }
+            const uint32_t s0 = wave_sum_u32(l.d0), s1 = wave_sum_u32(l.d1), s2 = wave_sum_u32(l.d2),
+                           s3 = wave_sum_u32(l.d3);
+            const int32_t s4 = (int32_t)wave_sum_u32((uint32_t)l.d4);
+            if (lane == 63) {
+                const hd_limbs L = hd_limbs26_to_limbs(s0, s1, s2, s3, s4);
+                s_part[wid][i * 3] = L.l0; s_part[wid][i * 3 + 1] = L.l1; s_part[wid][i * 3 + 2] = L.l2;
             }
-            if (lane == 0) { s_part[wid][i * 3] = a; s_part[wid][i * 3 + 1] = b; s_part[wid][i * 3 + 2] = c; }
         }
-    } else if (lane == 0) {
+    } else if (lane == 63) {
         for (int i = 0; i < NLIMB(N); ++i) s_part[wid][i] = 0;
     }
     __syncthreads();
+    long long *row = slots + (size_t)(blockIdx.x % ODO_SLOTS) * NLIMB(N);
     for (int t = threadIdx.x; t < NLIMB(N); t += RB) {
         long long s = 0;
 #pragma unroll
         for (int w = 0; w < RB / 64; ++w) s += s_part[w][t];
-        part[(size_t)blockIdx.x * NLIMB(N) + t] = s;
+        if (s != 0) atomicAdd((unsigned long long *)&row[t], (unsigned long long)s);
     }
 }
 
@@ -287,11 +312,11 @@ __global__ void k_pyrdown_u8(const uint8_t *__restrict__ src, int srows, int sco
 }
 
 // ------------------------------------------------------------------------------------------ small dense algebra
-template <typename T, int NMAX>
-__host__ __device__ inline void ldlt_solve(int n, const T *Ain, const T *b, T *x)
+// diagonal-pivoted LDL^T; A (n x n, overwritten), perm, y are caller-provided workspaces so that the
+// one-lane solve kernels keep them in LDS instead of per-lane scratch (runtime-indexed arrays).
+template <typename T>
+__host__ __device__ inline void ldlt_solve(int n, T *A, const T *b, T *x, int *perm, T *y)
 {
-    T A[NMAX * NMAX]; int perm[NMAX]; T y[NMAX];
-    for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
     for (int i = 0; i < n; ++i) perm[i] = i;
     for (int k = 0; k < n; ++k) {
         int piv = k; T best = A[k * n + k] < 0 ? -A[k * n + k] : A[k * n + k];
@@ -361,16 +386,15 @@ __host__ __device__ inline void inv3f_cof(const float *m, float *o)
     o[6] = c02 * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
 }
 
-// sum partial rows: totals[t] = sum_b part[b][t]   (one workgroup)
-__device__ __forceinline__ void sum_partials(const long long *__restrict__ part, int nblocks, int width,
+// totals[t] = sum over slot rows, then re-zero the rows for the next launch   (one workgroup, 1024 threads)
+__device__ __forceinline__ void sum_partials(long long *__restrict__ part, int nrows, int width,
                                              long long *__restrict__ totals)
 {
     __shared__ long long s_acc[8][128];
-    // width <= 87 < 128; 8 row groups x 128 columns = 1024 threads
     const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
     long long s = 0;
     if (col < width)
-        for (int b = grp; b < nblocks; b += 8) s += part[(size_t)b * width + col];
+        for (int b = grp; b < nrows; b += 8) { s += part[(size_t)b * width + col]; part[(size_t)b * width + col] = 0; }
     s_acc[grp][col] = s;
     __syncthreads();
     if (threadIdx.x < width) {
@@ -467,10 +491,11 @@ __global__ void k_odo_begin(OdoState *st, const DevPose *__restrict__ dp, OdoCon
     if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
 }
 
-__global__ __launch_bounds__(1024) void k_so3_solve(OdoState *st, const long long *__restrict__ part, int nblocks,
+__global__ __launch_bounds__(1024) void k_so3_solve(OdoState *st, long long *__restrict__ part, int nblocks,
                                                     long long *__restrict__ totals, int do_reduce, OdoConfig cfg)
 {
-    if (do_reduce) sum_partials(part, nblocks, 33, totals);
+    (void)nblocks;
+    if (do_reduce) sum_partials(part, ODO_SLOTS, 33, totals);
     if (threadIdx.x != 0) return;
     if (st->so3_done) return;
     double s[11];
@@ -492,8 +517,12 @@ __global__ __launch_bounds__(1024) void k_so3_solve(OdoState *st, const long lon
     }
     st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
     for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
-    float delta[3];
-    ldlt_solve<float, 3>(3, jtj, jtr, delta);
+    __shared__ float w_A[9], w_b[3], w_x[3], w_y[3];
+    __shared__ int w_perm[3];
+    for (int k = 0; k < 9; ++k) w_A[k] = jtj[k];
+    for (int k = 0; k < 3; ++k) w_b[k] = jtr[k];
+    ldlt_solve<float>(3, w_A, w_b, w_x, w_perm, w_y);
+    float delta[3] = {w_x[0], w_x[1], w_x[2]};
     double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
     rodrigues(dd, rotU);
     float rotUf[9], tmp[9];
@@ -692,7 +721,10 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
         if (threadIdx.x == 0) {
             long long c = 0, s = 0;
             for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
-            res_part[b * 2] = c; res_part[b * 2 + 1] = s;
+            if (c) {
+                atomicAdd((unsigned long long *)&res_part[(b % RES_SLOTS) * 2], (unsigned long long)c);
+                atomicAdd((unsigned long long *)&res_part[(b % RES_SLOTS) * 2 + 1], (unsigned long long)s);
+            }
         }
     }
 }
@@ -709,7 +741,8 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__rest
     __shared__ float s_sigma;
     __shared__ int s_break;
     long long cnt = 0, sig = 0;
-    for (int b = threadIdx.x; b < nb; b += RB) { cnt += res_part[b * 2]; sig += res_part[b * 2 + 1]; }
+    (void)nb;
+    for (int b = threadIdx.x; b < RES_SLOTS; b += RB) { cnt += res_part[b * 2]; sig += res_part[b * 2 + 1]; }
     for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
     if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
     __syncthreads();
@@ -783,14 +816,16 @@ __device__ inline void unpack27(const double *s, float *A, float *b)
 
 // solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93); also prepares the
 // operands of the next iteration (possibly on the next pyramid level).
-__global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, const long long *__restrict__ icp_part,
-                                                   const long long *__restrict__ rgb_part, int nb,
+__global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
+                                                   long long *__restrict__ rgb_part, long long *__restrict__ res_part, int nb,
                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
                                                    int next_level, int level_changes)
 {
+    (void)nb;
     if (do_reduce) {
-        sum_partials(icp_part, nb, 87, totals);
-        sum_partials(rgb_part, nb, 87, totals + 87);
+        sum_partials(icp_part, ODO_SLOTS, 87, totals);
+        sum_partials(rgb_part, ODO_SLOTS, 87, totals + 87);
+        if (threadIdx.x < RES_SLOTS * 2) res_part[threadIdx.x] = 0;
     }
     if (threadIdx.x != 0) return;
     const int rgbOnly = cfg.rgb_only;
@@ -802,11 +837,14 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, const long long
         if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
         if (!st->gn_break) st->lastRGBError = rgbError;
     }
+    __shared__ double w_A[36], w_b[6], w_x[6], w_y[6], w_s[29];
+    __shared__ float w_Aicp[36], w_bicp[6], w_Argb[36], w_brgb[6];
+    __shared__ int w_perm[6];
     if (!st->gn_break) {
-        float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+        float *A_icp = w_Aicp, *b_icp = w_bicp, *A_rgb = w_Argb, *b_rgb = w_brgb;
         for (int k = 0; k < 36; ++k) A_icp[k] = A_rgb[k] = 0.0f;
         for (int k = 0; k < 6; ++k) b_icp[k] = b_rgb[k] = 0.0f;
-        double s[29];
+        double *s = w_s;
         if (icp) {
             for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals, i);
             unpack27(s, A_icp, b_icp);
@@ -818,7 +856,7 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, const long long
             for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals + 87, i);
             unpack27(s, A_rgb, b_rgb);
         }
-        double lastA[36], lastb[6], result[6];
+        double *lastA = w_A, *lastb = w_b, *result = w_x;
         if (icp && rgb) {
             double w = cfg.icp_weight, ww = w * w;
             for (int k = 0; k < 36; ++k) lastA[k] = (double)A_rgb[k] + ww * (double)A_icp[k];
@@ -830,7 +868,7 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, const long long
             for (int k = 0; k < 36; ++k) lastA[k] = A_rgb[k];
             for (int k = 0; k < 6; ++k) lastb[k] = b_rgb[k];
         }
-        ldlt_solve<double, 6>(6, lastA, lastb, result);
+        ldlt_solve<double>(6, lastA, lastb, result, w_perm, w_y);
         double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
         rodrigues(rv, Ru);
         for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
@@ -995,6 +1033,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         hipLaunchKernelGGL(k_odo_sobel_cloud, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i], cfg.fx / div, cfg.fy / div,
                            cfg.cx / div, cfg.cy / div, rgb);
     }
+    hipMemsetAsync(ob.icp_part, 0, odo_slot_bytes(), s);   // icp | rgb | res | so3 slot rows, one allocation
     hipLaunchKernelGGL(k_odo_begin, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
     const bool multi = comm != nullptr && world > 1;
     // O2: SO3 pre-alignment on level 2
@@ -1032,8 +1071,8 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 for (int k = i - 1; k >= 0; --k) if (iterations[k] > 0) { next_level = k; break; }
             }
             (void)multi;
-            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, nb, ob.totals, 1,
-                               cfg, next_level, last_of_level ? 1 : 0);
+            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part, nb,
+                               ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0);
         }
     }
     hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
@@ -1074,16 +1113,18 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
     for (int k = 0; k < 3; ++k) { cur.t[k] = tcurr[k]; prv.t[k] = tprev[k]; }
     const int nb = (rows * cols + RB - 1) / RB;
     long long *part = nullptr;
-    HIP_CHECK(hipMalloc(&part, sizeof(long long) * 87 * (size_t)nb));
+    const size_t bytes = sizeof(long long) * 87 * ODO_SLOTS;
+    HIP_CHECK(hipMalloc(&part, bytes));
+    hipError_t e = hipMemsetAsync(part, 0, bytes, s);
     hipLaunchKernelGGL(k_icp_only, dim3(nb), dim3(RB), 0, s, A, cur, prv, part);
-    long long *h = (long long *)malloc(sizeof(long long) * 87 * (size_t)nb);
-    hipError_t e = hipMemcpyAsync(h, part, sizeof(long long) * 87 * (size_t)nb, hipMemcpyDeviceToHost, s);
+    long long *h = (long long *)malloc(bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, part, bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     hipFree(part);
     if (e != hipSuccess) { free(h); hrbf_set_error("icp_step: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
     long long tot[87];
     for (int t = 0; t < 87; ++t) tot[t] = 0;
-    for (int b = 0; b < nb; ++b) for (int t = 0; t < 87; ++t) tot[t] += h[(size_t)b * 87 + t];
+    for (int b = 0; b < ODO_SLOTS; ++b) for (int t = 0; t < 87; ++t) tot[t] += h[(size_t)b * 87 + t];
     free(h);
     double sums[29];
     for (int i = 0; i < 29; ++i) sums[i] = hd_acc_to_double(hd_limbs_combine(tot[i * 3], tot[i * 3 + 1], tot[i * 3 + 2]));

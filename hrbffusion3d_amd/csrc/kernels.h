@@ -33,19 +33,21 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
                        uint32_t cap, uint32_t *count);
 void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
                             const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
-                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin);
+                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
+                            float4 *clean_tex /* nullable: packed texels for the clean test */);
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
                  MapPlanes m, uint32_t *stats);
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
-                  int time, float clean_window_multiplier, MapPlanes in, MapPlanes out, RecPlanes rec, int32_t *rec_flag,
+                  int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
-                  const uint32_t *idx, const float4 *vertconf, const float4 *colortime,
-                  unsigned long long *tile_status, uint32_t max_tiles, uint32_t *ticket, hipEvent_t e0, hipEvent_t e1);
+                  const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
+                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 uint32_t fuse_tile_items();
+uint32_t fuse_tile_count_stride();
 
 // ---- k_predict.hip
 int predict_upload_tables();
@@ -79,10 +81,10 @@ struct OdoBuffers {
     OdoState *state;
     int16_t *corres;        // P*6
     float *corres_diff;     // P
-    long long *icp_part;    // max_blocks * 87
-    long long *rgb_part;    // max_blocks * 87
-    long long *res_part;    // max_blocks * 2
-    long long *so3_part;    // max_blocks * 33
+    long long *icp_part;    // 32 slot rows x 87 limbs   } one allocation, in this order
+    long long *rgb_part;    // 32 x 87                   }
+    long long *res_part;    // 64 x 2 (count, sigma)     }
+    long long *so3_part;    // 32 x 33                   }
     long long *totals;      // 87 + 87 + 2 + 33 (all-reduce buffer)
     int max_blocks;
 };
@@ -101,6 +103,7 @@ struct OdoConfig {
 };
 
 size_t odo_state_bytes();
+size_t odo_slot_bytes();
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
 // full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,

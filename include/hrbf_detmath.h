@@ -344,4 +344,40 @@ HD_FN hd_acc128 hd_limbs_combine(int64_t s0, int64_t s1, int64_t s2)
     return a;
 }
 
+/* ---------------------------------------------------------------- 26-bit limb form (wave-level)
+ * Q split into five limbs of 26 bits (four unsigned, the top one signed): the sum of 64 lanes of a
+ * 26-bit limb fits a 32-bit register, so a wave64 can reduce with plain 32-bit DPP adds, no carries.
+ * hd_limbs26_to_limbs turns the five 64-lane sums back into the int64 limb form. */
+typedef struct { uint32_t d0, d1, d2, d3; int32_t d4; } hd_limbs26;
+
+HD_FN hd_limbs26 hd_limbs26_from_f32(float p)
+{
+    hd_acc128 q = hd_acc_from_f32(p);
+    const uint64_t M = (1ull << 26) - 1ull;
+    hd_limbs26 r;
+    r.d0 = (uint32_t)(q.lo & M);
+    r.d1 = (uint32_t)((q.lo >> 26) & M);
+    r.d2 = (uint32_t)(((q.lo >> 52) | ((uint64_t)q.hi << 12)) & M);
+    r.d3 = (uint32_t)(((uint64_t)q.hi >> 14) & M);
+    r.d4 = (int32_t)(q.hi >> 40);
+    return r;
+}
+
+/* five limb SUMS (each < 2^32, top one signed) -> Q = s0 + s1 2^26 + s2 2^52 + s3 2^78 + s4 2^104 */
+HD_FN hd_limbs hd_limbs26_to_limbs(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, int32_t s4)
+{
+    hd_acc128 a, t;
+    a.lo = (uint64_t)s0; a.hi = 0;
+    t.lo = (uint64_t)s1 << 26; t.hi = 0; hd_acc_add(&a, t);
+    t.lo = (uint64_t)s2 << 52; t.hi = (int64_t)((uint64_t)s2 >> 12); hd_acc_add(&a, t);
+    t.lo = 0; t.hi = (int64_t)((uint64_t)s3 << 14); hd_acc_add(&a, t);
+    t.lo = 0; t.hi = (int64_t)((uint64_t)(int64_t)s4 << 40); hd_acc_add(&a, t);
+    const uint64_t M40 = (1ull << 40) - 1ull;
+    hd_limbs r;
+    r.l0 = (int64_t)(a.lo & M40);
+    r.l1 = (int64_t)(((a.lo >> 40) | ((uint64_t)a.hi << 24)) & M40);
+    r.l2 = a.hi >> 16;
+    return r;
+}
+
 #endif /* HRBF_DETMATH_H_ */

@@ -18,14 +18,24 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpute
 
 
 def bits(a):
-    return np.ascontiguousarray(a).view(np.uint8)
+    """raw bits with NaNs canonicalised: x86 SSE produces the negative quiet NaN (0xFFC00000) for 0/0,
+    gfx950 the positive one (0x7FC00000); both are NaN to every consumer, payload/sign carry no meaning."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        u = a.view(np.uint32).copy()
+        u[np.isnan(a)] = 0x7FC00000
+        return u
+    return a.view(np.uint8)
 
 
 def assert_same_state(o, g, tag="", images=None):
     for name in (images or IMAGES):
         a, b = o.get_image(name), g.get_image(name)
-        assert np.array_equal(bits(a), bits(b)), "%s image %s differs in %d values" % (
-            tag, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()) if a.dtype.itemsize == 4 else -1)
+        ba, bb = bits(a), bits(b)
+        if not np.array_equal(ba, bb):
+            w = np.argwhere(ba != bb)[:5]
+            raise AssertionError("%s image %s differs in %d values, first at %s: oracle %s gpu %s" % (
+                tag, name, int((ba != bb).sum()), w.tolist(), [a[tuple(i)] for i in w], [b[tuple(i)] for i in w]))
     assert o.surfel_count() == g.surfel_count(), tag
     assert np.array_equal(bits(o.download_map()), bits(g.download_map())), tag + " map"
     assert np.array_equal(bits(o.get_pose()), bits(g.get_pose())), tag + " pose"
@@ -222,8 +232,10 @@ def test_icp_step_seam(oracle_lib_built, gpu_available):
     J = np.concatenate([nm, np.cross(s, nm)], -1)[ok]; rr = ((s - dm) * nm).sum(-1)[ok]; ww = wm[ok]
     A_ref = (J * ww[:, None]).T @ J; b_ref = (J * ww[:, None]).T @ rr
     assert int(r1[1]) == int(ok.sum())
-    np.testing.assert_allclose(A1.reshape(6, 6), A_ref, rtol=1e-5, atol=1e-7 * np.abs(A_ref).max())
-    np.testing.assert_allclose(b1, b_ref, rtol=1e-5, atol=1e-6 * np.abs(b_ref).max())
+    # per-pixel rows are fp32 (like reduce.cu:494-545: s, d, n, cross products all in float), only the SUM is
+    # exact; against an all-fp64 evaluation that leaves ~1e-5 relative on A and on the (cancelling) b
+    np.testing.assert_allclose(A1.reshape(6, 6), A_ref, rtol=1e-4, atol=1e-5 * np.abs(A_ref).max())
+    np.testing.assert_allclose(b1, b_ref, rtol=1e-4, atol=1e-5 * np.abs(b_ref).max())
     g.close()
 
 
