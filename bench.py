@@ -142,6 +142,16 @@ def main():
     fuse_ms = float(ms[ok].mean()) if ok.any() else 0.0
     count1 = fus.surfel_count()
     P_end = fus.get_pose()
+    # PCIe-inclusive rate of the host-pointer entry point (never `value`): 1.5 MB upload + sync per frame
+    pcie_fps = None
+    if world == 1:
+        nh = min(20, K)
+        fus.enable_timing(False)
+        t1 = time.perf_counter()
+        for k in range(1 + Wm + K - nh, 1 + Wm + K):
+            fus.process_frame(frames[k][0], frames[k][1], k)
+        fus.synchronize()
+        pcie_fps = nh / (time.perf_counter() - t1)
     err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
     tm = fus.timings()
 
@@ -155,7 +165,7 @@ def main():
                                    "map pre-seeded to %d surfels, full processFrame per step" % (W, H, seed.shape[0]),
                        "surfels_start": int(count0), "surfels_end": int(count1),
                        "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
-                       "final_translation_error_mm": err_mm,
+                       "final_translation_error_mm": err_mm, "pcie_inclusive_fps": pcie_fps,
                        "last_frame_region_ms": {"Initialization": float(tm[0]), "Registration": float(tm[1]),
                                                 "Integration": float(tm[2]), "Prediction": float(tm[3]),
                                                 "fuse_stream_pass": float(tm[4])}},

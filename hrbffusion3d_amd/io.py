@@ -1,0 +1,114 @@
+"""Data formats either side of the hot path — host side, numpy only.
+
+  save_ply              binary PLY, 13 properties, normals negated   Core/src/HRBFFusion.cpp:1737-1853
+  save_trajectory       TUM / ICL-NUIM variant / zhou .log / lefloch   Core/src/Utils/TrajectoryManager.cpp:284-373
+  load_trajectory_tum   inverse of the TUM writer (for ATE)           Core/src/Utils/TrajectoryManager.cpp:27-120
+  load_associations     `ts depth_path ts rgb_path` per line           Core/src/HRBFFusion.cpp:212-238
+  ate_rmse              Horn-aligned absolute trajectory error (the reference ships no evaluation script)
+"""
+import numpy as np
+
+
+def rotation_to_quaternion(R):
+    """x, y, z, w with Eigen::Quaternionf(Matrix3f) branch order (w >= 0 on the trace branch)."""
+    R = np.asarray(R, np.float64)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0); w = 0.5 * s; s = 0.5 / s
+        return np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
+    i = 0
+    if R[1, 1] > R[0, 0]:
+        i = 1
+    if R[2, 2] > R[i, i]:
+        i = 2
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+    q = np.zeros(4); q[i] = 0.5 * s; s = 0.5 / s
+    q[3] = (R[k, j] - R[j, k]) * s; q[j] = (R[j, i] + R[i, j]) * s; q[k] = (R[k, i] + R[i, k]) * s
+    return q
+
+
+def quaternion_to_rotation(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def save_trajectory(path, poses, stamps_us=None, fmt="TUM", icl_nuim=False):
+    poses = [np.asarray(p, np.float64) for p in poses]
+    if stamps_us is None:
+        stamps_us = list(range(len(poses)))
+    with open(path, "w") as f:
+        for i, T in enumerate(poses):
+            if fmt == "TUM":
+                t = T[:3, 3].copy()
+                if icl_nuim:
+                    head = "%d " % int(stamps_us[i]); t[1] = -t[1]
+                else:
+                    head = "%.6f " % (stamps_us[i] / 1000000.0)
+                q = rotation_to_quaternion(T[:3, :3])
+                f.write(head + "%g %g %g %g %g %g %g\n" % (t[0], t[1], t[2], q[0], q[1], q[2], q[3]))
+            elif fmt == "zhou":
+                f.write("%d %d %d\n" % (i, i, i + 1))
+                for r in range(4):
+                    f.write("%f %f %f %f\n" % tuple(T[r]))
+            elif fmt == "lefloch":
+                f.write("%d " % i + " ".join("%g" % v for v in T.T.ravel()) + " \n")
+            else:
+                raise ValueError(fmt)
+
+
+def load_trajectory_tum(path):
+    stamps, poses = [], []
+    for line in open(path):
+        v = line.split()
+        if len(v) != 8 or line.startswith("#"):
+            continue
+        T = np.eye(4); T[:3, 3] = [float(x) for x in v[1:4]]
+        T[:3, :3] = quaternion_to_rotation([float(x) for x in v[4:8]])
+        stamps.append(float(v[0])); poses.append(T)
+    return np.array(stamps), poses
+
+
+def save_ply(path, surfels, conf_threshold=0.0):
+    """surfels: (N,20) float32 in the GlobalModel layout (hrbf_download_map)."""
+    s = np.asarray(surfels, np.float32)
+    s = s[s[:, 3] > conf_threshold]
+    rec = np.zeros(len(s), dtype=[("xyz", "<f4", 3), ("rgb", "u1", 3), ("n", "<f4", 3), ("kmax", "<f4"), ("kmin", "<f4"),
+                                  ("radius", "<f4"), ("submap", "<f4")])
+    rec["xyz"] = s[:, 0:3]
+    c = s[:, 4].astype(np.int64)
+    rec["rgb"] = np.stack([(c >> 16) & 255, (c >> 8) & 255, c & 255], 1)
+    rec["n"] = -s[:, 8:11]
+    rec["kmax"] = s[:, 15]; rec["kmin"] = s[:, 19]; rec["radius"] = s[:, 11]; rec["submap"] = s[:, 5]
+    head = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z"
+            "\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\nproperty float ny"
+            "\nproperty float nz\nproperty float curvature_max\nproperty float curvature_min\nproperty float radius"
+            "\nproperty float submapIndex\nend_header\n" % len(s))
+    with open(path, "wb") as f:
+        f.write(head.encode()); f.write(rec.tobytes())
+    return len(s)
+
+
+def load_associations(path):
+    """TUM associations: `t_depth depth_file t_rgb rgb_file` (the order HRBFFusion.cpp:226-236 reads)."""
+    out = []
+    for line in open(path):
+        v = line.split()
+        if len(v) >= 4 and not line.startswith("#"):
+            out.append((float(v[0]), v[1], float(v[2]), v[3]))
+    return out
+
+
+def ate_rmse(est, gt, align=True):
+    """translation RMSE (m); with align=True after the closed-form rigid alignment (Horn/Umeyama, no scale)."""
+    E = np.asarray([np.asarray(p)[:3, 3] for p in est], np.float64)
+    G = np.asarray([np.asarray(p)[:3, 3] for p in gt], np.float64)
+    if align and len(E) >= 3:
+        me, mg = E.mean(0), G.mean(0)
+        U, _, Vt = np.linalg.svd((G - mg).T @ (E - me))
+        S = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+        R = U @ S @ Vt
+        E = (E - me) @ R.T + mg
+    return float(np.sqrt(((E - G) ** 2).sum(1).mean()))

@@ -1,0 +1,229 @@
+/*
+ * HRBFFusion.h — header-only C++ shim with the reference's class surface over the C-ABI of
+ * libhrbf_mi355.so, so that a caller written against Core/src/HRBFFusion.h (e.g.
+ * GUI/src/HRBF_fusion.cpp:190-497) can switch libraries.
+ *
+ * Mirrors (reference file:line):
+ *   HRBFFusion::HRBFFusion(countThresh, errThresh, confidence, depthCut, icpThresh, fastOdom, so3,
+ *                          frameToFrameRGB)                         Core/src/HRBFFusion.h:87-94
+ *   void processFrame(rgb, depth, timestamp, weightMultiplier)      Core/src/HRBFFusion.h:110-113
+ *   getCurrPose / getTick / setTick / getGlobalModel / setters      Core/src/HRBFFusion.h:115-260
+ *   GlobalModel::lastCount / downloadMap                            Core/src/GlobalModel.cpp:770-804
+ *   savePly (binary PLY, 13 properties, normals negated)            Core/src/HRBFFusion.cpp:1737-1853
+ *   TrajectoryManager::SaveTrajectoryToFile (TUM / zhou / lefloch)   Core/src/Utils/TrajectoryManager.cpp:284-373
+ *
+ * Differences a maintainer must know:
+ *   - the reference reads resolution / intrinsics from the Resolution / Intrinsics singletons and
+ *     1/DepthMapFactor from a camera YAML; here they are constructor arguments;
+ *   - poses are exposed as 16 floats, column-major (bit-compatible with Eigen::Matrix4f::data());
+ *     with Eigen available (#include <Eigen/Core> first) getCurrPose() returns an Eigen::Map;
+ *   - GL handles (model(), textures) do not exist: use downloadMap() / getImage();
+ *   - downloadMap() returns the CURRENT map; the reference copies from vbos[renderSource]
+ *     (GlobalModel.cpp:791), i.e. the buffer of the previous pass with the new count;
+ *   - errors throw std::runtime_error instead of exit(0) (Core/src/Cuda/convenience.cuh:64-71).
+ */
+#ifndef HRBF_MI355_HRBFFUSION_H_
+#define HRBF_MI355_HRBFFUSION_H_
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hrbf_mi355.h"
+
+namespace hrbf_mi355 {
+
+struct Pose { float m[16]; };   // column-major 4x4, T_wc
+
+class GlobalModel {
+public:
+    explicit GlobalModel(hrbf_handle h) : h_(h) {}
+    unsigned int lastCount() const { return hrbf_surfel_count(h_); }
+    /* caller-owned array of lastCount()*20 floats (= Eigen::Vector4f[count*5]); delete[] it */
+    float *downloadMap() const
+    {
+        const unsigned int n = lastCount();
+        float *out = new float[(size_t)(n ? n : 1) * 20];
+        if (n && hrbf_download_map(h_, out, n) != HRBF_OK) { delete[] out; throw std::runtime_error(hrbf_last_error()); }
+        return out;
+    }
+private:
+    hrbf_handle h_;
+};
+
+class TrajectoryManager {
+public:
+    std::vector<Pose> poses;
+    std::vector<int64_t> timstamp;   // (sic) reference member name
+
+    /* format: "TUM" (ts tx ty tz qx qy qz qw; icl_nuim negates ty and prints an integer stamp),
+       "zhou" (.log) or "lefloch" — TrajectoryManager.cpp:284-373 */
+    bool SaveTrajectoryToFile(const std::string &type, const std::string &fname, bool icl_nuim = false) const
+    {
+        if (type == "zhou") {
+            FILE *f = fopen(fname.c_str(), "w");
+            if (!f) return false;
+            for (size_t i = 0; i < poses.size(); ++i) {
+                const float *m = poses[i].m;
+                fprintf(f, "%d %d %d\n", (int)i, (int)i, (int)(i + 1));
+                for (int r = 0; r < 4; ++r) fprintf(f, "%f %f %f %f\n", m[r], m[4 + r], m[8 + r], m[12 + r]);
+            }
+            fclose(f);
+            return true;
+        }
+        if (type == "TUM") {
+            FILE *f = fopen(fname.c_str(), "w");
+            if (!f) return false;
+            for (size_t i = 0; i < poses.size(); ++i) {
+                const float *m = poses[i].m;
+                float tx = m[12], ty = m[13], tz = m[14];
+                const int64_t ts = i < timstamp.size() ? timstamp[i] : (int64_t)i;
+                if (icl_nuim) { fprintf(f, "%d ", (int)ts); ty = -ty; }
+                else fprintf(f, "%.6f ", (double)ts / 1000000.0);
+                float q[4];
+                quaternion(m, q);
+                fprintf(f, "%g %g %g %g %g %g %g\n", tx, ty, tz, q[0], q[1], q[2], q[3]);
+            }
+            fclose(f);
+            return true;
+        }
+        if (type == "lefloch") {
+            FILE *f = fopen(fname.c_str(), "w");
+            if (!f) return false;
+            for (size_t i = 0; i < poses.size(); ++i) {
+                fprintf(f, "%zu ", i);
+                for (int k = 0; k < 16; ++k) fprintf(f, "%g ", poses[i].m[k]);   // column-major like poses[i](k, j)
+                fprintf(f, "\n");
+            }
+            fclose(f);
+            return true;
+        }
+        return false;
+    }
+
+    /* rotation (column-major 4x4) -> unit quaternion x y z w (Eigen::Quaternionf(Matrix3f) convention) */
+    static void quaternion(const float *m, float q[4])
+    {
+        const float r00 = m[0], r11 = m[5], r22 = m[10];
+        const float t = r00 + r11 + r22;
+        if (t > 0.0f) {
+            float s = std::sqrt(t + 1.0f);
+            q[3] = 0.5f * s; s = 0.5f / s;
+            q[0] = (m[6] - m[9]) * s; q[1] = (m[8] - m[2]) * s; q[2] = (m[1] - m[4]) * s;
+        } else {
+            int i = 0;
+            if (r11 > r00) i = 1;
+            if (r22 > (i == 0 ? r00 : r11)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            auto R = [&](int r, int c) { return m[c * 4 + r]; };
+            float s = std::sqrt(R(i, i) - R(j, j) - R(k, k) + 1.0f);
+            q[i] = 0.5f * s; s = 0.5f / s;
+            q[3] = (R(k, j) - R(j, k)) * s; q[j] = (R(j, i) + R(i, j)) * s; q[k] = (R(k, i) + R(i, k)) * s;
+        }
+    }
+};
+
+class HRBFFusion {
+public:
+    HRBFFusion(int width, int height, float fx, float fy, float cx, float cy, float depthScale,
+               const int countThresh = 35000, const float errThresh = 5e-05f, const float confidence = 10.0f,
+               const float depthCut = 3.0f, const float icpThresh = 10.0f, const bool fastOdom = false,
+               const bool so3 = true, const bool frameToFrameRGB = false, int maxSurfels = 4596 * 4596, int device = 0)
+        : h_(nullptr), model_(nullptr)
+    {
+        (void)countThresh; (void)errThresh;   // stored but never read on this path in the reference either
+        hrbf_params p;
+        hrbf_default_params(&p, width, height, fx, fy, cx, cy, depthScale);
+        p.confidence_threshold = confidence; p.depth_cutoff = depthCut; p.icp_weight = icpThresh;
+        p.fast_odom = fastOdom; p.so3 = so3; p.frame_to_frame_rgb = frameToFrameRGB; p.max_surfels = maxSurfels;
+        if (hrbf_create(&p, device, &h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+        model_ = new GlobalModel(h_);
+        trajectory_manager = new TrajectoryManager();
+    }
+    ~HRBFFusion() { delete trajectory_manager; delete model_; hrbf_destroy(h_); }
+    HRBFFusion(const HRBFFusion &) = delete;
+    HRBFFusion &operator=(const HRBFFusion &) = delete;
+
+    void processFrame(const unsigned char *rgb, const unsigned short *depth, const int64_t &timestamp,
+                      const float weightMultiplier = 1.f)
+    {
+        const int tick_before = hrbf_get_tick(h_);
+        if (hrbf_process_frame(h_, rgb, depth, timestamp, weightMultiplier) != HRBF_OK)
+            throw std::runtime_error(hrbf_last_error());
+        Pose p;
+        hrbf_get_pose(h_, p.m);
+        curr_ = p;
+        trajectory_manager->poses.push_back(p);                       /* HRBFFusion.cpp:1058,1129-1133 */
+        if (tick_before > 1) trajectory_manager->timstamp.push_back(timestamp);
+    }
+
+    const float *getCurrPoseData() { hrbf_get_pose(h_, curr_.m); return curr_.m; }
+#ifdef EIGEN_CORE_H
+    Eigen::Map<const Eigen::Matrix4f> getCurrPose() { return Eigen::Map<const Eigen::Matrix4f>(getCurrPoseData()); }
+#else
+    const float *getCurrPose() { return getCurrPoseData(); }
+#endif
+    const int getTick() { return hrbf_get_tick(h_); }
+    void setTick(const int &val) { hrbf_set_tick(h_, val); }
+    GlobalModel &getGlobalModel() { return *model_; }
+    float lastICPError() { float e, c; hrbf_last_icp(h_, &e, &c); return e; }
+    float lastICPCount() { float e, c; hrbf_last_icp(h_, &e, &c); return c; }
+    /* setters applied every GUI frame (GUI/src/HRBF_fusion.cpp:448-456) */
+    void setRgbOnly(const bool &val) { hrbf_set_rgb_only(h_, val); }
+    void setIcpWeight(const float &val) { hrbf_set_icp_weight(h_, val); }
+    void setPyramid(const bool &val) { hrbf_set_pyramid(h_, val); }
+    void setFastOdom(const bool &val) { hrbf_set_fast_odom(h_, val); }
+    void setSo3(const bool &val) { hrbf_set_so3(h_, val); }
+    void setFrameToFrameRGB(const bool &val) { hrbf_set_frame_to_frame_rgb(h_, val); }
+    void setConfidenceThreshold(const float &val) { hrbf_set_confidence_threshold(h_, val); }
+    void setDepthCutoff(const float &val) { hrbf_set_depth_cutoff(h_, val); }
+    bool getImage(int which, void *out, size_t bytes) { return hrbf_get_image(h_, which, out, bytes) == HRBF_OK; }
+    hrbf_handle handle() { return h_; }
+
+    /* binary little-endian PLY, 13 properties (HRBFFusion.cpp:1737-1853) */
+    void savePly(const std::string &filename, float confThreshold = 0.0f)
+    {
+        const unsigned int n = model_->lastCount();
+        float *map = model_->downloadMap();
+        int valid = 0;
+        for (unsigned int i = 0; i < n; ++i) valid += map[(size_t)i * 20 + 3] > confThreshold;
+        std::ofstream fs(filename.c_str(), std::ios::binary);
+        fs << "ply\nformat binary_little_endian 1.0\nelement vertex " << valid
+           << "\nproperty float x\nproperty float y\nproperty float z"
+              "\nproperty uchar red\nproperty uchar green\nproperty uchar blue"
+              "\nproperty float nx\nproperty float ny\nproperty float nz"
+              "\nproperty float curvature_max\nproperty float curvature_min"
+              "\nproperty float radius\nproperty float submapIndex\nend_header\n";
+        for (unsigned int i = 0; i < n; ++i) {
+            const float *s = &map[(size_t)i * 20];
+            if (!(s[3] > confThreshold)) continue;
+            fs.write((const char *)&s[0], 12);
+            const int c = (int)s[4];
+            const unsigned char rgb[3] = {(unsigned char)((c >> 16) & 0xFF), (unsigned char)((c >> 8) & 0xFF),
+                                          (unsigned char)(c & 0xFF)};
+            fs.write((const char *)rgb, 3);
+            const float nrm[3] = {-s[8], -s[9], -s[10]};
+            fs.write((const char *)nrm, 12);
+            fs.write((const char *)&s[15], 4);   /* curvature_max = curv_map_max.w */
+            fs.write((const char *)&s[19], 4);   /* curvature_min = curv_map_min.w */
+            fs.write((const char *)&s[11], 4);   /* radius */
+            fs.write((const char *)&s[5], 4);    /* submapIndex */
+        }
+        delete[] map;
+    }
+
+    TrajectoryManager *trajectory_manager;   /* public like HRBFFusion.h:383-384 */
+
+private:
+    hrbf_handle h_;
+    GlobalModel *model_;
+    Pose curr_;
+};
+
+}  // namespace hrbf_mi355
+#endif
