@@ -142,6 +142,7 @@ def main():
     fuse_ms = float(ms[ok].mean()) if ok.any() else 0.0
     count1 = fus.surfel_count()
     P_end = fus.get_pose()
+    tm = fus.timings()
     # PCIe-inclusive rate of the host-pointer entry point (never `value`): 1.5 MB upload + sync per frame
     pcie_fps = None
     if world == 1:
@@ -153,7 +154,6 @@ def main():
         fus.synchronize()
         pcie_fps = nh / (time.perf_counter() - t1)
     err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
-    tm = fus.timings()
 
     if rank == 0:
         out = {

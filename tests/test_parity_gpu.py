@@ -248,7 +248,7 @@ def test_full_size_properties_1M(gpu_available):
     fx, fy, cx, cy = synth.intrinsics(W, H)
     seed = synth.seed_map(1_050_000)
     seed[:, 6] = np.arange(len(seed)) % 16000 + 1      # initTime doubles as an order tag (kept < 2^24)
-    tag = (seed[:, 0].view(np.uint32).astype(np.uint64) << 32) | seed[:, 1].view(np.uint32)
+    tag = [r.tobytes() for r in np.ascontiguousarray(seed[:, 0:3])]      # 96-bit position key
     p = default_params(W, H, fx, fy, cx, cy, max_surfels=seed.shape[0] + 600_000)
 
     def run():
@@ -272,12 +272,12 @@ def test_full_size_properties_1M(gpu_available):
         assert removed >= 0 and st[1] > 30000 and st[2] <= (W // 2) * (H // 2)
         n_prev = len(m)
     # order preservation: the seeded surfels that survive appear in their original relative order.
-    # Unmerged surfels keep (x,y) bit for bit -> their tags form a subsequence of the seed tags.
+    # Unmerged surfels keep (x,y,z) bit for bit -> their keys form a subsequence of the seed keys.
     m = maps[-1]
     old = m[m[:, 7] == 1.0]                      # never merged, never appended
-    t_old = (old[:, 0].view(np.uint32).astype(np.uint64) << 32) | old[:, 1].view(np.uint32)
-    pos = {int(t): i for i, t in enumerate(tag)}
-    where = np.array([pos[int(t)] for t in t_old[::97]])
+    pos = {t: i for i, t in enumerate(tag)}
+    assert len(pos) == len(tag)
+    where = np.array([pos[r.tobytes()] for r in np.ascontiguousarray(old[::97, 0:3])])
     assert np.all(np.diff(where) > 0)
     assert np.array_equal(bits(old[::97]), bits(seed[where]))      # untouched surfels are bit-identical
     # appended surfels carry this run's time stamps and sit at the tail
