@@ -154,7 +154,7 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     { int r; if ((r = alloc_planes(c, c->map, c->cap)) || (r = alloc_planes(c, c->rec, c->Q))) { hrbf_destroy(c); return r; } }
     DA(c->d_count, 2);
     DA(c->d_rec_flag, c->Q); DA(c->d_rec_best, c->Q); DA(c->d_slot, c->cap);
-    DA(c->d_stats, 4); DA(c->d_init_flags, P); DA(c->d_init_offs, P);
+    DA(c->d_stats, 8); DA(c->d_init_flags, P); DA(c->d_init_offs, P);
     c->max_tiles = (c->cap + c->Q) / fuse_tile_items() + 2;
     DA(c->d_tile_count, (size_t)c->max_tiles * fuse_tile_count_stride()); DA(c->d_tile_done, c->max_tiles);
     DA(c->d_pose, 1);
@@ -313,7 +313,7 @@ static void st_fuse(hrbf_context *c)
 {
     launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, 0, c->d_depth_metric, c->d_normal_pca,
                 c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf, c->d_im_normrad, c->rec,
-                c->d_rec_flag, c->d_rec_best, c->d_slot, c->map, c->d_stats);
+                c->d_rec_flag, c->d_rec_best, c->d_slot, c->map, c->d_stats, c->prm.curv_valid_threshold);
     c->fuse_tick = c->tick;
 }
 static void st_clean(hrbf_context *c)

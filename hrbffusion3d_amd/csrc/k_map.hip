@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
 __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes rec,
                                                       const int32_t *__restrict__ rec_flag,
                                                       const uint32_t *__restrict__ rec_best, uint32_t *__restrict__ slot,
-                                                      MapPlanes m, uint32_t *__restrict__ merged)
+                                                      MapPlanes m, uint32_t *__restrict__ merged, float curvThr)
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q || rec_flag[q] != 1) return;
@@ -265,10 +265,15 @@ __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes
         f3 nn = normalize3(mk3(((c_k * vn.x) + (a * r2.x)) / sum, ((c_k * vn.y) + (a * r2.y)) / sum,
                                ((c_k * vn.z) + (a * r2.z)) / sum));
         m.p2[s] = make_float4(nn.x, nn.y, nn.z, ((c_k * vn.w) + (a * r2.w)) / sum);
+        const float nk1 = ((c_k * c1.w) + (a * r3.w)) / sum, nk2 = ((c_k * c2.w) + (a * r4.w)) / sum;
         m.p3[s] = make_float4(((c_k * c1.x) + (a * r3.x)) / sum, ((c_k * c1.y) + (a * r3.y)) / sum,
-                              ((c_k * c1.z) + (a * r3.z)) / sum, ((c_k * c1.w) + (a * r3.w)) / sum);
+                              ((c_k * c1.z) + (a * r3.z)) / sum, nk1);
         m.p4[s] = make_float4(((c_k * c2.x) + (a * r4.x)) / sum, ((c_k * c2.y) + (a * r4.y)) / sum,
-                              ((c_k * c2.z) + (a * r4.z)) / sum, ((c_k * c2.w) + (a * r4.w)) / sum);
+                              ((c_k * c2.z) + (a * r4.z)) / sum, nk2);
+        // The clean pass skips the curvature re-check of surfels it does not otherwise have to read.  A convex
+        // combination of two valid curvatures can leave [-thr, thr] only through fp32 rounding at the very edge;
+        // if it ever does, ask this frame's clean pass for a full check (merged[3] = force flag).
+        if (!(nk1 >= -curvThr && nk1 <= curvThr && nk2 >= -curvThr && nk2 <= curvThr)) merged[3] = 1u;
     } else {
         m.p0[s] = make_float4(vp.x, vp.y, vp.z, sum);
         m.p1[s] = make_float4(vc.x, vc.y, vc.z, (float)tick);
@@ -331,6 +336,47 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
     const bool nz_ok = hd_fabsf(ln.z) > 0.85f;
     const float rad14 = vn.w * 1.4f;
     const float ftime = (float)cp.time;
+    if (cp.nw == 4) {
+        // the 4 samples of an axis are non-decreasing with steps <= 1: values s0, s0+1, s0+2 with multiplicities.
+        // All (<= 9) distinct texels are requested in one batch (18 independent 16-B loads), then evaluated.
+        int sxk[4], syk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sxk[k] = clampi((int)hd_floorf(x + ((float)k * 0.5f - cp.w0)), 0, cam.W - 1);
+            syk[k] = clampi((int)hd_floorf(y + ((float)k * 0.5f - cp.w0)), 0, cam.H - 1);
+        }
+        int mx[3], my[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            mx[j] = (sxk[0] == sxk[0] + j) + (sxk[1] == sxk[0] + j) + (sxk[2] == sxk[0] + j) + (sxk[3] == sxk[0] + j);
+            my[j] = (syk[0] == syk[0] + j) + (syk[1] == syk[0] + j) + (syk[2] == syk[0] + j) + (syk[3] == syk[0] + j);
+        }
+        float4 ta[9], tb[9];
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+            for (int jy = 0; jy < 3; ++jy) {
+                const int wgt = mx[jx] * my[jy];
+                const int si = (syk[0] + jy) * cam.W + (sxk[0] + jx);
+                ta[jx * 3 + jy] = make_float4(0, 0, 0, 0); tb[jx * 3 + jy] = make_float4(0, 0, 0, 0);
+                if (wgt > 0) { ta[jx * 3 + jy] = clean_tex[2 * si]; tb[jx * 3 + jy] = clean_tex[2 * si + 1]; }
+            }
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+            for (int jy = 0; jy < 3; ++jy) {
+                const int wgt = mx[jx] * my[jy];
+                const float4 vcf = ta[jx * 3 + jy], tt = tb[jx * 3 + jy];
+                if (wgt > 0 && tt.z > 0.0f) {
+                    float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
+                    if (tt.x < init_time && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
+                        hd_sqrtf(dx * dx + dy * dy) < rad14)
+                        count += wgt;
+                    if (tt.y == ftime && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f && nz_ok) zCount += wgt;
+                }
+            }
+        return !(count > 8 || zCount > 4);
+    }
     int prev_sx = -1, colc = 0, colz = 0;
     for (int a = 0; a < cp.nw; ++a) {
         const int sx = clampi((int)hd_floorf(x + ((float)a * 0.5f - cp.w0)), 0, cam.W - 1);
@@ -382,29 +428,40 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     const uint32_t total = N + (uint32_t)Q;
     const Rigid tinv = cp.dp->tinv;
     const float ftime = (float)cp.time;
+    cp.full_check |= (int)stats[4];   // raised by k_apply_merges (see there)
     const uint32_t total64 = (total + 63u) & ~63u;
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[2] = 0;   // appended counter, accumulated by pass B
+    // Plain round-robin grid-stride on purpose: the in-view minority (the expensive items) is clustered in the
+    // array, and an XCD-contiguous chunking (one eighth of the array per XCD, better L2 locality for the clean
+    // texels) measured 2x SLOWER because one or two XCDs then own all the heavy work (profiles/r01 notes).
     for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < total64; it += gridDim.x * blockDim.x) {
         const bool is_surf = it < N;
         const uint32_t q = it - N;
         bool keep = false;
         if (it < total && (is_surf || rec_flag[q] != 0)) {
             const float4 vp = is_surf ? m.p0[it] : rec.p0[q];
-            const float4 vc = is_surf ? m.p1[it] : rec.p1[q];
             keep = true;
             f3 lp; float x, y;
-            if (in_view(cp, tinv, vp, lp, x, y)) {
+            const bool inv = in_view(cp, tinv, vp, lp, x, y);
+            // color_time is needed for in-view items (init time, merged-this-frame), for unstable surfels (stale
+            // test) and for records; a stable surfel outside the frustum is decided by pos_conf alone (16 B)
+            const bool need_ct = inv || !is_surf || vp.w < cp.confThr || cp.full_check;
+            float4 vc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (need_ct) vc = is_surf ? m.p1[it] : rec.p1[q];
+            if (inv) {
                 const float4 vn = is_surf ? m.p2[it] : rec.p2[q];
                 keep = clean_window(cp, tinv, lp, x, y, vc.z, vn, clean_tex);
             }
-            if (!is_surf || cp.full_check || vc.w == ftime) {
+            if (!is_surf || cp.full_check || (need_ct && vc.w == ftime)) {
                 const float k1 = is_surf ? m.p3[it].w : rec.p3[q].w;
                 const float k2 = is_surf ? m.p4[it].w : rec.p4[q].w;
                 if (k1 < -cp.curvThr || k1 > cp.curvThr || k2 < -cp.curvThr || k2 > cp.curvThr) keep = false;
             }
-            float lastw = vc.w;
-            if (lastw == -2.0f) lastw = ftime;
-            if (lastw == -1.0f || ((ftime - lastw) > 200.0f && vp.w < cp.confThr)) keep = false;
+            if (need_ct) {
+                float lastw = vc.w;
+                if (lastw == -2.0f) lastw = ftime;
+                if (lastw == -1.0f || ((ftime - lastw) > 200.0f && vp.w < cp.confThr)) keep = false;
+            }
         }
         if (it < total) keep_flags[it] = keep ? 1 : 0;
         // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
@@ -583,15 +640,15 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, uint32_t *stats)
+                 MapPlanes m, uint32_t *stats, float curvThr)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
-    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 4);
+    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 5);   // [0..3] statistics, [4] force-full-check flag
     hipLaunchKernelGGL(k_associate, dim3((Q + 255) / 256), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
                        rec_best, slot);
     hipLaunchKernelGGL(k_apply_merges, dim3((Q + 255) / 256), dim3(256), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
-                       stats + 1);
+                       stats + 1, curvThr);
 }
 
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,

@@ -39,7 +39,7 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, uint32_t *stats);
+                 MapPlanes m, uint32_t *stats, float curvThr);
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
