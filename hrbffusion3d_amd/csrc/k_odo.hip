@@ -45,60 +45,71 @@ size_t odo_slot_bytes() { return sizeof(long long) * (32 * 87 * 2 + 64 * 2 + 32 
 
 // ------------------------------------------------------------------------------------------
 // exact workgroup reduction of N floats per lane.
-//   lane: float -> five 26-bit limbs (hd_limbs26)            [exact, integer]
-//   wave: 32-bit DPP add tree (quad_perm, row_ror, row_bcast) [64 x 26 bits fits 32 bits: no carries]
-//   block: the 4 wave totals are folded to int64 limbs in LDS
+//   lane: float -> five signed 25-bit limbs (hd_limbs25, ~20 branch-free VALU ops) [exact]
+//   wave: 32-bit DPP add tree (quad_perm, row_ror, row_bcast)   [64 x 2^25 fits an int32: no carries]
+//   block: lane 63 of each wave parks its five sums in LDS; after the barrier thread t < N folds the
+//          waves for value t and converts to the 40-bit limb form
 //   grid: one 64-bit atomicAdd per limb into slot (blockIdx % ODO_SLOTS) — integer adds commute, so the
 //         result does not depend on arrival order.  The consumer sums the ODO_SLOTS rows and re-zeroes them.
 #define ODO_SLOTS 32
 #define RES_SLOTS 64
 
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+__device__ __forceinline__ int32_t dpp_i32(int32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)   // total in lane 63
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v)   // total in lane 63
 {
-    v += dpp_u32<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
-    v += dpp_u32<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
-    v += dpp_u32<0x124, 0xf>(v);   // row_ror:4
-    v += dpp_u32<0x128, 0xf>(v);   // row_ror:8
-    v += dpp_u32<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
-    v += dpp_u32<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    v += dpp_i32<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_i32<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_i32<0x124, 0xf>(v);   // row_ror:4
+    v += dpp_i32<0x128, 0xf>(v);   // row_ror:8
+    v += dpp_i32<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v += dpp_i32<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
     return v;
 }
+
+struct alignas(16) WaveSums { int32_t d0, d1, d2, d3, d4, pad[3]; };
 
 template <int N>
 __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ slots)
 {
-    __shared__ long long s_part[RB / 64][NLIMB(N)];
+    __shared__ WaveSums s_raw[RB / 64][N];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const bool any = __ballot(valid) != 0ull;
-    if (any) {
-#pragma unroll 1
+#ifdef ODO_EXP_NOREDUCE
+    if (vals[0] == 123456.0f) slots[0] = 1;
+    return;
+#endif
+    if (__ballot(valid) != 0ull) {
+#pragma unroll
         for (int i = 0; i < N; ++i) {
-            hd_limbs26 l;
-            if (valid) l = hd_limbs26_from_f32(vals[i]);
-            else { l.d0 = l.d1 = l.d2 = l.d3 = 0u; l.d4 = 0; }
-            const uint32_t s0 = wave_sum_u32(l.d0), s1 = wave_sum_u32(l.d1), s2 = wave_sum_u32(l.d2),
-                           s3 = wave_sum_u32(l.d3);
-            const int32_t s4 = (int32_t)wave_sum_u32((uint32_t)l.d4);
-            if (lane == 63) {
-                const hd_limbs L = hd_limbs26_to_limbs(s0, s1, s2, s3, s4);
-                s_part[wid][i * 3] = L.l0; s_part[wid][i * 3 + 1] = L.l1; s_part[wid][i * 3 + 2] = L.l2;
-            }
+            const hd_limbs25 l = hd_limbs25_from_f32(valid ? vals[i] : 0.0f);
+            WaveSums w;
+            w.d0 = wave_sum_i32(l.d0); w.d1 = wave_sum_i32(l.d1); w.d2 = wave_sum_i32(l.d2);
+            w.d3 = wave_sum_i32(l.d3); w.d4 = wave_sum_i32(l.d4);
+            w.pad[0] = w.pad[1] = w.pad[2] = 0;
+            if (lane == 63) s_raw[wid][i] = w;
         }
-    } else if (lane == 63) {
-        for (int i = 0; i < NLIMB(N); ++i) s_part[wid][i] = 0;
+    } else {
+        WaveSums z = {0, 0, 0, 0, 0, {0, 0, 0}};
+        for (int i = lane; i < N; i += 64) s_raw[wid][i] = z;
     }
     __syncthreads();
-    long long *row = slots + (size_t)(blockIdx.x % ODO_SLOTS) * NLIMB(N);
-    for (int t = threadIdx.x; t < NLIMB(N); t += RB) {
-        long long s = 0;
+    if (threadIdx.x < N) {
+        long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
 #pragma unroll
-        for (int w = 0; w < RB / 64; ++w) s += s_part[w][t];
-        if (s != 0) atomicAdd((unsigned long long *)&row[t], (unsigned long long)s);
+        for (int w = 0; w < RB / 64; ++w) {
+            const WaveSums q = s_raw[w][threadIdx.x];
+            s0 += q.d0; s1 += q.d1; s2 += q.d2; s3 += q.d3; s4 += q.d4;
+        }
+        if ((s0 | s1 | s2 | s3 | s4) != 0) {
+            const hd_limbs L = hd_limbs25_to_limbs(s0, s1, s2, s3, s4);
+            long long *row = slots + (size_t)(blockIdx.x % ODO_SLOTS) * NLIMB(N) + threadIdx.x * 3;
+            if (L.l0) atomicAdd((unsigned long long *)&row[0], (unsigned long long)L.l0);
+            if (L.l1) atomicAdd((unsigned long long *)&row[1], (unsigned long long)L.l1);
+            if (L.l2) atomicAdd((unsigned long long *)&row[2], (unsigned long long)L.l2);
+        }
     }
 }
 
@@ -312,37 +323,76 @@ __global__ void k_pyrdown_u8(const uint8_t *__restrict__ src, int srows, int sco
 }
 
 // ------------------------------------------------------------------------------------------ small dense algebra
-// diagonal-pivoted LDL^T; A (n x n, overwritten), perm, y are caller-provided workspaces so that the
-// one-lane solve kernels keep them in LDS instead of per-lane scratch (runtime-indexed arrays).
-template <typename T>
-__host__ __device__ inline void ldlt_solve(int n, T *A, const T *b, T *x, int *perm, T *y)
+// diagonal-pivoted LDL^T, same arithmetic as the oracle's ldlt (oracle/orc_odo.c).  Everything is indexed
+// by compile-time constants (pivot row/column swaps are select chains), so A, perm and y live in registers —
+// the one-lane solve kernels are pure latency and runtime-indexed arrays would sit in scratch memory.
+template <typename T, int N>
+__host__ __device__ __forceinline__ void ldlt_solve(T (&A)[N * N], const T (&b)[N], T (&x)[N])
 {
-    for (int i = 0; i < n; ++i) perm[i] = i;
-    for (int k = 0; k < n; ++k) {
-        int piv = k; T best = A[k * n + k] < 0 ? -A[k * n + k] : A[k * n + k];
-        for (int i = k + 1; i < n; ++i) {
-            T v = A[i * n + i] < 0 ? -A[i * n + i] : A[i * n + i];
+    int perm[N];
+    T y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) perm[i] = i;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int piv = k;
+        T best = A[k * N + k] < 0 ? -A[k * N + k] : A[k * N + k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            T v = A[i * N + i] < 0 ? -A[i * N + i] : A[i * N + i];
             if (v > best) { best = v; piv = i; }
         }
-        if (piv != k) {
-            for (int j = 0; j < n; ++j) { T t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
-            for (int j = 0; j < n; ++j) { T t = A[j * n + k]; A[j * n + k] = A[j * n + piv]; A[j * n + piv] = t; }
-            int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {       // swap rows k <-> piv
+            const bool sel = (i == piv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const T a = A[k * N + j], c = A[i * N + j]; A[k * N + j] = sel ? c : a; A[i * N + j] = sel ? a : c; }
         }
-        T d = A[k * n + k];
-        if (d == 0) continue;
-        for (int i = k + 1; i < n; ++i) A[i * n + k] = A[i * n + k] / d;
-        for (int i = k + 1; i < n; ++i)
-            for (int j = k + 1; j <= i; ++j) {
-                A[i * n + j] = A[i * n + j] - A[i * n + k] * d * A[j * n + k];
-                A[j * n + i] = A[i * n + j];
-            }
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {       // swap columns k <-> piv
+            const bool sel = (i == piv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const T a = A[j * N + k], c = A[j * N + i]; A[j * N + k] = sel ? c : a; A[j * N + i] = sel ? a : c; }
+            const int pa = perm[k], pc = perm[i];
+            perm[k] = sel ? pc : pa; perm[i] = sel ? pa : pc;
+        }
+        const T d = A[k * N + k];
+        if (d != 0) {
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) A[i * N + k] = A[i * N + k] / d;
+#pragma unroll
+            for (int i = k + 1; i < N; ++i)
+#pragma unroll
+                for (int j = k + 1; j <= i; ++j) {
+                    A[i * N + j] = A[i * N + j] - A[i * N + k] * d * A[j * N + k];
+                    A[j * N + i] = A[i * N + j];
+                }
+        }
     }
-    for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] = y[i] - A[i * n + j] * y[j];
-    for (int i = 0; i < n; ++i) y[i] = (A[i * n + i] == 0) ? 0 : y[i] / A[i * n + i];
-    for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] = y[i] - A[j * n + i] * y[j];
-    for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {               // y = P b
+        T v = b[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) v = (perm[i] == j) ? b[j] : v;
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) y[i] = y[i] - A[i * N + j] * y[j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = (A[i * N + i] == 0) ? 0 : y[i] / A[i * N + i];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) y[i] = y[i] - A[j * N + i] * y[j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {               // x = P^T y
+        T v = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) v = (perm[j] == i) ? y[j] : v;
+        x[i] = v;
+    }
 }
 
 __host__ __device__ inline void inv3d(const double *m, double *o)
@@ -517,12 +567,8 @@ __global__ __launch_bounds__(1024) void k_so3_solve(OdoState *st, long long *__r
     }
     st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
     for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
-    __shared__ float w_A[9], w_b[3], w_x[3], w_y[3];
-    __shared__ int w_perm[3];
-    for (int k = 0; k < 9; ++k) w_A[k] = jtj[k];
-    for (int k = 0; k < 3; ++k) w_b[k] = jtr[k];
-    ldlt_solve<float>(3, w_A, w_b, w_x, w_perm, w_y);
-    float delta[3] = {w_x[0], w_x[1], w_x[2]};
+    float delta[3];
+    ldlt_solve<float, 3>(jtj, jtr, delta);
     double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
     rodrigues(dd, rotU);
     float rotUf[9], tmp[9];
@@ -804,12 +850,14 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__rest
     block_reduce_exact<29>(out, valid, rgb_part);
 }
 
-__device__ inline void unpack27(const double *s, float *A, float *b)
+__device__ __forceinline__ void unpack27(const double (&s)[29], float (&A)[36], float (&b)[6])
 {
-    int shift = 0;
+#pragma unroll
     for (int i = 0; i < 6; ++i)
+#pragma unroll
         for (int j = i; j < 7; ++j) {
-            float value = (float)s[shift++];
+            const int shift = i * 7 - (i * (i - 1)) / 2 + (j - i);   // row-major upper triangle incl. the rhs column
+            const float value = (float)s[shift];
             if (j == 6) b[i] = value; else A[j * 6 + i] = A[i * 6 + j] = value;
         }
 }
@@ -837,15 +885,15 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__re
         if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
         if (!st->gn_break) st->lastRGBError = rgbError;
     }
-    __shared__ double w_A[36], w_b[6], w_x[6], w_y[6], w_s[29];
-    __shared__ float w_Aicp[36], w_bicp[6], w_Argb[36], w_brgb[6];
-    __shared__ int w_perm[6];
     if (!st->gn_break) {
-        float *A_icp = w_Aicp, *b_icp = w_bicp, *A_rgb = w_Argb, *b_rgb = w_brgb;
+        float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+#pragma unroll
         for (int k = 0; k < 36; ++k) A_icp[k] = A_rgb[k] = 0.0f;
+#pragma unroll
         for (int k = 0; k < 6; ++k) b_icp[k] = b_rgb[k] = 0.0f;
-        double *s = w_s;
+        double s[29];
         if (icp) {
+#pragma unroll
             for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals, i);
             unpack27(s, A_icp, b_icp);
             st->res_icp[0] = (float)s[27]; st->res_icp[1] = (float)s[28];
@@ -853,10 +901,11 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__re
         st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
         st->last_icp_count = st->res_icp[1];
         if (rgb) {
+#pragma unroll
             for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals + 87, i);
             unpack27(s, A_rgb, b_rgb);
         }
-        double *lastA = w_A, *lastb = w_b, *result = w_x;
+        double lastA[36], lastb[6], result[6];
         if (icp && rgb) {
             double w = cfg.icp_weight, ww = w * w;
             for (int k = 0; k < 36; ++k) lastA[k] = (double)A_rgb[k] + ww * (double)A_icp[k];
@@ -868,7 +917,7 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__re
             for (int k = 0; k < 36; ++k) lastA[k] = A_rgb[k];
             for (int k = 0; k < 6; ++k) lastb[k] = b_rgb[k];
         }
-        ldlt_solve<double>(6, lastA, lastb, result, w_perm, w_y);
+        ldlt_solve<double, 6>(lastA, lastb, result);
         double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
         rodrigues(rv, Ru);
         for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }

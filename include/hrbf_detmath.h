@@ -279,7 +279,7 @@ HD_FN hd_acc128 hd_acc_from_f32(float p)
     int sh = (int)e - 150 + HD_ACC_FRAC_BITS;
     uint64_t lo, hi;
     if (sh >= 0) {
-        if (sh > 100) sh = 100;
+        if (sh > 100) return q;                 /* |p| >= 2^84 contributes nothing, like inf/NaN */
         if (sh == 0) { lo = m; hi = 0; }
         else if (sh < 64) { lo = m << sh; hi = m >> (64 - sh); }
         else { lo = 0; hi = m << (sh - 64); }
@@ -344,34 +344,42 @@ HD_FN hd_acc128 hd_limbs_combine(int64_t s0, int64_t s1, int64_t s2)
     return a;
 }
 
-/* ---------------------------------------------------------------- 26-bit limb form (wave-level)
- * Q split into five limbs of 26 bits (four unsigned, the top one signed): the sum of 64 lanes of a
- * 26-bit limb fits a 32-bit register, so a wave64 can reduce with plain 32-bit DPP adds, no carries.
- * hd_limbs26_to_limbs turns the five 64-lane sums back into the int64 limb form. */
-typedef struct { uint32_t d0, d1, d2, d3; int32_t d4; } hd_limbs26;
+/* ---------------------------------------------------------------- 25-bit signed limb form (wave-level)
+ * Q split into five SIGNED limbs at bit offsets 0, 24, 49, 74, 99:
+ *     Q = d0 + d1 2^24 + d2 2^49 + d3 2^74 + d4 2^99,   |d0| <= 2^24, |d1..d4| < 2^25, all with the sign of p.
+ * 64 lanes x 2^25 stays inside an int32, so a wave64 reduces each limb with plain 32-bit DPP adds, no carries.
+ * The split is done in fp32 (exact: scaling by powers of two, truncation, and removal of leading bits are
+ * all error-free), about 20 VALU instructions, no branches.  hd_limbs25_to_limbs turns limb SUMS (int64)
+ * back into the 40-bit limb form. */
+typedef struct { int32_t d0, d1, d2, d3, d4; } hd_limbs25;
 
-HD_FN hd_limbs26 hd_limbs26_from_f32(float p)
+HD_FN hd_limbs25 hd_limbs25_from_f32(float p)
 {
-    hd_acc128 q = hd_acc_from_f32(p);
-    const uint64_t M = (1ull << 26) - 1ull;
-    hd_limbs26 r;
-    r.d0 = (uint32_t)(q.lo & M);
-    r.d1 = (uint32_t)((q.lo >> 26) & M);
-    r.d2 = (uint32_t)(((q.lo >> 52) | ((uint64_t)q.hi << 12)) & M);
-    r.d3 = (uint32_t)(((uint64_t)q.hi >> 14) & M);
-    r.d4 = (int32_t)(q.hi >> 40);
-    return r;
+    hd_limbs25 l;
+    const uint32_t mag = hd_f2u(p) & 0x7fffffffu;
+    const float a = mag < ((127u + 84u) << 23) ? p : 0.0f;    /* non-finite or |p| >= 2^84 -> 0 (hd_acc_from_f32) */
+    const float h4 = __builtin_truncf(a * 0x1p-59f);
+    float r = hd_fmaf(-h4, 0x1p59f, a);
+    const float h3 = __builtin_truncf(r * 0x1p-34f);
+    r = hd_fmaf(-h3, 0x1p34f, r);
+    const float h2 = __builtin_truncf(r * 0x1p-9f);
+    r = hd_fmaf(-h2, 0x1p9f, r);
+    const float h1 = __builtin_truncf(r * 0x1p16f);
+    r = hd_fmaf(-h1, 0x1p-16f, r);
+    const float h0 = hd_rintf(r * 0x1p40f);                       /* half-even (default rounding mode) */
+    l.d0 = (int32_t)h0; l.d1 = (int32_t)h1; l.d2 = (int32_t)h2; l.d3 = (int32_t)h3; l.d4 = (int32_t)h4;
+    return l;
 }
 
-/* five limb SUMS (each < 2^32, top one signed) -> Q = s0 + s1 2^26 + s2 2^52 + s3 2^78 + s4 2^104 */
-HD_FN hd_limbs hd_limbs26_to_limbs(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, int32_t s4)
+/* five limb SUMS (|s_j| < 2^39) -> Q as 40-bit limbs */
+HD_FN hd_limbs hd_limbs25_to_limbs(int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4)
 {
     hd_acc128 a, t;
-    a.lo = (uint64_t)s0; a.hi = 0;
-    t.lo = (uint64_t)s1 << 26; t.hi = 0; hd_acc_add(&a, t);
-    t.lo = (uint64_t)s2 << 52; t.hi = (int64_t)((uint64_t)s2 >> 12); hd_acc_add(&a, t);
-    t.lo = 0; t.hi = (int64_t)((uint64_t)s3 << 14); hd_acc_add(&a, t);
-    t.lo = 0; t.hi = (int64_t)((uint64_t)(int64_t)s4 << 40); hd_acc_add(&a, t);
+    a.lo = (uint64_t)s0; a.hi = s0 < 0 ? -1 : 0;
+    t.lo = (uint64_t)s1 << 24; t.hi = s1 >> 40; hd_acc_add(&a, t);
+    t.lo = (uint64_t)s2 << 49; t.hi = s2 >> 15; hd_acc_add(&a, t);
+    t.lo = 0; t.hi = (int64_t)((uint64_t)s3 << 10); hd_acc_add(&a, t);
+    t.lo = 0; t.hi = (int64_t)((uint64_t)s4 << 35); hd_acc_add(&a, t);
     const uint64_t M40 = (1ull << 40) - 1ull;
     hd_limbs r;
     r.l0 = (int64_t)(a.lo & M40);
