@@ -850,18 +850,6 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__rest
     block_reduce_exact<29>(out, valid, rgb_part);
 }
 
-__device__ __forceinline__ void unpack27(const double (&s)[29], float (&A)[36], float (&b)[6])
-{
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 7; ++j) {
-            const int shift = i * 7 - (i * (i - 1)) / 2 + (j - i);   // row-major upper triangle incl. the rhs column
-            const float value = (float)s[shift];
-            if (j == 6) b[i] = value; else A[j * 6 + i] = A[i * 6 + j] = value;
-        }
-}
-
 // solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93); also prepares the
 // operands of the next iteration (possibly on the next pyramid level).
 __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
@@ -870,53 +858,65 @@ __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__re
                                                    int next_level, int level_changes)
 {
     (void)nb;
+    // icp_part and rgb_part are adjacent (OdoBuffers): one pass over 32 slot rows x (87 + 87) limbs
+    __shared__ long long s_acc[4][176];
+    __shared__ long long s_tot[176];
+    __shared__ double s_val[58];
+    __shared__ double s_A[36], s_b[6];
+    const int tid = threadIdx.x;
     if (do_reduce) {
-        sum_partials(icp_part, ODO_SLOTS, 87, totals);
-        sum_partials(rgb_part, ODO_SLOTS, 87, totals + 87);
-        if (threadIdx.x < RES_SLOTS * 2) res_part[threadIdx.x] = 0;
-    }
-    if (threadIdx.x != 0) return;
+        const int col = tid & 255, grp = tid >> 8;
+        long long s = 0;
+        if (col < 174) {
+            long long *base = (col < 87) ? icp_part + col : rgb_part + (col - 87);
+#pragma unroll
+            for (int b = 0; b < ODO_SLOTS / 4; ++b) {
+                long long *q = base + (size_t)(grp + 4 * b) * 87;
+                s += *q; *q = 0;
+            }
+            s_acc[grp][col] = s;
+        }
+        if (tid < RES_SLOTS * 2) res_part[tid] = 0;
+        __syncthreads();
+        if (tid < 174) {
+            const long long t = (s_acc[0][tid] + s_acc[1][tid]) + (s_acc[2][tid] + s_acc[3][tid]);
+            s_tot[tid] = t; totals[tid] = t;
+        } else if (tid < 176) s_tot[tid] = totals[tid];
+    } else if (tid < 176) s_tot[tid] = totals[tid];
+    __syncthreads();
     const int rgbOnly = cfg.rgb_only;
     const int icp = !rgbOnly && cfg.icp_weight > 0.0f;
     const int rgb = rgbOnly || cfg.icp_weight < 100.0f;
-    const long long c = totals[174], sg = totals[175];
+    if (tid < 58) s_val[tid] = limbs_to_double(s_tot + (tid < 29 ? 0 : 87), tid < 29 ? tid : tid - 29);
+    __syncthreads();
+    if (tid < 42) {   // entries of the combined normal equations (RGBDOdometry.cpp:1162-1178)
+        const int r = tid < 36 ? tid / 6 : tid - 36, c = tid < 36 ? tid % 6 : 6;
+        const int i = r < c ? r : c, j = r < c ? c : r;
+        const int shift = i * 7 - (i * (i - 1)) / 2 + (j - i);   // row-major upper triangle incl. the rhs column
+        const float vi = icp ? (float)s_val[shift] : 0.0f, vr = rgb ? (float)s_val[29 + shift] : 0.0f;
+        const double w = cfg.icp_weight;
+        double v;
+        if (icp && rgb) v = (double)vr + (tid < 36 ? w * w : w) * (double)vi;
+        else v = icp ? (double)vi : (double)vr;
+        if (tid < 36) s_A[tid] = v; else s_b[tid - 36] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const long long c = s_tot[174], sg = s_tot[175];
     if (rgb) {
         float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
         if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
         if (!st->gn_break) st->lastRGBError = rgbError;
     }
     if (!st->gn_break) {
-        float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) A_icp[k] = A_rgb[k] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) b_icp[k] = b_rgb[k] = 0.0f;
-        double s[29];
-        if (icp) {
-#pragma unroll
-            for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals, i);
-            unpack27(s, A_icp, b_icp);
-            st->res_icp[0] = (float)s[27]; st->res_icp[1] = (float)s[28];
-        }
+        if (icp) { st->res_icp[0] = (float)s_val[27]; st->res_icp[1] = (float)s_val[28]; }
         st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
         st->last_icp_count = st->res_icp[1];
-        if (rgb) {
-#pragma unroll
-            for (int i = 0; i < 29; ++i) s[i] = limbs_to_double(totals + 87, i);
-            unpack27(s, A_rgb, b_rgb);
-        }
         double lastA[36], lastb[6], result[6];
-        if (icp && rgb) {
-            double w = cfg.icp_weight, ww = w * w;
-            for (int k = 0; k < 36; ++k) lastA[k] = (double)A_rgb[k] + ww * (double)A_icp[k];
-            for (int k = 0; k < 6; ++k) lastb[k] = (double)b_rgb[k] + w * (double)b_icp[k];
-        } else if (icp) {
-            for (int k = 0; k < 36; ++k) lastA[k] = A_icp[k];
-            for (int k = 0; k < 6; ++k) lastb[k] = b_icp[k];
-        } else {
-            for (int k = 0; k < 36; ++k) lastA[k] = A_rgb[k];
-            for (int k = 0; k < 6; ++k) lastb[k] = b_rgb[k];
-        }
+#pragma unroll
+        for (int k = 0; k < 36; ++k) lastA[k] = s_A[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lastb[k] = s_b[k];
         ldlt_solve<double, 6>(lastA, lastb, result);
         double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
         rodrigues(rv, Ru);
