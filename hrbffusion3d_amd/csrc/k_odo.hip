@@ -45,66 +45,100 @@ size_t odo_slot_bytes() { return sizeof(long long) * (32 * 87 * 2 + 64 * 2 + 32 
 
 // ------------------------------------------------------------------------------------------
 // exact workgroup reduction of N floats per lane.
-//   lane: float -> five signed 25-bit limbs (hd_limbs25, ~20 branch-free VALU ops) [exact]
-//   wave: 32-bit DPP add tree (quad_perm, row_ror, row_bcast)   [64 x 2^25 fits an int32: no carries]
-//   block: lane 63 of each wave parks its five sums in LDS; after the barrier thread t < N folds the
-//          waves for value t and converts to the 40-bit limb form
+//   lane: float -> five signed 25-bit limbs (hd_limbs25, ~20 branch-free VALU ops)  [exact]
+//   wave: transposing butterfly over the V = 5N limb registers: every stage pairs lanes (l, l ^ mask), one
+//         lane of the pair keeps the lower half of the register file and the other the upper half, so the
+//         work halves per stage (~2.3 V instructions in all instead of 6 V for V independent add trees).
+//         xor 32 / xor 16 are v_permlane{32,16}_swap (two registers exchanged per instruction), the four
+//         in-row stages are DPP adds (row_ror:8 = xor 8, row_half_mirror = xor 7, quad_perm = xor 2, xor 1).
+//         64 lanes x 2^25 fits an int32: no carries anywhere.  Afterwards lane l holds ceil(V/64) totals.
+//   block: the wave totals are parked in LDS; after the barrier thread t < N folds the waves for value t
+//          and converts to the 40-bit limb form
 //   grid: one 64-bit atomicAdd per limb into slot (blockIdx % ODO_SLOTS) — integer adds commute, so the
 //         result does not depend on arrival order.  The consumer sums the ODO_SLOTS rows and re-zeroes them.
 #define ODO_SLOTS 32
 #define RES_SLOTS 64
 
-template <int CTRL, int ROW_MASK>
+template <int CTRL>
 __device__ __forceinline__ int32_t dpp_i32(int32_t v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ int32_t wave_sum_i32(int32_t v)   // total in lane 63
-{
-    v += dpp_i32<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
-    v += dpp_i32<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
-    v += dpp_i32<0x124, 0xf>(v);   // row_ror:4
-    v += dpp_i32<0x128, 0xf>(v);   // row_ror:8
-    v += dpp_i32<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
-    v += dpp_i32<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
-    return v;
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
 
-struct alignas(16) WaveSums { int32_t d0, d1, d2, d3, d4, pad[3]; };
+// stage S of the butterfly on a[0..V): selector bit 5-S of the lane id
+template <int VM, int V, int S>
+__device__ __forceinline__ void wave_transpose_sum(int32_t (&a)[VM], const int lane)
+{
+    if constexpr (S < 6) {
+        constexpr int h = (V + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const int32_t x = a[i], y = (i + h < V) ? a[i + h] : 0;
+            if constexpr (S == 0) {
+                const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+                a[i] = (int32_t)(r[0] + r[1]);
+            } else if constexpr (S == 1) {
+                const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)y, false, false);
+                a[i] = (int32_t)(r[0] + r[1]);
+            } else {
+                const bool sel = ((lane >> (5 - S)) & 1) != 0;
+                const int32_t keep = sel ? y : x, send = sel ? x : y;
+                constexpr int ctrl = S == 2 ? 0x128 : S == 3 ? 0x141 : S == 4 ? 0x4e : 0xb1;
+                a[i] = keep + dpp_i32<ctrl>(send);
+            }
+        }
+        wave_transpose_sum<VM, h, S + 1>(a, lane);
+    }
+}
 
 template <int N>
 __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ slots)
 {
-    __shared__ WaveSums s_raw[RB / 64][N];
+    constexpr int V = 5 * N;
+    __shared__ int32_t s_sum[RB / 64][V];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #ifdef ODO_EXP_NOREDUCE
     if (vals[0] == 123456.0f) slots[0] = 1;
     return;
 #endif
+    int vs[7];
+    vs[0] = V;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vs[k + 1] = (vs[k] + 1) / 2;
     if (__ballot(valid) != 0ull) {
+        int32_t a[V];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const hd_limbs25 l = hd_limbs25_from_f32(valid ? vals[i] : 0.0f);
-            WaveSums w;
-            w.d0 = wave_sum_i32(l.d0); w.d1 = wave_sum_i32(l.d1); w.d2 = wave_sum_i32(l.d2);
-            w.d3 = wave_sum_i32(l.d3); w.d4 = wave_sum_i32(l.d4);
-            w.pad[0] = w.pad[1] = w.pad[2] = 0;
-            if (lane == 63) s_raw[wid][i] = w;
+            a[5 * i] = l.d0; a[5 * i + 1] = l.d1; a[5 * i + 2] = l.d2; a[5 * i + 3] = l.d3; a[5 * i + 4] = l.d4;
+        }
+        wave_transpose_sum<V, V, 0>(a, lane);
+        // register k of lane l now holds the wave total of limb  k + sum_S bit_{5-S}(l) * h_S  (if in range)
+#pragma unroll
+        for (int k = 0; k < (V + 63) / 64; ++k) {
+            int idx = k;
+            bool ok = k < vs[6];
+#pragma unroll
+            for (int S = 5; S >= 0; --S) {
+                idx += ((lane >> (5 - S)) & 1) * vs[S + 1];
+                ok = ok && idx < vs[S];
+            }
+            if (ok) s_sum[wid][idx] = a[k];
         }
     } else {
-        WaveSums z = {0, 0, 0, 0, 0, {0, 0, 0}};
-        for (int i = lane; i < N; i += 64) s_raw[wid][i] = z;
+        for (int i = lane; i < V; i += 64) s_sum[wid][i] = 0;
     }
     __syncthreads();
     if (threadIdx.x < N) {
-        long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        long long s[5];
 #pragma unroll
-        for (int w = 0; w < RB / 64; ++w) {
-            const WaveSums q = s_raw[w][threadIdx.x];
-            s0 += q.d0; s1 += q.d1; s2 += q.d2; s3 += q.d3; s4 += q.d4;
+        for (int j = 0; j < 5; ++j) {
+            s[j] = 0;
+#pragma unroll
+            for (int w = 0; w < RB / 64; ++w) s[j] += s_sum[w][threadIdx.x * 5 + j];
         }
-        if ((s0 | s1 | s2 | s3 | s4) != 0) {
-            const hd_limbs L = hd_limbs25_to_limbs(s0, s1, s2, s3, s4);
+        if ((s[0] | s[1] | s[2] | s[3] | s[4]) != 0) {
+            const hd_limbs L = hd_limbs25_to_limbs(s[0], s[1], s[2], s[3], s[4]);
             long long *row = slots + (size_t)(blockIdx.x % ODO_SLOTS) * NLIMB(N) + threadIdx.x * 3;
             if (L.l0) atomicAdd((unsigned long long *)&row[0], (unsigned long long)L.l0);
             if (L.l1) atomicAdd((unsigned long long *)&row[1], (unsigned long long)L.l1);
