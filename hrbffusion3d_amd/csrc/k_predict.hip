@@ -6,26 +6,28 @@
 // (HRBFFusion.cpp:974-988,1069-1070).
 //
 // One thread per pixel, 16x16 tiles.  The GLSL gathers up to 49 neighbours into five private
-// vec4[100] arrays; here the neighbour attributes the implicit needs (position, normal, support)
-// are staged ONCE per tile in LDS (tile + 3-texel halo, 22x22 x 32 B = 15.5 KB) and each thread
-// keeps only a 49-bit mask of accepted window slots in the shader's ring visiting order, so the
-// <= 46 implicit evaluations per pixel run entirely out of LDS + registers.
+// vec4[100] arrays; here
+//   * the per-texel part of the implicit (centre, support radius^2 and its reciprocal, 10 n) is staged ONCE
+//     per tile in LDS (tile + 3-texel halo, 22x22 x 32 B = 15.5 KB), together with one validity bit per
+//     texel (the acceptance test of predict_hrbf.frag:85-92 depends on the texel only);
+//   * each thread walks the window in the shader's ring order with compile-time offsets and writes the LDS
+//     addresses of its accepted neighbours to a private column of an LDS list (<= 49 x 2 B per thread), so
+//     the <= 46 implicit evaluations per pixel are a plain counted loop over LDS: one 2-byte and two 16-byte
+//     reads per neighbour, no table look-ups, no divisions.
 #include "common.h"
 #include "kernels.h"
 
 #define TB 16
 #define PR 3
 #define PTW (TB + 2 * PR)
+#define PNT (TB * TB)
 
-struct PTexel { float px, py, pz, conf, nx, ny, nz, rad; };
+struct alignas(16) PTexel { float px, py, pz, T2, sx, sy, sz, invT2; };
 
 // ring visiting order of predict_hrbf.frag:75-80: rings i = 0..3, x offset outer, y offset inner,
-// ring-border texels only.  slot -> (dx,dy) packed as (dx+3) | (dy+3) << 3; ring end markers.
-struct RingTable { unsigned char off[49]; unsigned char col_start[49]; };
-__constant__ unsigned char c_ring_off[49];
-__constant__ unsigned char c_ring_newcol[49];   // 1 if this slot starts a new x-offset column (the `k` loop restarts)
-
-static void build_ring_table(unsigned char *off, unsigned char *newcol)
+// ring-border texels only
+struct RingEntry { int dx, dy; bool newcol; };
+constexpr RingEntry ring_entry(int slot)
 {
     int n = 0;
     for (int i = 0; i <= 3; ++i)
@@ -33,49 +35,63 @@ static void build_ring_table(unsigned char *off, unsigned char *newcol)
             bool first = true;
             for (int dk = -i; dk <= i; ++dk) {
                 if (!(dj == -i || dk == -i || dj == i || dk == i)) continue;
-                off[n] = (unsigned char)((dj + 3) | ((dk + 3) << 3));
-                newcol[n] = first ? 1 : 0;
+                if (n == slot) return RingEntry{dj, dk, first};   // `first`: the inner (k) loop restarts here
                 first = false;
                 n++;
             }
         }
+    return RingEntry{0, 0, false};
 }
 
-int predict_upload_tables()
+int predict_upload_tables() { return 0; }   // the ring table is a compile-time constant
+
+// neighbour gathering with the reference's "break only the innermost loop" behaviour
+template <int SLOT>
+__device__ __forceinline__ void gather_ring(const uint32_t (&wrow)[7], int nslots, int maxn, uint32_t lbase_bytes,
+                                            uint16_t *__restrict__ list, int &n, bool &skip)
 {
-    unsigned char off[49], nc[49];
-    build_ring_table(off, nc);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ring_off), off, 49) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ring_newcol), nc, 49) != hipSuccess) return -1;
-    return 0;
+    if constexpr (SLOT < 49) {
+        constexpr RingEntry e = ring_entry(SLOT);
+        if (SLOT < nslots) {
+            if (e.newcol) skip = false;
+            const bool acc = !skip && ((wrow[e.dy + 3] >> (e.dx + 3)) & 1u);
+            if (acc) {
+                list[n * PNT] = (uint16_t)(lbase_bytes + (uint32_t)((e.dy * PTW + e.dx) * (int)sizeof(PTexel)));
+                n++;
+                if (n > maxn) skip = true;
+            }
+        }
+        gather_ring<SLOT + 1>(wrow, nslots, maxn, lbase_bytes, list, n, skip);
+    }
 }
 
-// hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34) over the masked neighbour set
-__device__ __forceinline__ float hrbf_value(const PTexel *__restrict__ tile, int lbase, unsigned long long mask,
+__device__ __forceinline__ const PTexel *texel_at(const PTexel *tile, uint32_t byte_off)
+{
+    return reinterpret_cast<const PTexel *>(reinterpret_cast<const char *>(tile) + byte_off);
+}
+
+// hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34) over the gathered neighbour list
+__device__ __forceinline__ float hrbf_value(const PTexel *__restrict__ tile, const uint16_t *__restrict__ list, int n,
                                             f3 p, int &nsup)
 {
     float value = 0.0f;
     int ns = 0;
-    while (mask) {
-        const int slot = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int o = c_ring_off[slot];
-        const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
-        const float sx = 10.0f * t.nx, sy = 10.0f * t.ny, sz = 10.0f * t.nz;
-        const float vx = p.x - t.px, vy = p.y - t.py, vz = p.z - t.pz;
+    for (int k = 0; k < n; ++k) {
+        const PTexel *t = texel_at(tile, list[k * PNT]);
+        const float4 a = *reinterpret_cast<const float4 *>(&t->px);
+        const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
         const float d2 = (vx * vx + vy * vy) + vz * vz;
-        const float T2 = t.rad * t.rad;
-        if (T2 < d2) continue;
+        if (a.w < d2) continue;
+        const float4 b = *reinterpret_cast<const float4 *>(&t->sx);
         float gx = 0.0f, gy = 0.0f, gz = 0.0f;
-        if (!(d2 > T2 || d2 == 0.0f)) {
-            float invT2 = 1.0f / T2;
-            float r = hd_sqrtf(d2 * invT2);
+        if (d2 != 0.0f) {
+            float r = hd_sqrtf(d2 * b.w);
             float s = 1.0f - r;
             float s3 = s * s * s;
-            float tt = -20.0f * s3 * invT2;
+            float tt = -20.0f * s3 * b.w;
             gx = vx * tt; gy = vy * tt; gz = vz * tt;
         }
-        value -= (gx * sx + gy * sy) + gz * sz;
+        value -= (gx * b.x + gy * b.y) + gz * b.z;
         ns++;
     }
     nsup = ns;
@@ -83,18 +99,17 @@ __device__ __forceinline__ float hrbf_value(const PTexel *__restrict__ tile, int
 }
 
 // hrbfgradient (hrbfbase.glsl:147-166) with getWeightH (:37-69)
-__device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, int lbase, unsigned long long mask, f3 p)
+__device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, const uint16_t *__restrict__ list, int n, f3 p)
 {
     float grx = 0.0f, gry = 0.0f, grz = 0.0f;
-    while (mask) {
-        const int slot = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int o = c_ring_off[slot];
-        const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
-        const float sx = 10.0f * t.nx, sy = 10.0f * t.ny, sz = 10.0f * t.nz;
-        const float vx = p.x - t.px, vy = p.y - t.py, vz = p.z - t.pz;
+    for (int k = 0; k < n; ++k) {
+        const PTexel *tp = texel_at(tile, list[k * PNT]);
+        const float4 a = *reinterpret_cast<const float4 *>(&tp->px);
+        const float4 b = *reinterpret_cast<const float4 *>(&tp->sx);
+        const float sx = b.x, sy = b.y, sz = b.z;
+        const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
         const float d2 = (vx * vx + vy * vy) + vz * vz;
-        const float T2 = t.rad * t.rad;
+        const float T2 = a.w;
         float h0, h1, h2, h4, h5, h8;
         if (d2 > T2) { h0 = h1 = h2 = h4 = h5 = h8 = 0.0f; }
         else if (d2 == 0.0f) { h0 = h4 = h8 = -20.0f / T2; h1 = h2 = h5 = 0.0f; }
@@ -129,41 +144,42 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
                                                       uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw)
 {
     __shared__ PTexel tile[PTW * PTW];
+    __shared__ uint16_t s_list[49 * PNT];
+    __shared__ uint32_t s_rowbits[PTW];
     const int W = cam.W, H = cam.H;
     const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
-    for (int i = threadIdx.y * TB + threadIdx.x; i < PTW * PTW; i += TB * TB) {
+    const int tid = threadIdx.y * TB + threadIdx.x;
+    if (tid < PTW) s_rowbits[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < PTW * PTW; i += PNT) {
         int tx = i % PTW, ty = i / PTW;
         int gx = bx + tx - PR, gy = by + ty - PR;
         PTexel t;
-        t.px = t.py = t.pz = t.conf = t.nx = t.ny = t.nz = t.rad = 0.0f;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+        t.px = t.py = t.pz = t.T2 = t.sx = t.sy = t.sz = t.invT2 = 0.0f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {   // outside the image: rejected like `j < 0 || j > 1` (:85)
             float4 v = vertconf[gy * W + gx], n = normrad[gy * W + gx];
-            t.px = v.x; t.py = v.y; t.pz = v.z; t.conf = v.w; t.nx = n.x; t.ny = n.y; t.nz = n.z; t.rad = n.w;
-        } else t.pz = -1.0f;   // outside the image: rejected like `j < 0 || j > 1` (predict_hrbf.frag:85)
+            t.px = v.x; t.py = v.y; t.pz = v.z;
+            t.T2 = n.w * n.w; t.invT2 = 1.0f / t.T2;
+            t.sx = 10.0f * n.x; t.sy = 10.0f * n.y; t.sz = 10.0f * n.z;
+            if (!(v.z < 0.1f || len3(mk3(n.x, n.y, n.z)) < 0.1f || v.w < cthr || n.z < 0.0f))
+                atomicOr(&s_rowbits[ty], 1u << tx);
+        }
         tile[i] = t;
     }
     __syncthreads();
     const int px = bx + threadIdx.x, py = by + threadIdx.y;
     if (px >= W || py >= H) return;
     const int pi = py * W + px;
-    const int lbase = (threadIdx.y + PR) * PTW + threadIdx.x + PR;
+    const uint32_t lbase_bytes = (uint32_t)(((threadIdx.y + PR) * PTW + threadIdx.x + PR) * (int)sizeof(PTexel));
+    const uint16_t *list = s_list + tid;
 
-    // neighbour gathering with the reference's "break only the innermost loop" behaviour
-    unsigned long long mask = 0ull;
     int n = 0;
     {
-        const int nslots = (2 * win + 1) * (2 * win + 1);
-        bool skip_col = false;
-        for (int slot = 0; slot < nslots; ++slot) {
-            if (c_ring_newcol[slot]) skip_col = false;
-            if (skip_col) continue;
-            const int o = c_ring_off[slot];
-            const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
-            if (t.pz < 0.1f || len3(mk3(t.nx, t.ny, t.nz)) < 0.1f || t.conf < cthr || t.nz < 0.0f) continue;
-            mask |= 1ull << slot;
-            n++;
-            if (n > maxn) skip_col = true;
-        }
+        uint32_t wrow[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) wrow[r] = s_rowbits[threadIdx.y + r] >> threadIdx.x;
+        bool skip = false;
+        gather_ring<0>(wrow, (2 * win + 1) * (2 * win + 1), maxn, lbase_bytes, s_list + tid, n, skip);
     }
 
     const float x = (float)px + 0.5f, y = (float)py + 0.5f;
@@ -173,13 +189,9 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     f3 closest = mk3(0, 0, 0);
     {
         float pmin = 1000000.0f;
-        unsigned long long m = mask;
-        while (m) {
-            const int slot = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int o = c_ring_off[slot];
-            const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
-            float pj = hd_fabsf(dot3(mk3(t.px, t.py, t.pz), ray));
+        for (int k = 0; k < n; ++k) {
+            const PTexel *t = texel_at(tile, list[k * PNT]);
+            float pj = hd_fabsf(dot3(mk3(t->px, t->py, t->pz), ray));
             if (pj < pmin) { closest = scale3(ray, pj); pmin = pj; }
         }
     }
@@ -187,20 +199,20 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), p_temp = mk3(0, 0, 0), ntemp = mk3(0, 0, 0);
     int nsup = 0;
     if (n > minn) {
-        float v0 = hrbf_value(tile, lbase, mask, closest, nsup);
+        float v0 = hrbf_value(tile, list, n, closest, nsup);
         if (nsup > minn) {
             if (v0 > 0.0f) {
                 ep = closest;
                 bool sfound = false;
                 for (int i = 0; i < 25; ++i) {
                     f3 p1 = sub3(ep, scale3(ray, 0.004f * (float)i));
-                    float v1 = hrbf_value(tile, lbase, mask, p1, nsup);
+                    float v1 = hrbf_value(tile, list, n, p1, nsup);
                     if (v1 < 0.0f) { sp = p1; sfound = true; break; }
                 }
                 if (sfound)
                     for (int i = 1; i < 11; ++i) {
                         f3 p2 = add3(sp, scale3(ray, 0.0004f * (float)i));
-                        float v2 = hrbf_value(tile, lbase, mask, p2, nsup);
+                        float v2 = hrbf_value(tile, list, n, p2, nsup);
                         if (v2 > 0.0f) { ep = p2; find_interval = true; break; }
                     }
             } else {
@@ -208,13 +220,13 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
                 bool efound = false;
                 for (int i = 0; i < 25; ++i) {
                     f3 p1 = add3(sp, scale3(ray, 0.004f * (float)i));
-                    float v1 = hrbf_value(tile, lbase, mask, p1, nsup);
+                    float v1 = hrbf_value(tile, list, n, p1, nsup);
                     if (v1 > 0.0f) { ep = p1; efound = true; break; }
                 }
                 if (efound)
                     for (int i = 1; i < 11; ++i) {
                         f3 p2 = sub3(ep, scale3(ray, 0.0004f * (float)i));
-                        float v2 = hrbf_value(tile, lbase, mask, p2, nsup);
+                        float v2 = hrbf_value(tile, list, n, p2, nsup);
                         if (v2 < 0.0f) { sp = p2; find_interval = true; break; }
                     }
             }
@@ -223,10 +235,10 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     if (find_interval) {
         for (int j = 0; j < 10; ++j) {
             f3 step = sub3(ep, sp);
-            if (len3(step) < 0.00001f) { ntemp = hrbf_gradient(tile, lbase, mask, p_temp); found = true; break; }
+            if (len3(step) < 0.00001f) { ntemp = hrbf_gradient(tile, list, n, p_temp); found = true; break; }
             p_temp = add3(sp, scale3(step, 0.5f));
-            float f_temp = hrbf_value(tile, lbase, mask, p_temp, nsup);
-            if (hd_fabsf(f_temp) < 0.00001f) { ntemp = hrbf_gradient(tile, lbase, mask, p_temp); found = true; break; }
+            float f_temp = hrbf_value(tile, list, n, p_temp, nsup);
+            if (hd_fabsf(f_temp) < 0.00001f) { ntemp = hrbf_gradient(tile, list, n, p_temp); found = true; break; }
             if (f_temp < 0.0f) sp = p_temp; else ep = p_temp;
         }
     }
@@ -240,19 +252,18 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
         p_surface = p_temp;
         p_normal = normalize3(ntemp);
         float dsm = 1000000.0f;
-        int best_o = -1;
-        unsigned long long m = mask;
-        while (m) {
-            const int slot = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int o = c_ring_off[slot];
-            const PTexel t = tile[lbase + ((o >> 3) - 3) * PTW + ((o & 7) - 3)];
-            float dx = p_surface.x - t.px, dy = p_surface.y - t.py, dz = p_surface.z - t.pz;
+        int best = -1;
+        for (int k = 0; k < n; ++k) {
+            const uint32_t off = list[k * PNT];
+            const PTexel *t = texel_at(tile, off);
+            float dx = p_surface.x - t->px, dy = p_surface.y - t->py, dz = p_surface.z - t->pz;
             float dist = hd_sqrtf((dx * dx + dy * dy) + dz * dz);
-            if (dist < dsm) { dsm = dist; best_o = o; confidence = t.conf; radius = t.rad; }
+            if (dist < dsm) { dsm = dist; best = (int)off; }
         }
-        if (best_o >= 0) {
-            const int gi = (py + (best_o >> 3) - 3) * W + (px + (best_o & 7) - 3);
+        if (best >= 0) {
+            const int ti = best / (int)sizeof(PTexel);
+            const int gi = (by + ti / PTW - PR) * W + (bx + ti % PTW - PR);
+            confidence = vertconf[gi].w; radius = normrad[gi].w;
             cmx = curvmax[gi]; cmn = curvmin[gi];
             float4 ct = colortime[gi];
             int ci = (int)ct.x;
