@@ -232,65 +232,73 @@ __device__ __forceinline__ void resize_planar(const float *__restrict__ in, int 
     for (int k = 0; k < 4; ++k) PLN(out, k, orows, ocols, y, x) = r[k];
 }
 
-__constant__ float c_gk[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
-
-// pyrDownKernelGaussF / pyrDownKernelIntensityGauss (cudafuncs.cu:493-524,818-848) incl. border quirk
+// pyrDownKernelGaussF / pyrDownKernelIntensityGauss (cudafuncs.cu:493-524,818-848) incl. border quirk:
+// the 5x5 binomial window is anchored at its (clamped) far corner, so at the right/bottom border the taps
+// shift instead of being cut.  Rows and columns are visited in increasing source order (tap index 4 -> 0),
+// the weights {1,4,6,4,1} x {1,4,6,4,1} are compile-time constants.
+template <typename T, typename ValidF>
+__device__ __forceinline__ void pyrdown_taps(const T *__restrict__ src, int srows, int scols, int x, int y,
+                                             float &sum, int &count, ValidF valid)
+{
+    const int tx = 2 * x + 3 < scols - 1 ? 2 * x + 3 : scols - 1;
+    const int ty = 2 * y + 3 < srows - 1 ? 2 * y + 3 : srows - 1;
+    const int lx = 2 * x - 2 > 0 ? 2 * x - 2 : 0, ly = 2 * y - 2 > 0 ? 2 * y - 2 : 0;
+    sum = 0.0f; count = 0;
+#pragma unroll
+    for (int kr = 4; kr >= 0; --kr) {
+        const int cy = ty - 1 - kr;
+        if (cy < ly) continue;
+#pragma unroll
+        for (int kc = 4; kc >= 0; --kc) {
+            const int cx = tx - 1 - kc;
+            if (cx < lx) continue;
+            constexpr int w[5] = {1, 4, 6, 4, 1};
+            const T s = src[cy * scols + cx];
+            if (valid(s)) { sum += (float)s * (float)(w[kr] * w[kc]); count += w[kr] * w[kc]; }
+        }
+    }
+}
 __device__ __forceinline__ float pyrdown_f(const float *__restrict__ src, int srows, int scols, int x, int y)
 {
-    int tx = 2 * x + 3 < scols - 1 ? 2 * x + 3 : scols - 1;
-    int ty = 2 * y + 3 < srows - 1 ? 2 * y + 3 : srows - 1;
-    float sum = 0.0f; int count = 0;
-    for (int cy = (2 * y - 2 > 0 ? 2 * y - 2 : 0); cy < ty; ++cy)
-        for (int cx = (2 * x - 2 > 0 ? 2 * x - 2 : 0); cx < tx; ++cx) {
-            float s = src[cy * scols + cx];
-            if (!hd_isnanf(s)) {
-                float g = c_gk[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                sum += s * g;
-                count += (int)g;
-            }
-        }
+    float sum; int count;
+    pyrdown_taps(src, srows, scols, x, y, sum, count, [](float s) { return !hd_isnanf(s); });
     return sum / (float)count;
 }
 __device__ __forceinline__ uint8_t pyrdown_u8(const uint8_t *__restrict__ src, int srows, int scols, int x, int y)
 {
-    int tx = 2 * x + 3 < scols - 1 ? 2 * x + 3 : scols - 1;
-    int ty = 2 * y + 3 < srows - 1 ? 2 * y + 3 : srows - 1;
-    float sum = 0.0f; int count = 0;
-    for (int cy = (2 * y - 2 > 0 ? 2 * y - 2 : 0); cy < ty; ++cy)
-        for (int cx = (2 * x - 2 > 0 ? 2 * x - 2 : 0); cx < tx; ++cx) {
-            uint8_t s = src[cy * scols + cx];
-            if (s > 0) {
-                float g = c_gk[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                sum += (float)s * g;
-                count += (int)g;
-            }
-        }
+    float sum; int count;
+    pyrdown_taps(src, srows, scols, x, y, sum, count, [](uint8_t s) { return s > 0; });
     return count > 0 ? (uint8_t)(int)(sum / (float)count) : (uint8_t)0;
 }
 
+// one pyramid level; blockIdx.y selects the map, so the 13 independent resamplings run side by side
+#define ODO_DOWN_TASKS 13
 __global__ void k_odo_downsample(OdoLevel I, OdoLevel O)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= O.rows * O.cols) return;
     int y = i / O.cols, x = i - y * O.cols;
-    resize_planar(I.vmap_g, I.rows, I.cols, O.vmap_g, O.rows, O.cols, x, y, 0, false);
-    resize_planar(I.nmap_g, I.rows, I.cols, O.nmap_g, O.rows, O.cols, x, y, 0, true);
-    resize_planar(I.ck1_g, I.rows, I.cols, O.ck1_g, O.rows, O.cols, x, y, 3, false);
-    resize_planar(I.ck2_g, I.rows, I.cols, O.ck2_g, O.rows, O.cols, x, y, 3, false);
-    resize_planar(I.vmap_c, I.rows, I.cols, O.vmap_c, O.rows, O.cols, x, y, 0, false);
-    resize_planar(I.nmap_c, I.rows, I.cols, O.nmap_c, O.rows, O.cols, x, y, 0, true);
-    resize_planar(I.ck1_c, I.rows, I.cols, O.ck1_c, O.rows, O.cols, x, y, 3, false);
-    resize_planar(I.ck2_c, I.rows, I.cols, O.ck2_c, O.rows, O.cols, x, y, 3, false);
-    {   // resizeicpWeightMapKernel cudafuncs.cu:694-726
+    switch (blockIdx.y) {
+    case 0: resize_planar(I.vmap_g, I.rows, I.cols, O.vmap_g, O.rows, O.cols, x, y, 0, false); break;
+    case 1: resize_planar(I.nmap_g, I.rows, I.cols, O.nmap_g, O.rows, O.cols, x, y, 0, true); break;
+    case 2: resize_planar(I.ck1_g, I.rows, I.cols, O.ck1_g, O.rows, O.cols, x, y, 3, false); break;
+    case 3: resize_planar(I.ck2_g, I.rows, I.cols, O.ck2_g, O.rows, O.cols, x, y, 3, false); break;
+    case 4: resize_planar(I.vmap_c, I.rows, I.cols, O.vmap_c, O.rows, O.cols, x, y, 0, false); break;
+    case 5: resize_planar(I.nmap_c, I.rows, I.cols, O.nmap_c, O.rows, O.cols, x, y, 0, true); break;
+    case 6: resize_planar(I.ck1_c, I.rows, I.cols, O.ck1_c, O.rows, O.cols, x, y, 3, false); break;
+    case 7: resize_planar(I.ck2_c, I.rows, I.cols, O.ck2_c, O.rows, O.cols, x, y, 3, false); break;
+    case 8: {   // resizeicpWeightMapKernel cudafuncs.cu:694-726
         const float qn = hd_nanf();
         float a = I.icpw[(2 * y) * I.cols + 2 * x], b = I.icpw[(2 * y) * I.cols + 2 * x + 1],
               c = I.icpw[(2 * y + 1) * I.cols + 2 * x], d = I.icpw[(2 * y + 1) * I.cols + 2 * x + 1];
         O.icpw[i] = (hd_isnanf(a) || hd_isnanf(b) || hd_isnanf(c) || hd_isnanf(d)) ? qn : (((a + b) + c) + d) / 4.0f;
+        break;
     }
-    O.last_depth[i] = pyrdown_f(I.last_depth, I.rows, I.cols, x, y);
-    O.next_depth[i] = pyrdown_f(I.next_depth, I.rows, I.cols, x, y);
-    O.last_image[i] = pyrdown_u8(I.last_image, I.rows, I.cols, x, y);
-    O.next_image[i] = pyrdown_u8(I.next_image, I.rows, I.cols, x, y);
+    case 9: O.last_depth[i] = pyrdown_f(I.last_depth, I.rows, I.cols, x, y); break;
+    case 10: O.next_depth[i] = pyrdown_f(I.next_depth, I.rows, I.cols, x, y); break;
+    case 11: O.last_image[i] = pyrdown_u8(I.last_image, I.rows, I.cols, x, y); break;
+    default: O.next_image[i] = pyrdown_u8(I.next_image, I.rows, I.cols, x, y); break;
+    }
 }
 
 // tranformMapsKernel / tranformCurvMapsKernel (cudafuncs.cu:213-322), in place, one level
@@ -1108,7 +1116,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                        cfg.curv_thr);
     for (int i = 1; i < HRBF_NUM_PYRS; ++i) {
         int n = ob.lv[i].rows * ob.lv[i].cols;
-        hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);
+        hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256, ODO_DOWN_TASKS), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);
     }
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         int n = ob.lv[i].rows * ob.lv[i].cols, div = 1 << i;
