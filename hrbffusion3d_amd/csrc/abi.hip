@@ -187,7 +187,12 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
       c->odo.res_part = c->odo.rgb_part + 32 * 87; c->odo.so3_part = c->odo.res_part + 64 * 2; }
     DA(c->odo.totals, 256);
     if (predict_upload_tables() != 0) { hrbf_set_error("constant upload failed"); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
+    // the zero-fills of dalloc() ran on the null stream and c->stream is non-blocking: drain them before the
+    // initialisation kernels touch the same buffers
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { hrbf_set_error("init sync: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     launch_fill_u32(c->stream, c->d_slot, c->cap, 0xFFFFFFFFu);
+    launch_zbuf_reset(c->stream, c->d_zbuf, P);
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     launch_pose_set(c->stream, c->d_pose, I, 1);
     { float one = 1.0f; hipMemcpyAsync(&c->d_pose->weighting, &one, sizeof(float), hipMemcpyHostToDevice, c->stream); }
@@ -269,7 +274,9 @@ static void st_curv(hrbf_context *c)
 {
     launch_curvature(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
                      c->d_normal_opt, (int)c->prm.curv_estimation_window);
-    hipMemcpyAsync(c->d_normal, c->d_normal_opt, sizeof(float4) * (size_t)c->P, hipMemcpyDeviceToDevice, c->stream);
+    // updateNormalRad: NORMAL <- NORMAL_OPT (HRBFFusion.cpp:1301-1310); the kernel rewrites every pixel, so the
+    // two buffers just trade places
+    float4 *t = c->d_normal; c->d_normal = c->d_normal_opt; c->d_normal_opt = t;
 }
 static void st_conf(hrbf_context *c)
 {

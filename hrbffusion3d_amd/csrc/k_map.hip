@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
 }
 
 __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m,
-                                                 const unsigned long long *__restrict__ zbuf,
+                                                 unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
                                                  float4 *__restrict__ curvmax, float4 *__restrict__ curvmin,
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
         if (clean_tex) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
         return;
     }
+    zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
     uint32_t s = (uint32_t)(key & 0xFFFFFFFFull);
     float4 p = m.p0[s], nr = m.p2[s];
     f3 h = xform(tinv, xyz(p));
@@ -627,8 +628,7 @@ void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, fl
                             float4 *clean_tex)
 {
     int P = cam.W * cam.H;
-    hipLaunchKernelGGL(k_fill_u64, dim3((P + 255) / 256), dim3(256), 0, s, zbuf, P, ZB_EMPTY);
-    uint32_t blocks = (count_ub + 255) / 256;
+    uint32_t blocks = (count_ub + 255) / 256;   // zbuf is ZB_EMPTY on entry: launch_zbuf_reset once, k_resolve afterwards
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride the rest
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf);
@@ -679,6 +679,10 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, Q, tile_count, tile_done, (int)tiles);
 }
 
+void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P)
+{
+    hipLaunchKernelGGL(k_fill_u64, dim3((P + 255) / 256), dim3(256), 0, s, zbuf, P, ZB_EMPTY);
+}
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
 {
     hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);

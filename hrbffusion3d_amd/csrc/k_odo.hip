@@ -36,6 +36,7 @@ struct OdoState {
     float res_icp[2];
     float last_icp_error, last_icp_count;
     float sigmaVal;
+    unsigned int ticket;              // last-workgroup election of the fused reduce+solve kernels
 };
 
 size_t odo_state_bytes() { return sizeof(OdoState); }
@@ -91,6 +92,45 @@ __device__ __forceinline__ void wave_transpose_sum(int32_t (&a)[VM], const int l
     }
 }
 
+// one wave: NL low limbs of N values per lane -> wave totals parked in sums[5 * value + limb]
+template <int N, int NL>
+__device__ __forceinline__ void wave_reduce_limbs(const float *vals, bool valid, int lane, int32_t *__restrict__ sums)
+{
+    constexpr int V = NL * N;
+    int vs[7];
+    vs[0] = V;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vs[k + 1] = (vs[k] + 1) / 2;
+    int32_t a[V];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float p = valid ? vals[i] : 0.0f;
+        if constexpr (NL == 5) {
+            const hd_limbs25 l = hd_limbs25_from_f32(p);
+            a[5 * i] = l.d0; a[5 * i + 1] = l.d1; a[5 * i + 2] = l.d2; a[5 * i + 3] = l.d3; a[5 * i + 4] = l.d4;
+        } else if constexpr (NL == 3) {
+            hd_limbs25_low3(p, &a[3 * i], &a[3 * i + 1], &a[3 * i + 2]);
+        } else {
+            hd_limbs25_low2(p, &a[2 * i], &a[2 * i + 1]);
+        }
+    }
+    wave_transpose_sum<V, V, 0>(a, lane);
+    // register k of lane l now holds the wave total of limb  k + sum_S bit_{5-S}(l) * h_S  (if in range)
+#pragma unroll
+    for (int k = 0; k < (V + 63) / 64; ++k) {
+        int idx = k;
+        bool ok = k < vs[6];
+#pragma unroll
+        for (int S = 5; S >= 0; --S) {
+            idx += ((lane >> (5 - S)) & 1) * vs[S + 1];
+            ok = ok && idx < vs[S];
+        }
+        if (ok) sums[5 * (idx / NL) + idx % NL] = a[k];
+    }
+    if constexpr (NL < 5)   // the limbs that were not computed are zero
+        for (int i = lane; i < N * (5 - NL); i += 64) sums[5 * (i / (5 - NL)) + NL + i % (5 - NL)] = 0;
+}
+
 template <int N>
 __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ slots)
 {
@@ -101,30 +141,16 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
     if (vals[0] == 123456.0f) slots[0] = 1;
     return;
 #endif
-    int vs[7];
-    vs[0] = V;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) vs[k + 1] = (vs[k] + 1) / 2;
     if (__ballot(valid) != 0ull) {
-        int32_t a[V];
+        // wave-uniform choice of how many limbs can be non-zero: |p| < 2^9 -> 2, |p| < 2^34 -> 3, else all 5
+        // (non-finite values have the largest magnitudes bits and take the general path, which zeroes them)
+        uint32_t m = 0u;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const hd_limbs25 l = hd_limbs25_from_f32(valid ? vals[i] : 0.0f);
-            a[5 * i] = l.d0; a[5 * i + 1] = l.d1; a[5 * i + 2] = l.d2; a[5 * i + 3] = l.d3; a[5 * i + 4] = l.d4;
-        }
-        wave_transpose_sum<V, V, 0>(a, lane);
-        // register k of lane l now holds the wave total of limb  k + sum_S bit_{5-S}(l) * h_S  (if in range)
-#pragma unroll
-        for (int k = 0; k < (V + 63) / 64; ++k) {
-            int idx = k;
-            bool ok = k < vs[6];
-#pragma unroll
-            for (int S = 5; S >= 0; --S) {
-                idx += ((lane >> (5 - S)) & 1) * vs[S + 1];
-                ok = ok && idx < vs[S];
-            }
-            if (ok) s_sum[wid][idx] = a[k];
-        }
+        for (int i = 0; i < N; ++i) { const uint32_t b = hd_f2u(vals[i]) & 0x7fffffffu; m = b > m ? b : m; }
+        if (!valid) m = 0u;
+        if (__ballot(m >= ((127u + 9u) << 23)) == 0ull) wave_reduce_limbs<N, 2>(vals, valid, lane, s_sum[wid]);
+        else if (__ballot(m >= ((127u + 34u) << 23)) == 0ull) wave_reduce_limbs<N, 3>(vals, valid, lane, s_sum[wid]);
+        else wave_reduce_limbs<N, 5>(vals, valid, lane, s_sum[wid]);
     } else {
         for (int i = lane; i < V; i += 64) s_sum[wid][i] = 0;
     }
@@ -311,11 +337,8 @@ __device__ __forceinline__ void transform_planar(float *m, int rows, int cols, i
     if (add_t) o = mk3(o.x + T.t[0], o.y + T.t[1], o.z + T.t[2]);
     m[i] = o.x; m[PP + i] = o.y; m[2 * PP + i] = o.z;
 }
-__global__ void k_odo_transform(OdoLevel L, const DevPose *__restrict__ dp)
+__device__ __forceinline__ void transform_pixel(const OdoLevel &L, int i, const Rigid &T)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.rows * L.cols) return;
-    const Rigid T = dp->pose;
     transform_planar(L.vmap_g, L.rows, L.cols, i, T, true);
     transform_planar(L.nmap_g, L.rows, L.cols, i, T, false);
     transform_planar(L.ck1_g, L.rows, L.cols, i, T, false);
@@ -323,12 +346,9 @@ __global__ void k_odo_transform(OdoLevel L, const DevPose *__restrict__ dp)
 }
 
 // applyKernel (Sobel, cudafuncs.cu:927-954, running kernelIndex quirk) + projectPointsKernel (:995-1013)
-__global__ void k_odo_sobel_cloud(OdoLevel L, float fx, float fy, float cx, float cy, int do_rgb)
+__device__ __forceinline__ void sobel_cloud_pixel(const OdoLevel &L, int i, float fx, float fy, float cx, float cy)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = L.rows, cols = L.cols;
-    if (i >= rows * cols) return;
-    if (!do_rgb) return;
     int y = i / cols, x = i - y * cols;
     const float gx[9] = {1, 0, -1, 2, 0, -2, 1, 0, -1};
     const float gy[9] = {1, 2, 1, 0, 0, 0, -1, -2, -1};
@@ -478,23 +498,58 @@ __host__ __device__ inline void inv3f_cof(const float *m, float *o)
     o[6] = c02 * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
 }
 
-// totals[t] = sum over slot rows, then re-zero the rows for the next launch   (one workgroup, 1024 threads)
-__device__ __forceinline__ void sum_partials(long long *__restrict__ part, int nrows, int width,
-                                             long long *__restrict__ totals)
+// The workgroup that takes the last ticket of a launch runs the launch's epilogue (slot fold + solve).
+// Everything the epilogue consumes from other workgroups arrives through the agent-scope slot atomics, which
+// block_reduce_exact issues from wave 0 only (threads < N <= 64).  So wave 0 alone executes the agent-scope
+// release fence (a workgroup-scope fence is a no-op for global memory on a single CU and was observed to let
+// the ticket overtake the atomics; a fence in every wave costs an L2 write-back each and was 4x slower), the
+// barrier collects the workgroup, and thread 0 — a lane of that same wave — takes the ticket.
+// The elected workgroup acquires once before it reads.  No spinning: no co-residency requirement.
+__device__ __forceinline__ bool elect_last_workgroup(unsigned int *ticket)
 {
-    __shared__ long long s_acc[8][128];
-    const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
-    long long s = 0;
-    if (col < width)
-        for (int b = grp; b < nrows; b += 8) { s += part[(size_t)b * width + col]; part[(size_t)b * width + col] = 0; }
-    s_acc[grp][col] = s;
+    __shared__ int s_last;
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (threadIdx.x < width) {
-        long long t = 0;
-        for (int g = 0; g < 8; ++g) t += s_acc[g][threadIdx.x];
-        totals[threadIdx.x] = t;
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return s_last != 0;
+}
+
+// s_tot[t] = totals[t] = sum over the slot rows of `part` (and, if given, of `part2` as columns width..2 width-1),
+// rows re-zeroed for the next launch.  NGRP * 256 threads: the rows are split into NGRP groups; every thread
+// issues all its loads before the first add (one memory latency).
+template <bool IN_LAUNCH /* rows written by other workgroups of this very launch */, int NGRP>
+__device__ __forceinline__ void fold_slots(long long *__restrict__ part, long long *__restrict__ part2, int width,
+                                           long long *__restrict__ s_tot, long long *__restrict__ totals)
+{
+    __shared__ long long s_grp[NGRP][256];
+    const int col = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    const int ncols = part2 ? 2 * width : width;
+    if (col < ncols && grp < NGRP) {
+        long long *base = col < width ? part + col : part2 + (col - width);
+        long long v[ODO_SLOTS / NGRP];
+#pragma unroll
+        for (int b = 0; b < ODO_SLOTS / NGRP; ++b) {
+            long long *q = base + (size_t)(grp + b * NGRP) * width;
+            v[b] = IN_LAUNCH ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        }
+        long long t = 0;
+#pragma unroll
+        for (int b = 0; b < ODO_SLOTS / NGRP; ++b) { t += v[b]; base[(size_t)(grp + b * NGRP) * width] = 0; }
+        s_grp[grp][col] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncols) {
+        long long t = 0;
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) t += s_grp[g][threadIdx.x];
+        s_tot[threadIdx.x] = t; totals[threadIdx.x] = t;
+    }
 }
 
 __device__ __forceinline__ double limbs_to_double(const long long *t, int i)
@@ -502,9 +557,137 @@ __device__ __forceinline__ double limbs_to_double(const long long *t, int i)
     return hd_acc_to_double(hd_limbs_combine(t[i * 3], t[i * 3 + 1], t[i * 3 + 2]));
 }
 
+// ------------------------------------------------------------------------------------------ step operands
+__device__ inline void so3_set_operands(OdoState *st, float fx, float fy, float cx, float cy)
+{
+    double K[9] = {0}, Kinv[9], KR[9], Hm[9];
+    K[0] = fx / 4; K[4] = fy / 4; K[2] = cx / 4; K[5] = cy / 4; K[8] = 1;
+    inv3d(K, Kinv);
+    mul3<double>(K, st->resultR, KR);
+    mul3<double>(KR, Kinv, Hm);
+    for (int k = 0; k < 9; ++k) { st->basis[k] = (float)Hm[k]; st->kinv[k] = (float)Kinv[k]; st->krlr[k] = (float)KR[k]; }
+}
+
+__device__ inline void gn_set_operands(OdoState *st, float fxl, float fyl, float cxl, float cyl)
+{
+    double K[9] = {0}, Kinv[9];
+    K[0] = fxl; K[4] = fyl; K[2] = cxl; K[5] = cyl; K[8] = 1;
+    inv3d(K, Kinv);
+    const double *Rt = st->Rt;
+    double L[9], Li[9], ti[3];
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) L[r * 3 + k] = Rt[r * 4 + k];
+    inv3d(L, Li);
+    for (int r = 0; r < 3; ++r) ti[r] = -((Li[r * 3] * Rt[3] + Li[r * 3 + 1] * Rt[7]) + Li[r * 3 + 2] * Rt[11]);
+    double KR[9], KRK[9];
+    mul3<double>(K, Li, KR); mul3<double>(KR, Kinv, KRK);
+    for (int k = 0; k < 9; ++k) st->krk[k] = (float)KRK[k];
+    for (int r = 0; r < 3; ++r)
+        st->kt[r] = (float)((K[r * 3] * ti[0] + K[r * 3 + 1] * ti[1]) + K[r * 3 + 2] * ti[2]);
+}
+
+// first Gauss-Newton operands: resultRt = [R_so3 | 0] (RGBDOdometry.cpp:700-712)
+__device__ inline void gn_begin_state(OdoState *st, const OdoConfig &cfg, int level)
+{
+    for (int k = 0; k < 16; ++k) st->Rt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (cfg.so3) for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) st->Rt[r * 4 + k] = st->resultR[r * 3 + k];
+    const int div = 1 << level;
+    gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+    st->lastRGBError = 3.402823466e+38f;
+}
+
+// begin of registration: latch previous pose, reset SO3 / GN state.  gn_level >= 0: no SO3 stage follows, so
+// the Gauss-Newton operands are prepared here as well.
+__device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__ dp, const OdoConfig &cfg, int gn_level)
+{
+    for (int k = 0; k < 9; ++k) { st->Rprev[k] = dp->pose.r[k]; st->Rcurr[k] = dp->pose.r[k]; }
+    for (int k = 0; k < 3; ++k) { st->tprev[k] = dp->pose.t[k]; st->tcurr[k] = dp->pose.t[k]; }
+    inv3f_cof(st->Rprev, st->Rprev_inv);
+    for (int k = 0; k < 9; ++k) { st->resultR[k] = st->lastResultR[k] = (k % 4 == 0) ? 1.0 : 0.0; st->R_lr[k] = (k % 4 == 0) ? 1.0f : 0.0f; }
+    st->so3_lastError = 3.402823466e+38f / 2.0f;
+    st->so3_lastCount = 3.402823466e+38f / 2.0f;
+    st->so3_done = cfg.so3 ? 0 : 1;
+    st->gn_break = 0;
+    st->res_icp[0] = st->res_icp[1] = 0.0f;
+    st->ticket = 0u;
+    if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
+    if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
+}
+
+// last pass over the pyramids, all levels in one launch (blockIdx.y = level): model maps into the global frame
+// (in place), Sobel + back-projected cloud of the live frame; workgroup (0,0) also resets the registration state
+struct OdoLevels { OdoLevel lv[HRBF_NUM_PYRS]; };
+__global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg, int do_rgb,
+                              int gn_level)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) odo_begin_state(st, dp, cfg, gn_level);
+    const int level = blockIdx.y;
+    const OdoLevel &L = all.lv[level];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.rows * L.cols) return;
+    transform_pixel(L, i, dp->pose);
+    if (do_rgb) {
+        const int div = 1 << level;
+        sobel_cloud_pixel(L, i, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+    }
+}
+
+// SO3 step (RGBDOdometry.cpp:551-640): fold the slot rows, solve the 3x3 system, update the homography
+// operands.  Runs in the elected last workgroup of k_so3_reduce (or alone, from k_so3_solve).
+// gn_level >= 0 marks the last SO3 iteration: the Gauss-Newton operands are prepared right away.
+__device__ __forceinline__ void so3_solve_block(OdoState *st, long long *__restrict__ part, long long *__restrict__ totals,
+                                                int do_reduce, const OdoConfig &cfg, int gn_level)
+{
+    __shared__ long long s_tot[33];
+    if (do_reduce == 2) fold_slots<true, 1>(part, nullptr, 33, s_tot, totals);
+    else if (do_reduce) fold_slots<false, 1>(part, nullptr, 33, s_tot, totals);
+    else if (threadIdx.x < 33) s_tot[threadIdx.x] = totals[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (!st->so3_done) {
+        double s[11];
+        for (int i = 0; i < 11; ++i) s[i] = limbs_to_double(s_tot, i);
+        float jtj[9], jtr[3];
+        int shift = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 4; ++j) {
+                float value = (float)s[shift++];
+                if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+            }
+        float res0 = (float)s[9], res1 = (float)s[10];
+        float so3err = hd_sqrtf(res0) / res1, so3cnt = res1;
+        if (so3err < st->so3_lastError && st->so3_lastCount == so3cnt) st->so3_done = 1;
+        else if (so3err > st->so3_lastError + 0.001f) {
+            for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
+            st->so3_done = 1;
+        } else {
+            st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
+            for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
+            float delta[3];
+            ldlt_solve<float, 3>(jtj, jtr, delta);
+            double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
+            rodrigues(dd, rotU);
+            float rotUf[9], tmp[9];
+            for (int k = 0; k < 9; ++k) rotUf[k] = (float)rotU[k];
+            mul3<float>(rotUf, st->R_lr, tmp);
+            for (int k = 0; k < 9; ++k) { st->R_lr[k] = tmp[k]; st->resultR[k] = tmp[k]; }
+            so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
+        }
+    }
+    if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
+}
+
+// stand-alone SO3 solve on totals that were summed elsewhere (row-sharded multi-GPU: all-reduce of the limb sums)
+__global__ __launch_bounds__(RB) void k_so3_solve(OdoState *st, long long *__restrict__ part,
+                                                  long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
+                                                  int gn_level)
+{
+    so3_solve_block(st, part, totals, do_reduce, cfg, gn_level);
+}
+
 // ------------------------------------------------------------------------------------------ O2: SO3 pre-alignment
-__global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, const OdoState *__restrict__ st,
-                                                   long long *__restrict__ part)
+__global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, OdoState *st, long long *__restrict__ part,
+                                                   long long *__restrict__ totals, OdoConfig cfg, int fused_solve,
+                                                   int gn_level)
 {
     const int rows = L.rows, cols = L.cols;
     const int i = blockIdx.x * RB + threadIdx.x;
@@ -555,97 +738,7 @@ __global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, const OdoState *_
         }
     }
     block_reduce_exact<11>(row4, valid, part);
-}
-
-__device__ inline void so3_set_operands(OdoState *st, float fx, float fy, float cx, float cy)
-{
-    double K[9] = {0}, Kinv[9], KR[9], Hm[9];
-    K[0] = fx / 4; K[4] = fy / 4; K[2] = cx / 4; K[5] = cy / 4; K[8] = 1;
-    inv3d(K, Kinv);
-    mul3<double>(K, st->resultR, KR);
-    mul3<double>(KR, Kinv, Hm);
-    for (int k = 0; k < 9; ++k) { st->basis[k] = (float)Hm[k]; st->kinv[k] = (float)Kinv[k]; st->krlr[k] = (float)KR[k]; }
-}
-
-// begin of registration: latch previous pose, reset SO3 / GN state
-__global__ void k_odo_begin(OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 9; ++k) { st->Rprev[k] = dp->pose.r[k]; st->Rcurr[k] = dp->pose.r[k]; }
-    for (int k = 0; k < 3; ++k) { st->tprev[k] = dp->pose.t[k]; st->tcurr[k] = dp->pose.t[k]; }
-    inv3f_cof(st->Rprev, st->Rprev_inv);
-    for (int k = 0; k < 9; ++k) { st->resultR[k] = st->lastResultR[k] = (k % 4 == 0) ? 1.0 : 0.0; st->R_lr[k] = (k % 4 == 0) ? 1.0f : 0.0f; }
-    st->so3_lastError = 3.402823466e+38f / 2.0f;
-    st->so3_lastCount = 3.402823466e+38f / 2.0f;
-    st->so3_done = cfg.so3 ? 0 : 1;
-    st->gn_break = 0;
-    st->res_icp[0] = st->res_icp[1] = 0.0f;
-    if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
-}
-
-__global__ __launch_bounds__(1024) void k_so3_solve(OdoState *st, long long *__restrict__ part, int nblocks,
-                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg)
-{
-    (void)nblocks;
-    if (do_reduce) sum_partials(part, ODO_SLOTS, 33, totals);
-    if (threadIdx.x != 0) return;
-    if (st->so3_done) return;
-    double s[11];
-    for (int i = 0; i < 11; ++i) s[i] = limbs_to_double(totals, i);
-    float jtj[9], jtr[3];
-    int shift = 0;
-    for (int i = 0; i < 3; ++i)
-        for (int j = i; j < 4; ++j) {
-            float value = (float)s[shift++];
-            if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
-        }
-    float res0 = (float)s[9], res1 = (float)s[10];
-    float so3err = hd_sqrtf(res0) / res1, so3cnt = res1;
-    if (so3err < st->so3_lastError && st->so3_lastCount == so3cnt) { st->so3_done = 1; return; }
-    else if (so3err > st->so3_lastError + 0.001f) {
-        for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
-        st->so3_done = 1;
-        return;
-    }
-    st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
-    for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
-    float delta[3];
-    ldlt_solve<float, 3>(jtj, jtr, delta);
-    double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
-    rodrigues(dd, rotU);
-    float rotUf[9], tmp[9];
-    for (int k = 0; k < 9; ++k) rotUf[k] = (float)rotU[k];
-    mul3<float>(rotUf, st->R_lr, tmp);
-    for (int k = 0; k < 9; ++k) { st->R_lr[k] = tmp[k]; st->resultR[k] = tmp[k]; }
-    so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
-}
-
-// ------------------------------------------------------------------------------------------ GN operands
-__device__ inline void gn_set_operands(OdoState *st, float fxl, float fyl, float cxl, float cyl)
-{
-    double K[9] = {0}, Kinv[9];
-    K[0] = fxl; K[4] = fyl; K[2] = cxl; K[5] = cyl; K[8] = 1;
-    inv3d(K, Kinv);
-    const double *Rt = st->Rt;
-    double L[9], Li[9], ti[3];
-    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) L[r * 3 + k] = Rt[r * 4 + k];
-    inv3d(L, Li);
-    for (int r = 0; r < 3; ++r) ti[r] = -((Li[r * 3] * Rt[3] + Li[r * 3 + 1] * Rt[7]) + Li[r * 3 + 2] * Rt[11]);
-    double KR[9], KRK[9];
-    mul3<double>(K, Li, KR); mul3<double>(KR, Kinv, KRK);
-    for (int k = 0; k < 9; ++k) st->krk[k] = (float)KRK[k];
-    for (int r = 0; r < 3; ++r)
-        st->kt[r] = (float)((K[r * 3] * ti[0] + K[r * 3 + 1] * ti[1]) + K[r * 3 + 2] * ti[2]);
-}
-
-__global__ void k_gn_begin(OdoState *st, OdoConfig cfg, int level)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 16; ++k) st->Rt[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    if (cfg.so3) for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) st->Rt[r * 4 + k] = st->resultR[r * 3 + k];
-    const int div = 1 << level;
-    gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
-    st->lastRGBError = 3.402823466e+38f;
+    if (fused_solve && elect_last_workgroup(&st->ticket)) so3_solve_block(st, part, totals, 2, cfg, gn_level);
 }
 
 // ------------------------------------------------------------------------------------------ O3 + O4 fused launch
@@ -817,13 +910,115 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
     }
 }
 
+// end of registration: 0.3 m guard (RGBDOdometry.cpp:1232-1236), publish the pose
+__device__ inline void odo_end_state(OdoState *st, DevPose *dp, const OdoConfig &cfg)
+{
+    const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
+    if (rgb) {
+        f3 d = mk3(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
+        if (len3(d) > 0.3f) {
+            for (int k = 0; k < 9; ++k) st->Rcurr[k] = st->Rprev[k];
+            for (int k = 0; k < 3; ++k) st->tcurr[k] = st->tprev[k];
+        }
+    }
+    for (int k = 0; k < 9; ++k) dp->pose.r[k] = st->Rcurr[k];
+    for (int k = 0; k < 3; ++k) dp->pose.t[k] = st->tcurr[k];
+    dp->tinv = rigid_inverse(dp->pose);
+    dp->last_icp_error = st->last_icp_error;
+    dp->last_icp_count = st->last_icp_count;
+}
+
+// solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93); also prepares the
+// operands of the next iteration (possibly on the next pyramid level).  res_c / res_s: the folded RGB residual
+// (count, sigma).
+// dp != null marks the last iteration of the registration: the pose is published.
+__device__ __forceinline__ void gn_solve_block(OdoState *st, long long *__restrict__ icp_part,
+                                               long long *__restrict__ rgb_part, long long *__restrict__ res_part,
+                                               long long *__restrict__ totals, int do_reduce, long long res_c,
+                                               long long res_s, const OdoConfig &cfg, int next_level, int level_changes,
+                                               DevPose *dp)
+{
+    // icp_part and rgb_part are adjacent (OdoBuffers): 32 slot rows x (87 + 87) limbs
+    __shared__ long long s_tot[176];
+    __shared__ double s_val[58];
+    __shared__ double s_A[36], s_b[6];
+    const int tid = threadIdx.x;
+    if (do_reduce) {
+        fold_slots<false, 4>(icp_part, rgb_part, 87, s_tot, totals);   // launched with 1024 threads
+        for (int t = tid; t < RES_SLOTS * 2; t += blockDim.x) res_part[t] = 0;
+    } else {
+        for (int t = tid; t < 174; t += blockDim.x) s_tot[t] = totals[t];
+    }
+    __syncthreads();
+    const int rgbOnly = cfg.rgb_only;
+    const int icp = !rgbOnly && cfg.icp_weight > 0.0f;
+    const int rgb = rgbOnly || cfg.icp_weight < 100.0f;
+    if (tid < 58) s_val[tid] = limbs_to_double(s_tot + (tid < 29 ? 0 : 87), tid < 29 ? tid : tid - 29);
+    __syncthreads();
+    if (tid < 42) {   // entries of the combined normal equations (RGBDOdometry.cpp:1162-1178)
+        const int r = tid < 36 ? tid / 6 : tid - 36, c = tid < 36 ? tid % 6 : 6;
+        const int i = r < c ? r : c, j = r < c ? c : r;
+        const int shift = i * 7 - (i * (i - 1)) / 2 + (j - i);   // row-major upper triangle incl. the rhs column
+        const float vi = icp ? (float)s_val[shift] : 0.0f, vr = rgb ? (float)s_val[29 + shift] : 0.0f;
+        const double w = cfg.icp_weight;
+        double v;
+        if (icp && rgb) v = (double)vr + (tid < 36 ? w * w : w) * (double)vi;
+        else v = icp ? (double)vi : (double)vr;
+        if (tid < 36) s_A[tid] = v; else s_b[tid - 36] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const long long c = res_c, sg = res_s;
+    if (rgb) {
+        float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
+        if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
+        if (!st->gn_break) st->lastRGBError = rgbError;
+    }
+    if (!st->gn_break) {
+        if (icp) { st->res_icp[0] = (float)s_val[27]; st->res_icp[1] = (float)s_val[28]; }
+        st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
+        st->last_icp_count = st->res_icp[1];
+        double lastA[36], lastb[6], result[6];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) lastA[k] = s_A[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lastb[k] = s_b[k];
+        ldlt_solve<double, 6>(lastA, lastb, result);
+        double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
+        rodrigues(rv, Ru);
+        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
+        U[12] = U[13] = U[14] = 0; U[15] = 1;
+        double *Rt = st->Rt;
+        for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k)
+            N[r * 4 + k] = ((U[r * 4] * Rt[k] + U[r * 4 + 1] * Rt[4 + k]) + U[r * 4 + 2] * Rt[8 + k]) + U[r * 4 + 3] * Rt[12 + k];
+        for (int k = 0; k < 16; ++k) Rt[k] = N[k];
+        float oR[9], ot[3];
+        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }
+        float iR[9], it_[3];
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[k * 3 + r];
+        for (int r = 0; r < 3; ++r) it_[r] = -((iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1]) + iR[r * 3 + 2] * ot[2]);
+        float Rc[9];
+        mul3<float>(st->Rprev, iR, Rc);
+        for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rc[k];
+        f3 rt = m33_mul(st->Rprev, mk3(it_[0], it_[1], it_[2]));
+        st->tcurr[0] = rt.x + st->tprev[0]; st->tcurr[1] = rt.y + st->tprev[1]; st->tcurr[2] = rt.z + st->tprev[2];
+    }
+    if (level_changes) { st->gn_break = 0; st->lastRGBError = 3.402823466e+38f; }
+    if (next_level >= 0) {
+        const int div = 1 << next_level;
+        gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+    }
+    if (dp) odo_end_state(st, dp, cfg);
+}
+
 // RGBReduction::getProducts (reduce.cu:717-808); every workgroup first folds the residual partials
 // into (count, sigma) and derives sigmaVal (RGBDOdometry.cpp:1017-1030)
-__global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__restrict__ st, int nb, float fx, float fy,
-                                                    int rgb_only, int use_grad, const long long *__restrict__ res_part,
+__global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *__restrict__ st, int nb, float fx,
+                                                    float fy, int rgb_only, int use_grad,
+                                                    const long long *__restrict__ res_part,
                                                     const int16_t *__restrict__ corres,
                                                     const float *__restrict__ corres_diff, long long *__restrict__ rgb_part,
-                                                    long long *__restrict__ totals_res)
+                                                    long long *__restrict__ totals)
 {
     __shared__ long long s_c[RB / 64], s_s[RB / 64];
     __shared__ float s_sigma;
@@ -843,7 +1038,7 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__rest
         if (rgb_only && rgbError > st->lastRGBError) brk = 1;
         if (rgb_only) sigmaVal = -1.0f;
         s_sigma = sigmaVal; s_break = brk;
-        if (blockIdx.x == 0) { totals_res[0] = c; totals_res[1] = s; }
+        if (blockIdx.x == 0) { totals[174] = c; totals[175] = s; }
     }
     __syncthreads();
     const float sigma = s_sigma;
@@ -892,117 +1087,21 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, OdoState *__rest
     block_reduce_exact<29>(out, valid, rgb_part);
 }
 
-// solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93); also prepares the
-// operands of the next iteration (possibly on the next pyramid level).
+// stand-alone solve on totals that were summed elsewhere (row-sharded multi-GPU: all-reduce of the limb sums)
 __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
-                                                   long long *__restrict__ rgb_part, long long *__restrict__ res_part, int nb,
+                                                   long long *__restrict__ rgb_part, long long *__restrict__ res_part,
                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
-                                                   int next_level, int level_changes)
+                                                   int next_level, int level_changes, DevPose *dp)
 {
-    (void)nb;
-    // icp_part and rgb_part are adjacent (OdoBuffers): one pass over 32 slot rows x (87 + 87) limbs
-    __shared__ long long s_acc[4][176];
-    __shared__ long long s_tot[176];
-    __shared__ double s_val[58];
-    __shared__ double s_A[36], s_b[6];
-    const int tid = threadIdx.x;
-    if (do_reduce) {
-        const int col = tid & 255, grp = tid >> 8;
-        long long s = 0;
-        if (col < 174) {
-            long long *base = (col < 87) ? icp_part + col : rgb_part + (col - 87);
-#pragma unroll
-            for (int b = 0; b < ODO_SLOTS / 4; ++b) {
-                long long *q = base + (size_t)(grp + 4 * b) * 87;
-                s += *q; *q = 0;
-            }
-            s_acc[grp][col] = s;
-        }
-        if (tid < RES_SLOTS * 2) res_part[tid] = 0;
-        __syncthreads();
-        if (tid < 174) {
-            const long long t = (s_acc[0][tid] + s_acc[1][tid]) + (s_acc[2][tid] + s_acc[3][tid]);
-            s_tot[tid] = t; totals[tid] = t;
-        } else if (tid < 176) s_tot[tid] = totals[tid];
-    } else if (tid < 176) s_tot[tid] = totals[tid];
-    __syncthreads();
-    const int rgbOnly = cfg.rgb_only;
-    const int icp = !rgbOnly && cfg.icp_weight > 0.0f;
-    const int rgb = rgbOnly || cfg.icp_weight < 100.0f;
-    if (tid < 58) s_val[tid] = limbs_to_double(s_tot + (tid < 29 ? 0 : 87), tid < 29 ? tid : tid - 29);
-    __syncthreads();
-    if (tid < 42) {   // entries of the combined normal equations (RGBDOdometry.cpp:1162-1178)
-        const int r = tid < 36 ? tid / 6 : tid - 36, c = tid < 36 ? tid % 6 : 6;
-        const int i = r < c ? r : c, j = r < c ? c : r;
-        const int shift = i * 7 - (i * (i - 1)) / 2 + (j - i);   // row-major upper triangle incl. the rhs column
-        const float vi = icp ? (float)s_val[shift] : 0.0f, vr = rgb ? (float)s_val[29 + shift] : 0.0f;
-        const double w = cfg.icp_weight;
-        double v;
-        if (icp && rgb) v = (double)vr + (tid < 36 ? w * w : w) * (double)vi;
-        else v = icp ? (double)vi : (double)vr;
-        if (tid < 36) s_A[tid] = v; else s_b[tid - 36] = v;
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    const long long c = s_tot[174], sg = s_tot[175];
-    if (rgb) {
-        float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
-        if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
-        if (!st->gn_break) st->lastRGBError = rgbError;
-    }
-    if (!st->gn_break) {
-        if (icp) { st->res_icp[0] = (float)s_val[27]; st->res_icp[1] = (float)s_val[28]; }
-        st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
-        st->last_icp_count = st->res_icp[1];
-        double lastA[36], lastb[6], result[6];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) lastA[k] = s_A[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) lastb[k] = s_b[k];
-        ldlt_solve<double, 6>(lastA, lastb, result);
-        double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
-        rodrigues(rv, Ru);
-        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
-        U[12] = U[13] = U[14] = 0; U[15] = 1;
-        double *Rt = st->Rt;
-        for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k)
-            N[r * 4 + k] = ((U[r * 4] * Rt[k] + U[r * 4 + 1] * Rt[4 + k]) + U[r * 4 + 2] * Rt[8 + k]) + U[r * 4 + 3] * Rt[12 + k];
-        for (int k = 0; k < 16; ++k) Rt[k] = N[k];
-        float oR[9], ot[3];
-        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }
-        float iR[9], it_[3];
-        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[k * 3 + r];
-        for (int r = 0; r < 3; ++r) it_[r] = -((iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1]) + iR[r * 3 + 2] * ot[2]);
-        float Rc[9];
-        mul3<float>(st->Rprev, iR, Rc);
-        for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rc[k];
-        f3 rt = m33_mul(st->Rprev, mk3(it_[0], it_[1], it_[2]));
-        st->tcurr[0] = rt.x + st->tprev[0]; st->tcurr[1] = rt.y + st->tprev[1]; st->tcurr[2] = rt.z + st->tprev[2];
-    }
-    if (level_changes) { st->gn_break = 0; st->lastRGBError = 3.402823466e+38f; }
-    if (next_level >= 0) {
-        const int div = 1 << next_level;
-        gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
-    }
+    gn_solve_block(st, icp_part, rgb_part, res_part, totals, do_reduce, totals[174], totals[175], cfg, next_level,
+                   level_changes, dp);
 }
 
-// end of registration: 0.3 m guard (RGBDOdometry.cpp:1232-1236), publish the pose
+// registration without any Gauss-Newton iteration configured: only the guard + publish
 __global__ void k_odo_end(OdoState *st, DevPose *dp, OdoConfig cfg)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
-    if (rgb) {
-        f3 d = mk3(st->tcurr[0] - st->tprev[0], st->tcurr[1] - st->tprev[1], st->tcurr[2] - st->tprev[2]);
-        if (len3(d) > 0.3f) {
-            for (int k = 0; k < 9; ++k) st->Rcurr[k] = st->Rprev[k];
-            for (int k = 0; k < 3; ++k) st->tcurr[k] = st->tprev[k];
-        }
-    }
-    for (int k = 0; k < 9; ++k) dp->pose.r[k] = st->Rcurr[k];
-    for (int k = 0; k < 3; ++k) dp->pose.t[k] = st->tcurr[k];
-    dp->tinv = rigid_inverse(dp->pose);
-    dp->last_icp_error = st->last_icp_error;
-    dp->last_icp_count = st->last_icp_count;
+    odo_end_state(st, dp, cfg);
 }
 
 // ------------------------------------------------------------------------------------------ pose bookkeeping
@@ -1118,29 +1217,29 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         int n = ob.lv[i].rows * ob.lv[i].cols;
         hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256, ODO_DOWN_TASKS), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);
     }
-    for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
-        int n = ob.lv[i].rows * ob.lv[i].cols, div = 1 << i;
-        hipLaunchKernelGGL(k_odo_transform, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i], dp);
-        hipLaunchKernelGGL(k_odo_sobel_cloud, dim3((n + 255) / 256), dim3(256), 0, s, ob.lv[i], cfg.fx / div, cfg.fy / div,
-                           cfg.cx / div, cfg.cy / div, rgb);
-    }
-    hipMemsetAsync(ob.icp_part, 0, odo_slot_bytes(), s);   // icp | rgb | res | so3 slot rows, one allocation
-    hipLaunchKernelGGL(k_odo_begin, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
+    // the slot rows (icp | rgb | res | so3) are zeroed once at allocation; every fold re-zeroes what it read
     const bool multi = comm != nullptr && world > 1;
-    // O2: SO3 pre-alignment on level 2
+    (void)multi;
+    int iterations[3] = {cfg.fast_odom ? 3 : 10, cfg.pyramid ? 5 : 0, cfg.pyramid ? 4 : 0};
+    int first_level = -1, last_level = -1;
+    for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) if (iterations[i] > 0) { first_level = i; break; }
+    for (int i = 0; i < HRBF_NUM_PYRS; ++i) if (iterations[i] > 0) { last_level = i; break; }
+    const int gn_level = first_level < 0 ? 0 : first_level;
+    {
+        OdoLevels all;
+        for (int i = 0; i < HRBF_NUM_PYRS; ++i) all.lv[i] = ob.lv[i];
+        hipLaunchKernelGGL(k_odo_prepare, dim3((P + 255) / 256, HRBF_NUM_PYRS), dim3(256), 0, s, all, ob.state, dp, cfg, rgb,
+                           cfg.so3 ? -1 : gn_level);
+    }
+    // O2: SO3 pre-alignment on level 2; the last workgroup of every launch takes the step
     if (cfg.so3) {
         const OdoLevel &L = ob.lv[2];
         const int nb = (L.rows * L.cols + RB - 1) / RB;
-        for (int it = 0; it < 10; ++it) {
-            hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part);
-            hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.so3_part, nb, ob.totals + 176, 1, cfg);
-        }
+        for (int it = 0; it < 10; ++it)
+            hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, ob.totals + 176, cfg, 1,
+                               it == 9 ? gn_level : -1);
     }
-    // O3-O6: coarse-to-fine Gauss-Newton
-    int iterations[3] = {cfg.fast_odom ? 3 : 10, cfg.pyramid ? 5 : 0, cfg.pyramid ? 4 : 0};
-    int first_level = -1;
-    for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) if (iterations[i] > 0) { first_level = i; break; }
-    hipLaunchKernelGGL(k_gn_begin, dim3(1), dim3(1), 0, s, ob.state, cfg, first_level < 0 ? 0 : first_level);
+    // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration
     const float minGrad[3] = {5, 3, 1};
     for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) {
         const OdoLevel &L = ob.lv[i];
@@ -1151,9 +1250,6 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         for (int j = 0; j < iterations[i]; ++j) {
             hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
                                ob.icp_part, ob.res_part, ob.corres, ob.corres_diff);
-            hipLaunchKernelGGL(k_gn_rgb_step, dim3(nb), dim3(RB), 0, s, L, ob.state, nb, cfg.fx / div, cfg.fy / div,
-                               cfg.rgb_only, cfg.rgb_use_grad, ob.res_part, ob.corres, ob.corres_diff, ob.rgb_part,
-                               ob.totals + 174);
             // operands for the next iteration: same level, or the next non-empty finer level
             const bool last_of_level = (j == iterations[i] - 1);
             int next_level = i;
@@ -1161,12 +1257,18 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 next_level = -1;
                 for (int k = i - 1; k >= 0; --k) if (iterations[k] > 0) { next_level = k; break; }
             }
-            (void)multi;
-            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part, nb,
-                               ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0);
+            const bool last_of_all = last_of_level && i == last_level;
+            // fusing the solve into the last workgroup of k_gn_rgb_step was measured slower (the fold then reads the
+            // slot rows from memory instead of L2 and pays a ticket round trip): 16.1 vs 6.3 + 8.8 us on level 2
+            hipLaunchKernelGGL(k_gn_rgb_step, dim3(nb), dim3(RB), 0, s, L, ob.state, nb, cfg.fx / div, cfg.fy / div,
+                               cfg.rgb_only, cfg.rgb_use_grad, ob.res_part, ob.corres, ob.corres_diff, ob.rgb_part,
+                               ob.totals);
+            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
+                               ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0,
+                               last_of_all ? dp : (DevPose *)nullptr);
         }
     }
-    hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
+    if (last_level < 0) hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
     if (cfg.so3)   // swap NextImage <-> lastNextImage (RGBDOdometry.cpp:1239-1245): pointer swap, no copy
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) { uint8_t *t = ob.lv[i].last_next_image; ob.lv[i].last_next_image = ob.lv[i].next_image; ob.lv[i].next_image = t; }
 }

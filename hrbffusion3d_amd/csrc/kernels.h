@@ -46,6 +46,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
+void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
 uint32_t fuse_tile_items();
 uint32_t fuse_tile_count_stride();
 

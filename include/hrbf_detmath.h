@@ -371,6 +371,25 @@ HD_FN hd_limbs25 hd_limbs25_from_f32(float p)
     return l;
 }
 
+/* the same split when the caller knows |p| < 2^34 (d3 = d4 = 0) or |p| < 2^9 (d2 = d3 = d4 = 0): the skipped
+ * steps of hd_limbs25_from_f32 would have produced exact zeros, so the low limbs are bit-identical */
+HD_FN void hd_limbs25_low3(float a, int32_t *d0, int32_t *d1, int32_t *d2)
+{
+    const float h2 = __builtin_truncf(a * 0x1p-9f);
+    float r = hd_fmaf(-h2, 0x1p9f, a);
+    const float h1 = __builtin_truncf(r * 0x1p16f);
+    r = hd_fmaf(-h1, 0x1p-16f, r);
+    const float h0 = hd_rintf(r * 0x1p40f);
+    *d0 = (int32_t)h0; *d1 = (int32_t)h1; *d2 = (int32_t)h2;
+}
+HD_FN void hd_limbs25_low2(float a, int32_t *d0, int32_t *d1)
+{
+    const float h1 = __builtin_truncf(a * 0x1p16f);
+    const float r = hd_fmaf(-h1, 0x1p-16f, a);
+    const float h0 = hd_rintf(r * 0x1p40f);
+    *d0 = (int32_t)h0; *d1 = (int32_t)h1;
+}
+
 /* five limb SUMS (|s_j| < 2^39) -> Q as 40-bit limbs */
 HD_FN hd_limbs hd_limbs25_to_limbs(int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4)
 {
