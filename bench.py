@@ -119,7 +119,7 @@ def main():
         fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), k)
     fus.synchronize()
     count0 = fus.surfel_count()
-    fus.enable_timing(True)
+    fus.enable_timing(2)     # only the two events around the fuse pass (roofline); region events stay off
     fus.reset_fuse_ring()
 
     barrier(); torch.cuda.synchronize(); fus.synchronize()
@@ -142,7 +142,7 @@ def main():
     fuse_ms = float(ms[ok].mean()) if ok.any() else 0.0
     count1 = fus.surfel_count()
     P_end = fus.get_pose()
-    tm = fus.timings()
+    tm = np.zeros(8, np.float32)
     # PCIe-inclusive rate of the host-pointer entry point (never `value`): 1.5 MB upload + sync per frame
     pcie_fps = None
     if world == 1:
@@ -153,6 +153,10 @@ def main():
             fus.process_frame(frames[k][0], frames[k][1], k)
         fus.synchronize()
         pcie_fps = nh / (time.perf_counter() - t1)
+        # Stopwatch regions of one more frame, outside every timed loop (twelve event records per frame)
+        fus.enable_timing(1)
+        fus.process_frame_device(d_rgb[Wm + K].data_ptr(), d_dep[Wm + K].data_ptr(), Wm + K)
+        tm = fus.timings()
     err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
 
     if rank == 0:

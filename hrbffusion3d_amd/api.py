@@ -205,7 +205,8 @@ class HRBFFusion:
         self._check(self.lib.hrbf_set_load_trajectory(self.h, int(v)))
 
     def enable_timing(self, on=True):
-        self._check(self.lib.hrbf_enable_timing(self.h, 1 if on else 0))
+        """False/0: off, True/1: Stopwatch regions + fuse ring, 2: fuse ring only"""
+        self._check(self.lib.hrbf_enable_timing(self.h, int(on)))
 
     def timings(self):
         o = np.zeros(8, np.float32)

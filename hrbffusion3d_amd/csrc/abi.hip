@@ -366,7 +366,7 @@ static void st_odometry(hrbf_context *c)
     launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, nullptr, 0, 1);
 }
 
-#define TIMER(i) do { if (c->timing) hipEventRecord(c->ev[i], c->stream); } while (0)
+#define TIMER(i) do { if (c->timing & 1) hipEventRecord(c->ev[i], c->stream); } while (0)
 
 static int process_frame_resident(hrbf_context *c, float wmul)
 {
@@ -653,14 +653,20 @@ extern "C" int hrbf_set_image(hrbf_handle c, int which, const void *in, size_t b
     return HRBF_OK;
 }
 
-extern "C" int hrbf_enable_timing(hrbf_handle c, int on) { if (!c) return HRBF_ERR_INVALID; c->timing = on; return HRBF_OK; }
+// on: 0 = off, 1 = region events + fuse ring, 2 = fuse ring only (two events per frame instead of twelve)
+extern "C" int hrbf_enable_timing(hrbf_handle c, int on)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    c->timing = on == 2 ? 2 : (on ? 3 : 0);
+    return HRBF_OK;
+}
 extern "C" int hrbf_get_timings(hrbf_handle c, float out[8])
 {
     if (!c || !out) return HRBF_ERR_INVALID;
     hipSetDevice(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 8; ++i) out[i] = 0.0f;
-    if (!c->timing) return HRBF_OK;
+    if (!(c->timing & 1)) return HRBF_OK;
     float ms;
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) out[0] = ms;   // Initialization
     if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) out[1] = ms;   // Registration

@@ -65,34 +65,42 @@ __device__ __forceinline__ void gather_ring(const uint32_t (&wrow)[7], int nslot
     }
 }
 
-__device__ __forceinline__ const PTexel *texel_at(const PTexel *tile, uint32_t byte_off)
+__device__ __forceinline__ float4 lds4(const PTexel *tile, uint32_t byte_off)
 {
-    return reinterpret_cast<const PTexel *>(reinterpret_cast<const char *>(tile) + byte_off);
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tile) + byte_off);
 }
 
-// hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34) over the gathered neighbour list
+// one neighbour of hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34): branch-free, the contribution of a
+// neighbour whose support does not reach p is computed and discarded
+__device__ __forceinline__ void hrbf_value_term(const float4 a, const float4 b, const f3 p, bool live, float &value, int &ns)
+{
+    const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
+    const float d2 = (vx * vx + vy * vy) + vz * vz;
+    const bool in = live && !(a.w < d2);
+    const float r = hd_sqrtf(d2 * b.w);
+    const float s = 1.0f - r;
+    const float s3 = s * s * s;
+    const float tt = -20.0f * s3 * b.w;
+    const bool nz = d2 != 0.0f;
+    const float gx = nz ? vx * tt : 0.0f, gy = nz ? vy * tt : 0.0f, gz = nz ? vz * tt : 0.0f;
+    const float c = (gx * b.x + gy * b.y) + gz * b.z;
+    value = in ? value - c : value;
+    ns += in ? 1 : 0;
+}
+
+// hrbfvalue over the gathered list, two neighbours per trip; the offsets of the next pair are fetched while the
+// current pair is evaluated.  list[n .. n+2] hold a valid dummy offset.
 __device__ __forceinline__ float hrbf_value(const PTexel *__restrict__ tile, const uint16_t *__restrict__ list, int n,
                                             f3 p, int &nsup)
 {
     float value = 0.0f;
     int ns = 0;
-    for (int k = 0; k < n; ++k) {
-        const PTexel *t = texel_at(tile, list[k * PNT]);
-        const float4 a = *reinterpret_cast<const float4 *>(&t->px);
-        const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
-        const float d2 = (vx * vx + vy * vy) + vz * vz;
-        if (a.w < d2) continue;
-        const float4 b = *reinterpret_cast<const float4 *>(&t->sx);
-        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
-        if (d2 != 0.0f) {
-            float r = hd_sqrtf(d2 * b.w);
-            float s = 1.0f - r;
-            float s3 = s * s * s;
-            float tt = -20.0f * s3 * b.w;
-            gx = vx * tt; gy = vy * tt; gz = vz * tt;
-        }
-        value -= (gx * b.x + gy * b.y) + gz * b.z;
-        ns++;
+    uint32_t o0 = list[0], o1 = list[PNT];
+    for (int k = 0; k < n; k += 2) {
+        const float4 a0 = lds4(tile, o0), b0 = lds4(tile, o0 + 16), a1 = lds4(tile, o1), b1 = lds4(tile, o1 + 16);
+        o0 = list[(k + 2) * PNT]; o1 = list[(k + 3) * PNT];
+        hrbf_value_term(a0, b0, p, true, value, ns);
+        hrbf_value_term(a1, b1, p, k + 1 < n, value, ns);
     }
     nsup = ns;
     return value;
@@ -103,9 +111,8 @@ __device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, con
 {
     float grx = 0.0f, gry = 0.0f, grz = 0.0f;
     for (int k = 0; k < n; ++k) {
-        const PTexel *tp = texel_at(tile, list[k * PNT]);
-        const float4 a = *reinterpret_cast<const float4 *>(&tp->px);
-        const float4 b = *reinterpret_cast<const float4 *>(&tp->sx);
+        const uint32_t o = list[k * PNT];
+        const float4 a = lds4(tile, o), b = lds4(tile, o + 16);
         const float sx = b.x, sy = b.y, sz = b.z;
         const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
         const float d2 = (vx * vx + vy * vy) + vz * vz;
@@ -133,6 +140,16 @@ __device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, con
     return mk3(grx, gry, grz);
 }
 
+// capacity of the per-thread neighbour list: once n exceeds maxn every later window column adds at most one
+// entry (15 columns can still follow), plus three dummy entries behind the list
+__host__ __device__ inline int predict_list_cap(int maxn)
+{
+    int c = maxn + 1 + 15;
+    if (c > 49) c = 49;
+    if (c < 1) c = 1;
+    return c + 3;
+}
+
 __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__restrict__ vertconf,
                                                       const float4 *__restrict__ normrad,
                                                       const float4 *__restrict__ colortime,
@@ -144,8 +161,8 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
                                                       uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw)
 {
     __shared__ PTexel tile[PTW * PTW];
-    __shared__ uint16_t s_list[49 * PNT];
     __shared__ uint32_t s_rowbits[PTW];
+    extern __shared__ uint16_t s_list[];   // predict_list_cap(maxn) x 256 entries
     const int W = cam.W, H = cam.H;
     const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
     const int tid = threadIdx.y * TB + threadIdx.x;
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     if (px >= W || py >= H) return;
     const int pi = py * W + px;
     const uint32_t lbase_bytes = (uint32_t)(((threadIdx.y + PR) * PTW + threadIdx.x + PR) * (int)sizeof(PTexel));
-    const uint16_t *list = s_list + tid;
+    uint16_t *list = s_list + tid;
 
     int n = 0;
     {
@@ -179,7 +196,8 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
 #pragma unroll
         for (int r = 0; r < 7; ++r) wrow[r] = s_rowbits[threadIdx.y + r] >> threadIdx.x;
         bool skip = false;
-        gather_ring<0>(wrow, (2 * win + 1) * (2 * win + 1), maxn, lbase_bytes, s_list + tid, n, skip);
+        gather_ring<0>(wrow, (2 * win + 1) * (2 * win + 1), maxn, lbase_bytes, list, n, skip);
+        list[n * PNT] = list[(n + 1) * PNT] = list[(n + 2) * PNT] = (uint16_t)lbase_bytes;   // dummies
     }
 
     const float x = (float)px + 0.5f, y = (float)py + 0.5f;
@@ -190,56 +208,59 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     {
         float pmin = 1000000.0f;
         for (int k = 0; k < n; ++k) {
-            const PTexel *t = texel_at(tile, list[k * PNT]);
-            float pj = hd_fabsf(dot3(mk3(t->px, t->py, t->pz), ray));
+            const float4 a = lds4(tile, list[k * PNT]);
+            float pj = hd_fabsf(dot3(mk3(a.x, a.y, a.z), ray));
             if (pj < pmin) { closest = scale3(ray, pj); pmin = pj; }
         }
     }
-    bool find_interval = false, found = false;
-    f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), p_temp = mk3(0, 0, 0), ntemp = mk3(0, 0, 0);
-    int nsup = 0;
-    if (n > minn) {
-        float v0 = hrbf_value(tile, list, n, closest, nsup);
-        if (nsup > minn) {
-            if (v0 > 0.0f) {
-                ep = closest;
-                bool sfound = false;
-                for (int i = 0; i < 25; ++i) {
-                    f3 p1 = sub3(ep, scale3(ray, 0.004f * (float)i));
-                    float v1 = hrbf_value(tile, list, n, p1, nsup);
-                    if (v1 < 0.0f) { sp = p1; sfound = true; break; }
-                }
-                if (sfound)
-                    for (int i = 1; i < 11; ++i) {
-                        f3 p2 = add3(sp, scale3(ray, 0.0004f * (float)i));
-                        float v2 = hrbf_value(tile, list, n, p2, nsup);
-                        if (v2 > 0.0f) { ep = p2; find_interval = true; break; }
-                    }
-            } else {
-                sp = closest;
-                bool efound = false;
-                for (int i = 0; i < 25; ++i) {
-                    f3 p1 = add3(sp, scale3(ray, 0.004f * (float)i));
-                    float v1 = hrbf_value(tile, list, n, p1, nsup);
-                    if (v1 > 0.0f) { ep = p1; efound = true; break; }
-                }
-                if (efound)
-                    for (int i = 1; i < 11; ++i) {
-                        f3 p2 = sub3(ep, scale3(ray, 0.0004f * (float)i));
-                        float v2 = hrbf_value(tile, list, n, p2, nsup);
-                        if (v2 < 0.0f) { sp = p2; find_interval = true; break; }
-                    }
-            }
+
+    // Ray march + bisection of predict_hrbf.frag:150-260 as one loop with a single evaluation site: every trip
+    // each live lane evaluates the implicit at the next sample of ITS OWN phase, so a wave needs
+    // max_lane(total samples) trips instead of sum_phase(max_lane(samples of the phase)).
+    //   phase 0: value at `closest`            phase 1: 25 steps of 4 mm away from it until the sign flips
+    //   phase 2: 10 steps of 0.4 mm back       phase 3: <= 10 bisections        phase 4: finished
+    // The first coarse sample (i = 0) is `closest` itself: its value is v0, which cannot flip the sign, so the
+    // march starts at i = 1.
+    bool found = false;
+    f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), p_temp = mk3(0, 0, 0), q = closest;
+    int phase = n > minn ? 0 : 4, it = 0;
+    bool pos = false;   // sign class of v0
+    while (phase != 4) {
+        int nsup;
+        const float v = hrbf_value(tile, list, n, q, nsup);
+        if (phase == 0) {
+            if (nsup > minn) {
+                pos = v > 0.0f;
+                if (pos) ep = closest; else sp = closest;
+                phase = 1; it = 1;
+                q = pos ? sub3(ep, scale3(ray, 0.004f * (float)it)) : add3(sp, scale3(ray, 0.004f * (float)it));
+            } else phase = 4;
+        } else if (phase == 1) {
+            if (pos ? v < 0.0f : v > 0.0f) {
+                if (pos) sp = q; else ep = q;
+                phase = 2; it = 1;
+                q = pos ? add3(sp, scale3(ray, 0.0004f * (float)it)) : sub3(ep, scale3(ray, 0.0004f * (float)it));
+            } else if (++it < 25) {
+                q = pos ? sub3(ep, scale3(ray, 0.004f * (float)it)) : add3(sp, scale3(ray, 0.004f * (float)it));
+            } else phase = 4;
+        } else if (phase == 2) {
+            if (pos ? v > 0.0f : v < 0.0f) {
+                if (pos) ep = q; else sp = q;
+                phase = 3; it = 0;
+            } else if (++it < 11) {
+                q = pos ? add3(sp, scale3(ray, 0.0004f * (float)it)) : sub3(ep, scale3(ray, 0.0004f * (float)it));
+            } else phase = 4;
+        } else {   // phase 3: v is the value at p_temp == q
+            if (hd_fabsf(v) < 0.00001f) { found = true; phase = 4; }
+            else { if (v < 0.0f) sp = p_temp; else ep = p_temp; ++it; }
         }
-    }
-    if (find_interval) {
-        for (int j = 0; j < 10; ++j) {
-            f3 step = sub3(ep, sp);
-            if (len3(step) < 0.00001f) { ntemp = hrbf_gradient(tile, list, n, p_temp); found = true; break; }
-            p_temp = add3(sp, scale3(step, 0.5f));
-            float f_temp = hrbf_value(tile, list, n, p_temp, nsup);
-            if (hd_fabsf(f_temp) < 0.00001f) { ntemp = hrbf_gradient(tile, list, n, p_temp); found = true; break; }
-            if (f_temp < 0.0f) sp = p_temp; else ep = p_temp;
+        if (phase == 3) {   // next bisection sample, or termination without a further evaluation
+            if (it >= 10) phase = 4;
+            else {
+                const f3 step = sub3(ep, sp);
+                if (len3(step) < 0.00001f) { found = true; phase = 4; }
+                else { p_temp = add3(sp, scale3(step, 0.5f)); q = p_temp; }
+            }
         }
     }
 
@@ -249,14 +270,15 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     float icpw = 0.0f, confidence = 0.0f, radius = 0.0f;
     uint32_t tm = 0;
     if (found) {
+        const f3 ntemp = hrbf_gradient(tile, list, n, p_temp);
         p_surface = p_temp;
         p_normal = normalize3(ntemp);
         float dsm = 1000000.0f;
         int best = -1;
         for (int k = 0; k < n; ++k) {
             const uint32_t off = list[k * PNT];
-            const PTexel *t = texel_at(tile, off);
-            float dx = p_surface.x - t->px, dy = p_surface.y - t->py, dz = p_surface.z - t->pz;
+            const float4 a = lds4(tile, off);
+            float dx = p_surface.x - a.x, dy = p_surface.y - a.y, dz = p_surface.z - a.z;
             float dist = hd_sqrtf((dx * dx + dy * dy) + dz * dz);
             if (dist < dsm) { dsm = dist; best = (int)off; }
         }
@@ -353,7 +375,8 @@ void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, 
                          float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw)
 {
     dim3 g((cam.W + TB - 1) / TB, (cam.H + TB - 1) / TB);
-    hipLaunchKernelGGL(k_predict_hrbf, g, dim3(TB, TB), 0, s, cam, vertconf, normrad, colortime, curvmax, curvmin, win,
+    const size_t list_bytes = (size_t)predict_list_cap(maxn) * PNT * sizeof(uint16_t);
+    hipLaunchKernelGGL(k_predict_hrbf, g, dim3(TB, TB), list_bytes, s, cam, vertconf, normrad, colortime, curvmax, curvmin, win,
                        minn, maxn, cthr, lambda, pr_image, pr_vertex, pr_normal, pr_curv1, pr_curv2, pr_time, pr_icpw);
 }
 

@@ -166,7 +166,8 @@ int hrbf_set_image(hrbf_handle h, int which, const void *in, size_t bytes); /* h
 
 /* per-region timings of the last frame in ms, named as the reference's Stopwatch regions
  * (Core/src/HRBFFusion.cpp:1016,1063,1196,1248): 0 Initialization 1 Registration 2 Integration 3 Prediction;
- * 4 = the fuse (clean+compact+append) streaming kernel alone.  Requires hrbf_enable_timing(h,1). */
+ * 4 = the fuse (clean+compact+append) streaming kernel alone.  Requires hrbf_enable_timing(h,1);
+ * hrbf_enable_timing(h,2) records only the two events per frame that feed hrbf_get_fuse_ring. */
 int hrbf_enable_timing(hrbf_handle h, int on);
 int hrbf_get_timings(hrbf_handle h, float out_ms[8]);
 /* ring of the last <= 1024 frames (timing enabled): duration in ms of the fuse streaming kernel alone
