@@ -37,10 +37,13 @@ struct OdoState {
     float last_icp_error, last_icp_count;
     float sigmaVal;
     unsigned int ticket;              // last-workgroup election of the fused reduce+solve kernels
+    unsigned int bar;                 // arrival counter of the grid barrier (persistent SO3 kernel)
+    int bar_timeout;                  // set if a barrier spin ran into its bound (never expected)
 };
 
 size_t odo_state_bytes() { return sizeof(OdoState); }
-size_t odo_slot_bytes() { return sizeof(long long) * (32 * 87 * 2 + 64 * 2 + 32 * 33); }
+#define SO3_ITERS 10
+size_t odo_slot_bytes() { return sizeof(long long) * (32 * 87 * 2 + 64 * 2 + SO3_ITERS * 32 * 33); }   // one SO3 slot set per iteration
 
 #define PLN(base, k, rows, cols, y, x) ((base)[((size_t)(k) * (rows) + (y)) * (cols) + (x)])
 
@@ -558,7 +561,8 @@ __device__ __forceinline__ double limbs_to_double(const long long *t, int i)
 }
 
 // ------------------------------------------------------------------------------------------ step operands
-__device__ inline void so3_set_operands(OdoState *st, float fx, float fy, float cx, float cy)
+template <class S>
+__device__ inline void so3_set_operands(S *st, float fx, float fy, float cx, float cy)
 {
     double K[9] = {0}, Kinv[9], KR[9], Hm[9];
     K[0] = fx / 4; K[4] = fy / 4; K[2] = cx / 4; K[5] = cy / 4; K[8] = 1;
@@ -608,7 +612,7 @@ __device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__
     st->so3_done = cfg.so3 ? 0 : 1;
     st->gn_break = 0;
     st->res_icp[0] = st->res_icp[1] = 0.0f;
-    st->ticket = 0u;
+    st->ticket = 0u; st->bar = 0u;
     if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
     if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
 }
@@ -617,9 +621,13 @@ __device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__
 // (in place), Sobel + back-projected cloud of the live frame; workgroup (0,0) also resets the registration state
 struct OdoLevels { OdoLevel lv[HRBF_NUM_PYRS]; };
 __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg, int do_rgb,
-                              int gn_level)
+                              int gn_level, long long *__restrict__ so3_sets)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) odo_begin_state(st, dp, cfg, gn_level);
+    if (blockIdx.y == 0) {   // the per-iteration SO3 slot sets start from zero every frame
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < SO3_ITERS * ODO_SLOTS * 33) so3_sets[t] = 0;
+    }
     const int level = blockIdx.y;
     const OdoLevel &L = all.lv[level];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -628,6 +636,41 @@ __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__rest
     if (do_rgb) {
         const int div = 1 << level;
         sobel_cloud_pixel(L, i, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+    }
+}
+
+// one SO3 step on folded totals (RGBDOdometry.cpp:551-640); S is OdoState or the LDS copy of the persistent kernel
+template <class S>
+__device__ inline void so3_step(S *st, const long long *s_tot, const OdoConfig &cfg)
+{
+    if (st->so3_done) return;
+    double s[11];
+    for (int i = 0; i < 11; ++i) s[i] = limbs_to_double(s_tot, i);
+    float jtj[9], jtr[3];
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            float value = (float)s[shift++];
+            if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+        }
+    float res0 = (float)s[9], res1 = (float)s[10];
+    float so3err = hd_sqrtf(res0) / res1, so3cnt = res1;
+    if (so3err < st->so3_lastError && st->so3_lastCount == so3cnt) st->so3_done = 1;
+    else if (so3err > st->so3_lastError + 0.001f) {
+        for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
+        st->so3_done = 1;
+    } else {
+        st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
+        for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
+        float delta[3];
+        ldlt_solve<float, 3>(jtj, jtr, delta);
+        double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
+        rodrigues(dd, rotU);
+        float rotUf[9], tmp[9];
+        for (int k = 0; k < 9; ++k) rotUf[k] = (float)rotU[k];
+        mul3<float>(rotUf, st->R_lr, tmp);
+        for (int k = 0; k < 9; ++k) { st->R_lr[k] = tmp[k]; st->resultR[k] = tmp[k]; }
+        so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
     }
 }
 
@@ -643,36 +686,7 @@ __device__ __forceinline__ void so3_solve_block(OdoState *st, long long *__restr
     else if (threadIdx.x < 33) s_tot[threadIdx.x] = totals[threadIdx.x];
     __syncthreads();
     if (threadIdx.x != 0) return;
-    if (!st->so3_done) {
-        double s[11];
-        for (int i = 0; i < 11; ++i) s[i] = limbs_to_double(s_tot, i);
-        float jtj[9], jtr[3];
-        int shift = 0;
-        for (int i = 0; i < 3; ++i)
-            for (int j = i; j < 4; ++j) {
-                float value = (float)s[shift++];
-                if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
-            }
-        float res0 = (float)s[9], res1 = (float)s[10];
-        float so3err = hd_sqrtf(res0) / res1, so3cnt = res1;
-        if (so3err < st->so3_lastError && st->so3_lastCount == so3cnt) st->so3_done = 1;
-        else if (so3err > st->so3_lastError + 0.001f) {
-            for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
-            st->so3_done = 1;
-        } else {
-            st->so3_lastError = so3err; st->so3_lastCount = so3cnt;
-            for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
-            float delta[3];
-            ldlt_solve<float, 3>(jtj, jtr, delta);
-            double dd[3] = {delta[0], delta[1], delta[2]}, rotU[9];
-            rodrigues(dd, rotU);
-            float rotUf[9], tmp[9];
-            for (int k = 0; k < 9; ++k) rotUf[k] = (float)rotU[k];
-            mul3<float>(rotUf, st->R_lr, tmp);
-            for (int k = 0; k < 9; ++k) { st->R_lr[k] = tmp[k]; st->resultR[k] = tmp[k]; }
-            so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
-        }
-    }
+    so3_step(st, s_tot, cfg);
     if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
 }
 
@@ -685,17 +699,13 @@ __global__ __launch_bounds__(RB) void k_so3_solve(OdoState *st, long long *__res
 }
 
 // ------------------------------------------------------------------------------------------ O2: SO3 pre-alignment
-__global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, OdoState *st, long long *__restrict__ part,
-                                                   long long *__restrict__ totals, OdoConfig cfg, int fused_solve,
-                                                   int gn_level)
+// one pixel of the SO3 photometric system (so3Step, reduce.cu:1102-1215): 3x4 upper products + residual + count
+template <class S>
+__device__ __forceinline__ bool so3_pixel(const OdoLevel &L, const S *st, int i, float (&row4)[11])
 {
     const int rows = L.rows, cols = L.cols;
-    const int i = blockIdx.x * RB + threadIdx.x;
-    float row4[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
     bool valid = false;
-    if (!st->so3_done && i < rows * cols) {
+    if (i < rows * cols) {
         const int y = i / cols, x = i - y * cols;
         const uint8_t *lastImage = L.last_next_image, *nextImage = L.next_image;
         f3 un = mk3((float)x, (float)y, 1.0f);
@@ -737,8 +747,100 @@ __global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, OdoState *st, lon
             }
         }
     }
+    return valid;
+}
+
+__global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, OdoState *st, long long *__restrict__ part,
+                                                   long long *__restrict__ totals, OdoConfig cfg, int fused_solve,
+                                                   int gn_level)
+{
+    const int i = blockIdx.x * RB + threadIdx.x;
+    float row4[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
+    const bool valid = !st->so3_done && so3_pixel(L, st, i, row4);
     block_reduce_exact<11>(row4, valid, part);
     if (fused_solve && elect_last_workgroup(&st->ticket)) so3_solve_block(st, part, totals, 2, cfg, gn_level);
+}
+
+// Grid barrier of the persistent SO3 kernel (its grid is launched only when it fits the device at once).  Data crosses
+// it only through agent-scope atomics (the slot rows), so no cache maintenance is needed: wave 0 — the wave that
+// issued this workgroup's slot atomics — waits until they are performed, arrives with one relaxed atomic and polls.
+// The poll is bounded: a barrier that cannot complete sets bar_timeout and lets the kernel finish with wrong
+// numbers instead of hanging the device.
+__device__ __forceinline__ void grid_barrier(unsigned int *ctr, unsigned int target, int *timeout_flag)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 18)) { *timeout_flag = 1; break; }
+        }
+    }
+    __syncthreads();
+}
+
+// LDS copy of the SO3 part of the state: every workgroup of the persistent kernel advances its own copy with the
+// same deterministic arithmetic, so nothing but the slot sums has to be exchanged
+struct So3Local {
+    double resultR[9], lastResultR[9];
+    float R_lr[9];
+    float so3_lastError, so3_lastCount;
+    int so3_done;
+    float basis[9], kinv[9], krlr[9];
+};
+
+// all SO3 iterations in one launch: per iteration products -> slot set `it` -> grid barrier -> every
+// workgroup folds the set and takes the step on its LDS copy.  Stops as soon as the alignment has converged
+// (the per-iteration launches had to be issued regardless).  Workgroup 0 publishes the final state.
+__global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st, long long *__restrict__ part,
+                                                       OdoConfig cfg, int gn_level)
+{
+    __shared__ So3Local S;
+    __shared__ long long s_tot[33];
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 9; ++k) {
+            S.resultR[k] = st->resultR[k]; S.lastResultR[k] = st->lastResultR[k]; S.R_lr[k] = st->R_lr[k];
+            S.basis[k] = st->basis[k]; S.kinv[k] = st->kinv[k]; S.krlr[k] = st->krlr[k];
+        }
+        S.so3_lastError = st->so3_lastError; S.so3_lastCount = st->so3_lastCount; S.so3_done = st->so3_done;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * RB + threadIdx.x;
+    for (int it = 0; it < SO3_ITERS; ++it) {
+        if (S.so3_done) break;                      // identical in every workgroup
+        long long *set = part + (size_t)it * ODO_SLOTS * 33;
+        float row4[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
+        const bool valid = so3_pixel(L, &S, i, row4);
+        block_reduce_exact<11>(row4, valid, set);
+        grid_barrier(&st->bar, (unsigned int)(it + 1) * gridDim.x, &st->bar_timeout);
+        if (threadIdx.x < 33) {
+            long long v[ODO_SLOTS];
+#pragma unroll
+            for (int b = 0; b < ODO_SLOTS; ++b)
+                v[b] = __hip_atomic_load(&set[b * 33 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long t = 0;
+#pragma unroll
+            for (int b = 0; b < ODO_SLOTS; ++b) t += v[b];
+            s_tot[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) so3_step(&S, s_tot, cfg);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 9; ++k) {
+            st->resultR[k] = S.resultR[k]; st->lastResultR[k] = S.lastResultR[k]; st->R_lr[k] = S.R_lr[k];
+            st->basis[k] = S.basis[k]; st->kinv[k] = S.kinv[k]; st->krlr[k] = S.krlr[k];
+        }
+        st->so3_lastError = S.so3_lastError; st->so3_lastCount = S.so3_lastCount; st->so3_done = S.so3_done;
+        if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ O3 + O4 fused launch
@@ -921,6 +1023,7 @@ __device__ inline void odo_end_state(OdoState *st, DevPose *dp, const OdoConfig 
             for (int k = 0; k < 3; ++k) st->tcurr[k] = st->tprev[k];
         }
     }
+    if (st->bar_timeout) st->tcurr[0] = hd_nanf();   // a grid barrier gave up: make the failure impossible to miss
     for (int k = 0; k < 9; ++k) dp->pose.r[k] = st->Rcurr[k];
     for (int k = 0; k < 3; ++k) dp->pose.t[k] = st->tcurr[k];
     dp->tinv = rigid_inverse(dp->pose);
@@ -1229,15 +1332,31 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         OdoLevels all;
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) all.lv[i] = ob.lv[i];
         hipLaunchKernelGGL(k_odo_prepare, dim3((P + 255) / 256, HRBF_NUM_PYRS), dim3(256), 0, s, all, ob.state, dp, cfg, rgb,
-                           cfg.so3 ? -1 : gn_level);
+                           cfg.so3 ? -1 : gn_level, ob.so3_part);
     }
-    // O2: SO3 pre-alignment on level 2; the last workgroup of every launch takes the step
+    // O2: SO3 pre-alignment on level 2: one persistent launch for all iterations when its grid fits the device at
+    // once (75 workgroups at VGA against 256 CUs; the stream is in-order, so nothing else is resident), else one
+    // launch per iteration whose last workgroup takes the step.  A plain launch on purpose:
+    // hipLaunchCooperativeKernel serialises against the whole device and cost 30 frames/s in the benchmark; the
+    // barrier polls are bounded, so a placement surprise cannot hang the GPU (it poisons the pose instead).
     if (cfg.so3) {
         const OdoLevel &L = ob.lv[2];
         const int nb = (L.rows * L.cols + RB - 1) / RB;
-        for (int it = 0; it < 10; ++it)
-            hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, ob.totals + 176, cfg, 1,
-                               it == 9 ? gn_level : -1);
+        static long long capacity = -1;   // co-resident workgroups of the persistent kernel, probed once
+        if (capacity < 0) {
+            int dev = 0, per_cu = 0;
+            hipDeviceProp_t prop;
+            hipGetDevice(&dev);
+            hipGetDeviceProperties(&prop, dev);
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_so3_persistent, RB, 0);
+            capacity = per_cu > 0 ? (long long)per_cu * prop.multiProcessorCount : 0;
+        }
+        if (2 * (long long)nb <= capacity)   // at most half of the slots: no dependence on the placement policy
+            hipLaunchKernelGGL(k_so3_persistent, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, cfg, gn_level);
+        else
+            for (int it = 0; it < SO3_ITERS; ++it)
+                hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, ob.totals + 176, cfg, 1,
+                                   it == SO3_ITERS - 1 ? gn_level : -1);
     }
     // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration
     const float minGrad[3] = {5, 3, 1};
