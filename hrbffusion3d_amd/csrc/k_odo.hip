@@ -572,7 +572,8 @@ __device__ inline void so3_set_operands(S *st, float fx, float fy, float cx, flo
     for (int k = 0; k < 9; ++k) { st->basis[k] = (float)Hm[k]; st->kinv[k] = (float)Kinv[k]; st->krlr[k] = (float)KR[k]; }
 }
 
-__device__ inline void gn_set_operands(OdoState *st, float fxl, float fyl, float cxl, float cyl)
+template <class S>
+__device__ inline void gn_set_operands(S *st, float fxl, float fyl, float cxl, float cyl)
 {
     double K[9] = {0}, Kinv[9];
     K[0] = fxl; K[4] = fyl; K[2] = cxl; K[5] = cyl; K[8] = 1;
@@ -925,16 +926,16 @@ __device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, 
     return true;
 }
 
-// RGBResidual::getProducts (reduce.cu:981-1060)
-__device__ __forceinline__ void rgb_residual_pixel(const OdoLevel &L, const OdoState *st, float minScale, int k,
-                                                   int16_t *__restrict__ corres, float *__restrict__ corres_diff,
-                                                   long long &cnt, long long &sig)
+// RGBResidual::getProducts (reduce.cu:981-1060).  The correspondence (u0, v0, x, y, valid) and the intensity
+// difference are returned in registers; the multi-launch path parks them in corres / corres_diff.
+struct RgbCorr { int16_t c0, c1, c2, c3, c4; float diff; };
+template <class S>
+__device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S *st, float minScale, int k,
+                                                      long long &cnt, long long &sig)
 {
     const int rows = L.rows, cols = L.cols;
     const int i = k / cols, j0 = k - i * cols;
-    int16_t *co = &corres[(size_t)k * 6];
-    int16_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-    float dout = 0.0f;
+    RgbCorr r; r.c0 = r.c1 = r.c2 = r.c3 = r.c4 = 0; r.diff = 0.0f;
     if (j0 < cols - 5 && i < rows - 1) {
         bool valid = true;
         for (int u = (i - 2 > 0 ? i - 2 : 0); u < (i + 2 < rows ? i + 2 : rows); ++u)
@@ -957,8 +958,8 @@ __device__ __forceinline__ void rgb_residual_pixel(const OdoLevel &L, const OdoS
                             float d0 = L.last_depth[v0 * cols + u0];
                             if (d0 > 0.0f && hd_fabsf(td1 - d0) <= 0.07f && L.last_image[v0 * cols + u0] != 0) {
                                 float diff = (float)L.next_image[y * cols + x] - (float)L.last_image[v0 * cols + u0];
-                                c0 = (int16_t)u0; c1 = (int16_t)v0; c2 = (int16_t)x; c3 = (int16_t)y; c4 = 1;
-                                dout = diff;
+                                r.c0 = (int16_t)u0; r.c1 = (int16_t)v0; r.c2 = (int16_t)x; r.c3 = (int16_t)y; r.c4 = 1;
+                                r.diff = diff;
                                 cnt += 1;
                                 sig += (long long)(diff * diff);
                             }
@@ -968,8 +969,45 @@ __device__ __forceinline__ void rgb_residual_pixel(const OdoLevel &L, const OdoS
             }
         }
     }
-    co[0] = c0; co[1] = c1; co[2] = c2; co[3] = c3; co[4] = c4; co[5] = 0;
-    corres_diff[k] = dout;
+    return r;
+}
+
+// RGBReduction::getProducts (reduce.cu:717-808) for one correspondence
+__device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbCorr &co, float sigma, float fx, float fy,
+                                                   int use_grad, float (&out)[29])
+{
+    if (!co.c4) return false;
+    const int cols = L.cols;
+    float diff = co.diff;
+    float w = sigma + hd_fabsf(diff);
+    w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
+    if (sigma == -1.0f) w = 1.0f;
+    float row[7];
+    row[6] = -w * diff;
+    const float *cpp = &L.cloud[((size_t)co.c1 * cols + co.c0) * 3];
+    const float cpx = cpp[0], cpy = cpp[1], cpz = cpp[2];
+    float invz = 1.0f / cpz;
+    float dIx = w * 0.125f * (float)L.dIdx[co.c3 * cols + co.c2];
+    float dIy = w * 0.125f * (float)L.dIdy[co.c3 * cols + co.c2];
+    float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
+    float v2 = -(v0 * cpx + v1 * cpy) * invz;
+    row[0] = v0; row[1] = v1; row[2] = v2;
+    row[3] = -cpz * v1 + cpy * v2;
+    row[4] = cpz * v0 - cpx * v2;
+    row[5] = -cpy * v0 + cpx * v1;
+    float rw = 1.0f;
+    if (use_grad) {
+        float gm = hd_sqrtf(dIx * dIx + dIy * dIy);
+        rw = hd_expf(-0.5f * (10.0f / gm) * (10.0f / gm));
+    }
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 7; ++j) out[q++] = rw * row[i] * row[j];
+    out[27] = rw * row[6] * row[6];
+    out[28] = 1.0f;
+    return true;
 }
 
 // blocks [0, nb) : ICP products ; blocks [nb, 2nb) : RGB residual.  Both read the same OdoState.
@@ -996,8 +1034,12 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
         const int b = blockIdx.x - nb;
         const int k = b * RB + threadIdx.x;
         long long cnt = 0, sig = 0;
-        if (do_rgb && !st->gn_break && k < L.rows * L.cols)
-            rgb_residual_pixel(L, st, minScale, k, corres, corres_diff, cnt, sig);
+        if (do_rgb && !st->gn_break && k < L.rows * L.cols) {
+            const RgbCorr r = rgb_residual_pixel(L, st, minScale, k, cnt, sig);
+            int16_t *co = &corres[(size_t)k * 6];
+            co[0] = r.c0; co[1] = r.c1; co[2] = r.c2; co[3] = r.c3; co[4] = r.c4; co[5] = 0;
+            corres_diff[k] = r.diff;
+        }
         for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
         if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
         __syncthreads();
@@ -1031,28 +1073,18 @@ __device__ inline void odo_end_state(OdoState *st, DevPose *dp, const OdoConfig 
     dp->last_icp_count = st->last_icp_count;
 }
 
-// solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93); also prepares the
-// operands of the next iteration (possibly on the next pyramid level).  res_c / res_s: the folded RGB residual
-// (count, sigma).
-// dp != null marks the last iteration of the registration: the pose is published.
-__device__ __forceinline__ void gn_solve_block(OdoState *st, long long *__restrict__ icp_part,
-                                               long long *__restrict__ rgb_part, long long *__restrict__ res_part,
-                                               long long *__restrict__ totals, int do_reduce, long long res_c,
-                                               long long res_s, const OdoConfig &cfg, int next_level, int level_changes,
-                                               DevPose *dp)
+// solve + SE3 update (RGBDOdometry.cpp:1162-1204, OdometryProvider.h:73-93) from the folded limb totals in
+// s_tot (LDS, icp 0..86 | rgb 87..173); also prepares the operands of the next iteration (possibly on the next
+// pyramid level).  res_c / res_s: the folded RGB residual (count, sigma).  Whole workgroup; S is OdoState or the
+// LDS copy of the persistent kernel.  dp != null marks the last iteration of the registration: the pose is
+// published (only meaningful when S is the global state).
+template <class S>
+__device__ __forceinline__ void gn_step_from_totals(S *st, const long long *s_tot, long long res_c, long long res_s,
+                                                    const OdoConfig &cfg, int next_level, int level_changes)
 {
-    // icp_part and rgb_part are adjacent (OdoBuffers): 32 slot rows x (87 + 87) limbs
-    __shared__ long long s_tot[176];
     __shared__ double s_val[58];
     __shared__ double s_A[36], s_b[6];
     const int tid = threadIdx.x;
-    if (do_reduce) {
-        fold_slots<false, 4>(icp_part, rgb_part, 87, s_tot, totals);   // launched with 1024 threads
-        for (int t = tid; t < RES_SLOTS * 2; t += blockDim.x) res_part[t] = 0;
-    } else {
-        for (int t = tid; t < 174; t += blockDim.x) s_tot[t] = totals[t];
-    }
-    __syncthreads();
     const int rgbOnly = cfg.rgb_only;
     const int icp = !rgbOnly && cfg.icp_weight > 0.0f;
     const int rgb = rgbOnly || cfg.icp_weight < 100.0f;
@@ -1070,65 +1102,85 @@ __device__ __forceinline__ void gn_solve_block(OdoState *st, long long *__restri
         if (tid < 36) s_A[tid] = v; else s_b[tid - 36] = v;
     }
     __syncthreads();
-    if (tid != 0) return;
-    const long long c = res_c, sg = res_s;
-    if (rgb) {
-        float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
-        if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
-        if (!st->gn_break) st->lastRGBError = rgbError;
-    }
-    if (!st->gn_break) {
-        if (icp) { st->res_icp[0] = (float)s_val[27]; st->res_icp[1] = (float)s_val[28]; }
-        st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
-        st->last_icp_count = st->res_icp[1];
-        double lastA[36], lastb[6], result[6];
+    if (tid == 0) {
+        const long long c = res_c, sg = res_s;
+        if (rgb) {
+            float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
+            if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
+            if (!st->gn_break) st->lastRGBError = rgbError;
+        }
+        if (!st->gn_break) {
+            if (icp) { st->res_icp[0] = (float)s_val[27]; st->res_icp[1] = (float)s_val[28]; }
+            st->last_icp_error = hd_sqrtf(st->res_icp[0]) / st->res_icp[1];
+            st->last_icp_count = st->res_icp[1];
+            double lastA[36], lastb[6], result[6];
 #pragma unroll
-        for (int k = 0; k < 36; ++k) lastA[k] = s_A[k];
+            for (int k = 0; k < 36; ++k) lastA[k] = s_A[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) lastb[k] = s_b[k];
-        ldlt_solve<double, 6>(lastA, lastb, result);
-        double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
-        rodrigues(rv, Ru);
-        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
-        U[12] = U[13] = U[14] = 0; U[15] = 1;
-        double *Rt = st->Rt;
-        for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k)
-            N[r * 4 + k] = ((U[r * 4] * Rt[k] + U[r * 4 + 1] * Rt[4 + k]) + U[r * 4 + 2] * Rt[8 + k]) + U[r * 4 + 3] * Rt[12 + k];
-        for (int k = 0; k < 16; ++k) Rt[k] = N[k];
-        float oR[9], ot[3];
-        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }
-        float iR[9], it_[3];
-        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[k * 3 + r];
-        for (int r = 0; r < 3; ++r) it_[r] = -((iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1]) + iR[r * 3 + 2] * ot[2]);
-        float Rc[9];
-        mul3<float>(st->Rprev, iR, Rc);
-        for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rc[k];
-        f3 rt = m33_mul(st->Rprev, mk3(it_[0], it_[1], it_[2]));
-        st->tcurr[0] = rt.x + st->tprev[0]; st->tcurr[1] = rt.y + st->tprev[1]; st->tcurr[2] = rt.z + st->tprev[2];
+            for (int k = 0; k < 6; ++k) lastb[k] = s_b[k];
+            ldlt_solve<double, 6>(lastA, lastb, result);
+            double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
+            rodrigues(rv, Ru);
+            for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
+            U[12] = U[13] = U[14] = 0; U[15] = 1;
+            double *Rt = st->Rt;
+            for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k)
+                N[r * 4 + k] = ((U[r * 4] * Rt[k] + U[r * 4 + 1] * Rt[4 + k]) + U[r * 4 + 2] * Rt[8 + k]) + U[r * 4 + 3] * Rt[12 + k];
+            for (int k = 0; k < 16; ++k) Rt[k] = N[k];
+            float oR[9], ot[3];
+            for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }
+            float iR[9], it_[3];
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[k * 3 + r];
+            for (int r = 0; r < 3; ++r) it_[r] = -((iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1]) + iR[r * 3 + 2] * ot[2]);
+            float Rc[9];
+            mul3<float>(st->Rprev, iR, Rc);
+            for (int k = 0; k < 9; ++k) st->Rcurr[k] = Rc[k];
+            f3 rt = m33_mul(st->Rprev, mk3(it_[0], it_[1], it_[2]));
+            st->tcurr[0] = rt.x + st->tprev[0]; st->tcurr[1] = rt.y + st->tprev[1]; st->tcurr[2] = rt.z + st->tprev[2];
+        }
+        if (level_changes) { st->gn_break = 0; st->lastRGBError = 3.402823466e+38f; }
+        if (next_level >= 0) {
+            const int div = 1 << next_level;
+            gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+        }
     }
-    if (level_changes) { st->gn_break = 0; st->lastRGBError = 3.402823466e+38f; }
-    if (next_level >= 0) {
-        const int div = 1 << next_level;
-        gn_set_operands(st, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
-    }
-    if (dp) odo_end_state(st, dp, cfg);
+    __syncthreads();
 }
 
-// RGBReduction::getProducts (reduce.cu:717-808); every workgroup first folds the residual partials
-// into (count, sigma) and derives sigmaVal (RGBDOdometry.cpp:1017-1030)
-__global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *__restrict__ st, int nb, float fx,
-                                                    float fy, int rgb_only, int use_grad,
-                                                    const long long *__restrict__ res_part,
-                                                    const int16_t *__restrict__ corres,
-                                                    const float *__restrict__ corres_diff, long long *__restrict__ rgb_part,
-                                                    long long *__restrict__ totals)
+// multi-launch path: fold the slot rows (or take totals that were summed elsewhere), then the step
+__device__ __forceinline__ void gn_solve_block(OdoState *st, long long *__restrict__ icp_part,
+                                               long long *__restrict__ rgb_part, long long *__restrict__ res_part,
+                                               long long *__restrict__ totals, int do_reduce, long long res_c,
+                                               long long res_s, const OdoConfig &cfg, int next_level, int level_changes,
+                                               DevPose *dp)
+{
+    // icp_part and rgb_part are adjacent (OdoBuffers): 32 slot rows x (87 + 87) limbs
+    __shared__ long long s_tot[176];
+    const int tid = threadIdx.x;
+    if (do_reduce) {
+        fold_slots<false, 4>(icp_part, rgb_part, 87, s_tot, totals);   // launched with 1024 threads
+        for (int t = tid; t < RES_SLOTS * 2; t += blockDim.x) res_part[t] = 0;
+    } else {
+        for (int t = tid; t < 174; t += blockDim.x) s_tot[t] = totals[t];
+    }
+    __syncthreads();
+    gn_step_from_totals(st, s_tot, res_c, res_s, cfg, next_level, level_changes);
+    if (tid == 0 && dp) odo_end_state(st, dp, cfg);
+}
+
+// every workgroup folds the residual slots into (count, sigma) and derives sigmaVal (RGBDOdometry.cpp:1017-1030)
+template <bool IN_LAUNCH>
+__device__ __forceinline__ void fold_residual(const long long *__restrict__ res_part, int gn_break, float lastRGBError,
+                                              int rgb_only, float *s_sigma, int *s_break, long long *s_res)
 {
     __shared__ long long s_c[RB / 64], s_s[RB / 64];
-    __shared__ float s_sigma;
-    __shared__ int s_break;
     long long cnt = 0, sig = 0;
-    (void)nb;
-    for (int b = threadIdx.x; b < RES_SLOTS; b += RB) { cnt += res_part[b * 2]; sig += res_part[b * 2 + 1]; }
+    for (int b = threadIdx.x; b < RES_SLOTS; b += RB) {
+        if (IN_LAUNCH) {
+            cnt += __hip_atomic_load(&res_part[b * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sig += __hip_atomic_load(&res_part[b * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { cnt += res_part[b * 2]; sig += res_part[b * 2 + 1]; }
+    }
     for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
     if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
     __syncthreads();
@@ -1137,13 +1189,28 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
         for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
         float sigmaVal = hd_sqrtf((((float)s / (float)c) == 0.0f) ? 1.0f : (float)c);
         float rgbError = (float)(hd_sqrt((double)s) / (double)(c == 0 ? 1 : c));
-        int brk = st->gn_break;
-        if (rgb_only && rgbError > st->lastRGBError) brk = 1;
+        int brk = gn_break;
+        if (rgb_only && rgbError > lastRGBError) brk = 1;
         if (rgb_only) sigmaVal = -1.0f;
-        s_sigma = sigmaVal; s_break = brk;
-        if (blockIdx.x == 0) { totals[174] = c; totals[175] = s; }
+        *s_sigma = sigmaVal; *s_break = brk;
+        s_res[0] = c; s_res[1] = s;
     }
     __syncthreads();
+}
+
+// RGBReduction::getProducts (reduce.cu:717-808) over the correspondences k_gn_icp_residual parked in corres
+__global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *__restrict__ st, int nb, float fx,
+                                                    float fy, int rgb_only, int use_grad,
+                                                    const long long *__restrict__ res_part,
+                                                    const int16_t *__restrict__ corres,
+                                                    const float *__restrict__ corres_diff, long long *__restrict__ rgb_part,
+                                                    long long *__restrict__ totals)
+{
+    __shared__ float s_sigma;
+    __shared__ int s_break;
+    __shared__ long long s_res[2];
+    fold_residual<false>(res_part, st->gn_break, st->lastRGBError, rgb_only, &s_sigma, &s_break, s_res);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[174] = s_res[0]; totals[175] = s_res[1]; }
     const float sigma = s_sigma;
     const int brk = s_break;
     float out[29];
@@ -1151,41 +1218,10 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
     for (int k = 0; k < 29; ++k) out[k] = 0.0f;
     bool valid = false;
     const int k = blockIdx.x * RB + threadIdx.x;
-    const int cols = L.cols;
-    if (!brk && k < L.rows * cols) {
+    if (!brk && k < L.rows * L.cols) {
         const int16_t *co = &corres[(size_t)k * 6];
-        if (co[4]) {
-            valid = true;
-            float diff = corres_diff[k];
-            float w = sigma + hd_fabsf(diff);
-            w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
-            if (sigma == -1.0f) w = 1.0f;
-            float row[7];
-            row[6] = -w * diff;
-            const float *cpp = &L.cloud[((size_t)co[1] * cols + co[0]) * 3];
-            const float cpx = cpp[0], cpy = cpp[1], cpz = cpp[2];
-            float invz = 1.0f / cpz;
-            float dIx = w * 0.125f * (float)L.dIdx[co[3] * cols + co[2]];
-            float dIy = w * 0.125f * (float)L.dIdy[co[3] * cols + co[2]];
-            float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
-            float v2 = -(v0 * cpx + v1 * cpy) * invz;
-            row[0] = v0; row[1] = v1; row[2] = v2;
-            row[3] = -cpz * v1 + cpy * v2;
-            row[4] = cpz * v0 - cpx * v2;
-            row[5] = -cpy * v0 + cpx * v1;
-            float rw = 1.0f;
-            if (use_grad) {
-                float gm = hd_sqrtf(dIx * dIx + dIy * dIy);
-                rw = hd_expf(-0.5f * (10.0f / gm) * (10.0f / gm));
-            }
-            int q = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = i; j < 7; ++j) out[q++] = rw * row[i] * row[j];
-            out[27] = rw * row[6] * row[6];
-            out[28] = 1.0f;
-        }
+        RgbCorr r; r.c0 = co[0]; r.c1 = co[1]; r.c2 = co[2]; r.c3 = co[3]; r.c4 = co[4]; r.diff = corres_diff[k];
+        valid = rgb_products_pixel(L, r, sigma, fx, fy, use_grad, out);
     }
     block_reduce_exact<29>(out, valid, rgb_part);
 }
