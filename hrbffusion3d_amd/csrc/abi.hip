@@ -75,6 +75,7 @@ struct hrbf_context {
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
     float4 *d_clean_tex;        // 2 x float4 per pixel: packed index-map texels for the clean test
     DevPose *d_pose;
+    int fill_flag_fresh;        // DevPose::should_fill_in was computed by the last k_fillin (nothing touched the prediction since)
     OdoBuffers odo;
     // timing
     int timing; hipEvent_t ev[12]; float timings[8];
@@ -345,25 +346,29 @@ static void st_clean(hrbf_context *c)
 }
 static void st_predict(hrbf_context *c)
 {
+    c->fill_flag_fresh = 0;
     launch_predict_hrbf(c->stream, c->cam, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax,
                         c->d_im_curvmin, (int)c->prm.predict_window_multiplier, c->prm.predict_min_neighbors,
                         c->prm.predict_max_neighbors, c->prm.predict_conf_threshold, c->prm.icp_curv_weight_lambda,
                         c->d_pr_image, c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_time,
                         c->d_pr_icpw);
 }
-static void st_fillin(hrbf_context *c)
+static void st_fillin(hrbf_context *c, bool end_of_frame = false)
 {
     launch_fillin(c->stream, c->P, c->prm.curv_valid_threshold, c->prm.icp_curv_weight_lambda, c->prm.frame_to_frame_rgb,
                   c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_icpw, c->d_pr_image,
                   c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_fi_vertex,
-                  c->d_fi_normal, c->d_fi_curv1, c->d_fi_curv2, c->d_fi_icpw, c->d_fi_image);
+                  c->d_fi_normal, c->d_fi_curv1, c->d_fi_curv2, c->d_fi_icpw, c->d_fi_image, c->cam,
+                  c->prm.dense_enough_thresh, end_of_frame ? c->d_pose : nullptr);
+    c->fill_flag_fresh = end_of_frame ? 1 : 0;
 }
-static void st_odometry(hrbf_context *c)
+static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
 {
-    launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
+    if (!c->fill_flag_fresh)
+        launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
     OdoSources src = make_sources(c);
     OdoConfig cfg = make_cfg(c);
-    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, nullptr, 0, 1);
+    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, nullptr, 0, 1, weight_multiplier);
 }
 
 #define TIMER(i) do { if (c->timing & 1) hipEventRecord(c->ev[i], c->stream); } while (0)
@@ -379,9 +384,10 @@ static int process_frame_resident(hrbf_context *c, float wmul)
         st_init(c);
         TIMER(2); TIMER(3); TIMER(4); TIMER(5); TIMER(6);
     } else {
-        if (!c->prm.load_trajectory) st_odometry(c);
+        const bool fused_weighting = !c->prm.load_trajectory && wmul >= 0.0f;   // the last solve also sets the weighting
+        if (!c->prm.load_trajectory) st_odometry(c, fused_weighting ? wmul : -1.0f);
+        if (!fused_weighting) launch_frame_epilogue(c->stream, c->d_pose, wmul, 1);
         TIMER(2);
-        launch_frame_epilogue(c->stream, c->d_pose, wmul, 1);
         st_conf(c);
         if (!c->prm.rgb_only) {
             st_indices(c, false);
@@ -398,8 +404,7 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     TIMER(7);
     st_predict(c);
     TIMER(8);
-    st_fillin(c);
-    launch_pose_commit_prev(c->stream, c->d_pose);
+    st_fillin(c, true);   // + shouldFillIn of the next frame + lastPose <- currPose
     TIMER(9);
     request_count(c);
     c->tick++;
@@ -431,9 +436,13 @@ extern "C" int hrbf_process_frame_device(hrbf_handle c, const void *d_rgb, const
     (void)ts;
     if (!c || !d_rgb || !d_depth) { hrbf_set_error("null argument"); return HRBF_ERR_INVALID; }
     hipSetDevice(c->device);
-    HIP_CHECK(hipMemcpyAsync(c->d_rgb, d_rgb, (size_t)c->P * 3, hipMemcpyDeviceToDevice, c->stream));
-    HIP_CHECK(hipMemcpyAsync(c->d_depth, d_depth, (size_t)c->P * 2, hipMemcpyDeviceToDevice, c->stream));
-    return process_frame_resident(c, wmul);
+    // no staging copy: every launch of this frame reads the caller's buffers directly (see the header for the
+    // lifetime contract); the context's own input buffers serve the host-pointer entry and the stage API
+    uint8_t *own_rgb = c->d_rgb; uint16_t *own_depth = c->d_depth;
+    c->d_rgb = (uint8_t *)d_rgb; c->d_depth = (uint16_t *)d_depth;
+    const int r = process_frame_resident(c, wmul);
+    c->d_rgb = own_rgb; c->d_depth = own_depth;
+    return r;
 }
 
 extern "C" int hrbf_bootstrap(hrbf_handle c, const uint8_t *rgb, const uint16_t *depth)
@@ -443,8 +452,7 @@ extern "C" int hrbf_bootstrap(hrbf_handle c, const uint8_t *rgb, const uint16_t 
     st_filter(c); st_vnr(c); st_curv(c);
     launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
     st_conf(c);
-    st_indices(c); st_predict(c); st_fillin(c);
-    launch_pose_commit_prev(c->stream, c->d_pose);
+    st_indices(c); st_predict(c); st_fillin(c, true);
     c->tick = 2;
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return HRBF_OK;
@@ -648,6 +656,7 @@ extern "C" int hrbf_set_image(hrbf_handle c, int which, const void *in, size_t b
     size_t b; void *p = img_ptr(c, which, &b);
     if (!p || bytes < b) { hrbf_set_error("set_image(%d): bad id or buffer too small", which); return HRBF_ERR_INVALID; }
     hipSetDevice(c->device);
+    c->fill_flag_fresh = 0;
     HIP_CHECK(hipMemcpyAsync(p, in, b, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return HRBF_OK;

@@ -1054,6 +1054,8 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
     }
 }
 
+__device__ inline void frame_weighting_state(DevPose *dp, float weight_multiplier);   // defined with the pose kernels
+
 // end of registration: 0.3 m guard (RGBDOdometry.cpp:1232-1236), publish the pose
 __device__ inline void odo_end_state(OdoState *st, DevPose *dp, const OdoConfig &cfg)
 {
@@ -1230,17 +1232,20 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
 __global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
                                                    long long *__restrict__ rgb_part, long long *__restrict__ res_part,
                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
-                                                   int next_level, int level_changes, DevPose *dp)
+                                                   int next_level, int level_changes, DevPose *dp, float weight_multiplier)
 {
     gn_solve_block(st, icp_part, rgb_part, res_part, totals, do_reduce, totals[174], totals[175], cfg, next_level,
                    level_changes, dp);
+    // last iteration of the registration: the frame's velocity weighting rides along (no separate launch)
+    if (threadIdx.x == 0 && dp && weight_multiplier >= 0.0f) frame_weighting_state(dp, weight_multiplier);
 }
 
 // registration without any Gauss-Newton iteration configured: only the guard + publish
-__global__ void k_odo_end(OdoState *st, DevPose *dp, OdoConfig cfg)
+__global__ void k_odo_end(OdoState *st, DevPose *dp, OdoConfig cfg, float weight_multiplier)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     odo_end_state(st, dp, cfg);
+    if (weight_multiplier >= 0.0f) frame_weighting_state(dp, weight_multiplier);
 }
 
 // ------------------------------------------------------------------------------------------ pose bookkeeping
@@ -1285,9 +1290,15 @@ __device__ inline f3 rodrigues2(const float *R)
 }
 
 // velocity weighting (HRBFFusion.cpp:1112-1123): diff = currPose^-1 * lastPose
+__device__ inline void frame_weighting_state(DevPose *dp, float weight_multiplier);
 __global__ void k_frame_weighting(DevPose *dp, float weight_multiplier)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    frame_weighting_state(dp, weight_multiplier);
+}
+// velocity weighting of the frame (HRBFFusion.cpp:1112-1123)
+__device__ inline void frame_weighting_state(DevPose *dp, float weight_multiplier)
+{
     const Rigid inv = dp->tinv, last = dp->prev;
     float Rm[9];
     mul3<float>(inv.r, last.r, Rm);
@@ -1343,7 +1354,7 @@ static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
 }
 
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp, void *comm,
-                     int rank, int world)
+                     int rank, int world, float weight_multiplier)
 {
     (void)rank;
     const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
@@ -1420,10 +1431,10 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                                ob.totals);
             hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
                                ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0,
-                               last_of_all ? dp : (DevPose *)nullptr);
+                               last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
         }
     }
-    if (last_level < 0) hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg);
+    if (last_level < 0) hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg, weight_multiplier);
     if (cfg.so3)   // swap NextImage <-> lastNextImage (RGBDOdometry.cpp:1239-1245): pointer swap, no copy
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) { uint8_t *t = ob.lv[i].last_next_image; ob.lv[i].last_next_image = ob.lv[i].next_image; ob.lv[i].next_image = t; }
 }

@@ -306,6 +306,32 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
     pr_icpw[pi] = icpw;
 }
 
+// Resize::vertex + denseEnough: *flag = 1 when the 20x20-cell thumbnail of the predicted vertex map
+// is NOT dense enough (=> shouldFillIn, HRBFFusion.cpp:1069-1070).  Stays on the device.  One workgroup.
+__device__ __forceinline__ void should_fill_in_block(const Cam &cam, const float4 *__restrict__ pr_vertex, float thresh,
+                                                     int *flag)
+{
+    const int cs = 20;
+    const int w = cam.W / cs, h = cam.H / cs;
+    int sum = 0;
+    for (int c = threadIdx.x; c < w * h; c += blockDim.x) {
+        int i = c % w, j = c / w;
+        int sx = (int)hd_floorf(((float)i + 0.5f) * (float)cam.W / (float)w);
+        int sy = (int)hd_floorf(((float)j + 0.5f) * (float)cam.H / (float)h);
+        sum += pr_vertex[sy * cam.W + sx].z > 0.0f ? 1 : 0;
+    }
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+    __shared__ int ws[16];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += ws[k];
+        float per = (float)tot / (float)(w * h);
+        *flag = (per > thresh) ? 0 : 1;
+    }
+}
+
 // fill_vertex.frag:43-72, fill_normal.frag:36-49, fill_curvature.frag:35-51, fill_rgb.frag:29-37
 __global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb, const float4 *__restrict__ pr_vertex,
                          const float4 *__restrict__ pr_normal, const float4 *__restrict__ pr_curv1,
@@ -315,8 +341,15 @@ __global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb,
                          const float4 *__restrict__ curv2, const float *__restrict__ confidence,
                          const uint8_t *__restrict__ rgb, float4 *__restrict__ fi_vertex,
                          float4 *__restrict__ fi_normal, float4 *__restrict__ fi_curv1, float4 *__restrict__ fi_curv2,
-                         float *__restrict__ fi_icpw, uint8_t *__restrict__ fi_image)
+                         float *__restrict__ fi_icpw, uint8_t *__restrict__ fi_image, Cam cam, float dense_thresh,
+                         DevPose *dp /* nullable: end-of-frame bookkeeping rides along */)
 {
+    // end of frame: the next registration's shouldFillIn flag (Resize::vertex + denseEnough on the prediction
+    // this kernel reads anyway) and lastPose <- currPose; one workgroup, no separate launches
+    if (dp && blockIdx.x == 0) {
+        should_fill_in_block(cam, pr_vertex, dense_thresh, &dp->should_fill_in);
+        if (threadIdx.x == 0) dp->prev = dp->pose;
+    }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     float4 s = pr_vertex[i];
@@ -344,29 +377,9 @@ __global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb,
     reinterpret_cast<uchar4 *>(fi_image)[i] = e;
 }
 
-// Resize::vertex + denseEnough: *flag = 1 when the 20x20-cell thumbnail of the predicted vertex map
-// is NOT dense enough (=> shouldFillIn, HRBFFusion.cpp:1069-1070).  Stays on the device.
 __global__ void k_should_fill_in(Cam cam, const float4 *__restrict__ pr_vertex, float thresh, int *flag)
 {
-    const int cs = 20;
-    const int w = cam.W / cs, h = cam.H / cs;
-    int sum = 0;
-    for (int c = threadIdx.x; c < w * h; c += blockDim.x) {
-        int i = c % w, j = c / w;
-        int sx = (int)hd_floorf(((float)i + 0.5f) * (float)cam.W / (float)w);
-        int sy = (int)hd_floorf(((float)j + 0.5f) * (float)cam.H / (float)h);
-        sum += pr_vertex[sy * cam.W + sx].z > 0.0f ? 1 : 0;
-    }
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
-    __shared__ int ws[16];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += ws[k];
-        float per = (float)tot / (float)(w * h);
-        *flag = (per > thresh) ? 0 : 1;
-    }
+    should_fill_in_block(cam, pr_vertex, thresh, flag);
 }
 
 void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, const float4 *normrad,
@@ -384,11 +397,12 @@ void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const
                    const float4 *pr_normal, const float4 *pr_curv1, const float4 *pr_curv2, const float *pr_icpw,
                    const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
                    const float4 *curv2, const float *confidence, const uint8_t *rgb, float4 *fi_vertex,
-                   float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image)
+                   float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image,
+                   const Cam &cam, float dense_thresh, DevPose *dp_end_of_frame)
 {
     hipLaunchKernelGGL(k_fillin, dim3((P + 255) / 256), dim3(256), 0, s, P, thr, lambda, f2f, pr_vertex, pr_normal,
                        pr_curv1, pr_curv2, pr_icpw, pr_image, vertex_filtered, normal, curv1, curv2, confidence, rgb,
-                       fi_vertex, fi_normal, fi_curv1, fi_curv2, fi_icpw, fi_image);
+                       fi_vertex, fi_normal, fi_curv1, fi_curv2, fi_icpw, fi_image, cam, dense_thresh, dp_end_of_frame);
 }
 
 void launch_should_fill_in(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float thresh, int *flag)

@@ -60,7 +60,8 @@ void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const
                    const float4 *pr_normal, const float4 *pr_curv1, const float4 *pr_curv2, const float *pr_icpw,
                    const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
                    const float4 *curv2, const float *confidence, const uint8_t *rgb, float4 *fi_vertex,
-                   float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image);
+                   float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image,
+                   const Cam &cam, float dense_thresh, DevPose *dp_end_of_frame /* nullable */);
 void launch_should_fill_in(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float thresh, int *flag);
 
 // ---- k_odo.hip
@@ -107,8 +108,9 @@ size_t odo_state_bytes();
 size_t odo_slot_bytes();
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
 // full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
+// weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
-                     void *comm /* ncclComm_t or null */, int rank, int world);
+                     void *comm /* ncclComm_t or null */, int rank, int world, float weight_multiplier);
 // pose bookkeeping
 void launch_pose_set(hipStream_t s, DevPose *dp, const float pose16_colmajor[16], int also_prev);
 void launch_frame_epilogue(hipStream_t s, DevPose *dp, float weight_multiplier, int tracked);

@@ -99,7 +99,9 @@ const char *hrbf_version(void);
  * rgb: W*H*3 uint8 (R,G,B), depth: W*H uint16 raw units; host pointers borrowed for the call. */
 int hrbf_process_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth, int64_t timestamp,
                        float weight_multiplier);
-/* same, inputs already resident in HBM (device pointers) — what bench.py times */
+/* same, inputs already resident in HBM (device pointers) — what bench.py times.  The call only enqueues and the
+ * kernels read d_rgb / d_depth in place (no staging copy): keep both buffers valid and unchanged until
+ * hrbf_synchronize() or any blocking getter returns. */
 int hrbf_process_frame_device(hrbf_handle h, const void *d_rgb, const void *d_depth, int64_t timestamp,
                               float weight_multiplier);
 /* block until all work queued on the context's stream is complete */
