@@ -159,6 +159,16 @@ def main():
         tm = fus.timings()
     err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
 
+    # HBM traffic of the fuse pass: PMC counters cannot be collected from inside this process; the figure is the
+    # one measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) over this very command
+    # and committed with its calibration under profiles/ (null if the file is missing)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_fuse_traffic.json")) as f:
+            traffic = float(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        traffic = None
+
     if rank == 0:
         out = {
             "metric": "frames/sec at 640x480, 1M-surfel map, 1 MI355X",
@@ -174,7 +184,7 @@ def main():
                                                 "Integration": float(tm[2]), "Prediction": float(tm[3]),
                                                 "fuse_stream_pass": float(tm[4])}},
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                         "traffic": None, "kernel": "k_fuse_stream", "avg_kernel_ms": fuse_ms,
+                         "traffic": traffic, "kernel": "k_clean_flags + k_fuse_stream", "avg_kernel_ms": fuse_ms,
                          "bytes_per_launch": float(B[ok].mean()) if ok.any() else 0.0},
         }
         if args.cpu_frames > 0 and world == 1:
