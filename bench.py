@@ -145,6 +145,7 @@ def main():
     tm = np.zeros(8, np.float32)
     # PCIe-inclusive rate of the host-pointer entry point (never `value`): 1.5 MB upload + sync per frame
     pcie_fps = None
+    update_model = None
     if world == 1:
         nh = min(20, K)
         fus.enable_timing(False)
@@ -157,6 +158,19 @@ def main():
         fus.enable_timing(1)
         fus.process_frame_device(d_rgb[Wm + K].data_ptr(), d_dep[Wm + K].data_ptr(), Wm + K)
         tm = fus.timings()
+        fus.enable_timing(False)
+        # the caller-side map correction (GlobalModel::updateModel), after everything that is reported:
+        # wall time per call including the 64-byte matrix upload and its sync; the kernel alone is in profiles/
+        eye = np.eye(4, dtype=np.float32)[None]
+        fus.update_model(eye); fus.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(20):
+            fus.update_model(eye)
+        fus.synchronize()
+        um_ms = 1000.0 * (time.perf_counter() - t2) / 20
+        n_now = fus.surfel_count()
+        update_model = {"ms_per_call_incl_upload": um_ms, "surfels": int(n_now),
+                        "algorithmic_GBps_160B_per_surfel": 160.0 * n_now / (um_ms * 1e-3) / 1e9}
     err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
 
     # HBM traffic of the fuse pass: PMC counters cannot be collected from inside this process; the figure is the
@@ -180,6 +194,7 @@ def main():
                        "surfels_start": int(count0), "surfels_end": int(count1),
                        "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
                        "final_translation_error_mm": err_mm, "pcie_inclusive_fps": pcie_fps,
+                       "update_model": update_model,
                        "last_frame_region_ms": {"Initialization": float(tm[0]), "Registration": float(tm[1]),
                                                 "Integration": float(tm[2]), "Prediction": float(tm[3]),
                                                 "fuse_stream_pass": float(tm[4])}},

@@ -24,6 +24,7 @@ EXPORTS = [
     "hrbf_set_so3", "hrbf_set_frame_to_frame_rgb", "hrbf_set_confidence_threshold", "hrbf_set_depth_cutoff",
     "hrbf_image_bytes", "hrbf_get_image", "hrbf_set_image", "hrbf_enable_timing", "hrbf_get_timings",
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
+    "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
 
@@ -53,6 +54,8 @@ def load_library():
     lib.hrbf_synchronize.argtypes = [vp]
     lib.hrbf_get_pose.argtypes = [vp, vp]; lib.hrbf_set_pose.argtypes = [vp, vp]
     lib.hrbf_get_tick.argtypes = [vp]; lib.hrbf_set_tick.argtypes = [vp, i32]
+    lib.hrbf_set_index_submap.argtypes = [vp, i32]; lib.hrbf_set_active_submaps.argtypes = [vp, vp, i32]
+    lib.hrbf_update_model.argtypes = [vp, vp, i32]
     lib.hrbf_surfel_count.argtypes = [vp]; lib.hrbf_surfel_count.restype = C.c_uint32
     lib.hrbf_download_map.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_upload_map.argtypes = [vp, vp, C.c_size_t]
     lib.hrbf_last_icp.argtypes = [vp, vp, vp]; lib.hrbf_last_weighting.argtypes = [vp, vp]
@@ -149,6 +152,20 @@ class HRBFFusion:
 
     def set_weighting(self, w):
         self._check(self.lib.hrbf_set_weighting(self.h, w))
+
+    # submap bookkeeping + rigid map correction (GlobalModel::updateModel), SURVEY §8f-3
+    def set_index_submap(self, idx):
+        self._check(self.lib.hrbf_set_index_submap(self.h, int(idx)))
+
+    def set_active_submaps(self, active):
+        """byte mask indexed by submap id (IndexMap::lActiveKFID); None / empty = all active"""
+        a = np.ascontiguousarray(np.asarray([] if active is None else active, np.uint8))
+        self._check(self.lib.hrbf_set_active_submaps(self.h, _p(a) if a.size else None, int(a.size)))
+
+    def update_model(self, deltas):
+        """deltas: (n, 4, 4) row-major numpy matrices, one rigid correction per submap id"""
+        d = np.ascontiguousarray(np.asarray(deltas, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))   # -> column-major
+        self._check(self.lib.hrbf_update_model(self.h, _p(d), int(d.shape[0])))
 
     def get_weighting(self):
         w = C.c_float()

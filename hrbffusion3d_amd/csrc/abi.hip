@@ -75,6 +75,9 @@ struct hrbf_context {
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
     float4 *d_clean_tex;        // 2 x float4 per pixel: packed index-map texels for the clean test
     DevPose *d_pose;
+    int index_submap;           // submap id stamped on new surfels (HRBFFusion::indexSubmap)
+    uint8_t *d_submap_active; int n_submap_active;   // KeyFrameIDMap (null = all active)
+    float *d_delta; int delta_cap;                   // updateModel matrices
     int fill_flag_fresh;        // DevPose::should_fill_in was computed by the last k_fillin (nothing touched the prediction since)
     OdoBuffers odo;
     // timing
@@ -232,6 +235,8 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     if (c->ring_e0) for (int i = 0; i < HRBF_RING; ++i) { if (c->ring_e0[i]) hipEventDestroy(c->ring_e0[i]); if (c->ring_e1[i]) hipEventDestroy(c->ring_e1[i]); }
     free(c->ring_e0); free(c->ring_e1);
     if (c->d_stats_ring) hipFree(c->d_stats_ring);
+    if (c->d_submap_active) hipFree(c->d_submap_active);
+    if (c->d_delta) hipFree(c->d_delta);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
 }
@@ -315,11 +320,11 @@ static void st_indices(hrbf_context *c, bool for_clean = true)
     launch_predict_indices(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->map,
                            &c->d_count[c->target], c->count_ub, c->d_zbuf, c->d_idx, c->d_im_vertconf,
                            c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin,
-                           for_clean ? c->d_clean_tex : nullptr);
+                           for_clean ? c->d_clean_tex : nullptr, c->d_submap_active, c->n_submap_active);
 }
 static void st_fuse(hrbf_context *c)
 {
-    launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, 0, c->d_depth_metric, c->d_normal_pca,
+    launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, c->index_submap, c->d_depth_metric, c->d_normal_pca,
                 c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf, c->d_im_normrad, c->rec,
                 c->d_rec_flag, c->d_rec_best, c->d_slot, c->map, c->d_stats, c->prm.curv_valid_threshold);
     c->fuse_tick = c->tick;
@@ -331,7 +336,7 @@ static void st_clean(hrbf_context *c)
                  c->rec, c->d_rec_flag, &c->d_count[c->target], &c->d_count[1 - c->target],
                  c->count_ub, c->d_stats, c->cap, c->d_clean_tex, c->d_keep_flags,
                  c->d_tile_count, c->d_tile_done, c->max_tiles, c->timing ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
-                 c->timing ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr);
+                 c->timing ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active);
     if (c->timing) {
         hipMemcpyAsync(c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4, c->d_stats, sizeof(uint32_t) * 4,
                        hipMemcpyDeviceToDevice, c->stream);
@@ -706,6 +711,47 @@ extern "C" int hrbf_get_fuse_ring(hrbf_handle c, int max_frames, float *kernel_m
 }
 extern "C" int hrbf_reset_fuse_ring(hrbf_handle c) { if (!c) return -1; c->ring_head = 0; c->ring_valid = 0; return 0; }
 extern "C" int hrbf_set_load_trajectory(hrbf_handle c, int v) { if (!c) return HRBF_ERR_INVALID; c->prm.load_trajectory = v; return HRBF_OK; }
+
+// ---- the callers' side of the path: submap bookkeeping and the rigid map correction
+extern "C" int hrbf_set_index_submap(hrbf_handle c, int index)
+{
+    if (!c || index < 0) return HRBF_ERR_INVALID;
+    c->index_submap = index;
+    return HRBF_OK;
+}
+extern "C" int hrbf_set_active_submaps(hrbf_handle c, const uint8_t *active, int n)
+{
+    if (!c || n < 0 || (n > 0 && !active)) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_submap_active) { hipFree(c->d_submap_active); c->d_submap_active = nullptr; }
+    c->n_submap_active = 0;
+    if (n > 0) {
+        HIP_CHECK(hipMalloc((void **)&c->d_submap_active, (size_t)n));
+        HIP_CHECK(hipMemcpy(c->d_submap_active, active, (size_t)n, hipMemcpyHostToDevice));
+        c->n_submap_active = n;
+    }
+    return HRBF_OK;
+}
+extern "C" int hrbf_update_model(hrbf_handle c, const float *delta16_colmajor, int n)
+{
+    if (!c || n < 0 || (n > 0 && !delta16_colmajor)) { hrbf_set_error("update_model: bad arguments"); return HRBF_ERR_INVALID; }
+    if (n == 0) return HRBF_OK;
+    hipSetDevice(c->device);
+    if (n > c->delta_cap) {
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_delta) hipFree(c->d_delta);
+        c->d_delta = nullptr; c->delta_cap = 0;
+        HIP_CHECK(hipMalloc((void **)&c->d_delta, sizeof(float) * 16 * (size_t)n));
+        c->delta_cap = n;
+    }
+    HIP_CHECK(hipMemcpyAsync(c->d_delta, delta16_colmajor, sizeof(float) * 16 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));   // host matrices are borrowed only for the call
+    launch_update_model(c->stream, c->map, &c->d_count[c->target], c->count_ub, c->d_delta, n);
+    c->map_dirty = 1;   // positions moved: the next clean re-checks everything
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
 
 extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
 {

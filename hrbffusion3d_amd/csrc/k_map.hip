@@ -108,12 +108,18 @@ __global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
 
 __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restrict__ dp, float maxDepth, const float4 *__restrict__ pos,
                                                  const uint32_t *__restrict__ count,
-                                                 unsigned long long *__restrict__ zbuf)
+                                                 unsigned long long *__restrict__ zbuf,
+                                                 const float4 *__restrict__ color_time /* read only with a mask */,
+                                                 const uint8_t *__restrict__ submap_active /* nullable */, int n_active)
 {
     const uint32_t n = *count;
     const Rigid tinv = dp->tinv;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         float4 p = pos[s];
+        if (submap_active) {   // index_map.vert:41-45: surfels of inactive submaps are not drawn
+            const uint32_t sm = (uint32_t)color_time[s].y;
+            if (sm >= (uint32_t)n_active || submap_active[sm] == 0) continue;
+        }
         f3 h = xform(tinv, xyz(p));
         if (h.z > maxDepth || h.z < 0.0f) continue;
         float u = ((cam.fx * h.x) / h.z) + cam.cx;
@@ -322,6 +328,8 @@ struct CleanParams {
     int nw;        // samples per axis = 2 * clean_window_multiplier
     float w0;      // clean_window_multiplier * 0.5
     int full_check;
+    const uint8_t *submap_active;   // nullable: KeyFrameIDMap (copy_unstable.vert:98-101)
+    int n_active;
 };
 
 // window part of the test; returns false when the surfel must be dropped.
@@ -329,12 +337,18 @@ struct CleanParams {
 // some visited twice.  Each distinct texel is fetched once from the packed clean texture (2 x float4,
 // written by k_resolve) and its two predicates are counted with the multiplicity of the visit pattern.
 __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid &tinv, f3 lp, float x, float y,
-                                             float init_time, float4 vn, const float4 *__restrict__ clean_tex)
+                                             float init_time, float submap, float4 vn,
+                                             const float4 *__restrict__ clean_tex)
 {
     const Cam &cam = cp.cam;
     int count = 0, zCount = 0;
     f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
-    const bool nz_ok = hd_fabsf(ln.z) > 0.85f;
+    bool own_active = true;
+    if (cp.submap_active) {
+        const uint32_t sm = (uint32_t)submap;
+        own_active = sm < (uint32_t)cp.n_active && cp.submap_active[sm] != 0;
+    }
+    const bool nz_ok = hd_fabsf(ln.z) > 0.85f && own_active;
     const float rad14 = vn.w * 1.4f;
     const float ftime = (float)cp.time;
     if (cp.nw == 4) {
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
             if (need_ct) vc = is_surf ? m.p1[it] : rec.p1[q];
             if (inv) {
                 const float4 vn = is_surf ? m.p2[it] : rec.p2[q];
-                keep = clean_window(cp, tinv, lp, x, y, vc.z, vn, clean_tex);
+                keep = clean_window(cp, tinv, lp, x, y, vc.z, vc.y, vn, clean_tex);
             }
             if (!is_surf || cp.full_check || (need_ct && vc.w == ftime)) {
                 const float k1 = is_surf ? m.p3[it].w : rec.p3[q].w;
@@ -625,13 +639,14 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
 void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
                             const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
                             float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                            float4 *clean_tex)
+                            float4 *clean_tex, const uint8_t *submap_active, int n_active)
 {
     int P = cam.W * cam.H;
     uint32_t blocks = (count_ub + 255) / 256;   // zbuf is ZB_EMPTY on entry: launch_zbuf_reset once, k_resolve afterwards
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride the rest
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf);
+    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf, m.p1, submap_active,
+                       n_active);
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, zbuf, idx, vertconf, colortime,
                        normrad, curvmax, curvmin, clean_tex);
 }
@@ -655,12 +670,13 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
-                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1)
+                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     CleanParams cp;
     cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
     cp.nw = (int)(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
+    cp.submap_active = submap_active; cp.n_active = n_active;
     const uint32_t items_ub = count_ub + (uint32_t)Q;
     uint32_t tiles = (items_ub + FUSE_TILE - 1) / FUSE_TILE;
     if (tiles > max_tiles) tiles = max_tiles;
@@ -690,3 +706,38 @@ void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
 
 uint32_t fuse_tile_items() { return FUSE_TILE; }
 uint32_t fuse_tile_count_stride() { return TC_STRIDE; }
+
+// ------------------------------------------------------------------------------------------------
+// GlobalModel::updateModel (GlobalModel.cpp:690-767 -> update_delta_trans.vert:41-104): every surfel is moved by the
+// rigid correction of its submap.  In place on the SoA planes: the reference streams the whole 80-byte record through
+// transform feedback into the other buffer (160 B/surfel); here colour/time is read for the submap id and only the two
+// planes that change are rewritten (48 B read + 32 B written per surfel).  The <= 1200 matrices sit in L2 / K$.
+__global__ __launch_bounds__(256) void k_update_model(MapPlanes m, const uint32_t *__restrict__ count,
+                                                      const float *__restrict__ delta /* n x 16, column-major */, int n)
+{
+    const uint32_t N = *count;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < N; s += gridDim.x * blockDim.x) {
+        const uint32_t sm = (uint32_t)m.p1[s].y;
+        if (sm >= (uint32_t)n) continue;   // texels the reference never uploaded: left alone (oracle/orc_map.c)
+        const float *T = delta + (size_t)sm * 16;
+        const float4 p = m.p0[s], nr = m.p2[s];
+        float4 po, no;
+        po.x = ((T[0] * p.x + T[4] * p.y) + T[8] * p.z) + T[12] * 1.0f;
+        po.y = ((T[1] * p.x + T[5] * p.y) + T[9] * p.z) + T[13] * 1.0f;
+        po.z = ((T[2] * p.x + T[6] * p.y) + T[10] * p.z) + T[14] * 1.0f;
+        po.w = p.w;
+        no.x = (T[0] * nr.x + T[4] * nr.y) + T[8] * nr.z;
+        no.y = (T[1] * nr.x + T[5] * nr.y) + T[9] * nr.z;
+        no.z = (T[2] * nr.x + T[6] * nr.y) + T[10] * nr.z;
+        no.w = nr.w;
+        m.p0[s] = po; m.p2[s] = no;
+    }
+}
+
+void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta, int n)
+{
+    uint32_t blocks = (count_ub + 255) / 256;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_update_model, dim3(blocks), dim3(256), 0, s, m, count, delta, n);
+}

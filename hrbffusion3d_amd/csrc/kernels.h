@@ -34,7 +34,8 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
 void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
                             const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
                             float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                            float4 *clean_tex /* nullable: packed texels for the clean test */);
+                            float4 *clean_tex /* nullable: packed texels for the clean test */,
+                            const uint8_t *submap_active /* nullable: KeyFrameIDMap */, int n_active);
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
@@ -44,7 +45,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
-                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1);
+                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active);
+void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
 uint32_t fuse_tile_items();

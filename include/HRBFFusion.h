@@ -52,6 +52,17 @@ public:
         if (n && hrbf_download_map(h_, out, n) != HRBF_OK) { delete[] out; throw std::runtime_error(hrbf_last_error()); }
         return out;
     }
+    /* GlobalModel::updateModel (GlobalModel.cpp:690-767): DeltaTransformKF as n column-major 4x4 matrices
+       (Eigen::Matrix4f::data() of each element, back to back) */
+    void updateModel(const float *deltaTransformKF16, int n)
+    {
+        if (hrbf_update_model(h_, deltaTransformKF16, n) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
+    /* lActiveKFID as a byte mask indexed by submap id; n = 0: all active */
+    void setActiveSubmaps(const unsigned char *active, int n)
+    {
+        if (hrbf_set_active_submaps(h_, active, n) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
 private:
     hrbf_handle h_;
 };

@@ -166,6 +166,17 @@ size_t hrbf_image_bytes(hrbf_handle h, int which);
 int hrbf_get_image(hrbf_handle h, int which, void *out, size_t bytes);   /* device -> host */
 int hrbf_set_image(hrbf_handle h, int which, const void *in, size_t bytes); /* host -> device (tests) */
 
+/* submap bookkeeping and rigid map correction — the callers either side of the path.
+ * hrbf_set_index_submap: HRBFFusion::indexSubmap, the id stamped on surfels created from now on (data.vert).
+ * hrbf_set_active_submaps: IndexMap::lActiveKFID as a byte mask (IndexMap.cpp:222-237); surfels of inactive submaps
+ *   are not drawn into the index map (index_map.vert:41-45) and cannot cause free-space removals
+ *   (copy_unstable.vert:98-134).  n = 0 restores "all active".
+ * hrbf_update_model: GlobalModel::updateModel (GlobalModel.cpp:690-767, update_delta_trans.vert): n column-major 4x4
+ *   corrections, surfel <- delta[submap(surfel)] applied to position and normal; ids >= n are left unchanged. */
+int hrbf_set_index_submap(hrbf_handle h, int index);
+int hrbf_set_active_submaps(hrbf_handle h, const uint8_t *active, int n);
+int hrbf_update_model(hrbf_handle h, const float *delta16_colmajor, int n);
+
 /* per-region timings of the last frame in ms, named as the reference's Stopwatch regions
  * (Core/src/HRBFFusion.cpp:1016,1063,1196,1248): 0 Initialization 1 Registration 2 Integration 3 Prediction;
  * 4 = the fuse (clean+compact+append) streaming kernel alone.  Requires hrbf_enable_timing(h,1);

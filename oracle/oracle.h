@@ -39,6 +39,8 @@ typedef struct orc_ctx {
     float weighting;
     float last_icp_error, last_icp_count;
     int index_submap;
+    uint8_t *submap_active;   /* NULL = every submap active; else n_submap_active flags (IndexMap.cpp:222-237) */
+    int n_submap_active;
     /* inputs */
     uint8_t *rgb;             /* P*3 */
     uint16_t *depth_raw;      /* P */
@@ -95,6 +97,10 @@ void orc_get_pose(orc_ctx *c, float out16[16]);
 void orc_set_pose(orc_ctx *c, const float in16[16]);
 int orc_get_tick(orc_ctx *c);
 void orc_set_tick(orc_ctx *c, int t);
+void orc_set_index_submap(orc_ctx *c, int idx);
+void orc_set_active_submaps(orc_ctx *c, const uint8_t *active, int n);   /* n = 0: all active */
+/* GlobalModel::updateModel (GlobalModel.cpp:690-767 -> update_delta_trans.vert:41-104) */
+void orc_update_model(orc_ctx *c, const float *delta16_colmajor, int n);
 void orc_set_weighting(orc_ctx *c, float w);
 float orc_get_weighting(orc_ctx *c);
 uint32_t orc_surfel_count(orc_ctx *c);

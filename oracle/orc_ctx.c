@@ -84,6 +84,7 @@ orc_ctx *orc_create(const hrbf_params *p)
 void orc_destroy(orc_ctx *c)
 {
     if (!c) return;
+    free(c->submap_active);
     free(c->rgb); free(c->depth_raw); free(c->depth_filtered); free(c->depth_metric); free(c->depth_metric_filtered);
     free(c->vertex_raw); free(c->vertex_filtered); free(c->normal); free(c->normal_pca); free(c->normal_opt);
     free(c->curv1); free(c->curv2); free(c->im_vertconf); free(c->im_colortime); free(c->im_normrad);
@@ -240,6 +241,16 @@ void orc_get_pose(orc_ctx *c, float o[16]) { memcpy(o, c->pose, 64); }
 void orc_set_pose(orc_ctx *c, const float in[16]) { memcpy(c->pose, in, 64); }
 int orc_get_tick(orc_ctx *c) { return c->tick; }
 void orc_set_tick(orc_ctx *c, int t) { c->tick = t; }
+void orc_set_index_submap(orc_ctx *c, int idx) { c->index_submap = idx; }
+void orc_set_active_submaps(orc_ctx *c, const uint8_t *active, int n)
+{
+    free(c->submap_active); c->submap_active = NULL; c->n_submap_active = 0;
+    if (active && n > 0) {
+        c->submap_active = (uint8_t *)malloc((size_t)n);
+        memcpy(c->submap_active, active, (size_t)n);
+        c->n_submap_active = n;
+    }
+}
 void orc_set_weighting(orc_ctx *c, float w) { c->weighting = w; }
 float orc_get_weighting(orc_ctx *c) { return c->weighting; }
 uint32_t orc_surfel_count(orc_ctx *c) { return c->count; }

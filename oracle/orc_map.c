@@ -70,8 +70,12 @@ void orc_predict_indices(orc_ctx *c)
     for (uint32_t s = 0; s < c->count; ++s) {
         f4 p = SURF(m, s, 0);
         f3 h = xform(tinv, xyz(p));
-        /* active-submap mask: only submap ids <= index_submap exist without the sparse back-end and
-           all of them are active (IndexMap.cpp:222-237 with lActiveKFID = {0..}) */
+        /* active-submap mask (index_map.vert:41-45, IndexMap.cpp:222-237): KeyFrameIDMap holds 1 for the ids in
+           lActiveKFID and 0 elsewhere.  No mask installed = every submap active (the scoped configs: one submap) */
+        if (c->submap_active) {
+            const uint32_t sm = (uint32_t)SURF(m, s, 1).y;
+            if (sm >= (uint32_t)c->n_submap_active || c->submap_active[sm] == 0) continue;
+        }
         if (h.z > maxDepth || h.z < 0.0f) continue;
         float u = ((fx * h.x) / h.z) + cx;
         float v = ((fy * h.y) / h.z) + cy;
@@ -217,7 +221,11 @@ static int clean_test(const orc_ctx *c, const float *tinv, f4 vp, f4 *vcol, f4 v
     float y = ((fy * lp.y) / lp.z) + cy;
     f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
     int count = 0, zCount = 0;
-    const float active = 1.0f;   /* all existing submaps active without the sparse back-end */
+    float active = 1.0f;   /* KeyFrameIDMap lookup of the surfel's own submap (copy_unstable.vert:98-101); no mask = all active */
+    if (c->submap_active) {
+        const uint32_t sm = (uint32_t)vcol->y;
+        active = (sm < (uint32_t)c->n_submap_active && c->submap_active[sm]) ? 1.0f : 0.0f;
+    }
     if (lp.z < maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)W && y < (float)H) {
         /* half-pixel steps over [x - w/2, x + w/2) px (copy_unstable.vert:84-108 with FACTOR = 1):
            samples at x + (k - w)*0.5, k = 0 .. 2w-1 */
@@ -280,4 +288,30 @@ void orc_clean(orc_ctx *c)
     c->fuse_stats[3] = n;
     /* records are consumed: a second clean without a fuse must not re-append them */
     memset(c->rec_flag, 0, sizeof(int32_t) * c->Q);
+}
+
+/* ---- GlobalModel::updateModel (GlobalModel.cpp:690-767) -> update_delta_trans.vert:41-104 ------------------
+ * Every surfel is moved by the rigid correction of ITS submap (colour_time.y): position <- T p (w kept),
+ * normal <- R n (radius kept); colour/time and both curvature vectors are copied unchanged (the shader does not
+ * rotate the principal directions - kept).  delta: n column-major 4x4 matrices, the layout updateModel() uploads
+ * (m(k,j), j outer).  A submap id >= n reads texels the reference never uploaded (undefined there): unchanged here. */
+void orc_update_model(orc_ctx *c, const float *delta, int n)
+{
+    f4 *m = c->map[c->target];
+    for (uint32_t s = 0; s < c->count; ++s) {
+        const uint32_t sm = (uint32_t)SURF(m, s, 1).y;
+        if (sm >= (uint32_t)n) continue;
+        const float *T = delta + (size_t)sm * 16;   /* T[col*4 + row] */
+        const f4 p = SURF(m, s, 0), nr = SURF(m, s, 2);
+        f4 po, no;
+        po.x = ((T[0] * p.x + T[4] * p.y) + T[8] * p.z) + T[12] * 1.0f;
+        po.y = ((T[1] * p.x + T[5] * p.y) + T[9] * p.z) + T[13] * 1.0f;
+        po.z = ((T[2] * p.x + T[6] * p.y) + T[10] * p.z) + T[14] * 1.0f;
+        po.w = p.w;
+        no.x = (T[0] * nr.x + T[4] * nr.y) + T[8] * nr.z;
+        no.y = (T[1] * nr.x + T[5] * nr.y) + T[9] * nr.z;
+        no.z = (T[2] * nr.x + T[6] * nr.y) + T[10] * nr.z;
+        no.w = nr.w;
+        SURF(m, s, 0) = po; SURF(m, s, 2) = no;
+    }
 }

@@ -33,6 +33,9 @@ def load(omp=False):
     lib.orc_get_tick.argtypes = [C.c_void_p]
     lib.orc_set_tick.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_weighting.argtypes = [C.c_void_p, C.c_float]
+    lib.orc_set_index_submap.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_set_active_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_update_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_get_weighting.argtypes = [C.c_void_p]
     lib.orc_get_weighting.restype = C.c_float
     lib.orc_surfel_count.argtypes = [C.c_void_p]
@@ -120,6 +123,17 @@ class Oracle:
 
     def set_weighting(self, w):
         self.lib.orc_set_weighting(self.h, w)
+
+    def set_index_submap(self, idx):
+        self.lib.orc_set_index_submap(self.h, int(idx))
+
+    def set_active_submaps(self, active):
+        a = np.ascontiguousarray(np.asarray([] if active is None else active, np.uint8))
+        self.lib.orc_set_active_submaps(self.h, _p(a) if a.size else None, int(a.size))
+
+    def update_model(self, deltas):
+        d = np.ascontiguousarray(np.asarray(deltas, np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))
+        self.lib.orc_update_model(self.h, _p(d), int(d.shape[0]))
 
     def get_weighting(self):
         return self.lib.orc_get_weighting(self.h)

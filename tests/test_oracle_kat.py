@@ -307,3 +307,64 @@ def test_merge_is_confidence_weighted_average(oracle_lib_built):
         assert np.all(old[changed, 3] > 1.0)
     assert np.all(m1[keep:, 7] == 2.0) and np.all(m1[keep:, 6] == 2.0)   # appended this frame
     o.close()
+
+
+def _rigid(rx, ry, rz, t):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4); T[:3, :3] = Rz @ Ry @ Rx; T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+def test_update_model_moves_each_submap_rigidly(oracle_lib_built):
+    """GlobalModel::updateModel (update_delta_trans.vert:41-104): position <- T p, normal <- R n with T picked by the
+    surfel's submap id; confidence, radius, colour/time and both curvature vectors are copied; ids without a matrix
+    stay put; the identity is a bit-exact no-op."""
+    p = default_params(160, 120, 132.0, 132.0, 80.0, 60.0, max_surfels=1 << 12)
+    o = oracle_lib_built.Oracle(p)
+    rng = np.random.default_rng(7)
+    n = 1000
+    m = rng.standard_normal((n, 20)).astype(np.float32)
+    m[:, 5] = rng.integers(0, 4, n)                      # submap ids 0..3 (3 has no matrix below)
+    nv = m[:, 8:11]; nv /= np.linalg.norm(nv, axis=1, keepdims=True)
+    o.upload_map(m)
+    o.update_model(np.stack([np.eye(4, dtype=np.float32)] * 3))
+    assert np.array_equal(o.download_map().view(np.uint32), m.view(np.uint32))
+    Ts = [_rigid(0.02, -0.01, 0.03, (0.01, 0.0, -0.02)), _rigid(0, 0, 0, (0.5, 0, 0)), _rigid(0.3, 0.2, 0.1, (0, 0, 0))]
+    o.update_model(np.stack(Ts))
+    out = o.download_map()
+    for s in range(3):
+        sel = m[:, 5] == s
+        T = Ts[s].astype(np.float64)
+        np.testing.assert_allclose(out[sel, :3], m[sel, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3], atol=2e-6)
+        np.testing.assert_allclose(out[sel, 8:11], m[sel, 8:11].astype(np.float64) @ T[:3, :3].T, atol=1e-6)
+    sel3 = m[:, 5] == 3
+    assert np.array_equal(out[sel3].view(np.uint32), m[sel3].view(np.uint32))
+    keep_cols = [3, 4, 5, 6, 7, 11] + list(range(12, 20))
+    assert np.array_equal(out[:, keep_cols].view(np.uint32), m[:, keep_cols].view(np.uint32))
+    o.close()
+
+
+def test_inactive_submaps_are_not_drawn(oracle_lib_built):
+    """index_map.vert:41-45: a surfel whose submap is not in lActiveKFID never reaches the index map."""
+    W, H, fx = 160, 120, 132.0
+    p = default_params(W, H, fx, fx, 80.0, 60.0, max_surfels=1 << 16, load_trajectory=1)
+    o = oracle_lib_built.Oracle(p)
+    z = scenes.plane_depth(W, H, fx, fx, 80.0, 60.0, (0.0, 0.0, 1.0), 1.5)
+    o.process_frame(scenes.gray_rgb(W, H), scenes.to_u16(z))
+    m = o.download_map()
+    m[::2, 5] = 1.0                                       # every other surfel moves to submap 1
+    o.upload_map(m)
+    o.run_stage("PREDICT_INDICES")
+    full = o.get_image("INDEX")
+    o.set_active_submaps([1, 0])
+    o.run_stage("PREDICT_INDICES")
+    only0 = o.get_image("INDEX")
+    hit = only0[only0 > 0]
+    assert hit.size > 0 and np.all(hit % 2 == 1)          # only submap-0 surfels (odd indices) are visible
+    assert (only0 > 0).sum() < (full > 0).sum()
+    o.set_active_submaps(None)
+    o.run_stage("PREDICT_INDICES")
+    assert np.array_equal(o.get_image("INDEX"), full)
+    o.close()

@@ -182,6 +182,43 @@ def test_stage_seams_in_isolation(pair):
     assert g.fuse_stats()[2] == 0 and len(g.download_map()) <= len(before)
 
 
+def test_update_model_and_submap_mask(pair):
+    """SURVEY §8f-3: GlobalModel::updateModel and the active-submap mask, GPU vs oracle bit for bit, inside a
+    tracked sequence (the corrected map is projected, fused, cleaned and predicted from afterwards)."""
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    for k in range(3):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+    for x in (o, g):
+        x.set_index_submap(1)                     # surfels created from now on belong to submap 1
+    for k in range(3, 5):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+    assert_same_state(o, g, "two submaps")
+    sm = g.download_map()[:, 5]
+    assert (sm == 0).any() and (sm == 1).any()
+    a, b = 0.004, -0.003
+    T0 = np.eye(4, dtype=np.float32); T0[:3, 3] = (0.002, -0.001, 0.003)
+    T1 = np.array([[np.cos(a), -np.sin(a), 0, 0.001], [np.sin(a), np.cos(a), 0, 0], [0, 0, 1, b], [0, 0, 0, 1]], np.float32)
+    for x in (o, g):
+        x.update_model(np.stack([T0, T1]))
+    assert np.array_equal(bits(o.download_map()), bits(g.download_map()))
+    for x in (o, g):
+        x.set_active_submaps([1, 0])              # submap 1 goes inactive
+    for k in range(5, 7):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "masked frame %d" % k)
+    for x in (o, g):
+        x.set_active_submaps(None)
+    rgb, d, _ = synth.frame(7, W, H, noise=True)
+    o.process_frame(rgb, d); g.process_frame(rgb, d)
+    assert_same_state(o, g, "mask removed")
+
+
 def test_icp_step_seam(oracle_lib_built, gpu_available):
     """hrbf_icp_step on caller-owned device maps == oracle (bit-exact sums) ~= fp64 numpy (1e-5)."""
     import torch
