@@ -25,6 +25,7 @@ EXPORTS = [
     "hrbf_image_bytes", "hrbf_get_image", "hrbf_set_image", "hrbf_enable_timing", "hrbf_get_timings",
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
+    "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
     "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
 
@@ -56,6 +57,9 @@ def load_library():
     lib.hrbf_get_tick.argtypes = [vp]; lib.hrbf_set_tick.argtypes = [vp, i32]
     lib.hrbf_set_index_submap.argtypes = [vp, i32]; lib.hrbf_set_active_submaps.argtypes = [vp, vp, i32]
     lib.hrbf_update_model.argtypes = [vp, vp, i32]
+    lib.hrbf_so3_step.argtypes = [vp, vp, vp, i32, i32] + [vp] * 6
+    lib.hrbf_rgb_residual.argtypes = [vp, f32] + [vp] * 6 + [i32, i32] + [vp] * 6
+    lib.hrbf_rgb_step.argtypes = [vp, vp, vp, f32, vp, f32, f32, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.hrbf_surfel_count.argtypes = [vp]; lib.hrbf_surfel_count.restype = C.c_uint32
     lib.hrbf_download_map.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_upload_map.argtypes = [vp, vp, C.c_size_t]
     lib.hrbf_last_icp.argtypes = [vp, vp, vp]; lib.hrbf_last_weighting.argtypes = [vp, vp]

@@ -712,6 +712,35 @@ extern "C" int hrbf_get_fuse_ring(hrbf_handle c, int max_frames, float *kernel_m
 extern "C" int hrbf_reset_fuse_ring(hrbf_handle c) { if (!c) return -1; c->ring_head = 0; c->ring_valid = 0; return 0; }
 extern "C" int hrbf_set_load_trajectory(hrbf_handle c, int v) { if (!c) return HRBF_ERR_INVALID; c->prm.load_trajectory = v; return HRBF_OK; }
 
+extern "C" int hrbf_so3_step(hrbf_handle c, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                             const float image_basis[9], const float kinv[9], const float krlr[9], double A_out[9],
+                             double b_out[3], double residual_out[2])
+{
+    if (!c || !last_image || !next_image || rows <= 0 || cols <= 0) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    return run_so3_step(c->stream, last_image, next_image, rows, cols, image_basis, kinv, krlr, A_out, b_out, residual_out);
+}
+extern "C" int hrbf_rgb_residual(hrbf_handle c, float min_scale, const int16_t *dIdx, const int16_t *dIdy,
+                                 const float *last_depth, const float *next_depth, const uint8_t *last_image,
+                                 const uint8_t *next_image, int rows, int cols, const float kt[3], const float krkinv[9],
+                                 int16_t *corres_out, float *diff_out, long long *count, long long *sigma)
+{
+    if (!c || !corres_out || !diff_out || !count || !sigma || rows <= 0 || cols <= 0) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    return run_rgb_residual(c->stream, min_scale, dIdx, dIdy, last_depth, next_depth, last_image, next_image, rows, cols, kt,
+                            krkinv, corres_out, diff_out, count, sigma);
+}
+extern "C" int hrbf_rgb_step(hrbf_handle c, const int16_t *corres, const float *corres_diff, float sigma,
+                             const float *cloud, float fx, float fy, const int16_t *dIdx, const int16_t *dIdy,
+                             int use_grad_weight, int rows, int cols, double A_out[36], double b_out[6],
+                             double residual_out[2])
+{
+    if (!c || !corres || !corres_diff || !cloud || rows <= 0 || cols <= 0) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    return run_rgb_step(c->stream, corres, corres_diff, sigma, cloud, fx, fy, dIdx, dIdy, use_grad_weight, rows, cols, A_out,
+                        b_out, residual_out);
+}
+
 // ---- the callers' side of the path: submap bookkeeping and the rigid map correction
 extern "C" int hrbf_set_index_submap(hrbf_handle c, int index)
 {

@@ -1496,3 +1496,154 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
     residual_out[0] = sums[27]; residual_out[1] = sums[28];
     return HRBF_OK;
 }
+
+// ------------------------------------------------------------------------------------------ standalone seams
+// so3Step / computeRgbResidual / rgbStep (cudafuncs.cuh:118-162) on caller-provided DEVICE images, like run_icp_step.
+struct So3Operands { float basis[9], kinv[9], krlr[9]; };
+struct RgbOperands { float krk[9], kt[3]; };
+
+__global__ __launch_bounds__(RB) void k_so3_only(OdoLevel L, So3Operands op, long long *__restrict__ part)
+{
+    float row4[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
+    const bool valid = so3_pixel(L, &op, blockIdx.x * RB + threadIdx.x, row4);
+    block_reduce_exact<11>(row4, valid, part);
+}
+
+__global__ __launch_bounds__(RB) void k_rgb_residual_only(OdoLevel L, RgbOperands op, float minScale,
+                                                          int16_t *__restrict__ corres, float *__restrict__ corres_diff,
+                                                          unsigned long long *__restrict__ count_sigma)
+{
+    __shared__ long long s_c[RB / 64], s_s[RB / 64];
+    const int k = blockIdx.x * RB + threadIdx.x;
+    long long cnt = 0, sig = 0;
+    if (k < L.rows * L.cols) {
+        const RgbCorr r = rgb_residual_pixel(L, &op, minScale, k, cnt, sig);
+        int16_t *co = &corres[(size_t)k * 6];
+        co[0] = r.c0; co[1] = r.c1; co[2] = r.c2; co[3] = r.c3; co[4] = r.c4; co[5] = 0;
+        corres_diff[k] = r.diff;
+    }
+    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c = 0, s = 0;
+        for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
+        if (c) { atomicAdd(&count_sigma[0], (unsigned long long)c); atomicAdd(&count_sigma[1], (unsigned long long)s); }
+    }
+}
+
+__global__ __launch_bounds__(RB) void k_rgb_only(OdoLevel L, const int16_t *__restrict__ corres,
+                                                 const float *__restrict__ corres_diff, float sigma, float fx, float fy,
+                                                 int use_grad, long long *__restrict__ part)
+{
+    float out[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+    bool valid = false;
+    const int k = blockIdx.x * RB + threadIdx.x;
+    if (k < L.rows * L.cols) {
+        const int16_t *co = &corres[(size_t)k * 6];
+        RgbCorr r; r.c0 = co[0]; r.c1 = co[1]; r.c2 = co[2]; r.c3 = co[3]; r.c4 = co[4]; r.diff = corres_diff[k];
+        valid = rgb_products_pixel(L, r, sigma, fx, fy, use_grad, out);
+    }
+    block_reduce_exact<29>(out, valid, part);
+}
+
+// slot rows -> exact sums on the host
+static int fetch_sums(hipStream_t s, long long *d_part, int nvals, double *sums, const char *what)
+{
+    const int width = nvals * 3;
+    const size_t bytes = sizeof(long long) * (size_t)width * ODO_SLOTS;
+    long long *h = (long long *)malloc(bytes);
+    hipError_t e = hipMemcpyAsync(h, d_part, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { free(h); hrbf_set_error("%s: %s", what, hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    for (int i = 0; i < nvals; ++i) {
+        long long t[3] = {0, 0, 0};
+        for (int b = 0; b < ODO_SLOTS; ++b) for (int l = 0; l < 3; ++l) t[l] += h[(size_t)b * width + i * 3 + l];
+        sums[i] = hd_acc_to_double(hd_limbs_combine(t[0], t[1], t[2]));
+    }
+    free(h);
+    return HRBF_OK;
+}
+
+int run_so3_step(hipStream_t s, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                 const float basis[9], const float kinv[9], const float krlr[9], double A_out[9], double b_out[3],
+                 double residual_out[2])
+{
+    OdoLevel L; memset(&L, 0, sizeof(L));
+    L.rows = rows; L.cols = cols; L.last_next_image = (uint8_t *)last_image; L.next_image = (uint8_t *)next_image;
+    So3Operands op;
+    for (int k = 0; k < 9; ++k) { op.basis[k] = basis[k]; op.kinv[k] = kinv[k]; op.krlr[k] = krlr[k]; }
+    long long *part = nullptr;
+    const size_t bytes = sizeof(long long) * 33 * ODO_SLOTS;
+    HIP_CHECK(hipMalloc(&part, bytes));
+    hipMemsetAsync(part, 0, bytes, s);
+    hipLaunchKernelGGL(k_so3_only, dim3((rows * cols + RB - 1) / RB), dim3(RB), 0, s, L, op, part);
+    double sums[11];
+    const int r = fetch_sums(s, part, 11, sums, "so3_step");
+    hipFree(part);
+    if (r) return r;
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            const double v = sums[shift++];
+            if (j == 3) b_out[i] = v; else A_out[j * 3 + i] = A_out[i * 3 + j] = v;
+        }
+    residual_out[0] = sums[9]; residual_out[1] = sums[10];
+    return HRBF_OK;
+}
+
+int run_rgb_residual(hipStream_t s, float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
+                     const float *next_depth, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                     const float kt[3], const float krkinv[9], int16_t *corres_out, float *diff_out, long long *count,
+                     long long *sigma)
+{
+    OdoLevel L; memset(&L, 0, sizeof(L));
+    L.rows = rows; L.cols = cols; L.dIdx = (int16_t *)dIdx; L.dIdy = (int16_t *)dIdy;
+    L.last_depth = (float *)last_depth; L.next_depth = (float *)next_depth;
+    L.last_image = (uint8_t *)last_image; L.next_image = (uint8_t *)next_image;
+    RgbOperands op;
+    for (int k = 0; k < 9; ++k) op.krk[k] = krkinv[k];
+    for (int k = 0; k < 3; ++k) op.kt[k] = kt[k];
+    unsigned long long *cs = nullptr;
+    HIP_CHECK(hipMalloc(&cs, 16));
+    hipMemsetAsync(cs, 0, 16, s);
+    hipLaunchKernelGGL(k_rgb_residual_only, dim3((rows * cols + RB - 1) / RB), dim3(RB), 0, s, L, op, min_scale, corres_out,
+                       diff_out, cs);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(h, cs, 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(cs);
+    if (e != hipSuccess) { hrbf_set_error("rgb_residual: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    *count = (long long)h[0]; *sigma = (long long)h[1];
+    return HRBF_OK;
+}
+
+int run_rgb_step(hipStream_t s, const int16_t *corres, const float *corres_diff, float sigma, const float *cloud, float fx,
+                 float fy, const int16_t *dIdx, const int16_t *dIdy, int use_grad_weight, int rows, int cols,
+                 double A_out[36], double b_out[6], double residual_out[2])
+{
+    OdoLevel L; memset(&L, 0, sizeof(L));
+    L.rows = rows; L.cols = cols; L.dIdx = (int16_t *)dIdx; L.dIdy = (int16_t *)dIdy; L.cloud = (float *)cloud;
+    long long *part = nullptr;
+    const size_t bytes = sizeof(long long) * 87 * ODO_SLOTS;
+    HIP_CHECK(hipMalloc(&part, bytes));
+    hipMemsetAsync(part, 0, bytes, s);
+    hipLaunchKernelGGL(k_rgb_only, dim3((rows * cols + RB - 1) / RB), dim3(RB), 0, s, L, corres, corres_diff, sigma, fx, fy,
+                       use_grad_weight, part);
+    double sums[29];
+    const int r = fetch_sums(s, part, 29, sums, "rgb_step");
+    hipFree(part);
+    if (r) return r;
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const double v = sums[shift++];
+            if (j == 6) b_out[i] = v; else A_out[j * 6 + i] = A_out[i * 6 + j] = v;
+        }
+    residual_out[0] = sums[27]; residual_out[1] = sums[28];
+    return HRBF_OK;
+}

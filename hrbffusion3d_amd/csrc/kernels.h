@@ -124,3 +124,15 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
                  const float *nmap_g_prev, const float *ck1_g_prev, const float *ck2_g_prev, const float *icpw, int rows,
                  int cols, float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
                  double residual_out[2]);
+
+// standalone so3Step / computeRgbResidual / rgbStep seams (device images, host matrices)
+int run_so3_step(hipStream_t s, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                 const float basis[9], const float kinv[9], const float krlr[9], double A_out[9], double b_out[3],
+                 double residual_out[2]);
+int run_rgb_residual(hipStream_t s, float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
+                     const float *next_depth, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                     const float kt[3], const float krkinv[9], int16_t *corres_out, float *diff_out, long long *count,
+                     long long *sigma);
+int run_rgb_step(hipStream_t s, const int16_t *corres, const float *corres_diff, float sigma, const float *cloud, float fx,
+                 float fy, const int16_t *dIdx, const int16_t *dIdy, int use_grad_weight, int rows, int cols,
+                 double A_out[36], double b_out[6], double residual_out[2]);

@@ -166,6 +166,24 @@ size_t hrbf_image_bytes(hrbf_handle h, int which);
 int hrbf_get_image(hrbf_handle h, int which, void *out, size_t bytes);   /* device -> host */
 int hrbf_set_image(hrbf_handle h, int which, const void *in, size_t bytes); /* host -> device (tests) */
 
+/* so3Step / computeRgbResidual / rgbStep seams (Core/src/Cuda/cudafuncs.cuh:118-162, reduce.cu:697-896,957-1359) on
+ * caller-provided DEVICE images (row-major rows x cols); matrices are host arrays, row-major 3x3.
+ * hrbf_so3_step: A_out 9 doubles row-major, b_out 3, residual_out {sum r^2, count}.
+ * hrbf_rgb_residual: corres_out = 6 int16 per pixel {u0, v0, x, y, valid, 0} (the reference's DataTerm zero/one/valid),
+ *   diff_out = intensity difference; *count / *sigma = the reference's count and sigmaSum (maxDepthDelta = 0.07).
+ * hrbf_rgb_step: cloud = 3 floats per pixel (projectToPointCloud), sobel scale 0.125; A_out 36 doubles row-major, b_out 6,
+ *   residual_out {sum (w r)^2, count}. */
+int hrbf_so3_step(hrbf_handle h, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                  const float image_basis[9], const float kinv[9], const float krlr[9], double A_out[9], double b_out[3],
+                  double residual_out[2]);
+int hrbf_rgb_residual(hrbf_handle h, float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
+                      const float *next_depth, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,
+                      const float kt[3], const float krkinv[9], int16_t *corres_out, float *diff_out, long long *count,
+                      long long *sigma);
+int hrbf_rgb_step(hrbf_handle h, const int16_t *corres, const float *corres_diff, float sigma, const float *cloud,
+                  float fx, float fy, const int16_t *dIdx, const int16_t *dIdy, int use_grad_weight, int rows, int cols,
+                  double A_out[36], double b_out[6], double residual_out[2]);
+
 /* submap bookkeeping and rigid map correction — the callers either side of the path.
  * hrbf_set_index_submap: HRBFFusion::indexSubmap, the id stamped on surfels created from now on (data.vert).
  * hrbf_set_active_submaps: IndexMap::lActiveKFID as a byte mask (IndexMap.cpp:222-237); surfels of inactive submaps

@@ -121,6 +121,15 @@ int orc_icp_step(const float Rcurr[9], const float tcurr[3],
                  const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
                  float dist_thresh, float angle_thresh, int use_weight,
                  double A_out[36], double b_out[6], double residual_out[2]);
+int orc_so3_step(const uint8_t *lastImage, const uint8_t *nextImage, int rows, int cols, const float basis[9],
+                 const float kinv[9], const float krlr[9], double A_out[9], double b_out[3], double residual_out[2]);
+int orc_rgb_residual(float minScale, const int16_t *dIdx, const int16_t *dIdy, const float *lastDepth,
+                     const float *nextDepth, const uint8_t *lastImage, const uint8_t *nextImage, int rows, int cols,
+                     const float kt[3], const float krkinv[9], int16_t *corres_out, float *diff_out, long long *count,
+                     long long *sigma);
+int orc_rgb_step(const int16_t *corres, const float *corres_diff, float sigma, const float *cloud, float fx, float fy,
+                 const int16_t *dIdx, const int16_t *dIdy, int use_grad_weight, int rows, int cols, double A_out[36],
+                 double b_out[6], double residual_out[2]);
 /* HRBF primitives for known-answer tests (hrbfbase.glsl:126-195) */
 float orc_hrbf_value(const float p[3], const f4 *vc, const f4 *nr, int n, int *nsupport);
 void orc_hrbf_gradient(const float p[3], const f4 *vc, const f4 *nr, int n, float out[3]);

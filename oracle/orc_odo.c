@@ -470,22 +470,20 @@ int orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_c
 }
 
 /* ------------------------------------------------------------------ O3: RGBResidual reduce.cu:957-1154 */
-static void rgb_residual(orc_ctx *c, int lvl, float minScale, const float *krk, f3 kt, int64_t *count_out,
-                         int64_t *sigma_out)
+static void rgb_residual_core(int rows, int cols, const int16_t *dIdx, const int16_t *dIdy, const float *lastDepth,
+                              const float *nextDepth, const uint8_t *lastImage, const uint8_t *nextImage, float minScale,
+                              const float *krk, f3 kt, int16_t *corres, float *corres_diff, int64_t *count_out,
+                              int64_t *sigma_out)
 {
-    const int rows = c->H >> lvl, cols = c->W >> lvl;
-    const int16_t *dIdx = c->dIdx[lvl], *dIdy = c->dIdy[lvl];
-    const float *lastDepth = c->last_depth[lvl], *nextDepth = c->next_depth[lvl];
-    const uint8_t *lastImage = c->last_image[lvl], *nextImage = c->next_image[lvl];
     const float maxDepthDelta = 0.07f;
     int64_t cnt = 0, sig = 0;
 #pragma omp parallel for schedule(static) reduction(+ : cnt, sig)
     for (int i = 0; i < rows; ++i)
         for (int j0 = 0; j0 < cols; ++j0) {
             int k = i * cols + j0;
-            int16_t *co = &c->corres[(size_t)k * 6];
+            int16_t *co = &corres[(size_t)k * 6];
             co[0] = co[1] = co[2] = co[3] = co[4] = co[5] = 0;
-            c->corres_diff[k] = 0.0f;
+            corres_diff[k] = 0.0f;
             if (!(j0 < cols - 5 && i < rows - 1)) continue;
             int valid = 1;
             for (int u = (i - 2 > 0 ? i - 2 : 0); u < (i + 2 < rows ? i + 2 : rows); ++u)
@@ -508,38 +506,45 @@ static void rgb_residual(orc_ctx *c, int lvl, float minScale, const float *krk, 
             if (d0 > 0.0f && fabsf(td1 - d0) <= maxDepthDelta && lastImage[v0 * cols + u0] != 0) {
                 float diff = (float)nextImage[y * cols + x] - (float)lastImage[v0 * cols + u0];
                 co[0] = (int16_t)u0; co[1] = (int16_t)v0; co[2] = (int16_t)x; co[3] = (int16_t)y; co[4] = 1;
-                c->corres_diff[k] = diff;
+                corres_diff[k] = diff;
                 cnt += 1;
                 sig += (int64_t)(diff * diff);
             }
         }
     *count_out = cnt; *sigma_out = sig;
 }
+static void rgb_residual(orc_ctx *c, int lvl, float minScale, const float *krk, f3 kt, int64_t *count_out,
+                         int64_t *sigma_out)
+{
+    rgb_residual_core(c->H >> lvl, c->W >> lvl, c->dIdx[lvl], c->dIdy[lvl], c->last_depth[lvl], c->next_depth[lvl],
+                      c->last_image[lvl], c->next_image[lvl], minScale, krk, kt, c->corres, c->corres_diff, count_out,
+                      sigma_out);
+}
 
 /* ------------------------------------------------------------------ O5: RGBReduction reduce.cu:697-896 */
-static void rgb_step(orc_ctx *c, int lvl, float sigma, float fx, float fy, double sums[29])
+static void rgb_step_core(int rows, int cols, const int16_t *corres, const float *corres_diff, const f3 *cloud,
+                          const int16_t *dIdxl, const int16_t *dIdyl, float sigma, float fx, float fy, int use_grad,
+                          double sums[29])
 {
-    const int rows = c->H >> lvl, cols = c->W >> lvl;
     const float sobelScale = 0.125f;
-    const int use_grad = c->prm.rgb_use_grad_weight;
     acc29 tot; for (int i = 0; i < 29; ++i) hd_acc_zero(&tot.a[i]);
 #pragma omp parallel
     {
         acc29 loc; for (int i = 0; i < 29; ++i) hd_acc_zero(&loc.a[i]);
 #pragma omp for schedule(static) nowait
         for (int k = 0; k < rows * cols; ++k) {
-            const int16_t *co = &c->corres[(size_t)k * 6];
+            const int16_t *co = &corres[(size_t)k * 6];
             if (!co[4]) continue;
-            float diff = c->corres_diff[k];
+            float diff = corres_diff[k];
             float w = sigma + fabsf(diff);
             w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
             if (sigma == -1.0f) w = 1.0f;
             float row[7];
             row[6] = -w * diff;
-            f3 cp = c->cloud[lvl][co[1] * cols + co[0]];
+            f3 cp = cloud[co[1] * cols + co[0]];
             float invz = 1.0f / cp.z;
-            float dIx = w * sobelScale * (float)c->dIdx[lvl][co[3] * cols + co[2]];
-            float dIy = w * sobelScale * (float)c->dIdy[lvl][co[3] * cols + co[2]];
+            float dIx = w * sobelScale * (float)dIdxl[co[3] * cols + co[2]];
+            float dIy = w * sobelScale * (float)dIdyl[co[3] * cols + co[2]];
             float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
             float v2 = -(v0 * cp.x + v1 * cp.y) * invz;
             row[0] = v0; row[1] = v1; row[2] = v2;
@@ -560,6 +565,11 @@ static void rgb_step(orc_ctx *c, int lvl, float sigma, float fx, float fy, doubl
         for (int i = 0; i < 29; ++i) hd_acc_add(&tot.a[i], loc.a[i]);
     }
     for (int i = 0; i < 29; ++i) sums[i] = hd_acc_to_double(tot.a[i]);
+}
+static void rgb_step(orc_ctx *c, int lvl, float sigma, float fx, float fy, double sums[29])
+{
+    rgb_step_core(c->H >> lvl, c->W >> lvl, c->corres, c->corres_diff, c->cloud[lvl], c->dIdx[lvl], c->dIdy[lvl], sigma,
+                  fx, fy, c->prm.rgb_use_grad_weight, sums);
 }
 
 /* ------------------------------------------------------------------ O2: SO3Reduction reduce.cu:1156-1359 */
@@ -607,6 +617,48 @@ static void so3_step(const uint8_t *lastImage, const uint8_t *nextImage, int row
             hd_acc_add_f32(&tot[10], 1.0f);
         }
     for (int i = 0; i < 11; ++i) sums[i] = hd_acc_to_double(tot[i]);
+}
+
+/* operator-level seams on caller-provided host arrays (cudafuncs.cuh:118-162): so3Step, computeRgbResidual, rgbStep */
+int orc_so3_step(const uint8_t *lastImage, const uint8_t *nextImage, int rows, int cols, const float basis[9],
+                 const float kinv[9], const float krlr[9], double A_out[9], double b_out[3], double residual_out[2])
+{
+    double s[11];
+    so3_step(lastImage, nextImage, rows, cols, basis, kinv, krlr, s);
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            double v = s[shift++];
+            if (j == 3) b_out[i] = v; else A_out[j * 3 + i] = A_out[i * 3 + j] = v;
+        }
+    residual_out[0] = s[9]; residual_out[1] = s[10];
+    return 0;
+}
+int orc_rgb_residual(float minScale, const int16_t *dIdx, const int16_t *dIdy, const float *lastDepth,
+                     const float *nextDepth, const uint8_t *lastImage, const uint8_t *nextImage, int rows, int cols,
+                     const float kt[3], const float krkinv[9], int16_t *corres_out, float *diff_out, long long *count,
+                     long long *sigma)
+{
+    int64_t c = 0, sg = 0;
+    rgb_residual_core(rows, cols, dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, minScale, krkinv,
+                      v3(kt[0], kt[1], kt[2]), corres_out, diff_out, &c, &sg);
+    *count = (long long)c; *sigma = (long long)sg;
+    return 0;
+}
+int orc_rgb_step(const int16_t *corres, const float *corres_diff, float sigma, const float *cloud, float fx, float fy,
+                 const int16_t *dIdx, const int16_t *dIdy, int use_grad_weight, int rows, int cols, double A_out[36],
+                 double b_out[6], double residual_out[2])
+{
+    double s[29];
+    rgb_step_core(rows, cols, corres, corres_diff, (const f3 *)cloud, dIdx, dIdy, sigma, fx, fy, use_grad_weight, s);
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            double v = s[shift++];
+            if (j == 6) b_out[i] = v; else A_out[j * 6 + i] = A_out[i * 6 + j] = v;
+        }
+    residual_out[0] = s[27]; residual_out[1] = s[28];
+    return 0;
 }
 
 /* projectPointsKernel cudafuncs.cu:995-1013 */

@@ -36,6 +36,10 @@ def load(omp=False):
     lib.orc_set_index_submap.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_active_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_update_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_so3_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+    lib.orc_rgb_residual.argtypes = [C.c_float] + [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 6
+    lib.orc_rgb_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_get_weighting.argtypes = [C.c_void_p]
     lib.orc_get_weighting.restype = C.c_float
     lib.orc_surfel_count.argtypes = [C.c_void_p]

@@ -276,6 +276,66 @@ def test_icp_step_seam(oracle_lib_built, gpu_available):
     g.close()
 
 
+def test_rgb_and_so3_step_seams(oracle_lib_built, gpu_available):
+    """hrbf_so3_step, hrbf_rgb_residual, hrbf_rgb_step on caller-owned device images == oracle: the correspondence
+    image byte for byte, count / sigma and every normal-equation entry bit for bit."""
+    import torch
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    f0, f1 = synth.frame(3, W, H, noise=True), synth.frame(4, W, H, noise=True)
+    grey = lambda rgb: (0.114 * rgb[..., 0] + 0.299 * rgb[..., 1] + 0.587 * rgb[..., 2]).astype(np.uint8)
+    last_img, next_img = np.ascontiguousarray(grey(f0[0])), np.ascontiguousarray(grey(f1[0]))
+    last_img[5:9, 7:30] = 0; next_img[40:44, 90:95] = 0                       # invalid intensities
+    dep = lambda d: np.where(d > 0, d.astype(np.float32) / 5000.0, np.nan).astype(np.float32)
+    last_d, next_d = dep(f0[1]), dep(f1[1])
+    gi = next_img.astype(np.int32)
+    dIdx = np.zeros((H, W), np.int16); dIdy = np.zeros((H, W), np.int16)
+    dIdx[:, 1:-1] = 4 * (gi[:, 2:] - gi[:, :-2]); dIdy[1:-1] = 4 * (gi[2:] - gi[:-2])
+    a = 0.01
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    krk = (K @ R @ np.linalg.inv(K)).astype(np.float32); kt = (K @ np.array([0.004, -0.002, 0.003])).astype(np.float32)
+    kinv = np.linalg.inv(K).astype(np.float32); krlr = (K @ R).astype(np.float32)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    z = np.nan_to_num(last_d, nan=0.0)
+    cloud = np.ascontiguousarray(np.stack([(xs - cx) * z / fx, (ys - cy) * z / fy, z], -1).astype(np.float32))
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib = oracle_lib_built.load()
+    g = HRBFFusion(default_params(W, H, fx, fy, cx, cy, max_surfels=1024))
+    dev = lambda a: torch.from_numpy(a).cuda()
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    d_last, d_next, d_ld, d_nd, d_ix, d_iy, d_cloud = map(dev, (last_img, next_img, last_d, next_d, dIdx, dIdy, cloud))
+
+    # --- so3Step
+    A0, b0, r0 = np.zeros(9), np.zeros(3), np.zeros(2); A1, b1, r1 = np.zeros(9), np.zeros(3), np.zeros(2)
+    lib.orc_so3_step(pp(last_img), pp(next_img), H, W, pp(krk), pp(kinv), pp(krlr), pp(A0), pp(b0), pp(r0))
+    assert g.lib.hrbf_so3_step(g.h, dp(d_last), dp(d_next), H, W, pp(krk), pp(kinv), pp(krlr), pp(A1), pp(b1), pp(r1)) == 0
+    assert np.array_equal(A0, A1) and np.array_equal(b0, b1) and np.array_equal(r0, r1) and r1[1] > 0.5 * W * H
+
+    # --- computeRgbResidual
+    co0 = np.zeros((H * W, 6), np.int16); df0 = np.zeros(H * W, np.float32)
+    c0, s0 = C.c_longlong(), C.c_longlong()
+    lib.orc_rgb_residual(25.0, pp(dIdx), pp(dIdy), pp(last_d), pp(next_d), pp(last_img), pp(next_img), H, W, pp(kt), pp(krk),
+                         pp(co0), pp(df0), C.byref(c0), C.byref(s0))
+    d_co = torch.zeros((H * W, 6), dtype=torch.int16, device="cuda"); d_df = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    c1, s1 = C.c_longlong(), C.c_longlong()
+    assert g.lib.hrbf_rgb_residual(g.h, 25.0, dp(d_ix), dp(d_iy), dp(d_ld), dp(d_nd), dp(d_last), dp(d_next), H, W, pp(kt),
+                                   pp(krk), dp(d_co), dp(d_df), C.byref(c1), C.byref(s1)) == 0
+    assert (c0.value, s0.value) == (c1.value, s1.value) and c1.value > 100
+    assert np.array_equal(d_co.cpu().numpy(), co0) and np.array_equal(bits(d_df.cpu().numpy()), bits(df0))
+
+    # --- rgbStep, plain and gradient-weighted, robust and sigma = -1
+    for sigma, use_grad in ((np.float32(np.sqrt(c0.value)), 0), (np.float32(-1.0), 0), (np.float32(30.0), 1)):
+        A0, b0, r0 = np.zeros(36), np.zeros(6), np.zeros(2); A1, b1, r1 = np.zeros(36), np.zeros(6), np.zeros(2)
+        lib.orc_rgb_step(pp(co0), pp(df0), float(sigma), pp(cloud), fx, fy, pp(dIdx), pp(dIdy), use_grad, H, W, pp(A0), pp(b0), pp(r0))
+        assert g.lib.hrbf_rgb_step(g.h, dp(d_co), dp(d_df), float(sigma), dp(d_cloud), fx, fy, dp(d_ix), dp(d_iy), use_grad, H, W,
+                                   pp(A1), pp(b1), pp(r1)) == 0
+        assert np.array_equal(bits(A0), bits(A1)) and np.array_equal(bits(b0), bits(b1)) and np.array_equal(bits(r0), bits(r1))
+        assert r1[1] == c0.value
+    g.close()
+
+
 def test_full_size_properties_1M(gpu_available):
     """BASELINE sizes (640x480, > 1 M surfels): size-independent properties instead of the oracle:
     count conservation, order preservation of the compaction, in-place invariance of untouched
