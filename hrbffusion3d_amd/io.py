@@ -112,3 +112,132 @@ def ate_rmse(est, gt, align=True):
         R = U @ S @ Vt
         E = (E - me) @ R.T + mg
     return float(np.sqrt(((E - G) ** 2).sum(1).mean()))
+
+
+# ------------------------------------------------------------------------------------------------
+# .klg raw logs — the frame source the reference's GUI feeds processFrame from
+# (GUI/src/Tools/RawLogReader.cpp:3-140).  Layout, little endian:
+#     int32 numFrames
+#     per frame: int64 timestamp, int32 depthSize, int32 imageSize, depthSize bytes, imageSize bytes
+# depth is W*H uint16 raw (depthSize == W*H*2) or a zlib stream of it; the image is W*H*3 uint8 raw
+# (imageSize == W*H*3), a JPEG (any other positive size) or absent (imageSize == 0 -> black).
+import struct
+import zlib
+
+
+class KlgReader:
+    """Sequential + random access reader.  `flip_colors` swaps the first and third channel like the reference's
+    flipColors flag (logs recorded as BGR).  Frames come back as (timestamp, rgb[H, W, 3] uint8, depth[H, W] uint16),
+    i.e. exactly the two buffers HRBFFusion::processFrame borrows."""
+
+    def __init__(self, path, width=640, height=480, flip_colors=False):
+        self.path, self.W, self.H, self.flip = path, int(width), int(height), bool(flip_colors)
+        self.f = open(path, "rb")
+        head = self.f.read(4)
+        if len(head) != 4:
+            raise ValueError("%s: not a .klg log (no frame count)" % path)
+        self.num_frames = struct.unpack("<i", head)[0]
+        if self.num_frames < 0:
+            raise ValueError("%s: negative frame count" % path)
+        self._offsets = [4]          # file offset of frame i, discovered as the log is walked (the reader's filePointers)
+        self.current = 0
+
+    def __len__(self):
+        return self.num_frames
+
+    def close(self):
+        self.f.close()
+
+    def has_more(self):
+        return self.current < self.num_frames
+
+    def _header(self, off):
+        self.f.seek(off)
+        h = self.f.read(16)
+        if len(h) != 16:
+            raise EOFError("%s: truncated at frame header (offset %d)" % (self.path, off))
+        return struct.unpack("<qii", h)
+
+    def _seek_frame(self, i):
+        if not 0 <= i < self.num_frames:
+            raise IndexError(i)
+        while len(self._offsets) <= i:                      # fastForward: skip payloads, remember offsets
+            off = self._offsets[-1]
+            _, dsz, isz = self._header(off)
+            if dsz < 0 or isz < 0:
+                raise ValueError("%s: negative payload size at offset %d" % (self.path, off))
+            self._offsets.append(off + 16 + dsz + isz)
+        return self._offsets[i]
+
+    def read_frame(self, i):
+        off = self._seek_frame(i)
+        ts, dsz, isz = self._header(off)
+        if dsz < 0 or isz < 0:
+            raise ValueError("%s: negative payload size at offset %d" % (self.path, off))
+        dbuf = self.f.read(dsz)
+        ibuf = self.f.read(isz) if isz > 0 else b""
+        if len(dbuf) != dsz or len(ibuf) != isz:
+            raise EOFError("%s: truncated payload of frame %d" % (self.path, i))
+        if len(self._offsets) == i + 1:
+            self._offsets.append(off + 16 + dsz + isz)
+        n = self.W * self.H
+        if dsz != n * 2:
+            dbuf = zlib.decompress(dbuf)
+            if len(dbuf) != n * 2:
+                raise ValueError("%s: frame %d depth inflates to %d bytes, expected %d" % (self.path, i, len(dbuf), n * 2))
+        depth = np.frombuffer(dbuf, dtype="<u2").reshape(self.H, self.W).copy()
+        if isz == n * 3:
+            rgb = np.frombuffer(ibuf, np.uint8).reshape(self.H, self.W, 3).copy()
+        elif isz > 0:
+            try:
+                from PIL import Image
+            except ImportError as e:       # pragma: no cover - PIL is present in the supported images
+                raise RuntimeError("JPEG-compressed .klg frames need Pillow") from e
+            import io as _io
+            rgb = np.asarray(Image.open(_io.BytesIO(ibuf)).convert("RGB"), np.uint8)
+            if rgb.shape != (self.H, self.W, 3):
+                raise ValueError("%s: frame %d JPEG is %s, expected %dx%d" % (self.path, i, rgb.shape, self.W, self.H))
+            rgb = rgb.copy()
+        else:
+            rgb = np.zeros((self.H, self.W, 3), np.uint8)
+        if self.flip:
+            rgb = rgb[..., ::-1].copy()
+        return ts, rgb, depth
+
+    def get_next(self):
+        fr = self.read_frame(self.current)
+        self.current += 1
+        return fr
+
+    def fast_forward(self, frame):
+        self.current = min(int(frame), self.num_frames)
+        if self.current < self.num_frames:
+            self._seek_frame(self.current)
+
+    def __iter__(self):
+        for i in range(self.num_frames):
+            yield self.read_frame(i)
+
+
+def write_klg(path, frames, compress_depth=True, jpeg_quality=None):
+    """Writer for tests and for converting other sources: frames = iterable of (timestamp, rgb uint8 [H,W,3] or None,
+    depth uint16 [H,W]).  jpeg_quality = None stores the image raw."""
+    frames = list(frames)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(frames)))
+        for ts, rgb, depth in frames:
+            d = np.ascontiguousarray(depth, "<u2").tobytes()
+            if compress_depth:
+                d = zlib.compress(d)
+            if rgb is None:
+                im = b""
+            elif jpeg_quality is None:
+                im = np.ascontiguousarray(rgb, np.uint8).tobytes()
+            else:
+                from PIL import Image
+                import io as _io
+                b = _io.BytesIO()
+                Image.fromarray(np.ascontiguousarray(rgb, np.uint8)).save(b, format="JPEG", quality=int(jpeg_quality))
+                im = b.getvalue()
+            f.write(struct.pack("<qii", int(ts), len(d), len(im)))
+            f.write(d); f.write(im)

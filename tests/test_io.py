@@ -63,3 +63,45 @@ def test_associations_and_ate(tmp_path):
     est = [T @ g for g in gt]
     assert io.ate_rmse(est, gt, align=True) < 1e-9
     assert io.ate_rmse(est, gt, align=False) > 1.0
+
+
+def test_klg_reader_round_trip(tmp_path):
+    """RawLogReader.cpp:3-140: frame count, per-frame (ts, depthSize, imageSize), raw or zlib depth, raw / JPEG / absent
+    image, flipColors, fastForward."""
+    from hrbffusion3d_amd.io import KlgReader, write_klg
+    W, H = 64, 48
+    rng = np.random.default_rng(3)
+    frames = []
+    for k in range(5):
+        d = rng.integers(0, 20000, (H, W)).astype(np.uint16); d[::5] = 0
+        yy, xx = np.mgrid[0:H, 0:W]
+        rgb = np.stack([(xx * 3 + k) % 256, (yy * 5) % 256, (xx + yy) % 256], -1).astype(np.uint8)
+        frames.append((1000000 * k + 17, rgb, d))
+    for name, kw in (("raw.klg", dict(compress_depth=False)), ("z.klg", dict(compress_depth=True))):
+        p = str(tmp_path / name)
+        write_klg(p, frames, **kw)
+        r = KlgReader(p, W, H)
+        assert len(r) == 5
+        got = list(r)
+        for (ts, rgb, d), (ts1, rgb1, d1) in zip(frames, got):
+            assert ts == ts1 and np.array_equal(rgb, rgb1) and np.array_equal(d, d1)
+        r.fast_forward(3)
+        assert r.has_more() and r.get_next()[0] == frames[3][0] and r.get_next()[0] == frames[4][0] and not r.has_more()
+        assert r.read_frame(1)[0] == frames[1][0]                      # random access back (getBack)
+        flipped = KlgReader(p, W, H, flip_colors=True).read_frame(2)[1]
+        assert np.array_equal(flipped, frames[2][1][..., ::-1])
+        r.close()
+    # JPEG image + absent image
+    p = str(tmp_path / "jpg.klg")
+    write_klg(p, [frames[0], (5, None, frames[1][2])], jpeg_quality=95)
+    r = KlgReader(p, W, H)
+    ts, rgb, d = r.read_frame(0)
+    assert np.array_equal(d, frames[0][2]) and np.abs(rgb.astype(int) - frames[0][1].astype(int)).mean() < 6.0
+    ts, rgb, d = r.read_frame(1)
+    assert ts == 5 and not rgb.any() and np.array_equal(d, frames[1][2])
+    # truncated file
+    raw = open(str(tmp_path / "raw.klg"), "rb").read()
+    open(str(tmp_path / "cut.klg"), "wb").write(raw[:len(raw) - 100])
+    import pytest
+    with pytest.raises(EOFError):
+        list(KlgReader(str(tmp_path / "cut.klg"), W, H))
