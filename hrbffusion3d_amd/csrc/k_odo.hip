@@ -140,10 +140,6 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
     constexpr int V = 5 * N;
     __shared__ int32_t s_sum[RB / 64][V];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#ifdef ODO_EXP_NOREDUCE
-    if (vals[0] == 123456.0f) slots[0] = 1;
-    return;
-#endif
     if (__ballot(valid) != 0ull) {
         // wave-uniform choice of how many limbs can be non-zero: |p| < 2^9 -> 2, |p| < 2^34 -> 3, else all 5
         // (non-finite values have the largest magnitudes bits and take the general path, which zeroes them)

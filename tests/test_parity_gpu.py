@@ -122,6 +122,21 @@ def test_parameter_variants(pair, variant):
         assert_same_state(o, g, "%s frame %d" % (variant, k))
 
 
+@pytest.mark.parametrize("size", [(320, 240), (1280, 960)])
+def test_other_resolutions(pair, size):
+    """QVGA (BASELINE config 1 geometry) and 1280x960 (config 5 geometry): same kernels, other grid shapes — the
+    level-2 SO3 grid is 19 / 300 workgroups, the fuse tiles and the pyramids change size."""
+    W, H = size
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << (19 if W < 1000 else 22))
+    o, g = pair(p)
+    for k in range(3):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "%dx%d frame %d" % (W, H, k))
+    assert g.surfel_count() > 0.5 * W * H
+
+
 def test_edge_cases_empty_and_invalid_depth(pair):
     """all-zero depth (no valid pixel), depth beyond the cut-off, and a frame after an empty one"""
     W, H = 160, 120
