@@ -157,6 +157,19 @@ class HRBFFusion:
     def set_weighting(self, w):
         self._check(self.lib.hrbf_set_weighting(self.h, w))
 
+    # row-sharded registration over RCCL; rank < 0 = virtual ranks in one process (test hook)
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        if lib.hrbf_comm_unique_id(buf) != 0:
+            raise HrbfError(lib.hrbf_last_error().decode())
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id=None):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        self._check(self.lib.hrbf_comm_init(self.h, int(rank), int(world), buf))
+
     # submap bookkeeping + rigid map correction (GlobalModel::updateModel), SURVEY §8f-3
     def set_index_submap(self, idx):
         self._check(self.lib.hrbf_set_index_submap(self.h, int(idx)))

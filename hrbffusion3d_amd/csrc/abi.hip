@@ -78,6 +78,7 @@ struct hrbf_context {
     int index_submap;           // submap id stamped on new surfels (HRBFFusion::indexSubmap)
     uint8_t *d_submap_active; int n_submap_active;   // KeyFrameIDMap (null = all active)
     float *d_delta; int delta_cap;                   // updateModel matrices
+    OdoComm comm;               // row-sharded registration (null comm + virtual_world <= 1: single GPU)
     int fill_flag_fresh;        // DevPose::should_fill_in was computed by the last k_fillin (nothing touched the prediction since)
     OdoBuffers odo;
     // timing
@@ -208,6 +209,45 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
 
 static void free_planes(MapPlanes &m) { hipFree(m.p0); hipFree(m.p1); hipFree(m.p2); hipFree(m.p3); hipFree(m.p4); }
 
+// ------------------------------------------------------------------------------------------ RCCL (row-sharded registration)
+// librccl is loaded on first use: a single-GPU process never touches it and the library keeps no link-time dependency.
+#include <dlfcn.h>
+namespace {
+struct RcclId128 { char b[128]; };   // ncclUniqueId: 128 opaque bytes, passed by value
+struct RcclApi {
+    void *lib;
+    int (*GetUniqueId)(void *id128);
+    int (*CommInitRank)(void **comm, int nranks, RcclId128 id, int rank);
+    int (*CommDestroy)(void *comm);
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s);
+    const char *(*GetErrorString)(int);
+};
+RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+const int kNcclInt64 = 4, kNcclSum = 0;   // ncclDataType_t::ncclInt64, ncclRedOp_t::ncclSum (rccl.h)
+
+int rccl_load()
+{
+    if (g_rccl.lib) return HRBF_OK;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { hrbf_set_error("librccl.so: %s", dlerror()); return HRBF_ERR_COMM; }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
+        hrbf_set_error("librccl.so lacks an expected entry point"); dlclose(lib); return HRBF_ERR_COMM;
+    }
+    g_rccl.lib = lib;
+    return HRBF_OK;
+}
+int rccl_allreduce_i64(void *comm, long long *buf, size_t count, hipStream_t s)
+{
+    return g_rccl.AllReduce(buf, buf, count, kNcclInt64, kNcclSum, comm, s);   // in place, on the context's stream
+}
+}   // namespace
+
 extern "C" void hrbf_destroy(hrbf_handle c)
 {
     if (!c) return;
@@ -235,6 +275,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     if (c->ring_e0) for (int i = 0; i < HRBF_RING; ++i) { if (c->ring_e0[i]) hipEventDestroy(c->ring_e0[i]); if (c->ring_e1[i]) hipEventDestroy(c->ring_e1[i]); }
     free(c->ring_e0); free(c->ring_e1);
     if (c->d_stats_ring) hipFree(c->d_stats_ring);
+    if (c->comm.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm.comm);
     if (c->d_submap_active) hipFree(c->d_submap_active);
     if (c->d_delta) hipFree(c->d_delta);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -373,7 +414,8 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
         launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
     OdoSources src = make_sources(c);
     OdoConfig cfg = make_cfg(c);
-    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, nullptr, 0, 1, weight_multiplier);
+    const bool sharded = c->comm.comm != nullptr || c->comm.virtual_world > 1;
+    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier);
 }
 
 #define TIMER(i) do { if (c->timing & 1) hipEventRecord(c->ev[i], c->stream); } while (0)
@@ -806,10 +848,35 @@ extern "C" int hrbf_icp_step(hrbf_handle c, const float Rcurr[9], const float tc
                         angle_thresh, use_weight, A_out, b_out, residual_out);
 }
 
-extern "C" int hrbf_comm_unique_id(uint8_t out128[128]) { (void)out128; hrbf_set_error("multi-GPU sharding: not built in this round"); return HRBF_ERR_COMM; }
-extern "C" int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
+extern "C" int hrbf_comm_unique_id(uint8_t out128[128])
 {
-    (void)h; (void)rank; (void)world; (void)id128;
-    hrbf_set_error("multi-GPU sharding: not built in this round");
-    return HRBF_ERR_COMM;
+    if (!out128) return HRBF_ERR_INVALID;
+    int r = rccl_load();
+    if (r) return r;
+    const int e = g_rccl.GetUniqueId(out128);
+    if (e != 0) { hrbf_set_error("ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
+    return HRBF_OK;
+}
+
+// rank >= 0: join the communicator `id128` as `rank` of `world` (one process per GPU).
+// rank < 0 (test hook, no RCCL): this single process plays `world` virtual ranks in turn — checks the strip
+// arithmetic of the sharded path on one GPU.  world <= 1 with rank < 0 returns to the single-GPU path.
+extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t id128[128])
+{
+    if (!c || world < 1) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
+    c->comm.rank = 0; c->comm.world = 1; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
+    if (rank < 0) { c->comm.virtual_world = world > 1 ? world : 0; return HRBF_OK; }
+    if (rank >= world || !id128) return HRBF_ERR_INVALID;
+    int r = rccl_load();
+    if (r) return r;
+    RcclId128 id;
+    memcpy(id.b, id128, 128);
+    void *comm = nullptr;
+    const int e = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (e != 0 || !comm) { hrbf_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
+    c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world; c->comm.allreduce_i64 = rccl_allreduce_i64;
+    return HRBF_OK;
 }

@@ -749,13 +749,13 @@ __device__ __forceinline__ bool so3_pixel(const OdoLevel &L, const S *st, int i,
 
 __global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, OdoState *st, long long *__restrict__ part,
                                                    long long *__restrict__ totals, OdoConfig cfg, int fused_solve,
-                                                   int gn_level)
+                                                   int gn_level, int p0, int p1 /* pixel range of this rank */)
 {
-    const int i = blockIdx.x * RB + threadIdx.x;
+    const int i = p0 + blockIdx.x * RB + threadIdx.x;
     float row4[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
-    const bool valid = !st->so3_done && so3_pixel(L, st, i, row4);
+    const bool valid = !st->so3_done && i < p1 && so3_pixel(L, st, i, row4);
     block_reduce_exact<11>(row4, valid, part);
     if (fused_solve && elect_last_workgroup(&st->ticket)) so3_solve_block(st, part, totals, 2, cfg, gn_level);
 }
@@ -1010,15 +1010,16 @@ __device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbC
 __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, const OdoState *__restrict__ st, int nb,
                                                        int do_icp, int do_rgb, float minScale,
                                                        long long *__restrict__ icp_part, long long *__restrict__ res_part,
-                                                       int16_t *__restrict__ corres, float *__restrict__ corres_diff)
+                                                       int16_t *__restrict__ corres, float *__restrict__ corres_diff,
+                                                       int p0, int p1 /* pixel range of this rank */)
 {
     if ((int)blockIdx.x < nb) {
         float out[29];
 #pragma unroll
         for (int k = 0; k < 29; ++k) out[k] = 0.0f;
         bool valid = false;
-        const int i = blockIdx.x * RB + threadIdx.x;
-        if (do_icp && !st->gn_break && i < A.rows * A.cols) {
+        const int i = p0 + blockIdx.x * RB + threadIdx.x;
+        if (do_icp && !st->gn_break && i < p1) {
             const int y = i / A.cols, x = i - y * A.cols;
             valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
                               mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
@@ -1028,9 +1029,9 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
     } else {
         __shared__ long long s_c[RB / 64], s_s[RB / 64];
         const int b = blockIdx.x - nb;
-        const int k = b * RB + threadIdx.x;
+        const int k = p0 + b * RB + threadIdx.x;
         long long cnt = 0, sig = 0;
-        if (do_rgb && !st->gn_break && k < L.rows * L.cols) {
+        if (do_rgb && !st->gn_break && k < p1) {
             const RgbCorr r = rgb_residual_pixel(L, st, minScale, k, cnt, sig);
             int16_t *co = &corres[(size_t)k * 6];
             co[0] = r.c0; co[1] = r.c1; co[2] = r.c2; co[3] = r.c3; co[4] = r.c4; co[5] = 0;
@@ -1202,7 +1203,7 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
                                                     const long long *__restrict__ res_part,
                                                     const int16_t *__restrict__ corres,
                                                     const float *__restrict__ corres_diff, long long *__restrict__ rgb_part,
-                                                    long long *__restrict__ totals)
+                                                    long long *__restrict__ totals, int p0, int p1)
 {
     __shared__ float s_sigma;
     __shared__ int s_break;
@@ -1215,13 +1216,37 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
 #pragma unroll
     for (int k = 0; k < 29; ++k) out[k] = 0.0f;
     bool valid = false;
-    const int k = blockIdx.x * RB + threadIdx.x;
-    if (!brk && k < L.rows * L.cols) {
+    const int k = p0 + blockIdx.x * RB + threadIdx.x;
+    if (!brk && k < p1) {
         const int16_t *co = &corres[(size_t)k * 6];
         RgbCorr r; r.c0 = co[0]; r.c1 = co[1]; r.c2 = co[2]; r.c3 = co[3]; r.c4 = co[4]; r.diff = corres_diff[k];
         valid = rgb_products_pixel(L, r, sigma, fx, fy, use_grad, out);
     }
     block_reduce_exact<29>(out, valid, rgb_part);
+}
+
+// ---- row-sharded path: slot rows -> totals on every rank, all-reduce in between (launch_odometry)
+__global__ __launch_bounds__(256) void k_fold_rows(long long *__restrict__ part, int width, long long *__restrict__ totals,
+                                                   long long *__restrict__ also_zero, int n_zero)
+{
+    for (int col = threadIdx.x; col < width; col += blockDim.x) {
+        long long t = 0;
+        for (int b = 0; b < ODO_SLOTS; ++b) { t += part[(size_t)b * width + col]; part[(size_t)b * width + col] = 0; }
+        totals[col] = t;
+    }
+    for (int k = threadIdx.x; k < n_zero; k += blockDim.x) also_zero[k] = 0;
+}
+__global__ void k_fold_residual_slots(long long *__restrict__ res_part, long long *__restrict__ totals2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long c = 0, s = 0;
+    for (int b = 0; b < RES_SLOTS; ++b) { c += res_part[b * 2]; s += res_part[b * 2 + 1]; res_part[b * 2] = 0; res_part[b * 2 + 1] = 0; }
+    totals2[0] = c; totals2[1] = s;
+}
+__global__ void k_residual_to_slot0(const long long *__restrict__ totals2, long long *__restrict__ res_part)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    res_part[0] = totals2[0]; res_part[1] = totals2[1];   // the other slots are zero: k_gn_rgb_step folds the global sums
 }
 
 // stand-alone solve on totals that were summed elsewhere (row-sharded multi-GPU: all-reduce of the limb sums)
@@ -1349,10 +1374,21 @@ static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
     return A;
 }
 
-void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp, void *comm,
-                     int rank, int world, float weight_multiplier)
+void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
+                     const OdoComm *oc, float weight_multiplier)
 {
-    (void)rank;
+    // sharded = the slot rows of this process do not hold the whole image: fold -> all-reduce -> stand-alone solve
+    const bool sharded = oc != nullptr && (oc->comm != nullptr || oc->virtual_world > 1);
+    const int vworld = sharded ? (oc->virtual_world > 1 ? oc->virtual_world : oc->world) : 1;
+    const int vfirst = sharded && oc->virtual_world <= 1 ? oc->rank : 0;            // ranks this process plays
+    const int vlast = sharded && oc->virtual_world <= 1 ? oc->rank + 1 : vworld;
+    auto strip = [&](const OdoLevel &L, int r, int &p0, int &p1) {                  // rows [r, r+1) * rows / world
+        p0 = (int)((long long)L.rows * r / vworld) * L.cols;
+        p1 = (int)((long long)L.rows * (r + 1) / vworld) * L.cols;
+    };
+    auto allreduce = [&](long long *buf, size_t n) {
+        if (sharded && oc->comm && oc->allreduce_i64) oc->allreduce_i64(oc->comm, buf, n, s);
+    };
     const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
     const int icp = !cfg.rgb_only && cfg.icp_weight > 0.0f;
     const int P = ob.lv[0].rows * ob.lv[0].cols;
@@ -1364,8 +1400,6 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256, ODO_DOWN_TASKS), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);
     }
     // the slot rows (icp | rgb | res | so3) are zeroed once at allocation; every fold re-zeroes what it read
-    const bool multi = comm != nullptr && world > 1;
-    (void)multi;
     int iterations[3] = {cfg.fast_odom ? 3 : 10, cfg.pyramid ? 5 : 0, cfg.pyramid ? 4 : 0};
     int first_level = -1, last_level = -1;
     for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) if (iterations[i] > 0) { first_level = i; break; }
@@ -1394,12 +1428,25 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_so3_persistent, RB, 0);
             capacity = per_cu > 0 ? (long long)per_cu * prop.multiProcessorCount : 0;
         }
-        if (2 * (long long)nb <= capacity)   // at most half of the slots: no dependence on the placement policy
+        if (sharded) {
+            for (int it = 0; it < SO3_ITERS; ++it) {
+                for (int r = vfirst; r < vlast; ++r) {
+                    int p0, p1; strip(L, r, p0, p1);
+                    if (p1 > p0)
+                        hipLaunchKernelGGL(k_so3_reduce, dim3((p1 - p0 + RB - 1) / RB), dim3(RB), 0, s, L, ob.state, ob.so3_part,
+                                           ob.totals + 176, cfg, 0, -1, p0, p1);
+                }
+                hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(256), 0, s, ob.so3_part, 33, ob.totals + 176, (long long *)nullptr, 0);
+                allreduce(ob.totals + 176, 33);
+                hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(RB), 0, s, ob.state, ob.so3_part, ob.totals + 176, 0, cfg,
+                                   it == SO3_ITERS - 1 ? gn_level : -1);
+            }
+        } else if (2 * (long long)nb <= capacity)   // at most half of the slots: no dependence on the placement policy
             hipLaunchKernelGGL(k_so3_persistent, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, cfg, gn_level);
         else
             for (int it = 0; it < SO3_ITERS; ++it)
                 hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, ob.totals + 176, cfg, 1,
-                                   it == SO3_ITERS - 1 ? gn_level : -1);
+                                   it == SO3_ITERS - 1 ? gn_level : -1, 0, L.rows * L.cols);
     }
     // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration
     const float minGrad[3] = {5, 3, 1};
@@ -1410,8 +1457,6 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         IcpArgs A = make_icp_args(L, cfg, i);
         const float minScale = (float)(((double)minGrad[i] * (double)minGrad[i]) / (0.125 * 0.125));
         for (int j = 0; j < iterations[i]; ++j) {
-            hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
-                               ob.icp_part, ob.res_part, ob.corres, ob.corres_diff);
             // operands for the next iteration: same level, or the next non-empty finer level
             const bool last_of_level = (j == iterations[i] - 1);
             int next_level = i;
@@ -1420,11 +1465,42 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 for (int k = i - 1; k >= 0; --k) if (iterations[k] > 0) { next_level = k; break; }
             }
             const bool last_of_all = last_of_level && i == last_level;
+            if (sharded) {
+                for (int r = vfirst; r < vlast; ++r) {
+                    int p0, p1; strip(L, r, p0, p1);
+                    const int nbr = (p1 - p0 + RB - 1) / RB;
+                    if (nbr > 0)
+                        hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nbr), dim3(RB), 0, s, L, A, ob.state, nbr, icp, rgb, minScale,
+                                           ob.icp_part, ob.res_part, ob.corres, ob.corres_diff, p0, p1);
+                }
+                // the robust weight needs the residual sums of the WHOLE image before any RGB product is formed
+                hipLaunchKernelGGL(k_fold_residual_slots, dim3(1), dim3(1), 0, s, ob.res_part, ob.totals + 174);
+                allreduce(ob.totals + 174, 2);
+                hipLaunchKernelGGL(k_residual_to_slot0, dim3(1), dim3(1), 0, s, ob.totals + 174, ob.res_part);
+                for (int r = vfirst; r < vlast; ++r) {
+                    int p0, p1; strip(L, r, p0, p1);
+                    const int nbr = (p1 - p0 + RB - 1) / RB;
+                    if (nbr > 0)
+                        hipLaunchKernelGGL(k_gn_rgb_step, dim3(nbr), dim3(RB), 0, s, L, ob.state, nbr, cfg.fx / div, cfg.fy / div,
+                                           cfg.rgb_only, cfg.rgb_use_grad, ob.res_part, ob.corres, ob.corres_diff, ob.rgb_part,
+                                           ob.totals, p0, p1);
+                }
+                // icp | rgb rows -> totals[0..173] (adjacent parts: one 174-wide view is NOT contiguous per row, fold each)
+                hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(256), 0, s, ob.icp_part, 87, ob.totals, ob.res_part, RES_SLOTS * 2);
+                hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(256), 0, s, ob.rgb_part, 87, ob.totals + 87, (long long *)nullptr, 0);
+                allreduce(ob.totals, 174);
+                hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
+                                   ob.totals, 0, cfg, next_level, last_of_level ? 1 : 0,
+                                   last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
+                continue;
+            }
+            hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
+                               ob.icp_part, ob.res_part, ob.corres, ob.corres_diff, 0, L.rows * L.cols);
             // fusing the solve into the last workgroup of k_gn_rgb_step was measured slower (the fold then reads the
             // slot rows from memory instead of L2 and pays a ticket round trip): 16.1 vs 6.3 + 8.8 us on level 2
             hipLaunchKernelGGL(k_gn_rgb_step, dim3(nb), dim3(RB), 0, s, L, ob.state, nb, cfg.fx / div, cfg.fy / div,
                                cfg.rgb_only, cfg.rgb_use_grad, ob.res_part, ob.corres, ob.corres_diff, ob.rgb_part,
-                               ob.totals);
+                               ob.totals, 0, L.rows * L.cols);
             hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
                                ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0,
                                last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);

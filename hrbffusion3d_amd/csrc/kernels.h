@@ -110,9 +110,20 @@ size_t odo_state_bytes();
 size_t odo_slot_bytes();
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
 // full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
+// Row-sharded registration (SURVEY §8e sharding 1): every rank holds the full pyramids and reduces the image rows
+// [rank, rank+1) * rows / world of each level; the int64 limb sums are all-reduced (SUM) and every rank takes the same
+// step.  allreduce_i64 is ncclAllReduce(ncclInt64, ncclSum) bound by abi.hip; `virtual_world` > 1 is a test hook: one
+// process plays all ranks in turn into the same slot rows (no collective), which checks the strip arithmetic on a
+// single GPU.
+struct OdoComm {
+    void *comm;
+    int rank, world;
+    int virtual_world;
+    int (*allreduce_i64)(void *comm, long long *buf, size_t count, hipStream_t s);
+};
 // weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
-                     void *comm /* ncclComm_t or null */, int rank, int world, float weight_multiplier);
+                     const OdoComm *oc /* nullable */, float weight_multiplier);
 // pose bookkeeping
 void launch_pose_set(hipStream_t s, DevPose *dp, const float pose16_colmajor[16], int also_prev);
 void launch_frame_epilogue(hipStream_t s, DevPose *dp, float weight_multiplier, int tracked);

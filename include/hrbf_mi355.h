@@ -247,8 +247,15 @@ int hrbf_icp_step(hrbf_handle h, const float Rcurr[9], const float tcurr[3],
                   float dist_thresh, float angle_thresh, int use_weight,
                   double A_out[36], double b_out[6], double residual_out[2]);
 
-/* multi-GPU: join an RCCL communicator; afterwards the odometry reductions are
- * row-sharded over ranks and all-reduced (exact int64 limbs) every Gauss-Newton iteration. */
+/* multi-GPU (sharding 1): one process per GPU joins an RCCL communicator (librccl is loaded on first use);
+ * afterwards every rank still runs the whole frame on its own full map, but the registration reductions (SO3, RGB
+ * residual, ICP and RGB normal equations) cover only the image rows [rank, rank+1) * rows / world of each pyramid
+ * level and the exact int64 limb sums are all-reduced (ncclInt64, ncclSum) on the context's stream, 29 times per
+ * frame (+ <= 10 for SO3) — every rank then takes the identical step, bit-identical to the single-GPU result.
+ * At VGA this is a latency cost, not a speed-up (the reductions are launch-bound); it is the exchange step a
+ * spatially sharded map would need and is exercised by tests, while bench.py scales by independent replicas.
+ * hrbf_comm_init(h, -1, world, NULL) is a test hook without RCCL: the process plays `world` virtual ranks in turn
+ * (world <= 1 returns to the single-GPU path). */
 int hrbf_comm_unique_id(uint8_t out128[128]);
 int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
 

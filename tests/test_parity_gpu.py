@@ -234,6 +234,30 @@ def test_update_model_and_submap_mask(pair):
     assert_same_state(o, g, "mask removed")
 
 
+@pytest.mark.parametrize("mode", ["virtual3", "rccl1"])
+def test_row_sharded_registration(pair, mode):
+    """SURVEY §8e sharding 1: registration reductions over row strips + all-reduce of the exact limb sums give the
+    single-GPU bits.  virtual3: one process plays three ranks in turn (strip arithmetic, no collective);
+    rccl1: a real RCCL communicator of world size 1 (library binding, ncclAllReduce(int64, sum) on the stream)."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    if mode == "virtual3":
+        g.comm_init(-1, 3)
+    else:
+        g.comm_init(0, 1, HRBFFusion.comm_unique_id())
+    for k in range(5):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "%s frame %d" % (mode, k))
+    g.comm_init(-1, 1)                                      # back to the single-GPU path, same context
+    rgb, d, _ = synth.frame(5, W, H, noise=True)
+    o.process_frame(rgb, d); g.process_frame(rgb, d)
+    assert_same_state(o, g, mode + " back to single")
+
+
 def test_icp_step_seam(oracle_lib_built, gpu_available):
     """hrbf_icp_step on caller-owned device maps == oracle (bit-exact sums) ~= fp64 numpy (1e-5)."""
     import torch
