@@ -356,12 +356,13 @@ static void st_init(hrbf_context *c)
     c->count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
     launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
 }
-static void st_indices(hrbf_context *c, bool for_clean = true)
+// what: which outputs of the projection the next consumer reads (k_resolve); the stage API asks for everything
+static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
 {
     launch_predict_indices(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->map,
                            &c->d_count[c->target], c->count_ub, c->d_zbuf, c->d_idx, c->d_im_vertconf,
                            c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin,
-                           for_clean ? c->d_clean_tex : nullptr, c->d_submap_active, c->n_submap_active);
+                           for_clean ? c->d_clean_tex : nullptr, c->d_submap_active, c->n_submap_active, what);
 }
 static void st_fuse(hrbf_context *c)
 {
@@ -437,17 +438,17 @@ static int process_frame_resident(hrbf_context *c, float wmul)
         TIMER(2);
         st_conf(c);
         if (!c->prm.rgb_only) {
-            st_indices(c, false);
+            st_indices(c, false, 1);     // association reads the index, vertex/conf and normal/radius images
             TIMER(3);
             st_fuse(c);
             TIMER(4);
-            st_indices(c, true);
+            st_indices(c, true, 4);      // the clean test reads the packed texels only
             TIMER(5);
             st_clean(c);
             TIMER(6);
         } else { TIMER(3); TIMER(4); TIMER(5); TIMER(6); }
     }
-    st_indices(c, false);
+    st_indices(c, false, 3);             // prediction + the images a caller can fetch
     TIMER(7);
     st_predict(c);
     TIMER(8);

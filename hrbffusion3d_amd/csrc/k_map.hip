@@ -133,12 +133,18 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
     }
 }
 
+// `what`: 1 = vertconf + normrad (association), 2 = colortime + curvature images (prediction), 4 = packed clean
+// texels (clean test).  A frame projects three times and each consumer reads a different subset, so each pass
+// gathers and writes only its own (84 -> 36 / 36 / 84 bytes per pixel); the index image is always written.
+#define RESOLVE_GEOM 1
+#define RESOLVE_ATTR 2
+#define RESOLVE_CLEAN 4
 __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m,
                                                  unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
                                                  float4 *__restrict__ curvmax, float4 *__restrict__ curvmin,
-                                                 float4 *__restrict__ clean_tex)
+                                                 float4 *__restrict__ clean_tex, int what)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cam.W * cam.H) return;
@@ -146,25 +152,33 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
     const Rigid tinv = dp->tinv;
     const float4 z4 = make_float4(0, 0, 0, 0);
     if (key == ZB_EMPTY) {
-        idx[i] = 0; vertconf[i] = z4; colortime[i] = z4; normrad[i] = z4; curvmax[i] = z4; curvmin[i] = z4;
-        if (clean_tex) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
+        idx[i] = 0;
+        if (what & RESOLVE_GEOM) { vertconf[i] = z4; normrad[i] = z4; }
+        if (what & RESOLVE_ATTR) { colortime[i] = z4; curvmax[i] = z4; curvmin[i] = z4; }
+        if (what & RESOLVE_CLEAN) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
         return;
     }
     zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
     uint32_t s = (uint32_t)(key & 0xFFFFFFFFull);
-    float4 p = m.p0[s], nr = m.p2[s];
-    f3 h = xform(tinv, xyz(p));
-    f3 n = normalize3(rot_mul(tinv, xyz(nr)));
     idx[i] = s;
-    vertconf[i] = make_float4(h.x, h.y, h.z, p.w);
-    const float4 ct = m.p1[s];
-    colortime[i] = ct;
-    // packed texel for the clean test (pass A of the fuse): 32 contiguous bytes instead of three gathers;
-    // .w of the second half = the reference's `current > 0U` gate (copy_unstable.vert:111)
-    if (clean_tex) { clean_tex[2 * i] = make_float4(h.x, h.y, h.z, p.w); clean_tex[2 * i + 1] = make_float4(ct.z, ct.w, s > 0u ? 1.0f : 0.0f, 0.0f); }
-    normrad[i] = make_float4(n.x, n.y, n.z, nr.w);
-    curvmax[i] = m.p3[s];
-    curvmin[i] = m.p4[s];
+    const float4 p = m.p0[s];
+    const f3 h = xform(tinv, xyz(p));
+    if (what & RESOLVE_GEOM) {
+        const float4 nr = m.p2[s];
+        const f3 n = normalize3(rot_mul(tinv, xyz(nr)));
+        vertconf[i] = make_float4(h.x, h.y, h.z, p.w);
+        normrad[i] = make_float4(n.x, n.y, n.z, nr.w);
+    }
+    if (what & (RESOLVE_ATTR | RESOLVE_CLEAN)) {
+        const float4 ct = m.p1[s];
+        if (what & RESOLVE_ATTR) { colortime[i] = ct; curvmax[i] = m.p3[s]; curvmin[i] = m.p4[s]; }
+        // packed texel for the clean test (pass A of the fuse): 32 contiguous bytes instead of three gathers;
+        // .w of the second half = the reference's `current > 0U` gate (copy_unstable.vert:111)
+        if (what & RESOLVE_CLEAN) {
+            clean_tex[2 * i] = make_float4(h.x, h.y, h.z, p.w);
+            clean_tex[2 * i + 1] = make_float4(ct.z, ct.w, s > 0u ? 1.0f : 0.0f, 0.0f);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -639,7 +653,7 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
 void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
                             const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
                             float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                            float4 *clean_tex, const uint8_t *submap_active, int n_active)
+                            float4 *clean_tex, const uint8_t *submap_active, int n_active, int what)
 {
     int P = cam.W * cam.H;
     uint32_t blocks = (count_ub + 255) / 256;   // zbuf is ZB_EMPTY on entry: launch_zbuf_reset once, k_resolve afterwards
@@ -647,8 +661,9 @@ void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, fl
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf, m.p1, submap_active,
                        n_active);
+    if (!clean_tex) what &= ~RESOLVE_CLEAN;
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, zbuf, idx, vertconf, colortime,
-                       normrad, curvmax, curvmin, clean_tex);
+                       normrad, curvmax, curvmin, clean_tex, what);
 }
 
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,

@@ -35,7 +35,8 @@ void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, fl
                             const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
                             float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
                             float4 *clean_tex /* nullable: packed texels for the clean test */,
-                            const uint8_t *submap_active /* nullable: KeyFrameIDMap */, int n_active);
+                            const uint8_t *submap_active /* nullable: KeyFrameIDMap */, int n_active,
+                            int what /* 1 geometry images | 2 attribute images | 4 clean texels */);
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
