@@ -196,11 +196,17 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                                                    uint32_t *__restrict__ slot)
 {
     const int QW = cam.W / 2, QH = cam.H / 2;
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= QW * QH) return;
+    // Threads walk the quarter grid ROW-major so that a wave reads 64 neighbouring pixels of one image row (the
+    // per-pixel loads and the 16 index-map samples coalesce); the record index q stays the reference's COLUMN-major
+    // draw order (data.vert), which decides "first primitive wins" and the append order.  Only the five record
+    // stores are strided by this.
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= QW * QH) return;
+    const int qx = t % QW, qy = t / QW;
+    const int q = qx * QH + qy;
     const Rigid pose = dp->pose;
     const int tpar = tick % 2;
-    const int px = (q / QH) * 2 + tpar, py = (q % QH) * 2 + tpar;
+    const int px = qx * 2 + tpar, py = qy * 2 + tpar;
     int flag = 0;
     uint32_t best = 0;
     if (px < cam.W && py < cam.H) {
@@ -268,9 +274,14 @@ __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes
                                                       MapPlanes m, uint32_t *__restrict__ merged, float curvThr)
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q || rec_flag[q] != 1) return;
-    const uint32_t s = rec_best[q];
-    if (slot[s] != (uint32_t)q) return;
+    bool act = q < Q && rec_flag[q] == 1;
+    uint32_t s = 0;
+    if (act) { s = rec_best[q]; act = slot[s] == (uint32_t)q; }
+    {   // merged count: one atomic per wave instead of one per merge on a single address
+        const unsigned long long bal = __ballot(act);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(merged, (uint32_t)__popcll(bal));
+    }
+    if (!act) return;
     slot[s] = 0xFFFFFFFFu;   // re-arm for the next frame (only touched entries are reset)
     const float4 r0 = rec.p0[q], r1 = rec.p1[q], r2 = rec.p2[q], r3 = rec.p3[q], r4 = rec.p4[q];
     const float4 vp = m.p0[s], vc = m.p1[s], vn = m.p2[s];
@@ -299,7 +310,6 @@ __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes
         m.p0[s] = make_float4(vp.x, vp.y, vp.z, sum);
         m.p1[s] = make_float4(vc.x, vc.y, vc.z, (float)tick);
     }
-    atomicAdd(merged, 1u);
 }
 
 // ------------------------------------------------------------------------------------------
