@@ -614,6 +614,24 @@ __device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__
     if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
 }
 
+// packed ICP operands of one pixel, after the model maps were moved to the global frame (k_odo_prepare)
+__device__ __forceinline__ void pack_icp_texels(const OdoLevel &L, int i)
+{
+    const size_t PP = (size_t)L.rows * L.cols;
+    {
+        const float vx = L.vmap_c[i], nx = L.nmap_c[i], k1 = L.ck1_c[3 * PP + i], k2 = L.ck2_c[3 * PP + i];
+        const bool ok = !(hd_isnanf(vx) || hd_isnanf(nx) || hd_isnanf(k1) || hd_isnanf(k2));
+        L.icp_cur[2 * i] = make_float4(vx, L.vmap_c[PP + i], L.vmap_c[2 * PP + i], ok ? 1.0f : 0.0f);
+        L.icp_cur[2 * i + 1] = make_float4(nx, L.nmap_c[PP + i], L.nmap_c[2 * PP + i], 0.0f);
+    }
+    {
+        const float vx = L.vmap_g[i], nx = L.nmap_g[i], k1 = L.ck1_g[3 * PP + i], k2 = L.ck2_g[3 * PP + i];
+        const bool ok = !(hd_isnanf(vx) || hd_isnanf(nx) || hd_isnanf(k1) || hd_isnanf(k2));
+        L.icp_model[2 * i] = make_float4(vx, L.vmap_g[PP + i], L.vmap_g[2 * PP + i], L.icpw[i]);
+        L.icp_model[2 * i + 1] = make_float4(nx, L.nmap_g[PP + i], L.nmap_g[2 * PP + i], ok ? 1.0f : 0.0f);
+    }
+}
+
 // last pass over the pyramids, all levels in one launch (blockIdx.y = level): model maps into the global frame
 // (in place), Sobel + back-projected cloud of the live frame; workgroup (0,0) also resets the registration state
 struct OdoLevels { OdoLevel lv[HRBF_NUM_PYRS]; };
@@ -630,6 +648,7 @@ __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__rest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.rows * L.cols) return;
     transform_pixel(L, i, dp->pose);
+    pack_icp_texels(L, i);
     if (do_rgb) {
         const int div = 1 << level;
         sobel_cloud_pixel(L, i, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
@@ -843,14 +862,60 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
 // ------------------------------------------------------------------------------------------ O3 + O4 fused launch
 struct IcpArgs {
     const float *vmap_c, *nmap_c, *ck1_c, *ck2_c, *vmap_g, *nmap_g, *ck1_g, *ck2_g, *icpw;
+    const float4 *cur_tex, *model_tex;   // packed operands (pack_icp_texels); null in the icpStep seam
     int rows, cols;
     float fx, fy, cx, cy, distThres, angleThres;
     int use_search, radius, use_weight;
 };
 
+// The same association for the common case (no windowed search) on the packed operands written once per frame by
+// pack_icp_texels: current pixel {v.xyz, valid} {n.xyz, -}, model pixel {v.xyz, icp weight} {n.xyz, valid} — two
+// 16-byte loads + two 16-byte gathers instead of eight 4-byte plane loads + nine 4-byte plane gathers per pixel
+// and iteration.  `valid` folds the four NaN tests of the planar version; every arithmetic step is the same.
+__device__ __forceinline__ bool icp_pixel_packed(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                                 int x, int y, float *out)
+{
+    const int rows = A.rows, cols = A.cols;
+    const float4 c0 = A.cur_tex[2 * (y * cols + x)];
+    if (c0.w == 0.0f) return false;
+    const float4 c1 = A.cur_tex[2 * (y * cols + x) + 1];
+    const f3 vcur = mk3(c0.x, c0.y, c0.z), ncur = mk3(c1.x, c1.y, c1.z);
+    f3 vg_ = add3(m33_mul(Rcurr, vcur), tcurr);
+    f3 vcp = m33_mul(Rpi, sub3(vg_, tprev));
+    float fu = vcp.x * A.fx / vcp.z + A.cx, fv = vcp.y * A.fy / vcp.z + A.cy;
+    if (hd_isnanf(fu) || hd_isnanf(fv)) return false;
+    if (!(fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f)) return false;
+    int ux = (int)hd_rintf(fu), uy = (int)hd_rintf(fv);
+    if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcp.z < 0.0f) return false;
+    f3 ncur_g = m33_mul(Rcurr, ncur);
+    const float4 m0 = A.model_tex[2 * (uy * cols + ux)], m1 = A.model_tex[2 * (uy * cols + ux) + 1];
+    if (m1.w == 0.0f) return false;
+    const f3 bv = mk3(m0.x, m0.y, m0.z), bn = mk3(m1.x, m1.y, m1.z);
+    float dist = len3(sub3(bv, vg_)), sine = len3(cross3(ncur_g, bn));
+    if (sine > A.angleThres || dist > A.distThres) return false;
+    f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
+    f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
+    f3 n_cp = m33_mul(Rpi, bn);
+    float weight = 1.0f;
+    if (A.use_weight) { float w = m0.w; weight = hd_isnanf(w) ? 0.0f : w; }
+    float row[7];
+    f3 cr = cross3(s_cp, n_cp);
+    row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
+    row[6] = dot3(n_cp, sub3(s_cp, d_cp));
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 7; ++j) out[k++] = weight * row[i] * row[j];
+    out[27] = weight * row[6] * row[6];
+    out[28] = 1.0f;
+    return true;
+}
+
 __device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
                                           int x, int y, float *out)
 {
+    if (A.cur_tex && !A.use_search) return icp_pixel_packed(A, Rcurr, tcurr, Rpi, tprev, x, y, out);
     const int rows = A.rows, cols = A.cols;
     f3 vcur = mk3(PLN(A.vmap_c, 0, rows, cols, y, x), PLN(A.vmap_c, 1, rows, cols, y, x), PLN(A.vmap_c, 2, rows, cols, y, x));
     f3 ncur = mk3(PLN(A.nmap_c, 0, rows, cols, y, x), PLN(A.nmap_c, 1, rows, cols, y, x), PLN(A.nmap_c, 2, rows, cols, y, x));
@@ -1366,6 +1431,7 @@ static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
     IcpArgs A;
     A.vmap_c = L.vmap_c; A.nmap_c = L.nmap_c; A.ck1_c = L.ck1_c; A.ck2_c = L.ck2_c;
     A.vmap_g = L.vmap_g; A.nmap_g = L.nmap_g; A.ck1_g = L.ck1_g; A.ck2_g = L.ck2_g; A.icpw = L.icpw;
+    A.cur_tex = L.icp_cur; A.model_tex = L.icp_model;
     A.rows = L.rows; A.cols = L.cols;
     const int div = 1 << level;
     A.fx = cfg.fx / div; A.fy = cfg.fy / div; A.cx = cfg.cx / div; A.cy = cfg.cy / div;
@@ -1537,6 +1603,7 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
     IcpArgs A;
     A.vmap_c = vmap_curr; A.nmap_c = nmap_curr; A.ck1_c = ck1_curr; A.ck2_c = ck2_curr;
     A.vmap_g = vmap_g_prev; A.nmap_g = nmap_g_prev; A.ck1_g = ck1_g_prev; A.ck2_g = ck2_g_prev; A.icpw = icpw;
+    A.cur_tex = nullptr; A.model_tex = nullptr;
     A.rows = rows; A.cols = cols; A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
     A.distThres = dist_thresh; A.angleThres = angle_thresh; A.use_search = 0; A.radius = 0; A.use_weight = use_weight;
     Rigid cur, prv;
