@@ -159,6 +159,9 @@ def main():
     if world == 1:
         nh = min(20, K)
         fus.enable_timing(False)
+        for k in range(1 + Wm, 1 + Wm + min(3, K)):      # first use allocates the pinned staging ring
+            fus.process_frame(frames[k][0], frames[k][1], k)
+        fus.synchronize()
         t1 = time.perf_counter()
         for k in range(1 + Wm + K - nh, 1 + Wm + K):
             fus.process_frame(frames[k][0], frames[k][1], k)

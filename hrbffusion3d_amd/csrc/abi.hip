@@ -68,6 +68,7 @@ struct hrbf_context {
     uint32_t *d_count;          // [2], ping-pong with the map
     uint32_t count_ub;          // host upper bound of the surfel count
     uint32_t *h_count_pinned;   // async read-back (1-frame lag)
+    uint8_t *h_stage[3]; hipEvent_t ev_stage[3]; bool stage_used[3]; uint32_t stage_head;   // pinned input staging ring
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best; uint32_t *d_slot;
     uint32_t *d_stats; uint32_t *d_init_flags, *d_init_offs;
@@ -271,6 +272,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
         for (void *p : q) if (p) hipFree(p);
     }
     if (c->h_count_pinned) hipHostFree(c->h_count_pinned);
+    for (int k = 0; k < 3; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->ev_stage[k]) hipEventDestroy(c->ev_stage[k]); }
     if (c->ev_count) hipEventDestroy(c->ev_count);
     for (int i = 0; i < 12; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->ring_e0) for (int i = 0; i < HRBF_RING; ++i) { if (c->ring_e0[i]) hipEventDestroy(c->ring_e0[i]); if (c->ring_e1[i]) hipEventDestroy(c->ring_e1[i]); }
@@ -475,8 +477,28 @@ extern "C" int hrbf_upload_frame(hrbf_handle c, const uint8_t *rgb, const uint16
 extern "C" int hrbf_process_frame(hrbf_handle c, const uint8_t *rgb, const uint16_t *depth, int64_t ts, float wmul)
 {
     (void)ts;
-    int r = hrbf_upload_frame(c, rgb, depth);
-    if (r) return r;
+    if (!c || !rgb || !depth) { hrbf_set_error("null argument"); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    // The caller's buffers are borrowed for the call only: they are copied into a pinned staging slot (ring of 3,
+    // allocated on first use) and uploaded from there asynchronously, so the call never waits for the GPU unless the
+    // host runs three frames ahead.
+    const size_t nrgb = (size_t)c->P * 3, ndep = (size_t)c->P * 2;
+    const int slot = (int)(c->stage_head % 3u);
+    if (!c->h_stage[slot]) {
+        HIP_CHECK(hipHostMalloc((void **)&c->h_stage[slot], nrgb + ndep + 16, hipHostMallocMapped));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[slot], hipEventDisableTiming));
+    }
+    if (c->stage_used[slot]) HIP_CHECK(hipEventSynchronize(c->ev_stage[slot]));
+    memcpy(c->h_stage[slot], rgb, nrgb);
+    memcpy(c->h_stage[slot] + ((nrgb + 15) & ~(size_t)15), depth, ndep);
+    // uploaded by a kernel that reads the pinned slot over PCIe: no copy-engine hand-over on the compute stream
+    uint8_t *dev_view = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&dev_view, c->h_stage[slot], 0));
+    const size_t dep_off = (nrgb + 15) & ~(size_t)15;   // keeps the depth half 16-byte aligned
+    launch_copy_inputs(c->stream, dev_view, nrgb, dev_view + dep_off, ndep, c->d_rgb, (uint8_t *)c->d_depth);
+    HIP_CHECK(hipEventRecord(c->ev_stage[slot], c->stream));
+    c->stage_used[slot] = true;
+    c->stage_head++;
     return process_frame_resident(c, wmul);
 }
 

@@ -766,3 +766,22 @@ void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_update_model, dim3(blocks), dim3(256), 0, s, m, count, delta, n);
 }
+
+// Input upload as a kernel: reads the pinned staging slot over PCIe and writes the two device input images.  A copy
+// engine transfer (hipMemcpyAsync) on the compute stream costs two cross-engine hand-overs per copy (~50-100 us each
+// measured); a kernel on the same queue costs none.
+__global__ void k_copy_inputs(const uint8_t *__restrict__ src_rgb, size_t nrgb, const uint8_t *__restrict__ src_dep,
+                              size_t ndep, uint8_t *__restrict__ d_rgb, uint8_t *__restrict__ d_dep)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    const size_t v_rgb = nrgb / 16, v_dep = ndep / 16;
+    for (size_t i = t; i < v_rgb; i += nt) reinterpret_cast<uint4 *>(d_rgb)[i] = reinterpret_cast<const uint4 *>(src_rgb)[i];
+    for (size_t i = t; i < v_dep; i += nt) reinterpret_cast<uint4 *>(d_dep)[i] = reinterpret_cast<const uint4 *>(src_dep)[i];
+    for (size_t i = v_rgb * 16 + t; i < nrgb; i += nt) d_rgb[i] = src_rgb[i];
+    for (size_t i = v_dep * 16 + t; i < ndep; i += nt) d_dep[i] = src_dep[i];
+}
+void launch_copy_inputs(hipStream_t s, const uint8_t *src_rgb, size_t nrgb, const uint8_t *src_dep, size_t ndep,
+                        uint8_t *d_rgb, uint8_t *d_dep)
+{
+    hipLaunchKernelGGL(k_copy_inputs, dim3(512), dim3(256), 0, s, src_rgb, nrgb, src_dep, ndep, d_rgb, d_dep);
+}

@@ -50,6 +50,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
+void launch_copy_inputs(hipStream_t s, const uint8_t *src_rgb, size_t nrgb, const uint8_t *src_dep, size_t ndep,
+                        uint8_t *d_rgb, uint8_t *d_dep);   // src: device-visible pinned host memory
 uint32_t fuse_tile_items();
 uint32_t fuse_tile_count_stride();
 

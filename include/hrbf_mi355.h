@@ -96,7 +96,8 @@ const char *hrbf_last_error(void);
 const char *hrbf_version(void);
 
 /* primary entry: HRBFFusion::processFrame (Core/src/HRBFFusion.h:110-113).
- * rgb: W*H*3 uint8 (R,G,B), depth: W*H uint16 raw units; host pointers borrowed for the call. */
+ * rgb: W*H*3 uint8 (R,G,B), depth: W*H uint16 raw units; host pointers borrowed for the call (copied into pinned
+ * staging, uploaded asynchronously — the call enqueues the frame and returns). */
 int hrbf_process_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth, int64_t timestamp,
                        float weight_multiplier);
 /* same, inputs already resident in HBM (device pointers) — what bench.py times.  The call only enqueues and the
