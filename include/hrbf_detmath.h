@@ -51,11 +51,12 @@ HD_FN int hd_isnanf(float a) { return a != a; }
 HD_FN float hd_nanf(void) { return hd_u2f(0x7fffffffu); }
 
 /* ---------------------------------------------------------------- expf */
-HD_FN float hd_expf(float x)
+HD_FN float hd_expf(float x0)
 {
-    if (x != x) return x;
-    if (x > 88.7228f) return hd_u2f(0x7f800000u);
-    if (x < -103.9f) return 0.0f;
+    /* branch-free: the core runs on a clamped copy (identical to x0 whenever the core's result is the one returned),
+       the three special cases are selected at the end — 169 calls per pixel in the bilateral filter */
+    const int is_nan = x0 != x0, over = x0 > 88.7228f, under = x0 < -103.9f;
+    const float x = is_nan ? 0.0f : (over ? 88.7228f : (under ? -103.9f : x0));
     float kf = hd_rintf(x * 1.44269504088896341f);
     float r = hd_fmaf(kf, -0.693359375f, x);
     r = hd_fmaf(kf, 2.12194440e-4f, r);
@@ -73,7 +74,8 @@ HD_FN float hd_expf(float x)
     int k1 = k / 2, k2 = k - k1;
     float s1 = hd_u2f((uint32_t)(k1 + 127) << 23);
     float s2 = hd_u2f((uint32_t)(k2 + 127) << 23);
-    return (p * s1) * s2;
+    const float core = (p * s1) * s2;
+    return is_nan ? x0 : (over ? hd_u2f(0x7f800000u) : (under ? 0.0f : core));
 }
 
 /* ---------------------------------------------------------------- asin/acos (float) */
