@@ -106,6 +106,41 @@ def test_tracked_synthetic_stream(pair, noise):
     assert err < 0.05
 
 
+def test_long_sequence_trajectory_and_determinism(gpu_available):
+    """150 noisy QVGA frames from an empty map (frame 0 seeds it): the trajectory stays near the ground truth (ATE, the
+    north star's other metric, against the stream's analytic poses) and a second run reproduces pose and map bit for
+    bit (the property that lets the short oracle comparisons stand for long sequences).
+    The bound is loose on purpose: the reference back-projects the live frame at INTEGER pixel coordinates
+    (depth_vertex_normal_radius.frag:25-29, "not the half-pixel coordinates") but ray-casts the model through pixel
+    CENTRES (predict_hrbf.frag:42-47); registration absorbs that half pixel as ~0.1 deg per frame while the map is
+    young, which saturates at about 6 cm at QVGA (2 cm at VGA).  Kept, like every other quirk."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 320, 240
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 21)
+    frames = [synth.frame(k, W, H, noise=True) for k in range(150)]
+
+    def run():
+        g = HRBFFusion(p)
+        g.set_pose(frames[0][2])
+        est = []
+        for rgb, d, _ in frames:
+            g.process_frame(rgb, d)
+            est.append(g.get_pose())
+        m = g.download_map()
+        g.close()
+        return est, m
+
+    est, m = run()
+    gt = [f[2] for f in frames]
+    ate = synth.ate_rmse(est, gt)
+    assert ate < 0.10, ate
+    assert len(m) > 0.8 * W * H
+    est2, m2 = run()
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(est, est2))
+    assert np.array_equal(bits(m), bits(m2))
+
+
 @pytest.mark.parametrize("variant", ["gauss_filter", "central_diff_normals", "no_so3_no_pyramid", "conf_eval", "rgb_only",
                                      "icp_only"])
 def test_parameter_variants(pair, variant):
