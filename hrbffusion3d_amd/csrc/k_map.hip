@@ -552,17 +552,23 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlane
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float ftime = (float)time;
 
+    // every tile count is staged in LDS once (one round of global loads per workgroup); the per-tile prefixes are
+    // then summed out of LDS — a workgroup walks 2-8 tiles and used to pay a dependent global round trip for each
+    extern __shared__ uint32_t s_cnt[];
+    for (uint32_t t = threadIdx.x; t < num_tiles; t += FUSE_THREADS) s_cnt[t] = tile_count[(size_t)t * TC_STRIDE];
+    __syncthreads();
+
     for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const uint32_t base = tile * FUSE_TILE;
         uint32_t psum = 0;
-        for (uint32_t t = threadIdx.x; t < tile; t += FUSE_THREADS) psum += tile_count[(size_t)t * TC_STRIDE];
+        for (uint32_t t = threadIdx.x; t < tile; t += FUSE_THREADS) psum += s_cnt[t];
         for (int d = 32; d > 0; d >>= 1) psum += __shfl_down(psum, d);
         if (lane == 0) s_psum[wid] = psum;
         __syncthreads();
         uint32_t prefix = 0;
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) prefix += s_psum[w];
-        const uint32_t tile_total = tile_count[(size_t)tile * TC_STRIDE];
+        const uint32_t tile_total = s_cnt[tile];
         if (tile == num_tiles - 1 && threadIdx.x == 0) {
             const uint32_t tot = prefix + tile_total;
             *count_out = tot > cap ? cap : tot;
@@ -713,7 +719,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                        keep_flags, tile_count, stats);
     uint32_t blocks = tiles < 256u ? tiles : 256u;   // co-resident: ONE 512-thread workgroup per CU (132 VGPR -> 12 waves/CU)
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), 0, s, time, m, rec, Q, keep_flags, tile_count,
+    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), sizeof(uint32_t) * (size_t)tiles, s, time, m, rec, Q, keep_flags, tile_count,
                        count_in, count_out, stats, cap, tile_done);
     if (e1) hipEventRecord(e1, s);
     int nz = Q > (int)tiles ? Q : (int)tiles;
