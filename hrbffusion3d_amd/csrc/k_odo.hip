@@ -614,6 +614,25 @@ __device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__
     if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
 }
 
+// pose-independent part of RGBResidual::getProducts' pixel test (reduce.cu:981-1010): away from the right / bottom
+// border, 4x4 neighbourhood of the live intensity image all non-zero, gradient magnitude above the level's
+// threshold, live depth present
+__device__ __forceinline__ bool rgb_residual_static_test(const OdoLevel &L, float minScale, int k)
+{
+    const int rows = L.rows, cols = L.cols;
+    const int i = k / cols, j0 = k - i * cols;
+    if (!(j0 < cols - 5 && i < rows - 1)) return false;
+    bool valid = true;
+    for (int u = (i - 2 > 0 ? i - 2 : 0); u < (i + 2 < rows ? i + 2 : rows); ++u)
+        for (int v = (j0 - 2 > 0 ? j0 - 2 : 0); v < (j0 + 2 < cols ? j0 + 2 : cols); ++v)
+            valid = valid && (L.next_image[u * cols + v] > 0);
+    if (!valid) return false;
+    int valx = L.dIdx[k], valy = L.dIdy[k];
+    float mTwo = (float)((valx * valx) + (valy * valy));
+    if (!(mTwo >= minScale)) return false;
+    return !hd_isnanf(L.next_depth[k]);
+}
+
 // packed ICP operands of one pixel, after the model maps were moved to the global frame (k_odo_prepare)
 __device__ __forceinline__ void pack_icp_texels(const OdoLevel &L, int i)
 {
@@ -652,6 +671,10 @@ __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__rest
     if (do_rgb) {
         const int div = 1 << level;
         sobel_cloud_pixel(L, i, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
+        // dIdx / dIdy of this pixel were just written by this very thread; the mask is read by other kernels only
+        const float minGrad = level == 0 ? 5.0f : (level == 1 ? 3.0f : 1.0f);   // RGBDOdometry.cpp:78-80
+        const float minScale = (float)(((double)minGrad * (double)minGrad) / (0.125 * 0.125));
+        L.rgb_mask[i] = rgb_residual_static_test(L, minScale, i) ? 1 : 0;
     }
 }
 
@@ -996,37 +1019,28 @@ __device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S
 {
     const int rows = L.rows, cols = L.cols;
     const int i = k / cols, j0 = k - i * cols;
+    (void)rows;
     RgbCorr r; r.c0 = r.c1 = r.c2 = r.c3 = r.c4 = 0; r.diff = 0.0f;
-    if (j0 < cols - 5 && i < rows - 1) {
-        bool valid = true;
-        for (int u = (i - 2 > 0 ? i - 2 : 0); u < (i + 2 < rows ? i + 2 : rows); ++u)
-            for (int v = (j0 - 2 > 0 ? j0 - 2 : 0); v < (j0 + 2 < cols ? j0 + 2 : cols); ++v)
-                valid = valid && (L.next_image[u * cols + v] > 0);
-        if (valid) {
-            int valx = L.dIdx[k], valy = L.dIdy[k];
-            float mTwo = (float)((valx * valx) + (valy * valy));
-            if (mTwo >= minScale) {
-                const int y = i, x = j0;
-                float d1 = L.next_depth[y * cols + x];
-                if (!hd_isnanf(d1)) {
-                    const float *krk = st->krk;
-                    float td1 = d1 * ((krk[6] * (float)x + krk[7] * (float)y) + krk[8]) + st->kt[2];
-                    float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + st->kt[0]) / td1;
-                    float fv = (d1 * ((krk[3] * (float)x + krk[4] * (float)y) + krk[5]) + st->kt[1]) / td1;
-                    if (fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f) {
-                        int u0 = (int)hd_rintf(fu), v0 = (int)hd_rintf(fv);
-                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                            float d0 = L.last_depth[v0 * cols + u0];
-                            if (d0 > 0.0f && hd_fabsf(td1 - d0) <= 0.07f && L.last_image[v0 * cols + u0] != 0) {
-                                float diff = (float)L.next_image[y * cols + x] - (float)L.last_image[v0 * cols + u0];
-                                r.c0 = (int16_t)u0; r.c1 = (int16_t)v0; r.c2 = (int16_t)x; r.c3 = (int16_t)y; r.c4 = 1;
-                                r.diff = diff;
-                                cnt += 1;
-                                sig += (long long)(diff * diff);
-                            }
-                        }
-                    }
-                }
+    // the window / gradient / depth part of the test does not depend on the pose: k_odo_prepare evaluates it once per
+    // frame (rgb_mask), the iterations read one byte instead of 16 + 2 + 1 values; the seam kernels pass no mask
+    const bool pre = L.rgb_mask ? L.rgb_mask[k] != 0 : rgb_residual_static_test(L, minScale, k);
+    if (!pre) return r;
+    const int y = i, x = j0;
+    const float d1 = L.next_depth[y * cols + x];
+    const float *krk = st->krk;
+    float td1 = d1 * ((krk[6] * (float)x + krk[7] * (float)y) + krk[8]) + st->kt[2];
+    float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + st->kt[0]) / td1;
+    float fv = (d1 * ((krk[3] * (float)x + krk[4] * (float)y) + krk[5]) + st->kt[1]) / td1;
+    if (fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f) {
+        int u0 = (int)hd_rintf(fu), v0 = (int)hd_rintf(fv);
+        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+            float d0 = L.last_depth[v0 * cols + u0];
+            if (d0 > 0.0f && hd_fabsf(td1 - d0) <= 0.07f && L.last_image[v0 * cols + u0] != 0) {
+                float diff = (float)L.next_image[y * cols + x] - (float)L.last_image[v0 * cols + u0];
+                r.c0 = (int16_t)u0; r.c1 = (int16_t)v0; r.c2 = (int16_t)x; r.c3 = (int16_t)y; r.c4 = 1;
+                r.diff = diff;
+                cnt += 1;
+                sig += (long long)(diff * diff);
             }
         }
     }

@@ -80,6 +80,7 @@ struct OdoLevel {
     int16_t *dIdx, *dIdy;
     float *cloud;                             // rows*cols*3 (x,y,z interleaved)
     float4 *icp_cur, *icp_model;              // 2 x float4 per pixel: packed operands of the ICP kernel (k_odo_prepare)
+    uint8_t *rgb_mask;                        // iteration-invariant part of the RGB residual's pixel test (k_odo_prepare)
 };
 
 struct OdoState;   // device-resident Gauss-Newton state, defined in k_odo.hip
