@@ -184,7 +184,7 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
         DA(L.icpw, n); DA(L.last_depth, n); DA(L.next_depth, n);
         DA(L.last_image, n); DA(L.next_image, n); DA(L.last_next_image, n);
         DA(L.dIdx, n); DA(L.dIdy, n); DA(L.cloud, 3 * n);
-        DA(L.icp_cur, 2 * n); DA(L.icp_model, 2 * n); DA(L.rgb_mask, n);
+        DA(L.icp_cur, 2 * n); DA(L.icp_model, 2 * n); DA(L.rgb_mask, n); DA(L.cloud4, n); DA(L.dIxy, n);
     }
     { uint8_t *st; DA(st, odo_state_bytes()); c->odo.state = (OdoState *)st; }
     DA(c->odo.corres, P * 6); DA(c->odo.corres_diff, P);
@@ -268,7 +268,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         OdoLevel &L = c->odo.lv[i];
         void *q[] = {L.vmap_g, L.nmap_g, L.ck1_g, L.ck2_g, L.vmap_c, L.nmap_c, L.ck1_c, L.ck2_c, L.icpw, L.last_depth,
-                     L.next_depth, L.last_image, L.next_image, L.last_next_image, L.dIdx, L.dIdy, L.cloud, L.icp_cur, L.icp_model, L.rgb_mask};
+                     L.next_depth, L.last_image, L.next_image, L.last_next_image, L.dIdx, L.dIdy, L.cloud, L.icp_cur, L.icp_model, L.rgb_mask, L.cloud4, L.dIxy};
         for (void *p : q) if (p) hipFree(p);
     }
     if (c->h_count_pinned) hipHostFree(c->h_count_pinned);

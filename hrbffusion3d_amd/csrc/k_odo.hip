@@ -364,9 +364,14 @@ __device__ __forceinline__ void sobel_cloud_pixel(const OdoLevel &L, int i, floa
     L.dIdy[i] = (int16_t)dyv;
     float invFx = 1.0f / fx, invFy = 1.0f / fy;
     float z = L.last_depth[i];
-    L.cloud[i * 3] = ((float)x - cx) * z * invFx;
-    L.cloud[i * 3 + 1] = ((float)y - cy) * z * invFy;
+    const float px_ = ((float)x - cx) * z * invFx, py_ = ((float)y - cy) * z * invFy;
+    L.cloud[i * 3] = px_;
+    L.cloud[i * 3 + 1] = py_;
     L.cloud[i * 3 + 2] = z;
+    if (L.cloud4) {   // in-frame consumers read one texel / one word instead of three floats / two shorts
+        L.cloud4[i] = make_float4(px_, py_, z, 0.0f);
+        L.dIxy[i] = (int32_t)(((uint32_t)(uint16_t)(int16_t)dxv) | ((uint32_t)(uint16_t)(int16_t)dyv << 16));
+    }
 }
 
 __global__ void k_first_rgb(int P, const uint8_t *__restrict__ rgb, uint8_t *__restrict__ out)
@@ -1047,23 +1052,18 @@ __device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S
     return r;
 }
 
-// RGBReduction::getProducts (reduce.cu:717-808) for one correspondence
-__device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbCorr &co, float sigma, float fx, float fy,
-                                                   int use_grad, float (&out)[29])
+// RGBReduction::getProducts (reduce.cu:717-808) for one correspondence: operands already fetched
+__device__ __forceinline__ void rgb_products_core(float diff, float cpx, float cpy, float cpz, int gx_raw, int gy_raw,
+                                                  float sigma, float fx, float fy, int use_grad, float (&out)[29])
 {
-    if (!co.c4) return false;
-    const int cols = L.cols;
-    float diff = co.diff;
     float w = sigma + hd_fabsf(diff);
     w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
     if (sigma == -1.0f) w = 1.0f;
     float row[7];
     row[6] = -w * diff;
-    const float *cpp = &L.cloud[((size_t)co.c1 * cols + co.c0) * 3];
-    const float cpx = cpp[0], cpy = cpp[1], cpz = cpp[2];
     float invz = 1.0f / cpz;
-    float dIx = w * 0.125f * (float)L.dIdx[co.c3 * cols + co.c2];
-    float dIy = w * 0.125f * (float)L.dIdy[co.c3 * cols + co.c2];
+    float dIx = w * 0.125f * (float)gx_raw;
+    float dIy = w * 0.125f * (float)gy_raw;
     float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
     float v2 = -(v0 * cpx + v1 * cpy) * invz;
     row[0] = v0; row[1] = v1; row[2] = v2;
@@ -1082,6 +1082,16 @@ __device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbC
         for (int j = i; j < 7; ++j) out[q++] = rw * row[i] * row[j];
     out[27] = rw * row[6] * row[6];
     out[28] = 1.0f;
+}
+// the same on the seam layout: DataTerm as 6 x int16 + diff plane, cloud as 3 floats, gradients as two short planes
+__device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbCorr &co, float sigma, float fx, float fy,
+                                                   int use_grad, float (&out)[29])
+{
+    if (!co.c4) return false;
+    const int cols = L.cols;
+    const float *cpp = &L.cloud[((size_t)co.c1 * cols + co.c0) * 3];
+    rgb_products_core(co.diff, cpp[0], cpp[1], cpp[2], (int)L.dIdx[co.c3 * cols + co.c2], (int)L.dIdy[co.c3 * cols + co.c2],
+                      sigma, fx, fy, use_grad, out);
     return true;
 }
 
@@ -1112,9 +1122,9 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
         long long cnt = 0, sig = 0;
         if (do_rgb && !st->gn_break && k < p1) {
             const RgbCorr r = rgb_residual_pixel(L, st, minScale, k, cnt, sig);
-            int16_t *co = &corres[(size_t)k * 6];
-            co[0] = r.c0; co[1] = r.c1; co[2] = r.c2; co[3] = r.c3; co[4] = r.c4; co[5] = 0;
-            corres_diff[k] = r.diff;
+            // compact in-frame record (the pixel's own x, y are implied by k): {u0 | v0 << 16 or -1, diff}
+            reinterpret_cast<int2 *>(corres)[k] =
+                make_int2(r.c4 ? (int)((uint32_t)(uint16_t)r.c0 | ((uint32_t)(uint16_t)r.c1 << 16)) : -1, __float_as_int(r.diff));
         }
         for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); sig += __shfl_down(sig, d); }
         if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cnt; s_s[threadIdx.x >> 6] = sig; }
@@ -1297,9 +1307,15 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
     bool valid = false;
     const int k = p0 + blockIdx.x * RB + threadIdx.x;
     if (!brk && k < p1) {
-        const int16_t *co = &corres[(size_t)k * 6];
-        RgbCorr r; r.c0 = co[0]; r.c1 = co[1]; r.c2 = co[2]; r.c3 = co[3]; r.c4 = co[4]; r.diff = corres_diff[k];
-        valid = rgb_products_pixel(L, r, sigma, fx, fy, use_grad, out);
+        const int2 rec = reinterpret_cast<const int2 *>(corres)[k];
+        if (rec.x != -1) {
+            const int u0 = rec.x & 0xffff, v0 = (int)((uint32_t)rec.x >> 16);
+            const float4 cp = L.cloud4[(size_t)v0 * L.cols + u0];
+            const int g = L.dIxy[k];
+            rgb_products_core(__int_as_float(rec.y), cp.x, cp.y, cp.z, (int)(int16_t)(g & 0xffff), (int)(int16_t)((uint32_t)g >> 16),
+                              sigma, fx, fy, use_grad, out);
+            valid = true;
+        }
     }
     block_reduce_exact<29>(out, valid, rgb_part);
 }

@@ -81,6 +81,8 @@ struct OdoLevel {
     float *cloud;                             // rows*cols*3 (x,y,z interleaved)
     float4 *icp_cur, *icp_model;              // 2 x float4 per pixel: packed operands of the ICP kernel (k_odo_prepare)
     uint8_t *rgb_mask;                        // iteration-invariant part of the RGB residual's pixel test (k_odo_prepare)
+    float4 *cloud4;                           // back-projected cloud as one 16-B texel per pixel (xyz, -), in-frame RGB step
+    int32_t *dIxy;                            // Sobel gradients packed: dIdx in the low, dIdy in the high 16 bits
 };
 
 struct OdoState;   // device-resident Gauss-Newton state, defined in k_odo.hip
