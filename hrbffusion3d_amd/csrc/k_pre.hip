@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256) void k_vertex_normal_radius(Cam cam, const flo
 // (depth_curvature_gradient.frag:28-142 + hrbfbase.glsl:37-124,147-195).  The neighbour list of the
 // GLSL is never materialised: gradient and Hessian sums are accumulated in one pass in the same
 // visiting order (x outer, y inner).  LDS: vertex xyz + normal xyzw for tile + halo.
-struct NbTexel { float px, py, pz, nx, ny, nz, rad, valid; };
+// per-centre quantities are formed once per texel while staging: 10 n, T^2, T^4, 60 / T^4 and -20 / T^2 were recomputed
+// (two of them divisions) for each of the <= 49 pixels a texel is a neighbour of
+struct alignas(16) NbTexel { float px, py, pz, valid, sx, sy, sz, T2, T2T2, s3, m20, pad; };
 
 __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__restrict__ vertex_filtered,
                                                    const float4 *__restrict__ normal_in,
@@ -237,10 +239,12 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
         int tx = i % TW, ty = i / TW;
         int gx = bx + tx - RMAX, gy = by + ty - RMAX;
         NbTexel t;
-        t.px = t.py = t.pz = t.nx = t.ny = t.nz = t.rad = 0.0f; t.valid = 0.0f;
+        t.px = t.py = t.pz = t.valid = t.sx = t.sy = t.sz = t.T2 = t.T2T2 = t.s3 = t.m20 = t.pad = 0.0f;
         if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
             float4 v = vertex_filtered[gy * W + gx], n = normal_in[gy * W + gx];
-            t.px = v.x; t.py = v.y; t.pz = v.z; t.nx = n.x; t.ny = n.y; t.nz = n.z; t.rad = n.w;
+            t.px = v.x; t.py = v.y; t.pz = v.z;
+            t.sx = 10.0f * n.x; t.sy = 10.0f * n.y; t.sz = 10.0f * n.z;
+            t.T2 = n.w * n.w; t.T2T2 = t.T2 * t.T2; t.s3 = 60.0f / t.T2T2; t.m20 = -20.0f / t.T2;
             t.valid = (v.z > 0.3f && len3(mk3(n.x, n.y, n.z)) > 0.8f) ? 1.0f : 0.0f;
         }
         tile[i] = t;
@@ -250,9 +254,10 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
     if (px >= W || py >= H) return;
     const int i = py * W + px;
     const NbTexel me = tile[(threadIdx.y + RMAX) * TW + threadIdx.x + RMAX];
+    const float4 me_n = normal_in[i];   // the centre's own normal (the tile keeps 10 n)
     float4 pcmax = make_float4(0, 0, 0, 1000.0f), pcmin = make_float4(0, 0, 0, 1000.0f), nopt = make_float4(0, 0, 0, 0);
     float gmag = 0.0f;
-    if (me.pz > 0.3f && len3(mk3(me.nx, me.ny, me.nz)) > 0.5f) {
+    if (me.pz > 0.3f && len3(mk3(me_n.x, me_n.y, me_n.z)) > 0.5f) {
         float k1 = 1000.0f, k2 = 1000.0f;
         f3 pmax = mk3(0, 0, 0), pmin = mk3(0, 0, 0);
         int x0 = px - win < 0 ? 0 : px - win, x1 = px + win > W - 1 ? W - 1 : px + win;
@@ -265,63 +270,66 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
                 const NbTexel nb = tile[(iy - by + RMAX) * TW + (ix - bx + RMAX)];
                 if (!(hd_fabsf(nb.pz - me.pz) < 0.10f && nb.valid > 0.0f)) continue;
                 n++;
-                const float sx = 10.0f * nb.nx, sy = 10.0f * nb.ny, sz = 10.0f * nb.nz;
+                const float sx = nb.sx, sy = nb.sy, sz = nb.sz;
                 const float vx = me.px - nb.px, vy = me.py - nb.py, vz = me.pz - nb.pz;
                 const float d2 = (vx * vx + vy * vy) + vz * vz;
-                const float T2 = nb.rad * nb.rad;
-                // getWeightH (hrbfbase.glsl:37-69)
+                const float T2 = nb.T2;
+                // getWeightH (hrbfbase.glsl:37-69) and, inside the support, getWeightT (:72-124, only the 18 entries
+                // the Hessian consumes) — r = sqrt(d2 / T2) is formed once for both
                 float h0, h1, h2, h4, h5, h8;
+                bool third = false;
+                float t0 = 0, t1_ = 0, t2_ = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, t13 = 0, t14 = 0, t16 = 0, t17 = 0,
+                      t26 = 0;
                 if (d2 > T2) { h0 = h1 = h2 = h4 = h5 = h8 = 0.0f; }
-                else if (d2 == 0.0f) { h0 = h4 = h8 = -20.0f / T2; h1 = h2 = h5 = 0.0f; }
+                else if (d2 == 0.0f) { h0 = h4 = h8 = nb.m20; h1 = h2 = h5 = 0.0f; }
                 else {
-                    float r = hd_sqrtf(d2 / T2);
-                    float s = 1.0f - r;
-                    float s2 = s * s;
-                    float t1 = 20.0f * s2 / (T2 * T2 * r);
-                    float t2 = -r * s * T2;
-                    h0 = t1 * (3.0f * (vx * vx) + t2);
-                    h1 = t1 * 3.0f * vx * vy;
-                    h2 = t1 * 3.0f * vx * vz;
-                    h4 = t1 * (3.0f * (vy * vy) + t2);
-                    h5 = t1 * 3.0f * vy * vz;
-                    h8 = t1 * (3.0f * (vz * vz) + t2);
-                }
-                grx -= (sx * h0 + sy * h1) + sz * h2;
-                gry -= (sx * h1 + sy * h4) + sz * h5;
-                grz -= (sx * h2 + sy * h5) + sz * h8;
-                // getWeightT (hrbfbase.glsl:72-124), only the 18 entries the Hessian consumes
-                if (!(d2 > T2 || d2 == 0.0f)) {
-                    float r = hd_sqrtf(d2 / T2);
-                    float s = 1.0f - r;
+                    const float r = hd_sqrtf(d2 / T2);
+                    const float s = 1.0f - r;
+                    {
+                        float s2 = s * s;
+                        float t1 = 20.0f * s2 / (nb.T2T2 * r);
+                        float t2 = -r * s * T2;
+                        h0 = t1 * (3.0f * (vx * vx) + t2);
+                        h1 = t1 * 3.0f * vx * vy;
+                        h2 = t1 * 3.0f * vx * vz;
+                        h4 = t1 * (3.0f * (vy * vy) + t2);
+                        h5 = t1 * 3.0f * vy * vz;
+                        h8 = t1 * (3.0f * (vz * vz) + t2);
+                    }
+                    third = true;
                     float s2 = r - 2.0f + 1.0f / r;
-                    float s3 = 60.0f / (T2 * T2);
+                    float s3 = nb.s3;
                     float s4 = 1.0f / (r * r);
                     float prx = vx / (T2 * r), pry = vy / (T2 * r), prz = vz / (T2 * r);
                     float qx = prx - s4 * prx, qy = pry - s4 * pry, qz = prz - s4 * prz;
                     float tss = T2 * s * s;
-                    float t0 = s3 * (tss * prx + 2.0f * vx * s2 + vx * vx * qx);
-                    float t1_ = s3 * vy * (qx * vx + s2);
-                    float t2_ = s3 * vz * (qx * vx + s2);
-                    float t3 = s3 * (tss * pry + vx * vx * qy);
-                    float t4 = s3 * vx * (qy * vy + s2);
-                    float t5 = s3 * vx * vz * qy;
-                    float t6 = s3 * (tss * prz + vx * vx * qz);
-                    float t7 = s3 * vx * vy * qz;
-                    float t8 = s3 * vx * (qz * vz + s2);
-                    float t13 = s3 * (tss * pry + 2.0f * vy * s2 + vy * vy * qy);
-                    float t14 = s3 * vz * (qy * vy + s2);
-                    float t16 = s3 * (tss * prz + vy * vy * qz);
-                    float t17 = s3 * vy * (qz * vz + s2);
-                    float t26 = s3 * (tss * prz + 2.0f * vz * s2 + vz * vz * qz);
+                    t0 = s3 * (tss * prx + 2.0f * vx * s2 + vx * vx * qx);
+                    t1_ = s3 * vy * (qx * vx + s2);
+                    t2_ = s3 * vz * (qx * vx + s2);
+                    t3 = s3 * (tss * pry + vx * vx * qy);
+                    t4 = s3 * vx * (qy * vy + s2);
+                    t5 = s3 * vx * vz * qy;
+                    t6 = s3 * (tss * prz + vx * vx * qz);
+                    t7 = s3 * vx * vy * qz;
+                    t8 = s3 * vx * (qz * vz + s2);
+                    t13 = s3 * (tss * pry + 2.0f * vy * s2 + vy * vy * qy);
+                    t14 = s3 * vz * (qy * vy + s2);
+                    t16 = s3 * (tss * prz + vy * vy * qz);
+                    t17 = s3 * vy * (qz * vz + s2);
+                    t26 = s3 * (tss * prz + 2.0f * vz * s2 + vz * vz * qz);
+                }
+                grx -= (sx * h0 + sy * h1) + sz * h2;
+                gry -= (sx * h1 + sy * h4) + sz * h5;
+                grz -= (sx * h2 + sy * h5) + sz * h8;
+                if (third) {
                     g0 -= (sx * t0 + sy * t1_) + sz * t2_;
                     g1 -= (sx * t3 + sy * t4) + sz * t5;
                     g2 -= (sx * t6 + sy * t7) + sz * t8;
                     g4 -= (sx * t4 + sy * t13) + sz * t14;      // hw[12] = t[4]
                     g5 -= (sx * t7 + sy * t16) + sz * t17;      // hw[15] = t[7]
                     g8 -= (sx * t8 + sy * t17) + sz * t26;      // hw[24] = t[8], hw[25] = t[17]
-                } else {
-                    // zero third derivatives still perform "g -= 0" in the oracle: a no-op in IEEE
                 }
+                // outside the support the third derivatives are zero: "g -= 0" in the oracle, a no-op in IEEE
             }
         if (n > 15) {
             float4 vn = normal_in[i];
