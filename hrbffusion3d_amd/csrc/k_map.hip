@@ -226,28 +226,35 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
             f3 ray = mk3(xl, yl, 1.0f);
             float lray = len3(ray);
             float lnl = len3(nl);
+            // The reference walks a 4x4 half-pixel grid (data.vert:108-160) = offsets {-1, 0, 0, +1} per axis.  A texel
+            // met a second time offers the same distance and `dist < bestDist` is strict, so revisits (and the extra
+            // ones border clamping creates) never change anything: the 9 distinct texels in first-visit order (x outer,
+            // y inner) give the same result.  All 9 + 9 + 9 loads are issued before the first test.
+            uint32_t cur[9]; float4 vcf9[9], nr9[9];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int ox = (a == 0) ? -1 : (a == 3 ? 1 : 0);
-                const int sx = clampi(px + ox, 0, cam.W - 1);
+            for (int a = 0; a < 3; ++a) {
+                const int sx = clampi(px + a - 1, 0, cam.W - 1);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int oy = (b == 0) ? -1 : (b == 3 ? 1 : 0);
-                    const int sy = clampi(py + oy, 0, cam.H - 1);
+                for (int b = 0; b < 3; ++b) {
+                    const int sy = clampi(py + b - 1, 0, cam.H - 1);
                     const int si = sy * cam.W + sx;
-                    uint32_t current = idx[si];
-                    if (current > 0u) {
-                        float4 vcf = vertconf[si];
-                        if (hd_fabsf((vcf.z * lambda) - (vl.z * lambda)) < 0.05f) {
-                            float dist = len3(cross3(ray, xyz(vcf))) / lray;
-                            float4 nr = normrad[si];
-                            bool ok = hd_fabsf(nr.z) < 0.75f;
-                            if (!ok) {
-                                float ang = hd_acosf(dot3(xyz(nr), nl) / (len3(xyz(nr)) * lnl));
-                                ok = hd_fabsf(ang) < 0.5f;
-                            }
-                            if (dist < bestDist && ok) { counter++; bestDist = dist; best = current; }
+                    cur[a * 3 + b] = idx[si]; vcf9[a * 3 + b] = vertconf[si]; nr9[a * 3 + b] = normrad[si];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const uint32_t current = cur[t];
+                if (current > 0u) {
+                    const float4 vcf = vcf9[t];
+                    if (hd_fabsf((vcf.z * lambda) - (vl.z * lambda)) < 0.05f) {
+                        float dist = len3(cross3(ray, xyz(vcf))) / lray;
+                        const float4 nr = nr9[t];
+                        bool ok = hd_fabsf(nr.z) < 0.75f;
+                        if (!ok) {
+                            float ang = hd_acosf(dot3(xyz(nr), nl) / (len3(xyz(nr)) * lnl));
+                            ok = hd_fabsf(ang) < 0.5f;
                         }
+                        if (dist < bestDist && ok) { counter++; bestDist = dist; best = current; }
                     }
                 }
             }
