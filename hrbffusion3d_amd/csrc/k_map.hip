@@ -282,19 +282,22 @@ __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     bool act = q < Q && rec_flag[q] == 1;
-    uint32_t s = 0;
-    if (act) { s = rec_best[q]; act = slot[s] == (uint32_t)q; }
+    const uint32_t s = act ? rec_best[q] : 0u;
+    // everything the merge may need is requested in one round (record planes, the slot word and the target surfel's
+    // planes) instead of slot -> surfel in two dependent rounds; surfel 0 stands in for inactive lanes
+    const uint32_t winner = slot[s];
+    const int qs = q < Q ? q : 0;
+    const float4 r0 = rec.p0[qs], r1 = rec.p1[qs], r2 = rec.p2[qs], r3 = rec.p3[qs], r4 = rec.p4[qs];
+    const float4 vp = m.p0[s], vc = m.p1[s], vn = m.p2[s], c1 = m.p3[s], c2 = m.p4[s];
+    act = act && winner == (uint32_t)q;
     {   // merged count: one atomic per wave instead of one per merge on a single address
         const unsigned long long bal = __ballot(act);
         if ((threadIdx.x & 63) == 0 && bal) atomicAdd(merged, (uint32_t)__popcll(bal));
     }
     if (!act) return;
     slot[s] = 0xFFFFFFFFu;   // re-arm for the next frame (only touched entries are reset)
-    const float4 r0 = rec.p0[q], r1 = rec.p1[q], r2 = rec.p2[q], r3 = rec.p3[q], r4 = rec.p4[q];
-    const float4 vp = m.p0[s], vc = m.p1[s], vn = m.p2[s];
     const float c_k = vp.w, a = r0.w, sum = c_k + a;
     if (r2.w < (1.0f + 0.5f) * vn.w) {
-        const float4 c1 = m.p3[s], c2 = m.p4[s];
         m.p0[s] = make_float4(((c_k * vp.x) + (a * r0.x)) / sum, ((c_k * vp.y) + (a * r0.y)) / sum,
                               ((c_k * vp.z) + (a * r0.z)) / sum, sum);
         f3 oc = decode_color(vc.x), nc = decode_color(r1.x);
