@@ -255,6 +255,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    odo_release(c->odo);
     void *ptrs[] = {c->d_rgb, c->d_depth, c->d_depth_filtered, c->d_depth_metric, c->d_depth_metric_f, c->d_radius,
                     c->d_gradmag, c->d_confidence, c->d_vertex_raw, c->d_vertex_filtered, c->d_normal, c->d_normal_opt,
                     c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_idx, c->d_zbuf, c->d_im_vertconf, c->d_im_colortime,

@@ -42,6 +42,11 @@ struct OdoState {
 };
 
 size_t odo_state_bytes() { return sizeof(OdoState); }
+void odo_release(OdoBuffers &ob)
+{
+    for (int k = 0; k < 2; ++k)
+        if (ob.gn_graph_exec[k]) { hipGraphExecDestroy((hipGraphExec_t)ob.gn_graph_exec[k]); ob.gn_graph_exec[k] = nullptr; }
+}
 #define SO3_ITERS 10
 size_t odo_slot_bytes() { return sizeof(long long) * (32 * 87 * 2 + 64 * 2 + SO3_ITERS * 32 * 33); }   // one SO3 slot set per iteration
 
@@ -1544,7 +1549,22 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, ob.totals + 176, cfg, 1,
                                    it == SO3_ITERS - 1 ? gn_level : -1, 0, L.rows * L.cols);
     }
-    // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration
+    // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration.  On the single-GPU path the whole loop (57
+    // launches whose arguments only depend on the configuration and on which of the two image-pointer parities is
+    // current) is captured once into a hipGraph and replayed: one submission instead of 57.
+    static const bool use_graph = getenv("HRBF_NO_GN_GRAPH") == nullptr;
+    const int par = ob.swap_parity & 1;
+    bool replayed = false, capturing = false;
+    if (use_graph && !sharded) {
+        if (ob.gn_graph_exec[par] && memcmp(&ob.gn_graph_cfg[par], &cfg, sizeof(cfg)) == 0 &&
+            ob.gn_graph_wmul[par] == weight_multiplier && ob.gn_graph_dp[par] == (void *)dp) {
+            replayed = hipGraphLaunch((hipGraphExec_t)ob.gn_graph_exec[par], s) == hipSuccess;
+        } else {
+            if (ob.gn_graph_exec[par]) { hipGraphExecDestroy((hipGraphExec_t)ob.gn_graph_exec[par]); ob.gn_graph_exec[par] = nullptr; }
+            capturing = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        }
+    }
+    auto enqueue_gn = [&]() {
     const float minGrad[3] = {5, 3, 1};
     for (int i = HRBF_NUM_PYRS - 1; i >= 0; --i) {
         const OdoLevel &L = ob.lv[i];
@@ -1602,9 +1622,26 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                                last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
         }
     }
+    };
+    if (capturing) {
+        enqueue_gn();
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        const bool ok = hipStreamEndCapture(s, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) hipGraphDestroy(g);
+        if (ok) {
+            ob.gn_graph_exec[par] = (void *)ge; ob.gn_graph_cfg[par] = cfg; ob.gn_graph_wmul[par] = weight_multiplier;
+            ob.gn_graph_dp[par] = (void *)dp;
+            replayed = hipGraphLaunch(ge, s) == hipSuccess;
+        } else (void)hipGetLastError();
+    }
+    if (!replayed) enqueue_gn();   // sharded path, graphs switched off, or capture / replay refused: plain launches
     if (last_level < 0) hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg, weight_multiplier);
     if (cfg.so3)   // swap NextImage <-> lastNextImage (RGBDOdometry.cpp:1239-1245): pointer swap, no copy
+    {
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) { uint8_t *t = ob.lv[i].last_next_image; ob.lv[i].last_next_image = ob.lv[i].next_image; ob.lv[i].next_image = t; }
+        ob.swap_parity ^= 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ icpStep seam

@@ -85,6 +85,13 @@ struct OdoLevel {
     int32_t *dIxy;                            // Sobel gradients packed: dIdx in the low, dIdy in the high 16 bits
 };
 
+struct OdoConfig {
+    float fx, fy, cx, cy;
+    int rgb_only; float icp_weight; int pyramid, fast_odom, so3, frame_to_frame_rgb;
+    int use_search, search_radius, use_weighted, rgb_use_grad;
+    float curv_thr;
+};
+
 struct OdoState;   // device-resident Gauss-Newton state, defined in k_odo.hip
 
 struct OdoBuffers {
@@ -98,6 +105,8 @@ struct OdoBuffers {
     long long *so3_part;    // 32 x 33                   }
     long long *totals;      // 87 + 87 + 2 + 33 (all-reduce buffer)
     int max_blocks;
+    // the 57 launches of the Gauss-Newton loop replayed as one hipGraph (one instance per image-pointer parity)
+    void *gn_graph_exec[2]; OdoConfig gn_graph_cfg[2]; float gn_graph_wmul[2]; void *gn_graph_dp[2]; int swap_parity;
 };
 
 struct OdoSources {   // images the odometry is initialised from (selected on device by should_fill_in)
@@ -106,15 +115,10 @@ struct OdoSources {   // images the odometry is initialised from (selected on de
     const float4 *vertex_filtered, *normal, *curv1, *curv2; const uint8_t *rgb;
 };
 
-struct OdoConfig {
-    float fx, fy, cx, cy;
-    int rgb_only; float icp_weight; int pyramid, fast_odom, so3, frame_to_frame_rgb;
-    int use_search, search_radius, use_weighted, rgb_use_grad;
-    float curv_thr;
-};
 
 size_t odo_state_bytes();
 size_t odo_slot_bytes();
+void odo_release(OdoBuffers &ob);   // destroys the cached graphs
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
 // full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
 // Row-sharded registration (SURVEY §8e sharding 1): every rank holds the full pyramids and reduces the image rows
