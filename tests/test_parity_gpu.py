@@ -106,6 +106,26 @@ def test_tracked_synthetic_stream(pair, noise):
     assert err < 0.05
 
 
+def test_tracked_vga_stream_against_large_map(pair):
+    """The benchmark's geometry — 640x480, tracking against a pre-seeded 400 k-surfel map, noisy input — compared with
+    the oracle bit for bit over 6 frames: the 1200-workgroup reduction grids, several fuse tiles per workgroup and the
+    hipGraph replay (frames 3+ replay the captured loop) are only exercised at this size."""
+    W, H = 640, 480
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    seed = synth.seed_map(400_000, width=W)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=seed.shape[0] + 800_000)
+    o, g = pair(p)
+    rgb, d, T = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
+    for k in range(1, 7):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "vga frame %d" % k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+    assert np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3]) < 0.02
+
+
 def test_long_sequence_trajectory_and_determinism(gpu_available):
     """150 noisy QVGA frames from an empty map (frame 0 seeds it): the trajectory stays near the ground truth (ATE, the
     north star's other metric, against the stream's analytic poses) and a second run reproduces pose and map bit for
