@@ -1,0 +1,131 @@
+"""Run a recorded sequence through the MI355X path: the caller's side of HRBFFusion::processFrame
+(GUI/src/HRBF_fusion.cpp:190-497 without the GUI): frame source -> processFrame per frame -> trajectory + PLY.
+
+    python -m hrbffusion3d_amd.run --klg log.klg --out traj.freiburg --ply map.ply
+    python -m hrbffusion3d_amd.run --tum /data/rgbd_dataset_freiburg1_desk --fx 517.3 --fy 516.5 --cx 318.6 --cy 255.3 \
+           --out traj.freiburg --groundtruth /data/.../groundtruth.txt
+    python -m hrbffusion3d_amd.run --synthetic 200 --noise --out traj.freiburg        # the bench stream, with ATE
+
+Frame sources: a .klg raw log (io.KlgReader), a TUM directory with associations.txt (PNG decoding needs Pillow), or the
+synthetic stream.  There is no CPU fallback: the HIP library and a gfx950 device are required.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import io as hio
+from . import synth
+from .params import default_params
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    src = ap.add_mutually_exclusive_group(required=True)
+    src.add_argument("--klg", help=".klg raw log (RawLogReader format)")
+    src.add_argument("--tum", help="TUM RGB-D directory containing associations.txt (ts depth ts rgb)")
+    src.add_argument("--synthetic", type=int, metavar="N", help="N frames of the synthetic stream")
+    ap.add_argument("--width", type=int, default=640); ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--fx", type=float, default=528.0); ap.add_argument("--fy", type=float, default=528.0)
+    ap.add_argument("--cx", type=float, default=320.0); ap.add_argument("--cy", type=float, default=240.0)
+    ap.add_argument("--depth-factor", type=float, default=5000.0, help="raw units per metre (DepthMapFactor)")
+    ap.add_argument("--flip-colors", action="store_true", help=".klg stored BGR")
+    ap.add_argument("--noise", action="store_true", help="synthetic: Kinect-style depth noise + drop-outs")
+    ap.add_argument("--max-frames", type=int, default=0)
+    ap.add_argument("--max-surfels", type=int, default=4 * 1024 * 1024)
+    ap.add_argument("--icp-weight", type=float, default=None); ap.add_argument("--rgb-only", action="store_true")
+    ap.add_argument("--no-so3", action="store_true"); ap.add_argument("--fast-odom", action="store_true")
+    ap.add_argument("--out", help="trajectory file (TUM format; --icl-nuim for that variant)")
+    ap.add_argument("--icl-nuim", action="store_true")
+    ap.add_argument("--ply", help="write the final surfel map as binary PLY")
+    ap.add_argument("--ply-confidence", type=float, default=0.0)
+    ap.add_argument("--groundtruth", help="TUM-format ground truth: report the Horn-aligned ATE RMSE")
+    ap.add_argument("--device", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def frame_source(args):
+    """yields (timestamp_us, rgb uint8 [H,W,3], depth uint16 [H,W], ground-truth pose or None)"""
+    if args.klg:
+        r = hio.KlgReader(args.klg, args.width, args.height, flip_colors=args.flip_colors)
+        for ts, rgb, depth in r:
+            yield ts, rgb, depth, None
+        r.close()
+    elif args.tum:
+        from PIL import Image
+        for td, fd, tr, fr in hio.load_associations(os.path.join(args.tum, "associations.txt")):
+            depth = np.asarray(Image.open(os.path.join(args.tum, fd)), np.uint16)
+            rgb = np.asarray(Image.open(os.path.join(args.tum, fr)).convert("RGB"), np.uint8)
+            yield int(round(td * 1e6)), np.ascontiguousarray(rgb), np.ascontiguousarray(depth), None
+    else:
+        for k in range(args.synthetic):
+            rgb, depth, T = synth.frame(k, args.width, args.height, noise=args.noise, depth_units=args.depth_factor)
+            yield k * 33333, rgb, depth, T
+
+
+def match_groundtruth(stamps_s, gt_stamps, gt_poses, max_dt=0.02):
+    """nearest ground-truth pose per estimate (TUM's associate.py rule, 20 ms)"""
+    idx = np.searchsorted(gt_stamps, stamps_s)
+    pairs = []
+    for i, (t, j) in enumerate(zip(stamps_s, idx)):
+        best = None
+        for c in (j - 1, j):
+            if 0 <= c < len(gt_stamps) and (best is None or abs(gt_stamps[c] - t) < abs(gt_stamps[best] - t)):
+                best = c
+        if best is not None and abs(gt_stamps[best] - t) <= max_dt:
+            pairs.append((i, best))
+    return pairs
+
+
+def main(argv=None):
+    args = parse(argv)
+    from .api import HRBFFusion
+    if args.synthetic is not None:
+        args.fx, args.fy, args.cx, args.cy = synth.intrinsics(args.width, args.height)
+    kw = dict(max_surfels=args.max_surfels, depth_scale=1.0 / args.depth_factor)
+    if args.icp_weight is not None:
+        kw["icp_weight"] = args.icp_weight
+    if args.rgb_only:
+        kw["rgb_only"] = 1
+    if args.no_so3:
+        kw["so3"] = 0
+    if args.fast_odom:
+        kw["fast_odom"] = 1
+    p = default_params(args.width, args.height, args.fx, args.fy, args.cx, args.cy, **kw)
+    fus = HRBFFusion(p, device=args.device)
+    poses, stamps, gts = [], [], []
+    t0 = time.perf_counter()
+    n = 0
+    for ts, rgb, depth, T in frame_source(args):
+        if n == 0 and T is not None:
+            fus.set_pose(T)          # the synthetic stream starts at its analytic pose
+        fus.process_frame(rgb, depth, ts)
+        poses.append(fus.get_pose()); stamps.append(ts); gts.append(T)
+        n += 1
+        if args.max_frames and n >= args.max_frames:
+            break
+    fus.synchronize()
+    dt = time.perf_counter() - t0
+    report = {"frames": n, "seconds": dt, "fps_including_io_and_pose_readback": n / dt if dt > 0 else 0.0,
+              "surfels": fus.surfel_count()}
+    if args.out:
+        hio.save_trajectory(args.out, poses, stamps_us=stamps, fmt="TUM", icl_nuim=args.icl_nuim)
+    if args.ply:
+        report["ply_vertices"] = hio.save_ply(args.ply, fus.download_map(), conf_threshold=args.ply_confidence)
+    if args.groundtruth:
+        gs, gp = hio.load_trajectory_tum(args.groundtruth)
+        pairs = match_groundtruth(np.asarray(stamps, np.float64) / 1e6, gs, gp)
+        if len(pairs) >= 3:
+            report["ate_rmse_m"] = hio.ate_rmse([poses[i] for i, _ in pairs], [gp[j] for _, j in pairs], align=True)
+            report["ate_pairs"] = len(pairs)
+    elif all(g is not None for g in gts) and n >= 3:
+        report["ate_rmse_m"] = hio.ate_rmse(poses, gts, align=False)
+    fus.close()
+    print(report)
+    return report
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() else 1)

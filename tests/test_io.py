@@ -105,3 +105,21 @@ def test_klg_reader_round_trip(tmp_path):
     import pytest
     with pytest.raises(EOFError):
         list(KlgReader(str(tmp_path / "cut.klg"), W, H))
+
+
+def test_run_cli_helpers(tmp_path):
+    """hrbffusion3d_amd.run: argument parsing, the .klg frame source and ground-truth matching (no GPU needed)."""
+    from hrbffusion3d_amd import run
+    from hrbffusion3d_amd.io import write_klg
+    W, H = 32, 24
+    frames = [(1000 * k, np.full((H, W, 3), k, np.uint8), np.full((H, W), 1000 + k, np.uint16)) for k in range(3)]
+    p = str(tmp_path / "s.klg")
+    write_klg(p, frames)
+    a = run.parse(["--klg", p, "--width", str(W), "--height", str(H), "--out", str(tmp_path / "t.txt")])
+    got = list(run.frame_source(a))
+    assert [g[0] for g in got] == [0, 1000, 2000] and got[2][2][0, 0] == 1002 and got[1][3] is None
+    a = run.parse(["--synthetic", "2", "--width", "64", "--height", "48"])
+    got = list(run.frame_source(a))
+    assert len(got) == 2 and got[0][1].shape == (48, 64, 3) and got[0][3].shape == (4, 4)
+    pairs = run.match_groundtruth(np.array([0.00, 0.10, 0.50]), np.array([0.001, 0.095, 0.30]), [None] * 3)
+    assert pairs == [(0, 0), (1, 1)]

@@ -487,3 +487,27 @@ def test_full_size_properties_1M(gpu_available):
     maps2, stats2, pose2, idx2, _, _ = run()
     assert np.array_equal(bits(maps[-1]), bits(maps2[-1])) and np.array_equal(bits(pose), bits(pose2))
     assert np.array_equal(idx, idx2)
+
+
+def test_run_cli_over_a_klg_log(gpu_available, tmp_path):
+    """The caller's side (`python -m hrbffusion3d_amd.run`, the MainController/RawLogReader loop without the GUI):
+    a synthetic QVGA stream written as a .klg log, replayed through process_frame; the trajectory file and the PLY are
+    written, the map grows, and the ATE against the stream's ground truth (saved as a TUM file) is small."""
+    from hrbffusion3d_amd import run
+    from hrbffusion3d_amd.io import write_klg, save_trajectory, load_trajectory_tum
+    W, H, N = 320, 240, 30
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    fr = [synth.frame(k, W, H) for k in range(N)]
+    klg = str(tmp_path / "s.klg")
+    write_klg(klg, [(k * 33333, f[0], f[1]) for k, f in enumerate(fr)])
+    gt = str(tmp_path / "gt.txt")
+    save_trajectory(gt, [f[2] for f in fr], stamps_us=[k * 33333 for k in range(N)])
+    out, ply = str(tmp_path / "traj.txt"), str(tmp_path / "map.ply")
+    rep = run.main(["--klg", klg, "--width", str(W), "--height", str(H), "--fx", str(fx), "--fy", str(fy),
+                    "--cx", str(cx), "--cy", str(cy), "--max-surfels", str(1 << 20), "--out", out, "--ply", ply,
+                    "--groundtruth", gt])
+    assert rep["frames"] == N and rep["surfels"] > 0.8 * W * H and rep["ply_vertices"] > 0
+    assert rep["ate_pairs"] == N and rep["ate_rmse_m"] < 0.05, rep
+    st, ps = load_trajectory_tum(out)
+    assert len(ps) == N and np.isfinite(np.asarray(ps)).all()
+    assert open(ply, "rb").read(3) == b"ply"
