@@ -117,7 +117,6 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
         hrbf_set_error("width/height must be positive multiples of 8 (3-level pyramid + quarter grid)");
         return HRBF_ERR_INVALID;
     }
-    if (p->use_sparse_icp) { hrbf_set_error("registrationICPUseSparseICP is not supported (SURVEY §8f-4)"); return HRBF_ERR_INVALID; }
     if (p->curv_estimation_window > 3.0f || p->predict_window_multiplier > 3.0f || p->clean_window_multiplier > 8.0f) {
         hrbf_set_error("window multipliers above the reference defaults (3/3/8) are not supported");
         return HRBF_ERR_INVALID;
@@ -185,6 +184,7 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
         DA(L.last_image, n); DA(L.next_image, n); DA(L.last_next_image, n);
         DA(L.dIdx, n); DA(L.dIdy, n); DA(L.cloud, 3 * n);
         DA(L.icp_cur, 2 * n); DA(L.icp_model, 2 * n); DA(L.rgb_mask, n); DA(L.cloud4, n); DA(L.dIxy, n);
+        if (c->prm.use_sparse_icp) DA(L.sparse, 2 * n);
     }
     { uint8_t *st; DA(st, odo_state_bytes()); c->odo.state = (OdoState *)st; }
     DA(c->odo.corres, P * 6); DA(c->odo.corres_diff, P);
@@ -269,7 +269,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         OdoLevel &L = c->odo.lv[i];
         void *q[] = {L.vmap_g, L.nmap_g, L.ck1_g, L.ck2_g, L.vmap_c, L.nmap_c, L.ck1_c, L.ck2_c, L.icpw, L.last_depth,
-                     L.next_depth, L.last_image, L.next_image, L.last_next_image, L.dIdx, L.dIdy, L.cloud, L.icp_cur, L.icp_model, L.rgb_mask, L.cloud4, L.dIxy};
+                     L.next_depth, L.last_image, L.next_image, L.last_next_image, L.dIdx, L.dIdy, L.cloud, L.icp_cur, L.icp_model, L.rgb_mask, L.cloud4, L.dIxy, L.sparse};
         for (void *p : q) if (p) hipFree(p);
     }
     if (c->h_count_pinned) hipHostFree(c->h_count_pinned);
@@ -307,6 +307,7 @@ static OdoConfig make_cfg(hrbf_context *c)
     g.frame_to_frame_rgb = p.frame_to_frame_rgb;
     g.use_search = p.icp_use_corr_search; g.search_radius = p.icp_search_radius; g.use_weighted = p.icp_use_weighted;
     g.rgb_use_grad = p.rgb_use_grad_weight; g.curv_thr = p.curv_valid_threshold;
+    g.use_sparse = p.use_sparse_icp;
     return g;
 }
 

@@ -899,7 +899,11 @@ struct IcpArgs {
     int rows, cols;
     float fx, fy, cx, cy, distThres, angleThres;
     int use_search, radius, use_weight;
+    float4 *sparse;       // sparse (ADMM) ICP side image of this level, or null: {lambda.xyz, corres} {z.xyz, -}
+    int sparse_first;     // first iteration of the level: the multiplier starts from zero (RGBDOdometry.cpp:964-977)
 };
+// per-pixel in/out of the sparse variant: multiplier in; shrunk residual and chosen model pixel out
+struct SparseIo { f3 lambda, z; int bx, by; };
 
 // The same association for the common case (no windowed search) on the packed operands written once per frame by
 // pack_icp_texels: current pixel {v.xyz, valid} {n.xyz, -}, model pixel {v.xyz, icp weight} {n.xyz, valid} — two
@@ -945,10 +949,11 @@ __device__ __forceinline__ bool icp_pixel_packed(const IcpArgs &A, const float *
     return true;
 }
 
+template <bool SPARSE = false>
 __device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
-                                          int x, int y, float *out)
+                                          int x, int y, float *out, SparseIo *io = nullptr)
 {
-    if (A.cur_tex && !A.use_search) return icp_pixel_packed(A, Rcurr, tcurr, Rpi, tprev, x, y, out);
+    if (!SPARSE && A.cur_tex && !A.use_search) return icp_pixel_packed(A, Rcurr, tcurr, Rpi, tprev, x, y, out);
     const int rows = A.rows, cols = A.cols;
     f3 vcur = mk3(PLN(A.vmap_c, 0, rows, cols, y, x), PLN(A.vmap_c, 1, rows, cols, y, x), PLN(A.vmap_c, 2, rows, cols, y, x));
     f3 ncur = mk3(PLN(A.nmap_c, 0, rows, cols, y, x), PLN(A.nmap_c, 1, rows, cols, y, x), PLN(A.nmap_c, 2, rows, cols, y, x));
@@ -1004,6 +1009,14 @@ __device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, 
     f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
     f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
     f3 n_cp = m33_mul(Rpi, bn);
+    if (SPARSE) {   // reduce.cu:479-492: the target moves by the shrunk residual minus the scaled multiplier
+        io->bx = bx; io->by = by;
+        const f3 lm = mk3(io->lambda.x / HD_SPARSE_MU, io->lambda.y / HD_SPARSE_MU, io->lambda.z / HD_SPARSE_MU);
+        const f3 h = add3(sub3(s_cp, d_cp), lm);
+        const float beta = hd_sparse_shrink_factor(len3(h));
+        io->z = mk3(beta * h.x, beta * h.y, beta * h.z);
+        d_cp = sub3(add3(d_cp, io->z), lm);
+    }
     float weight = 1.0f;
     if (A.use_weight) { float w = A.icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
     float row[7];
@@ -1018,6 +1031,37 @@ __device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, 
     out[27] = weight * row[6] * row[6];
     out[28] = 1.0f;
     return true;
+}
+
+// Sparse (ADMM) ICP, use_sparse_icp: updateLambdaMapKernel (cudafuncs.cu:1030-1080) of the previous iteration is
+// folded into the head of this one — it only touches the pixel's own multiplier, at the pose this iteration runs at —
+// then the association with the shrink step; {lambda, corres} {z} go back to the side image for the next iteration.
+// The update tests corresp.x > 0, so matches in model column 0 never move their multiplier (kept).
+__device__ __forceinline__ bool icp_pixel_sparse(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                                 int x, int y, float *out)
+{
+    const int rows = A.rows, cols = A.cols, k = y * cols + x;
+    SparseIo io;
+    io.lambda = mk3(0, 0, 0); io.z = mk3(0, 0, 0); io.bx = -1; io.by = -1;
+    if (!A.sparse_first) {
+        const float4 s0 = A.sparse[2 * k], s1 = A.sparse[2 * k + 1];
+        io.lambda = mk3(s0.x, s0.y, s0.z);
+        const int cp = __float_as_int(s0.w);
+        const int ux = cp == -1 ? -1 : (cp & 0xffff), uy = cp >> 16;
+        if (ux > 0) {
+            const f3 vcur = mk3(PLN(A.vmap_c, 0, rows, cols, y, x), PLN(A.vmap_c, 1, rows, cols, y, x), PLN(A.vmap_c, 2, rows, cols, y, x));
+            const f3 vlp = m33_mul(Rpi, sub3(add3(m33_mul(Rcurr, vcur), tcurr), tprev));
+            const f3 vp = m33_mul(Rpi, sub3(mk3(PLN(A.vmap_g, 0, rows, cols, uy, ux), PLN(A.vmap_g, 1, rows, cols, uy, ux),
+                                                 PLN(A.vmap_g, 2, rows, cols, uy, ux)), tprev));
+            const f3 d = sub3(sub3(vlp, vp), mk3(s1.x, s1.y, s1.z));
+            io.lambda = add3(io.lambda, mk3(HD_SPARSE_MU * d.x, HD_SPARSE_MU * d.y, HD_SPARSE_MU * d.z));
+        }
+    }
+    const bool found = icp_pixel<true>(A, Rcurr, tcurr, Rpi, tprev, x, y, out, &io);
+    const int cp = io.bx < 0 ? -1 : (int)((uint32_t)io.bx | ((uint32_t)io.by << 16));
+    A.sparse[2 * k] = make_float4(io.lambda.x, io.lambda.y, io.lambda.z, __int_as_float(cp));
+    A.sparse[2 * k + 1] = make_float4(io.z.x, io.z.y, io.z.z, 0.0f);
+    return found;
 }
 
 // RGBResidual::getProducts (reduce.cu:981-1060).  The correspondence (u0, v0, x, y, valid) and the intensity
@@ -1101,6 +1145,7 @@ __device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbC
 }
 
 // blocks [0, nb) : ICP products ; blocks [nb, 2nb) : RGB residual.  Both read the same OdoState.
+template <bool SPARSE>
 __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, const OdoState *__restrict__ st, int nb,
                                                        int do_icp, int do_rgb, float minScale,
                                                        long long *__restrict__ icp_part, long long *__restrict__ res_part,
@@ -1115,8 +1160,12 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
         const int i = p0 + blockIdx.x * RB + threadIdx.x;
         if (do_icp && !st->gn_break && i < p1) {
             const int y = i / A.cols, x = i - y * A.cols;
-            valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
-                              mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
+            if (SPARSE)
+                valid = icp_pixel_sparse(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
+                                         mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
+            else
+                valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
+                                  mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
         }
         // icp_part rows are indexed by blockIdx.x in [0, nb)
         block_reduce_exact<29>(out, valid, icp_part);
@@ -1472,6 +1521,7 @@ static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
     A.fx = cfg.fx / div; A.fy = cfg.fy / div; A.cx = cfg.cx / div; A.cy = cfg.cy / div;
     A.distThres = 0.1f; A.angleThres = 0.3420201433f;   // sin(20 deg), RGBDOdometry.h:65-66
     A.use_search = cfg.use_search; A.radius = cfg.search_radius; A.use_weight = cfg.use_weighted;
+    A.sparse = cfg.use_sparse ? L.sparse : nullptr; A.sparse_first = 1;
     return A;
 }
 
@@ -1572,7 +1622,9 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         const int div = 1 << i;
         IcpArgs A = make_icp_args(L, cfg, i);
         const float minScale = (float)(((double)minGrad[i] * (double)minGrad[i]) / (0.125 * 0.125));
+        const auto k_icp_res = A.sparse ? k_gn_icp_residual<true> : k_gn_icp_residual<false>;
         for (int j = 0; j < iterations[i]; ++j) {
+            A.sparse_first = (j == 0);
             // operands for the next iteration: same level, or the next non-empty finer level
             const bool last_of_level = (j == iterations[i] - 1);
             int next_level = i;
@@ -1586,7 +1638,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                     int p0, p1; strip(L, r, p0, p1);
                     const int nbr = (p1 - p0 + RB - 1) / RB;
                     if (nbr > 0)
-                        hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nbr), dim3(RB), 0, s, L, A, ob.state, nbr, icp, rgb, minScale,
+                        hipLaunchKernelGGL(k_icp_res, dim3(2 * nbr), dim3(RB), 0, s, L, A, ob.state, nbr, icp, rgb, minScale,
                                            ob.icp_part, ob.res_part, ob.corres, ob.corres_diff, p0, p1);
                 }
                 // the robust weight needs the residual sums of the WHOLE image before any RGB product is formed
@@ -1610,7 +1662,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                                    last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
                 continue;
             }
-            hipLaunchKernelGGL(k_gn_icp_residual, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
+            hipLaunchKernelGGL(k_icp_res, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
                                ob.icp_part, ob.res_part, ob.corres, ob.corres_diff, 0, L.rows * L.cols);
             // fusing the solve into the last workgroup of k_gn_rgb_step was measured slower (the fold then reads the
             // slot rows from memory instead of L2 and pays a ticket round trip): 16.1 vs 6.3 + 8.8 us on level 2
@@ -1673,6 +1725,7 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
     A.cur_tex = nullptr; A.model_tex = nullptr;
     A.rows = rows; A.cols = cols; A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy;
     A.distThres = dist_thresh; A.angleThres = angle_thresh; A.use_search = 0; A.radius = 0; A.use_weight = use_weight;
+    A.sparse = nullptr; A.sparse_first = 1;
     Rigid cur, prv;
     for (int k = 0; k < 9; ++k) { cur.r[k] = Rcurr[k]; prv.r[k] = Rprev_inv[k]; }
     for (int k = 0; k < 3; ++k) { cur.t[k] = tcurr[k]; prv.t[k] = tprev[k]; }

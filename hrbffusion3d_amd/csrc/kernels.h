@@ -83,6 +83,7 @@ struct OdoLevel {
     uint8_t *rgb_mask;                        // iteration-invariant part of the RGB residual's pixel test (k_odo_prepare)
     float4 *cloud4;                           // back-projected cloud as one 16-B texel per pixel (xyz, -), in-frame RGB step
     int32_t *dIxy;                            // Sobel gradients packed: dIdx in the low, dIdy in the high 16 bits
+    float4 *sparse;                           // sparse ICP only: {lambda.xyz, corres} {z.xyz, -} per pixel, else null
 };
 
 struct OdoConfig {
@@ -90,6 +91,7 @@ struct OdoConfig {
     int rgb_only; float icp_weight; int pyramid, fast_odom, so3, frame_to_frame_rgb;
     int use_search, search_radius, use_weighted, rgb_use_grad;
     float curv_thr;
+    int use_sparse;
 };
 
 struct OdoState;   // device-resident Gauss-Newton state, defined in k_odo.hip

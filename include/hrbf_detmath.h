@@ -409,4 +409,21 @@ HD_FN hd_limbs hd_limbs25_to_limbs(int64_t s0, int64_t s1, int64_t s2, int64_t s
     return r;
 }
 
+/* ---------------------------------------------------------------- sparse-ICP shrink factor
+   ICPReduction::thrink (Core/src/Cuda/reduce.cu:302-315) for the only parameters the reference ever sets
+   (p = 0.5, mu = 10, three fixed-point sweeps; reduce.cu:652-654): z = factor * h.  With p = 1/2 the two pow() calls
+   are pow(x, -1.5) and pow(beta, -0.5); they are restated with the correctly rounded sqrt and division so device and
+   oracle agree bit for bit.  alpha_a = 0.1^(2/3) and hTilde = alpha_a + 0.05 * alpha_a^(-1/2) are the fp32 roundings
+   of those expressions. */
+#define HD_SPARSE_MU 10.0f
+HD_FN float hd_sparse_shrink_factor(float hnorm)
+{
+    const float alpha_a = 0.21544346f, h_tilde = 0.3231652f, p_over_mu = 0.05f;
+    if (hnorm <= h_tilde) return 0.0f;
+    float beta = (alpha_a / hnorm + 1.0f) / 2.0f;
+    const float hp = 1.0f / (hnorm * hd_sqrtf(hnorm));
+    for (int i = 0; i < 3; ++i) beta = 1.0f - (p_over_mu * hp) * (1.0f / hd_sqrtf(beta));
+    return beta;
+}
+
 #endif /* HRBF_DETMATH_H_ */

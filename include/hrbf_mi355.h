@@ -70,7 +70,7 @@ typedef struct hrbf_params {
     int32_t icp_use_weighted;       /* true */
     float icp_curv_weight_lambda;   /* registrationICPCurvWeightImpactControl = 10 */
     int32_t rgb_use_grad_weight;    /* registrationColorUseRGBGrad = false */
-    int32_t use_sparse_icp;         /* registrationICPUseSparseICP = false; true is rejected */
+    int32_t use_sparse_icp;         /* registrationICPUseSparseICP = false; 1 = ADMM variant (reduce.cu:302-315,479-492) */
     /* prediction */
     float predict_window_multiplier;/* 3.0 */
     int32_t predict_min_neighbors;  /* 6 */

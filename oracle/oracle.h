@@ -74,6 +74,9 @@ typedef struct orc_ctx {
     orc_planar vmap_g[ORC_NUM_PYRS], nmap_g[ORC_NUM_PYRS], ck1_g[ORC_NUM_PYRS], ck2_g[ORC_NUM_PYRS];
     orc_planar vmap_c[ORC_NUM_PYRS], nmap_c[ORC_NUM_PYRS], ck1_c[ORC_NUM_PYRS], ck2_c[ORC_NUM_PYRS];
     float *icpw[ORC_NUM_PYRS];
+    f3 *sp_lambda[ORC_NUM_PYRS], *sp_z[ORC_NUM_PYRS];   /* sparse ICP: lambdaMap, z_thrinkMap, corresICP */
+    int32_t *sp_corres[ORC_NUM_PYRS];
+    int64_t sp_shrunk;        /* pixels x iterations whose shrink factor was non-zero, since creation */
     float *last_depth[ORC_NUM_PYRS], *next_depth[ORC_NUM_PYRS];
     uint8_t *last_image[ORC_NUM_PYRS], *next_image[ORC_NUM_PYRS], *last_next_image[ORC_NUM_PYRS];
     int16_t *dIdx[ORC_NUM_PYRS], *dIdy[ORC_NUM_PYRS];
@@ -141,6 +144,8 @@ double orc_acos(double x);
 void orc_acc_test(const float *v, int n, double *out);
 /* 6x6 solve and SE3 update used by the GN loop (RGBDOdometry.cpp:1162-1204) */
 void orc_solve6(const double A[36], const double b[6], double x[6]);
+float orc_sparse_shrink_factor(float hnorm);
+int64_t orc_sparse_shrunk_count(const orc_ctx *c);
 
 #ifdef __cplusplus
 }

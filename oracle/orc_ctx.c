@@ -72,6 +72,8 @@ orc_ctx *orc_create(const hrbf_params *p)
         planar_alloc(&c->vmap_c[i], r, w); planar_alloc(&c->nmap_c[i], r, w);
         planar_alloc(&c->ck1_c[i], r, w); planar_alloc(&c->ck2_c[i], r, w);
         c->icpw[i] = zalloc(sizeof(float) * r * w);
+        c->sp_lambda[i] = zalloc(sizeof(f3) * r * w); c->sp_z[i] = zalloc(sizeof(f3) * r * w);
+        c->sp_corres[i] = zalloc(sizeof(int32_t) * 2 * r * w);
         c->last_depth[i] = zalloc(sizeof(float) * r * w); c->next_depth[i] = zalloc(sizeof(float) * r * w);
         c->last_image[i] = zalloc(r * w); c->next_image[i] = zalloc(r * w); c->last_next_image[i] = zalloc(r * w);
         c->dIdx[i] = zalloc(2 * r * w); c->dIdy[i] = zalloc(2 * r * w);
@@ -96,6 +98,7 @@ void orc_destroy(orc_ctx *c)
     for (int i = 0; i < ORC_NUM_PYRS; ++i) {
         free(c->vmap_g[i].p); free(c->nmap_g[i].p); free(c->ck1_g[i].p); free(c->ck2_g[i].p);
         free(c->vmap_c[i].p); free(c->nmap_c[i].p); free(c->ck1_c[i].p); free(c->ck2_c[i].p);
+        free(c->sp_lambda[i]); free(c->sp_z[i]); free(c->sp_corres[i]);
         free(c->icpw[i]); free(c->last_depth[i]); free(c->next_depth[i]); free(c->last_image[i]);
         free(c->next_image[i]); free(c->last_next_image[i]); free(c->dIdx[i]); free(c->dIdy[i]); free(c->cloud[i]);
     }

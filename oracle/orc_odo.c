@@ -335,15 +335,22 @@ static void rodrigues(const double *src, double *R)
 
 /* ------------------------------------------------------------------ O4: icpStep reduce.cu:253-693 */
 typedef struct { hd_acc128 a[29]; } acc29;
+/* side images of the sparse (ADMM) variant, one level: multiplier lambdaMap, shrunk residual z_thrinkMap, corresICP */
+typedef struct { f3 *lambda, *z; int32_t *corres; int64_t *shrunk; } orc_sparse;
 
 static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const orc_planar *nc,
                       const orc_planar *k1c, const orc_planar *k2c, const float *Rpi, f3 tprev,
                       float fx, float fy, float cx, float cy, const orc_planar *vg, const orc_planar *ng,
                       const orc_planar *k1g, const orc_planar *k2g, const float *icpw, float distThres,
-                      float angleThres, int use_search, int radius, int use_weight, int x, int y, float out[29])
+                      float angleThres, int use_search, int radius, int use_weight, const orc_sparse *sp, int x, int y,
+                      float out[29])
 {
     int rows = vc->rows, cols = vc->cols;
     for (int i = 0; i < 29; ++i) out[i] = 0.0f;
+    if (sp) {   /* getProducts writes both side outputs for every pixel before the found test (reduce.cu:455-471) */
+        sp->z[y * cols + x] = v3(0, 0, 0);
+        sp->corres[2 * (y * cols + x)] = -1; sp->corres[2 * (y * cols + x) + 1] = -1;
+    }
     f3 vcur = v3(PL(*vc, 0, y, x), PL(*vc, 1, y, x), PL(*vc, 2, y, x));
     f3 ncur = v3(PL(*nc, 0, y, x), PL(*nc, 1, y, x), PL(*nc, 2, y, x));
     float ck1 = PL(*k1c, 3, y, x), ck2 = PL(*k2c, 3, y, x);
@@ -398,6 +405,20 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
     f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
     f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
     f3 n_cp = m33_mul(Rpi, bn);
+    if (sp) {   /* sparse ICP (reduce.cu:479-492): the target moves by the shrunk residual minus the scaled multiplier */
+        const int k = y * cols + x;
+        sp->corres[2 * k] = bx; sp->corres[2 * k + 1] = by;
+        f3 lm = v3(sp->lambda[k].x / HD_SPARSE_MU, sp->lambda[k].y / HD_SPARSE_MU, sp->lambda[k].z / HD_SPARSE_MU);
+        f3 h = add3(sub3(s_cp, d_cp), lm);
+        float beta = hd_sparse_shrink_factor(len3(h));
+        if (beta != 0.0f && sp->shrunk) {   /* test evidence only: how often the non-trivial branch ran */
+#pragma omp atomic
+            ++*sp->shrunk;
+        }
+        f3 z = v3(beta * h.x, beta * h.y, beta * h.z);
+        d_cp = sub3(add3(d_cp, z), lm);
+        sp->z[k] = z;
+    }
     float weight = 1.0f;
     if (use_weight) { float w = icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
     float row[7];
@@ -424,7 +445,7 @@ static void icp_step(const float *Rcurr, f3 tcurr, const orc_planar *vc, const o
                      const orc_planar *k1c, const orc_planar *k2c, const float *Rpi, f3 tprev,
                      float fx, float fy, float cx, float cy, const orc_planar *vg, const orc_planar *ng,
                      const orc_planar *k1g, const orc_planar *k2g, const float *icpw, float distThres,
-                     float angleThres, int use_search, int radius, int use_weight, double sums[29])
+                     float angleThres, int use_search, int radius, int use_weight, const orc_sparse *sp, double sums[29])
 {
     acc29 tot; for (int i = 0; i < 29; ++i) hd_acc_zero(&tot.a[i]);
 #pragma omp parallel
@@ -435,7 +456,7 @@ static void icp_step(const float *Rcurr, f3 tcurr, const orc_planar *vc, const o
             for (int x = 0; x < vc->cols; ++x) {
                 float o[29];
                 icp_pixel(Rcurr, tcurr, vc, nc, k1c, k2c, Rpi, tprev, fx, fy, cx, cy, vg, ng, k1g, k2g, icpw,
-                          distThres, angleThres, use_search, radius, use_weight, x, y, o);
+                          distThres, angleThres, use_search, radius, use_weight, sp, x, y, o);
                 if (o[28] != 0.0f) for (int i = 0; i < 29; ++i) hd_acc_add_f32(&loc.a[i], o[i]);
             }
 #pragma omp critical
@@ -443,6 +464,28 @@ static void icp_step(const float *Rcurr, f3 tcurr, const orc_planar *vc, const o
     }
     for (int i = 0; i < 29; ++i) sums[i] = hd_acc_to_double(tot.a[i]);
 }
+
+/* updateLambdaMapKernel (cudafuncs.cu:1030-1080): lambda += mu * (s' - d - z) at the pose just solved for, where the
+   last icpStep found a correspondence — tested as corresp.x > 0, so matches in column 0 never update (kept) */
+static void sparse_update_lambda(const float *Rcurr, f3 tcurr, const orc_planar *vc, const float *Rpi, f3 tprev,
+                                 const orc_planar *vg, const orc_sparse *sp)
+{
+    const int rows = vc->rows, cols = vc->cols;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const int k = y * cols + x, ux = sp->corres[2 * k], uy = sp->corres[2 * k + 1];
+            if (ux <= 0) continue;
+            f3 vcur = v3(PL(*vc, 0, y, x), PL(*vc, 1, y, x), PL(*vc, 2, y, x));
+            f3 vlp = m33_mul(Rpi, sub3(add3(m33_mul(Rcurr, vcur), tcurr), tprev));
+            f3 vp = m33_mul(Rpi, sub3(v3(PL(*vg, 0, uy, ux), PL(*vg, 1, uy, ux), PL(*vg, 2, uy, ux)), tprev));
+            f3 d = sub3(sub3(vlp, vp), sp->z[k]);
+            sp->lambda[k] = add3(sp->lambda[k], v3(HD_SPARSE_MU * d.x, HD_SPARSE_MU * d.y, HD_SPARSE_MU * d.z));
+        }
+}
+
+float orc_sparse_shrink_factor(float hnorm) { return hd_sparse_shrink_factor(hnorm); }
+int64_t orc_sparse_shrunk_count(const orc_ctx *c) { return c->sp_shrunk; }
 
 int orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
                  const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9], const float tprev[3],
@@ -458,7 +501,7 @@ int orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_c
     double s[29];
     icp_step(Rcurr, v3(tcurr[0], tcurr[1], tcurr[2]), &vc, &nc, &k1c, &k2c, Rprev_inv,
              v3(tprev[0], tprev[1], tprev[2]), fx, fy, cx, cy, &vg, &ng, &k1g, &k2g, icp_weight_prev,
-             dist_thresh, angle_thresh, 0, 0, use_weight, s);
+             dist_thresh, angle_thresh, 0, 0, use_weight, NULL, s);
     int shift = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 7; ++j) {
@@ -755,6 +798,9 @@ void orc_odo_track(orc_ctx *c)
         K[0] = fxl; K[4] = fyl; K[2] = cxl; K[5] = cyl; K[8] = 1;
         inv3d(K, Kinv);
         float lastRGBError = 3.402823466e+38f;
+        const int sparse = icp && c->prm.use_sparse_icp;
+        orc_sparse sp = {c->sp_lambda[i], c->sp_z[i], c->sp_corres[i], &c->sp_shrunk};
+        if (sparse) memset(sp.lambda, 0, sizeof(f3) * (size_t)(c->H >> i) * (c->W >> i));   /* RGBDOdometry.cpp:964-977 */
         for (int j = 0; j < iterations[i]; ++j) {
             /* Rt = resultRt.inverse() (rigid: cofactor inverse of the linear part) */
             double L[9], Li[9], ti[3];
@@ -789,7 +835,7 @@ void orc_odo_track(orc_ctx *c)
                 icp_step(Rcurr, tcurr, &c->vmap_c[i], &c->nmap_c[i], &c->ck1_c[i], &c->ck2_c[i], Rprev_inv, tprev,
                          fxl, fyl, cxl, cyl, &c->vmap_g[i], &c->nmap_g[i], &c->ck1_g[i], &c->ck2_g[i], c->icpw[i],
                          distThres, angleThres, c->prm.icp_use_corr_search, c->prm.icp_search_radius,
-                         c->prm.icp_use_weighted, s);
+                         c->prm.icp_use_weighted, sparse ? &sp : NULL, s);
                 unpack27(s, A_icp, b_icp);
                 res_icp[0] = (float)s[27]; res_icp[1] = (float)s[28];
             }
@@ -830,6 +876,8 @@ void orc_odo_track(orc_ctx *c)
             mul3f(Rprev, iR, Rcurr);
             f3 rt = m33_mul(Rprev, v3(it_[0], it_[1], it_[2]));
             tcurr = add3(rt, tprev);
+            if (sparse)   /* RGBDOdometry.cpp:1206-1227 */
+                sparse_update_lambda(Rcurr, tcurr, &c->vmap_c[i], Rprev_inv, tprev, &c->vmap_g[i], &sp);
         }
     }
     if (rgb) {

@@ -66,8 +66,7 @@ def test_create_fails_loudly_without_a_gpu(lib):
 
 def test_invalid_parameters_are_rejected(lib):
     h = C.c_void_p()
-    p = default_params(max_surfels=1024)
-    p.use_sparse_icp = 1
+    p = default_params(max_surfels=1024, predict_window_multiplier=4.0)
     assert lib.hrbf_create(C.byref(p), 0, C.byref(h)) == -1
     p = default_params(width=642, max_surfels=1024)
     assert lib.hrbf_create(C.byref(p), 0, C.byref(h)) == -1

@@ -368,3 +368,54 @@ def test_inactive_submaps_are_not_drawn(oracle_lib_built):
     o.run_stage("PREDICT_INDICES")
     assert np.array_equal(o.get_image("INDEX"), full)
     o.close()
+
+
+def test_sparse_icp_shrink_operator(lib):
+    """ICPReduction::thrink (reduce.cu:302-315) at p = 1/2, mu = 10: zero up to hTilde = alpha + 0.05 alpha^-1/2 with
+    alpha = 0.1^(2/3); above it the three sweeps approach the fixed point beta = 1 - 0.05 h^-3/2 beta^-1/2, which
+    rises monotonically towards 1."""
+    alpha = 0.1 ** (2.0 / 3.0)
+    h_tilde = alpha + 0.05 / np.sqrt(alpha)
+    f = lib.orc_sparse_shrink_factor
+    assert f(0.0) == 0.0 and f(0.1) == 0.0 and f(np.float32(h_tilde - 1e-4)) == 0.0
+    prev = 0.0
+    for h in (h_tilde + 1e-3, 0.4, 0.6, 1.0, 3.0, 30.0):
+        b = f(np.float32(h))
+        beta = (alpha / h + 1.0) / 2.0
+        for _ in range(3):
+            beta = 1.0 - 0.05 * h ** -1.5 * beta ** -0.5
+        assert abs(b - beta) < 1e-6 and prev < b < 1.0
+        prev = b
+    b = f(np.float32(30.0))
+    assert abs(b - (1.0 - 0.05 * 30.0 ** -1.5 * b ** -0.5)) < 1e-6      # converged to the fixed point
+    assert np.isnan(f(np.float32(np.nan)))
+
+
+def test_sparse_icp_tracks_and_downweights_an_outlier_slab(oracle_lib_built):
+    """use_sparse_icp: on clean data the multiplier stays small and the pose matches plain ICP to a
+    fraction of a millimetre; with a patch of the live depth pushed 9 cm back the multipliers of the patch grow by
+    mu * residual per iteration until the shrink step absorbs the outliers (non-zero z), and the pose error is no
+    worse than plain ICP's."""
+    from hrbffusion3d_amd import synth
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    frames = [synth.frame(k, W, H) for k in range(4)]
+    slab = frames[3][1].copy()
+    slab[40:80, 50:110] += 450                                      # 9 cm at 5000 units / m
+    res = {}
+    for sparse in (0, 1):
+        p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17, use_sparse_icp=sparse, icp_weight=100.0)
+        o = oracle_lib_built.Oracle(p, omp=True)
+        o.set_pose(frames[0][2])
+        for rgb, d, _ in frames[:3]:
+            o.process_frame(rgb, d)
+        clean_pose, clean_shrunk = o.get_pose(), (o.sparse_shrunk_count() if sparse else 0)
+        o.process_frame(frames[3][0], slab)
+        res[sparse] = (clean_pose, o.get_pose(), clean_shrunk, o.sparse_shrunk_count() if sparse else 0)
+        o.close()
+    assert np.abs(res[0][0][:3, 3] - res[1][0][:3, 3]).max() < 1e-3
+    assert not np.array_equal(res[0][0], res[1][0])                 # the multiplier does act
+    assert res[1][2] == 0 and res[1][3] > 100                       # shrink ran on the slab only
+    gt = frames[3][2][:3, 3]
+    e_plain, e_sparse = np.linalg.norm(res[0][1][:3, 3] - gt), np.linalg.norm(res[1][1][:3, 3] - gt)
+    assert e_sparse <= e_plain + 1e-3, (e_plain, e_sparse)

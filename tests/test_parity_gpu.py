@@ -162,13 +162,14 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
 
 
 @pytest.mark.parametrize("variant", ["gauss_filter", "central_diff_normals", "no_so3_no_pyramid", "conf_eval", "rgb_only",
-                                     "icp_only"])
+                                     "icp_only", "corr_search", "sparse_icp_corr_search"])
 def test_parameter_variants(pair, variant):
     W, H = 160, 120
     fx, fy, cx, cy = synth.intrinsics(W, H)
     kw = {"gauss_filter": dict(use_bilateral=0), "central_diff_normals": dict(normal_estimation_pca=0.0),
           "no_so3_no_pyramid": dict(so3=0, pyramid=0, fast_odom=1), "conf_eval": dict(use_conf_eval=1),
-          "rgb_only": dict(rgb_only=1), "icp_only": dict(icp_weight=100.0)}[variant]
+          "rgb_only": dict(rgb_only=1), "icp_only": dict(icp_weight=100.0), "corr_search": dict(icp_use_corr_search=1),
+          "sparse_icp_corr_search": dict(use_sparse_icp=1, icp_use_corr_search=1)}[variant]
     p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17, **kw)
     o, g = pair(p)
     for k in range(4):
@@ -311,6 +312,29 @@ def test_row_sharded_registration(pair, mode):
     rgb, d, _ = synth.frame(5, W, H, noise=True)
     o.process_frame(rgb, d); g.process_frame(rgb, d)
     assert_same_state(o, g, mode + " back to single")
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_sparse_icp_with_outlier_slab(pair, sharded):
+    """SURVEY §8f-4, use_sparse_icp: the ADMM variant of icpStep (multiplier image, shrink step, updateLambdaMap folded
+    into the head of the next iteration on the GPU, a separate pass in the oracle).  Frame 3 carries a patch pushed
+    9 cm back so the shrink step's non-trivial branch runs (the oracle counts it); everything stays bit-identical,
+    also with the reductions split over three row strips."""
+    W, H = 320, 240
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 19, use_sparse_icp=1)
+    o, g = pair(p)
+    if sharded:
+        g.comm_init(-1, 3)
+    for k in range(5):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        if k == 3:
+            d = d.copy(); d[80:160, 100:220] += 450
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "sparse frame %d" % k)
+        if k == 2:
+            assert o.sparse_shrunk_count() == 0
+    assert o.sparse_shrunk_count() > 1000
 
 
 def test_icp_step_seam(oracle_lib_built, gpu_available):
