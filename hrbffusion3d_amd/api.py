@@ -26,7 +26,8 @@ EXPORTS = [
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
-    "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
+    "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
+    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
 
 
@@ -77,8 +78,23 @@ def load_library():
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
+    lib.hrbf_rebalance_plan.argtypes = [vp, i32, vp, vp, vp]
+    lib.hrbf_local_surfel_count.argtypes = [vp]; lib.hrbf_local_surfel_count.restype = C.c_uint32
     _lib = lib
     return lib
+
+
+def rebalance_plan(counts):
+    """hrbf_rebalance_plan: the even re-cut of contiguous shards -> (new_counts, [(src, dst, src_off, dst_off, len)])"""
+    lib = load_library()
+    c = np.ascontiguousarray(counts, np.uint32)
+    G = len(c)
+    new = np.zeros(G, np.uint32); moves = np.zeros((2 * G, 5), np.uint32); n = C.c_int(0)
+    rc = lib.hrbf_rebalance_plan(_p(c), G, _p(new), _p(moves), C.byref(n))
+    if rc != 0:
+        raise HrbfError("hrbf_rebalance_plan failed with status %d" % rc)
+    return new, [tuple(int(v) for v in m) for m in moves[:n.value]]
 
 
 def _p(a):
@@ -171,6 +187,16 @@ class HRBFFusion:
         self._check(self.lib.hrbf_comm_init(self.h, int(rank), int(world), buf))
 
     # submap bookkeeping + rigid map correction (GlobalModel::updateModel), SURVEY §8f-3
+    def map_shard_init(self, enable=True):
+        """cut the surfel map over the ranks of comm_init (SURVEY §8e sharding 2); the map must be empty"""
+        self._check(self.lib.hrbf_map_shard_init(self.h, int(bool(enable))))
+
+    def map_rebalance(self):
+        self._check(self.lib.hrbf_map_rebalance(self.h))
+
+    def local_surfel_count(self):
+        return int(self.lib.hrbf_local_surfel_count(self.h))
+
     def set_index_submap(self, idx):
         self._check(self.lib.hrbf_set_index_submap(self.h, int(idx)))
 
@@ -193,7 +219,8 @@ class HRBFFusion:
         return int(self.lib.hrbf_surfel_count(self.h))
 
     def download_map(self):
-        n = self.surfel_count()
+        """the local range(s) in global order: the whole map unless this context is one rank of a sharded map"""
+        n = self.local_surfel_count()
         o = np.zeros((n, 20), np.float32)
         if n:
             self._check(self.lib.hrbf_download_map(self.h, _p(o), n))

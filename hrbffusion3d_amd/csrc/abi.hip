@@ -41,6 +41,23 @@ extern "C" void hrbf_default_params(hrbf_params *p, int width, int height, float
 }
 
 #define HRBF_RING 1024
+#define HRBF_MAX_SHARDS 8
+
+// one shard of the surfel map (SURVEY §8e sharding 2): a contiguous range of the global surfel order.  A single-GPU
+// context has exactly one; a rank of a sharded map has one (its own); the single-process test mode has all G.
+struct MapShard {
+    MapPlanes map;              // single copy: the fuse pass compacts in place
+    uint32_t count_ub;          // host upper bound of this shard's surfel count
+    uint32_t *d_slot;           // per-surfel merge slot (lowest draw-order record wins)
+    uint32_t *d_stats;
+    uint32_t *d_tile_count; uint32_t *d_tile_done;
+    uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
+};
+// private projection outputs of the virtual shards k >= 1 (reduced into the context's own images)
+struct ShardScratch {
+    unsigned long long *zbuf; uint32_t *idx;
+    float4 *vertconf, *colortime, *normrad, *curvmax, *curvmin, *clean_tex;
+};
 
 struct hrbf_context {
     hrbf_params prm;
@@ -60,20 +77,23 @@ struct hrbf_context {
     float4 *d_pr_vertex, *d_pr_normal, *d_pr_curv1, *d_pr_curv2, *d_fi_vertex, *d_fi_normal, *d_fi_curv1, *d_fi_curv2;
     uint32_t *d_pr_time; float *d_pr_icpw, *d_fi_icpw;
     // map
-    MapPlanes map;              // single copy: the fuse pass compacts in place
-    int target;                 // index of the live surfel-count word (d_count ping-pongs)
+    MapShard sh[HRBF_MAX_SHARDS];   // local shards (nsh of them)
+    int nsh;                    // local shard count: 1, or G in the single-process test mode
+    int G;                      // global shard count (1 = the map is not sharded)
+    int shard_first;            // global index of sh[0] (the rank in real mode)
+    int shard_real;             // one shard per rank, reductions through RCCL
+    ShardScratch x;
+    int target;                 // index of the live row of d_counts (ping-pong)
     int map_dirty;              // map uploaded from outside since the last fuse pass -> full curvature re-check
     int fuse_tick;              // tick of the last association/merge (a clean at another tick re-checks everything)
-    uint32_t cap;
-    uint32_t *d_count;          // [2], ping-pong with the map
-    uint32_t count_ub;          // host upper bound of the surfel count
-    uint32_t *h_count_pinned;   // async read-back (1-frame lag)
+    uint32_t cap;               // per shard
+    uint32_t *d_counts;         // [2][HRBF_MAX_SHARDS]: live surfel counts of all G shards, ping-pong with the clean pass
+    uint32_t *h_count_pinned;   // [HRBF_MAX_SHARDS] async read-back (1-frame lag)
     uint8_t *h_stage[3]; hipEvent_t ev_stage[3]; bool stage_used[3]; uint32_t stage_head;   // pinned input staging ring
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
-    RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best; uint32_t *d_slot;
-    uint32_t *d_stats; uint32_t *d_init_flags, *d_init_offs;
-    uint32_t *d_tile_count; uint32_t *d_tile_done; uint32_t max_tiles;
-    uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
+    RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
+    uint32_t *d_init_flags, *d_init_offs;
+    uint32_t max_tiles;
     float4 *d_clean_tex;        // 2 x float4 per pixel: packed index-map texels for the clean test
     DevPose *d_pose;
     int index_submap;           // submap id stamped on new surfels (HRBFFusion::indexSubmap)
@@ -108,6 +128,40 @@ static int alloc_planes(hrbf_context *c, MapPlanes &m, size_t n)
     (void)c;
     return HRBF_OK;
 }
+
+static void free_planes(MapPlanes &m)
+{
+    hipFree(m.p0); hipFree(m.p1); hipFree(m.p2); hipFree(m.p3); hipFree(m.p4);
+    m.p0 = m.p1 = m.p2 = m.p3 = m.p4 = nullptr;
+}
+// everything a shard owns; the merge slots still have to be filled with 0xFFFFFFFF by the caller
+static int alloc_shard(hrbf_context *c, MapShard &sh)
+{
+    int r = alloc_planes(c, sh.map, c->cap);
+    if (!r) r = dalloc(&sh.d_slot, c->cap);
+    if (!r) r = dalloc(&sh.d_stats, 8);
+    if (!r) r = dalloc(&sh.d_tile_count, (size_t)c->max_tiles * fuse_tile_count_stride());
+    if (!r) r = dalloc(&sh.d_tile_done, c->max_tiles);
+    if (!r) r = dalloc(&sh.d_keep_flags, (size_t)c->cap + (size_t)c->Q + 64);
+    sh.count_ub = 0;
+    return r;
+}
+static void free_shard(MapShard &sh)
+{
+    free_planes(sh.map);
+    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count, sh.d_tile_done, sh.d_keep_flags};
+    for (void *p : q) if (p) hipFree(p);
+    sh.d_slot = sh.d_stats = sh.d_tile_count = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr;
+}
+static void free_scratch(ShardScratch &x)
+{
+    void *q[] = {x.zbuf, x.idx, x.vertconf, x.colortime, x.normrad, x.curvmax, x.curvmin, x.clean_tex};
+    for (void *p : q) if (p) hipFree(p);
+    memset(&x, 0, sizeof(x));
+}
+static uint32_t *counts_live(hrbf_context *c) { return c->d_counts + (size_t)c->target * HRBF_MAX_SHARDS; }
+static uint32_t *counts_next(hrbf_context *c) { return c->d_counts + (size_t)(1 - c->target) * HRBF_MAX_SHARDS; }
+static ShardRef shard_ref(hrbf_context *c, int k) { ShardRef r = {counts_live(c), c->shard_first + k, c->G}; return r; }
 
 extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
 {
@@ -156,16 +210,15 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     DA(c->d_fi_vertex, P); DA(c->d_fi_normal, P); DA(c->d_fi_curv1, P); DA(c->d_fi_curv2, P);
     DA(c->d_pr_time, P); DA(c->d_pr_icpw, P); DA(c->d_fi_icpw, P);
     c->cap = (uint32_t)p->max_surfels;
-    { int r; if ((r = alloc_planes(c, c->map, c->cap)) || (r = alloc_planes(c, c->rec, c->Q))) { hrbf_destroy(c); return r; } }
-    DA(c->d_count, 2);
-    DA(c->d_rec_flag, c->Q); DA(c->d_rec_best, c->Q); DA(c->d_slot, c->cap);
-    DA(c->d_stats, 8); DA(c->d_init_flags, P); DA(c->d_init_offs, P);
     c->max_tiles = (c->cap + c->Q) / fuse_tile_items() + 2;
-    DA(c->d_tile_count, (size_t)c->max_tiles * fuse_tile_count_stride()); DA(c->d_tile_done, c->max_tiles);
+    c->nsh = 1; c->G = 1; c->shard_first = 0; c->shard_real = 0;
+    { int r; if ((r = alloc_shard(c, c->sh[0])) || (r = alloc_planes(c, c->rec, c->Q))) { hrbf_destroy(c); return r; } }
+    DA(c->d_counts, 2 * HRBF_MAX_SHARDS);
+    DA(c->d_rec_flag, c->Q); DA(c->d_rec_best, c->Q);
+    DA(c->d_init_flags, P); DA(c->d_init_offs, P);
     DA(c->d_pose, 1);
-    DA(c->d_keep_flags, (size_t)c->cap + (size_t)c->Q + 64);
     DA(c->d_clean_tex, 2 * P);
-    e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * 2, hipHostMallocDefault);
+    e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * HRBF_MAX_SHARDS, hipHostMallocDefault);
     if (e != hipSuccess) { hrbf_set_error("hipHostMalloc: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     c->h_count_pinned[0] = 0;
     hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming);
@@ -198,7 +251,7 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     // initialisation kernels touch the same buffers
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { hrbf_set_error("init sync: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
-    launch_fill_u32(c->stream, c->d_slot, c->cap, 0xFFFFFFFFu);
+    launch_fill_u32(c->stream, c->sh[0].d_slot, c->cap, 0xFFFFFFFFu);
     launch_zbuf_reset(c->stream, c->d_zbuf, P);
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     launch_pose_set(c->stream, c->d_pose, I, 1);
@@ -209,7 +262,6 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     return HRBF_OK;
 }
 
-static void free_planes(MapPlanes &m) { hipFree(m.p0); hipFree(m.p1); hipFree(m.p2); hipFree(m.p3); hipFree(m.p4); }
 
 // ------------------------------------------------------------------------------------------ RCCL (row-sharded registration)
 // librccl is loaded on first use: a single-GPU process never touches it and the library keeps no link-time dependency.
@@ -223,9 +275,15 @@ struct RcclApi {
     int (*CommDestroy)(void *comm);
     int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s);
     const char *(*GetErrorString)(int);
+    int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t s);
+    int (*Send)(const void *send, size_t count, int dtype, int peer, void *comm, hipStream_t s);
+    int (*Recv)(void *recv, size_t count, int dtype, int peer, void *comm, hipStream_t s);
+    int (*GroupStart)();
+    int (*GroupEnd)();
 };
-RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-const int kNcclInt64 = 4, kNcclSum = 0;   // ncclDataType_t::ncclInt64, ncclRedOp_t::ncclSum (rccl.h)
+RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// ncclDataType_t / ncclRedOp_t values (rccl.h)
+const int kNcclUint32 = 3, kNcclInt64 = 4, kNcclUint64 = 5, kNcclSum = 0, kNcclMin = 3;
 
 int rccl_load()
 {
@@ -238,7 +296,13 @@ int rccl_load()
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.Send = (decltype(g_rccl.Send))dlsym(lib, "ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(lib, "ncclRecv");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather ||
+        !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         hrbf_set_error("librccl.so lacks an expected entry point"); dlclose(lib); return HRBF_ERR_COMM;
     }
     g_rccl.lib = lib;
@@ -247,6 +311,20 @@ int rccl_load()
 int rccl_allreduce_i64(void *comm, long long *buf, size_t count, hipStream_t s)
 {
     return g_rccl.AllReduce(buf, buf, count, kNcclInt64, kNcclSum, comm, s);   // in place, on the context's stream
+}
+// the three collectives of a sharded map: z-buffer keys (min), resolved images as integers (sum: one owner per pixel,
+// zeros elsewhere -> exact), live counts (all-gather; `own` = row + rank, the in-place form)
+int rccl_allreduce_min_u64(void *comm, unsigned long long *buf, size_t count, hipStream_t s)
+{
+    return g_rccl.AllReduce(buf, buf, count, kNcclUint64, kNcclMin, comm, s);
+}
+int rccl_allreduce_sum_u32(void *comm, uint32_t *buf, size_t count, hipStream_t s)
+{
+    return g_rccl.AllReduce(buf, buf, count, kNcclUint32, kNcclSum, comm, s);
+}
+int rccl_allgather_u32(void *comm, const uint32_t *own, uint32_t *row, size_t count_each, hipStream_t s)
+{
+    return g_rccl.AllGather(own, row, count_each, kNcclUint32, comm, s);
 }
 }   // namespace
 
@@ -261,11 +339,13 @@ extern "C" void hrbf_destroy(hrbf_handle c)
                     c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_idx, c->d_zbuf, c->d_im_vertconf, c->d_im_colortime,
                     c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, c->d_pr_image, c->d_fi_image, c->d_pr_vertex,
                     c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_fi_vertex, c->d_fi_normal, c->d_fi_curv1,
-                    c->d_fi_curv2, c->d_pr_time, c->d_pr_icpw, c->d_fi_icpw, c->d_count, c->d_rec_flag, c->d_rec_best,
-                    c->d_slot, c->d_stats, c->d_init_flags, c->d_init_offs, c->d_tile_count, c->d_tile_done, c->d_pose, c->d_keep_flags, c->d_clean_tex,
+                    c->d_fi_curv2, c->d_pr_time, c->d_pr_icpw, c->d_fi_icpw, c->d_counts, c->d_rec_flag, c->d_rec_best,
+                    c->d_init_flags, c->d_init_offs, c->d_pose, c->d_clean_tex,
                     c->odo.state, c->odo.corres, c->odo.corres_diff, c->odo.icp_part, c->odo.totals};
     for (void *p : ptrs) if (p) hipFree(p);
-    free_planes(c->map); free_planes(c->rec);
+    for (int k = 0; k < HRBF_MAX_SHARDS; ++k) free_shard(c->sh[k]);
+    free_scratch(c->x);
+    free_planes(c->rec);
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         OdoLevel &L = c->odo.lv[i];
         void *q[] = {L.vmap_g, L.nmap_g, L.ck1_g, L.ck2_g, L.vmap_c, L.nmap_c, L.ck1_c, L.ck2_c, L.icpw, L.last_depth,
@@ -337,63 +417,140 @@ static void st_conf(hrbf_context *c)
 }
 static void refresh_count_ub(hrbf_context *c)
 {
-    // 1-frame-lag read-back of the surfel count; never blocks in steady state
+    // 1-frame-lag read-back of the surfel counts; never blocks in steady state
     if (c->ev_pending && hipEventQuery(c->ev_count) == hipSuccess) {
         c->ev_pending = false;
-        uint32_t known = c->h_count_pinned[0];
-        uint32_t ub = known + c->ub_growth_since;
-        if (ub < c->count_ub) c->count_ub = ub;
+        for (int k = 0; k < c->nsh; ++k) {
+            const int gk = c->shard_first + k;
+            const uint32_t ub = c->h_count_pinned[gk] + (gk == c->G - 1 ? c->ub_growth_since : 0u);   // only the last shard grows
+            if (ub < c->sh[k].count_ub) c->sh[k].count_ub = ub;
+        }
     }
 }
 static void request_count(hrbf_context *c)
 {
     if (c->ev_pending) return;
-    hipMemcpyAsync(c->h_count_pinned, &c->d_count[c->target], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(c->h_count_pinned, counts_live(c), sizeof(uint32_t) * (size_t)c->G, hipMemcpyDeviceToHost, c->stream);
     hipEventRecord(c->ev_count, c->stream);
     c->ev_pending = true;
     c->ub_growth_since = 0;
 }
+
+// ---- collectives of a sharded map.  Real mode (one shard per rank): RCCL on the context's stream, in place.  The
+// single-process test mode reduces the private outputs of the virtual shards with local kernels instead (st_indices).
+static void shard_allgather_counts(hrbf_context *c, uint32_t *row)
+{
+    if (c->shard_real && c->comm.comm) rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
+}
+struct ImgRef { void *p; size_t words; };
+static int what_images(hrbf_context *c, bool primary, bool for_clean, int what, ImgRef out[6])
+{
+    const size_t P = (size_t)c->P;
+    int n = 0;
+    if (what & 1) { out[n++] = {primary ? c->d_im_vertconf : c->x.vertconf, P * 4}; out[n++] = {primary ? c->d_im_normrad : c->x.normrad, P * 4}; }
+    if (what & 2) {
+        out[n++] = {primary ? c->d_im_colortime : c->x.colortime, P * 4}; out[n++] = {primary ? c->d_im_curvmax : c->x.curvmax, P * 4};
+        out[n++] = {primary ? c->d_im_curvmin : c->x.curvmin, P * 4};
+    }
+    if ((what & 4) && for_clean) out[n++] = {primary ? c->d_clean_tex : c->x.clean_tex, P * 8};
+    return n;
+}
+
 static void st_init(hrbf_context *c)
 {
-    launch_initialise(c->stream, c->cam, c->d_pose, c->d_vertex_raw, c->d_normal, c->d_rgb, c->d_curv1, c->d_curv2,
-                      c->d_gradmag, c->prm.use_conf_eval, c->prm.conf_eval_epsilon, c->prm.curv_valid_threshold,
-                      c->d_init_flags, c->d_init_offs, c->map, c->cap, &c->d_count[c->target]);
-    c->count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
+    // the seed goes to the end of the global order = the last shard; every other shard starts empty
+    const int kl = c->G - 1 - c->shard_first;
+    if (c->G > 1) hipMemsetAsync(counts_live(c), 0, sizeof(uint32_t) * HRBF_MAX_SHARDS, c->stream);
+    for (int k = 0; k < c->nsh; ++k) c->sh[k].count_ub = 0;
+    if (kl >= 0 && kl < c->nsh) {
+        launch_initialise(c->stream, c->cam, c->d_pose, c->d_vertex_raw, c->d_normal, c->d_rgb, c->d_curv1, c->d_curv2,
+                          c->d_gradmag, c->prm.use_conf_eval, c->prm.conf_eval_epsilon, c->prm.curv_valid_threshold,
+                          c->d_init_flags, c->d_init_offs, c->sh[kl].map, c->cap, counts_live(c) + (c->G - 1));
+        c->sh[kl].count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
+    }
+    shard_allgather_counts(c, counts_live(c));
     launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
 }
 // what: which outputs of the projection the next consumer reads (k_resolve); the stage API asks for everything
 static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
 {
-    launch_predict_indices(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->map,
-                           &c->d_count[c->target], c->count_ub, c->d_zbuf, c->d_idx, c->d_im_vertconf,
-                           c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin,
-                           for_clean ? c->d_clean_tex : nullptr, c->d_submap_active, c->n_submap_active, what);
+    const float maxd = c->prm.max_depth_processed;
+    float4 *ctex = for_clean ? c->d_clean_tex : nullptr;
+    if (c->G == 1 && !c->shard_real) {
+        launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[0].map, shard_ref(c, 0), c->sh[0].count_ub, c->d_zbuf,
+                       c->d_submap_active, c->n_submap_active);
+        launch_resolve(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), c->d_zbuf, c->d_idx, c->d_im_vertconf,
+                       c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctex, what, 1);
+        return;
+    }
+    // sharded map: every shard projects its own surfels under GLOBAL ids -> min-reduce of the packed keys -> every
+    // shard gathers the winners it owns and writes zeros elsewhere -> sum-reduce of the images (as integers: exact).
+    for (int k = 0; k < c->nsh; ++k) {
+        unsigned long long *zb = k == 0 ? c->d_zbuf : c->x.zbuf;
+        launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[k].map, shard_ref(c, k), c->sh[k].count_ub, zb,
+                       c->d_submap_active, c->n_submap_active);
+        if (k > 0) launch_zbuf_min_merge(c->stream, c->d_zbuf, c->x.zbuf, c->P);
+    }
+    if (c->shard_real && c->comm.comm) rccl_allreduce_min_u64(c->comm.comm, c->d_zbuf, (size_t)c->P, c->stream);
+    ImgRef prim[6], scr[6];
+    const int ni = what_images(c, true, for_clean, what, prim);
+    for (int k = 0; k < c->nsh; ++k) {
+        const bool p0 = k == 0;
+        launch_resolve(c->stream, c->cam, c->d_pose, c->sh[k].map, shard_ref(c, k), c->d_zbuf, p0 ? c->d_idx : c->x.idx,
+                       p0 ? c->d_im_vertconf : c->x.vertconf, p0 ? c->d_im_colortime : c->x.colortime,
+                       p0 ? c->d_im_normrad : c->x.normrad, p0 ? c->d_im_curvmax : c->x.curvmax,
+                       p0 ? c->d_im_curvmin : c->x.curvmin, for_clean ? (p0 ? c->d_clean_tex : c->x.clean_tex) : nullptr, what,
+                       k == c->nsh - 1 ? 1 : 0);
+        if (!p0) {
+            what_images(c, false, for_clean, what, scr);
+            for (int t = 0; t < ni; ++t) launch_add_u32(c->stream, (uint32_t *)prim[t].p, (const uint32_t *)scr[t].p, prim[t].words);
+        }
+    }
+    if (c->shard_real && c->comm.comm) {
+        g_rccl.GroupStart();
+        for (int t = 0; t < ni; ++t) rccl_allreduce_sum_u32(c->comm.comm, (uint32_t *)prim[t].p, prim[t].words, c->stream);
+        g_rccl.GroupEnd();
+    }
 }
 static void st_fuse(hrbf_context *c)
 {
-    launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, c->index_submap, c->d_depth_metric, c->d_normal_pca,
-                c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf, c->d_im_normrad, c->rec,
-                c->d_rec_flag, c->d_rec_best, c->d_slot, c->map, c->d_stats, c->prm.curv_valid_threshold);
+    // association is replicated (it reads images only); each shard keeps the merge slots of its own surfels and applies
+    // the merges that land on them
+    for (int k = 0; k < c->nsh; ++k)
+        launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, c->index_submap, c->d_depth_metric,
+                    c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf,
+                    c->d_im_normrad, c->rec, c->d_rec_flag, c->d_rec_best, c->sh[k].d_slot, c->sh[k].map, shard_ref(c, k),
+                    c->sh[k].d_stats, c->prm.curv_valid_threshold);
     c->fuse_tick = c->tick;
 }
 static void st_clean(hrbf_context *c)
 {
-    launch_clean(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->prm.confidence_threshold,
-                 c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier, (c->map_dirty || c->fuse_tick != c->tick) ? 1 : 0, c->map,
-                 c->rec, c->d_rec_flag, &c->d_count[c->target], &c->d_count[1 - c->target],
-                 c->count_ub, c->d_stats, c->cap, c->d_clean_tex, c->d_keep_flags,
-                 c->d_tile_count, c->d_tile_done, c->max_tiles, c->timing ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
-                 c->timing ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active);
-    if (c->timing) {
-        hipMemcpyAsync(c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4, c->d_stats, sizeof(uint32_t) * 4,
+    const bool ring = c->timing && c->G == 1;
+    for (int k = 0; k < c->nsh; ++k) {
+        const int gk = c->shard_first + k;
+        const bool last = gk == c->G - 1;   // new surfels are appended at the end of the global order
+        MapShard &sh = c->sh[k];
+        launch_clean(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->prm.confidence_threshold,
+                     c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier,
+                     (c->map_dirty || c->fuse_tick != c->tick) ? 1 : 0, sh.map, c->rec, c->d_rec_flag, counts_live(c) + gk,
+                     counts_next(c) + gk, sh.count_ub, sh.d_stats, c->cap, c->d_clean_tex, sh.d_keep_flags, sh.d_tile_count,
+                     sh.d_tile_done, c->max_tiles, ring ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
+                     ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
+                     last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0);
+        if (last) {
+            const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
+            sh.count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
+        }
+    }
+    shard_allgather_counts(c, counts_next(c));
+    if (ring) {
+        hipMemcpyAsync(c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4, c->sh[0].d_stats, sizeof(uint32_t) * 4,
                        hipMemcpyDeviceToDevice, c->stream);
         c->ring_head++;
         if (c->ring_valid < HRBF_RING) c->ring_valid++;
     }
     c->target = 1 - c->target;
     c->map_dirty = 0;
-    uint64_t ub = (uint64_t)c->count_ub + (uint64_t)c->Q;
-    c->count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
     c->ub_growth_since += (uint32_t)c->Q;
 }
 static void st_predict(hrbf_context *c)
@@ -600,15 +757,23 @@ extern "C" int hrbf_last_weighting(hrbf_handle c, float *w)
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return HRBF_OK;
 }
+static int read_counts(hrbf_context *c, uint32_t out[HRBF_MAX_SHARDS])
+{
+    if (hipMemcpyAsync(out, counts_live(c), sizeof(uint32_t) * HRBF_MAX_SHARDS, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : -1;
+}
+// the GLOBAL count (all shards; on a rank of a sharded map the other ranks' counts are the all-gathered ones)
 extern "C" uint32_t hrbf_surfel_count(hrbf_handle c)
 {
     if (!c) return 0;
     hipSetDevice(c->device);
-    uint32_t n = 0;
-    if (hipMemcpyAsync(&n, &c->d_count[c->target], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
-    hipStreamSynchronize(c->stream);
-    if (n < c->count_ub) c->count_ub = n;   // exact knowledge tightens the launch bound
-    return n;
+    uint32_t n[HRBF_MAX_SHARDS];
+    if (read_counts(c, n)) return 0;
+    uint64_t tot = 0;
+    for (int g = 0; g < c->G; ++g) tot += n[g];
+    for (int k = 0; k < c->nsh; ++k)   // exact knowledge tightens the launch bounds
+        if (n[c->shard_first + k] < c->sh[k].count_ub) c->sh[k].count_ub = n[c->shard_first + k];
+    return (uint32_t)tot;
 }
 extern "C" int hrbf_last_icp(hrbf_handle c, float *err, float *cnt)
 {
@@ -637,41 +802,78 @@ __global__ void k_map_from_aos(MapPlanes m, uint32_t n, const float4 *__restrict
     m.p3[i] = in[(size_t)i * 5 + 3]; m.p4[i] = in[(size_t)i * 5 + 4];
 }
 
+// The local shards in global order: the whole map for a single-GPU context and in the single-process sharded mode;
+// a rank of a sharded map returns its own range (its size: hrbf_local_surfel_count).
+extern "C" uint32_t hrbf_local_surfel_count(hrbf_handle c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    uint32_t n[HRBF_MAX_SHARDS];
+    if (read_counts(c, n)) return 0;
+    uint64_t tot = 0;
+    for (int k = 0; k < c->nsh; ++k) tot += n[c->shard_first + k];
+    return (uint32_t)tot;
+}
 extern "C" int hrbf_download_map(hrbf_handle c, float *out, size_t cap_surfels)
 {
     if (!c || !out) return HRBF_ERR_INVALID;
-    uint32_t n = hrbf_surfel_count(c);
-    if (cap_surfels < n) { hrbf_set_error("download_map: buffer holds %zu surfels, map has %u", cap_surfels, n); return HRBF_ERR_CAPACITY; }
+    hipSetDevice(c->device);
+    uint32_t cnt[HRBF_MAX_SHARDS];
+    if (read_counts(c, cnt)) { hrbf_set_error("download_map: count read-back failed"); return HRBF_ERR_DEVICE; }
+    size_t n = 0;
+    for (int k = 0; k < c->nsh; ++k) n += cnt[c->shard_first + k];
+    if (cap_surfels < n) { hrbf_set_error("download_map: buffer holds %zu surfels, map has %zu", cap_surfels, n); return HRBF_ERR_CAPACITY; }
     if (n == 0) return HRBF_OK;
     float4 *tmp = nullptr;
-    HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * (size_t)n));
-    hipLaunchKernelGGL(k_map_to_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->map, n, tmp);
-    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(float4) * 5 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * n));
+    size_t at = 0;
+    for (int k = 0; k < c->nsh; ++k) {
+        const uint32_t nk = cnt[c->shard_first + k];
+        if (nk) hipLaunchKernelGGL(k_map_to_aos, dim3((nk + 255) / 256), dim3(256), 0, c->stream, c->sh[k].map, nk, tmp + at * 5);
+        at += nk;
+    }
+    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(float4) * 5 * n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(tmp);
     if (e != hipSuccess) { hrbf_set_error("download_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
     return HRBF_OK;
 }
+// equal split of n items over G shards: shard g gets [lo, hi)
+static void shard_slice(size_t n, int G, int g, size_t *lo, size_t *hi)
+{
+    const size_t base = n / (size_t)G, rem = n % (size_t)G;
+    *lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
+    *hi = *lo + base + ((size_t)g < rem ? 1 : 0);
+}
+// `in` is always the WHOLE map (n surfels in global order); a sharded context keeps the slices of its local shards
 extern "C" int hrbf_upload_map(hrbf_handle c, const float *in, size_t n)
 {
     if (!c || (!in && n)) return HRBF_ERR_INVALID;
-    if (n > c->cap) { hrbf_set_error("upload_map: %zu surfels exceed capacity %u", n, c->cap); return HRBF_ERR_CAPACITY; }
     hipSetDevice(c->device);
-    uint32_t n32 = (uint32_t)n;
-    if (n) {
-        float4 *tmp = nullptr;
-        HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * n));
-        hipError_t e = hipMemcpyAsync(tmp, in, sizeof(float4) * 5 * n, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_map_from_aos, dim3((n32 + 255) / 256), dim3(256), 0, c->stream, c->map, n32, tmp);
-            e = hipStreamSynchronize(c->stream);
-        }
-        hipFree(tmp);
-        if (e != hipSuccess) { hrbf_set_error("upload_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    uint32_t cnt[HRBF_MAX_SHARDS] = {0};
+    for (int g = 0; g < c->G; ++g) {
+        size_t lo, hi; shard_slice(n, c->G, g, &lo, &hi);
+        if (hi - lo > c->cap) { hrbf_set_error("upload_map: %zu surfels exceed the shard capacity %u", hi - lo, c->cap); return HRBF_ERR_CAPACITY; }
+        cnt[g] = (uint32_t)(hi - lo);
     }
-    HIP_CHECK(hipMemcpyAsync(&c->d_count[c->target], &n32, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < c->nsh; ++k) {
+        size_t lo, hi; shard_slice(n, c->G, c->shard_first + k, &lo, &hi);
+        const uint32_t nk = (uint32_t)(hi - lo);
+        if (nk) {
+            float4 *tmp = nullptr;
+            HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * (size_t)nk));
+            hipError_t e = hipMemcpyAsync(tmp, in + lo * 20, sizeof(float4) * 5 * (size_t)nk, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_map_from_aos, dim3((nk + 255) / 256), dim3(256), 0, c->stream, c->sh[k].map, nk, tmp);
+                e = hipStreamSynchronize(c->stream);
+            }
+            hipFree(tmp);
+            if (e != hipSuccess) { hrbf_set_error("upload_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+        }
+        c->sh[k].count_ub = nk;
+    }
+    HIP_CHECK(hipMemcpyAsync(counts_live(c), cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->count_ub = n32;
     c->map_dirty = 1;
     return HRBF_OK;
 }
@@ -844,7 +1046,8 @@ extern "C" int hrbf_update_model(hrbf_handle c, const float *delta16_colmajor, i
     }
     HIP_CHECK(hipMemcpyAsync(c->d_delta, delta16_colmajor, sizeof(float) * 16 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));   // host matrices are borrowed only for the call
-    launch_update_model(c->stream, c->map, &c->d_count[c->target], c->count_ub, c->d_delta, n);
+    for (int k = 0; k < c->nsh; ++k)
+        launch_update_model(c->stream, c->sh[k].map, counts_live(c) + c->shard_first + k, c->sh[k].count_ub, c->d_delta, n);
     c->map_dirty = 1;   // positions moved: the next clean re-checks everything
     HIP_CHECK(hipGetLastError());
     return HRBF_OK;
@@ -854,8 +1057,14 @@ extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
 {
     if (!c || !out) return HRBF_ERR_INVALID;
     hipSetDevice(c->device);
-    HIP_CHECK(hipMemcpyAsync(out, c->d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    // summed over the local shards (every shard sees the whole record set, so `in`/`out` add up and merged/appended too)
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int k = 0; k < c->nsh; ++k) {
+        uint32_t v[4];
+        HIP_CHECK(hipMemcpyAsync(v, c->sh[k].d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (int t = 0; t < 4; ++t) out[t] += v[t];
+    }
     return HRBF_OK;
 }
 
@@ -904,5 +1113,131 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     const int e = g_rccl.CommInitRank(&comm, world, id, rank);
     if (e != 0 || !comm) { hrbf_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
     c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world; c->comm.allreduce_i64 = rccl_allreduce_i64;
+    return HRBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ sharded surfel map
+// SURVEY §8e sharding 2.  The global surfel order (the order a single GPU would hold) is cut into G contiguous ranges,
+// one per rank; ids in the index map stay GLOBAL, so z-test ties, the association, the merge rule and the order of the
+// map are exactly the single-GPU ones.  New surfels are appended at the end of the order, i.e. on the last shard;
+// hrbf_map_rebalance() re-cuts the ranges evenly.  Uses the communicator of hrbf_comm_init: a real one (one shard per
+// rank) or the virtual one (this process plays all G shards in turn, reductions done by local kernels).
+extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (hrbf_surfel_count(c) != 0) { hrbf_set_error("map_shard_init: the map must be empty (upload it afterwards)"); return HRBF_ERR_INVALID; }
+    int G = 1, nsh = 1, first = 0, real = 0;
+    if (enable) {
+        if (c->comm.comm) { G = c->comm.world; nsh = 1; first = c->comm.rank; real = 1; }
+        else if (c->comm.virtual_world > 1) { G = c->comm.virtual_world; nsh = G; }
+        else { hrbf_set_error("map_shard_init: call hrbf_comm_init first"); return HRBF_ERR_INVALID; }
+        if (G > HRBF_MAX_SHARDS) { hrbf_set_error("map_shard_init: at most %d shards", HRBF_MAX_SHARDS); return HRBF_ERR_INVALID; }
+    }
+    for (int k = nsh; k < HRBF_MAX_SHARDS; ++k) free_shard(c->sh[k]);
+    for (int k = 1; k < nsh; ++k)
+        if (!c->sh[k].map.p0) {
+            int r = alloc_shard(c, c->sh[k]);
+            if (r) return r;
+            HIP_CHECK(hipDeviceSynchronize());   // dalloc zero-fills on the null stream
+            launch_fill_u32(c->stream, c->sh[k].d_slot, c->cap, 0xFFFFFFFFu);
+        }
+    if (nsh > 1 && !c->x.zbuf) {
+        const size_t P = (size_t)c->P;
+        int r = dalloc(&c->x.zbuf, P);
+        if (!r) r = dalloc(&c->x.idx, P);
+        if (!r) r = dalloc(&c->x.vertconf, P);
+        if (!r) r = dalloc(&c->x.colortime, P);
+        if (!r) r = dalloc(&c->x.normrad, P);
+        if (!r) r = dalloc(&c->x.curvmax, P);
+        if (!r) r = dalloc(&c->x.curvmin, P);
+        if (!r) r = dalloc(&c->x.clean_tex, 2 * P);
+        if (r) return r;
+        HIP_CHECK(hipDeviceSynchronize());
+        launch_zbuf_reset(c->stream, c->x.zbuf, c->P);
+    }
+    if (nsh == 1) free_scratch(c->x);
+    c->G = G; c->nsh = nsh; c->shard_first = first; c->shard_real = real;
+    for (int k = 0; k < nsh; ++k) c->sh[k].count_ub = 0;
+    HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->ev_pending = false;
+    return HRBF_OK;
+}
+
+// Pure host logic (no device needed): the even re-cut of G contiguous ranges.  counts[g] -> new_counts[g], and the
+// list of moves {src shard, dst shard, offset in src, offset in dst, length} that realises it (at most 2G - 1).
+extern "C" int hrbf_rebalance_plan(const uint32_t *counts, int G, uint32_t *new_counts, uint32_t *moves5, int *n_moves)
+{
+    if (!counts || !new_counts || !moves5 || !n_moves || G < 1 || G > HRBF_MAX_SHARDS) return HRBF_ERR_INVALID;
+    uint64_t N = 0;
+    for (int g = 0; g < G; ++g) N += counts[g];
+    uint64_t oa = 0;
+    int nm = 0;
+    for (int a = 0; a < G; ++a) {            // old range of shard a: [oa, oa + counts[a])
+        uint64_t tb = 0;
+        for (int b = 0; b < G; ++b) {        // new range of shard b: [tb, tb + m_b)
+            size_t lo_, hi_; shard_slice((size_t)N, G, b, &lo_, &hi_);
+            const uint64_t mb = hi_ - lo_;
+            if (a == 0) new_counts[b] = (uint32_t)mb;
+            const uint64_t lo = oa > tb ? oa : tb, hi = (oa + counts[a]) < (tb + mb) ? (oa + counts[a]) : (tb + mb);
+            if (hi > lo) {
+                uint32_t *m = moves5 + 5 * nm++;
+                m[0] = (uint32_t)a; m[1] = (uint32_t)b; m[2] = (uint32_t)(lo - oa); m[3] = (uint32_t)(lo - tb); m[4] = (uint32_t)(hi - lo);
+            }
+            tb += mb;
+        }
+        oa += counts[a];
+    }
+    *n_moves = nm;
+    return HRBF_OK;
+}
+
+// Re-cut the shards evenly (synchronous; call it every few hundred frames or after a bulk upload).  Pieces that change
+// owner travel with ncclSend / ncclRecv (real mode) or device copies (single-process mode) into a second set of planes,
+// which then becomes the shard.
+extern "C" int hrbf_map_rebalance(hrbf_handle c)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    if (c->G == 1) return HRBF_OK;
+    hipSetDevice(c->device);
+    uint32_t cnt[HRBF_MAX_SHARDS], ncnt[HRBF_MAX_SHARDS] = {0}, moves[5 * 2 * HRBF_MAX_SHARDS];
+    if (read_counts(c, cnt)) { hrbf_set_error("map_rebalance: count read-back failed"); return HRBF_ERR_DEVICE; }
+    int nm = 0;
+    int r = hrbf_rebalance_plan(cnt, c->G, ncnt, moves, &nm);
+    if (r) return r;
+    for (int g = 0; g < c->G; ++g)
+        if (ncnt[g] > c->cap) { hrbf_set_error("map_rebalance: %u surfels per shard exceed the capacity %u", ncnt[g], c->cap); return HRBF_ERR_CAPACITY; }
+    MapPlanes tmp[HRBF_MAX_SHARDS];
+    memset(tmp, 0, sizeof(tmp));
+    for (int k = 0; k < c->nsh; ++k)
+        if ((r = alloc_planes(c, tmp[k], c->cap))) { for (int t = 0; t <= k; ++t) free_planes(tmp[t]); return r; }
+    HIP_CHECK(hipDeviceSynchronize());
+    const int first = c->shard_first;
+    if (c->shard_real) g_rccl.GroupStart();
+    for (int i = 0; i < nm; ++i) {
+        const int a = (int)moves[5 * i], b = (int)moves[5 * i + 1];
+        const size_t so = moves[5 * i + 2], d_o = moves[5 * i + 3], len = moves[5 * i + 4];
+        const bool src_local = a >= first && a < first + c->nsh, dst_local = b >= first && b < first + c->nsh;
+        for (int pl = 0; pl < 5; ++pl) {
+            float4 *sp = src_local ? (&c->sh[a - first].map.p0)[pl] + so : nullptr;
+            float4 *dp = dst_local ? (&tmp[b - first].p0)[pl] + d_o : nullptr;
+            if (src_local && dst_local) hipMemcpyAsync(dp, sp, sizeof(float4) * len, hipMemcpyDeviceToDevice, c->stream);
+            else if (src_local) g_rccl.Send(sp, len * 4, kNcclUint32, b, c->comm.comm, c->stream);
+            else if (dst_local) g_rccl.Recv(dp, len * 4, kNcclUint32, a, c->comm.comm, c->stream);
+        }
+    }
+    if (c->shard_real) g_rccl.GroupEnd();
+    hipError_t e = hipMemcpyAsync(counts_live(c), ncnt, sizeof(ncnt), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int k = 0; k < c->nsh; ++k) {
+        MapPlanes old = c->sh[k].map;
+        c->sh[k].map = tmp[k];
+        free_planes(old);
+        c->sh[k].count_ub = ncnt[first + k];
+    }
+    c->ev_pending = false;
+    if (e != hipSuccess) { hrbf_set_error("map_rebalance: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
     return HRBF_OK;
 }

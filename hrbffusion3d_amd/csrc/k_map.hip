@@ -106,13 +106,20 @@ __global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
     if (i < n) p[i] = v;
 }
 
+__device__ __forceinline__ uint32_t shard_offset(const ShardRef &sh)
+{
+    uint32_t o = 0;
+    for (int j = 0; j < sh.k; ++j) o += sh.counts[j];
+    return o;
+}
+
 __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restrict__ dp, float maxDepth, const float4 *__restrict__ pos,
-                                                 const uint32_t *__restrict__ count,
+                                                 ShardRef sh,
                                                  unsigned long long *__restrict__ zbuf,
                                                  const float4 *__restrict__ color_time /* read only with a mask */,
                                                  const uint8_t *__restrict__ submap_active /* nullable */, int n_active)
 {
-    const uint32_t n = *count;
+    const uint32_t n = sh.counts[sh.k], off = shard_offset(sh);   // ids in the keys are GLOBAL
     const Rigid tinv = dp->tinv;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         float4 p = pos[s];
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
         float v = ((cam.fy * h.y) / h.z) + cam.cy;
         if (!(u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H)) continue;
         int ix = (int)hd_floorf(u), iy = (int)hd_floorf(v);
-        unsigned long long key = ((unsigned long long)hd_f2u(h.z) << 32) | (unsigned long long)s;
+        unsigned long long key = ((unsigned long long)hd_f2u(h.z) << 32) | (unsigned long long)(off + s);
         unsigned long long *cell = &zbuf[iy * cam.W + ix];
         // cheap pre-filter: keys only ever decrease, so a stale larger-or-equal read is conclusive
         if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell, key);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
 #define RESOLVE_GEOM 1
 #define RESOLVE_ATTR 2
 #define RESOLVE_CLEAN 4
-__global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m,
+__global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m, ShardRef sh, int rearm,
                                                  unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
@@ -158,9 +165,16 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
         if (what & RESOLVE_CLEAN) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
         return;
     }
-    zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
-    uint32_t s = (uint32_t)(key & 0xFFFFFFFFull);
-    idx[i] = s;
+    if (rearm) zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
+    const uint32_t sg = (uint32_t)(key & 0xFFFFFFFFull);   // global id of the winner
+    idx[i] = sg;
+    const uint32_t s = sg - shard_offset(sh);
+    if (s >= sh.counts[sh.k]) {   // the winner lives on another shard: contribute zeros to the sum-reduction
+        if (what & RESOLVE_GEOM) { vertconf[i] = z4; normrad[i] = z4; }
+        if (what & RESOLVE_ATTR) { colortime[i] = z4; curvmax[i] = z4; curvmin[i] = z4; }
+        if (what & RESOLVE_CLEAN) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
+        return;
+    }
     const float4 p = m.p0[s];
     const f3 h = xform(tinv, xyz(p));
     if (what & RESOLVE_GEOM) {
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
         // .w of the second half = the reference's `current > 0U` gate (copy_unstable.vert:111)
         if (what & RESOLVE_CLEAN) {
             clean_tex[2 * i] = make_float4(h.x, h.y, h.z, p.w);
-            clean_tex[2 * i + 1] = make_float4(ct.z, ct.w, s > 0u ? 1.0f : 0.0f, 0.0f);
+            clean_tex[2 * i + 1] = make_float4(ct.z, ct.w, sg > 0u ? 1.0f : 0.0f, 0.0f);
         }
     }
 }
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                                                    const float4 *__restrict__ vertconf,
                                                    const float4 *__restrict__ normrad, RecPlanes rec,
                                                    int32_t *__restrict__ rec_flag, uint32_t *__restrict__ rec_best,
-                                                   uint32_t *__restrict__ slot)
+                                                   uint32_t *__restrict__ slot, ShardRef sh)
 {
     const int QW = cam.W / 2, QH = cam.H / 2;
     // Threads walk the quarter grid ROW-major so that a wave reads 64 neighbouring pixels of one image row (the
@@ -267,7 +281,10 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
             rec.p3[q] = k1;
             rec.p4[q] = k2;
             flag = counter > 0 ? 1 : 2;
-            if (counter > 0) atomicMin(&slot[best], (uint32_t)q);   // first primitive in draw order wins
+            if (counter > 0) {   // first primitive in draw order wins; the slot lives with the surfel's owner
+                const uint32_t l = best - shard_offset(sh);
+                if (l < sh.counts[sh.k]) atomicMin(&slot[l], (uint32_t)q);
+            }
         }
     }
     rec_flag[q] = flag;
@@ -278,11 +295,13 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
 __global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes rec,
                                                       const int32_t *__restrict__ rec_flag,
                                                       const uint32_t *__restrict__ rec_best, uint32_t *__restrict__ slot,
-                                                      MapPlanes m, uint32_t *__restrict__ merged, float curvThr)
+                                                      MapPlanes m, ShardRef sh, uint32_t *__restrict__ merged, float curvThr)
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     bool act = q < Q && rec_flag[q] == 1;
-    const uint32_t s = act ? rec_best[q] : 0u;
+    const uint32_t l = act ? rec_best[q] - shard_offset(sh) : 0u;
+    act = act && l < sh.counts[sh.k];   // only the owner of the matched surfel applies the merge
+    const uint32_t s = act ? l : 0u;
     // everything the merge may need is requested in one round (record planes, the slot word and the target surfel's
     // planes) instead of slot -> surfel in two dependent rounds; surfel 0 stands in for inactive lanes
     const uint32_t winner = slot[s];
@@ -561,6 +580,10 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlane
     const uint32_t surfel_tiles = (N + FUSE_TILE - 1) / FUSE_TILE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float ftime = (float)time;
+    if (num_tiles == 0) {   // an empty shard that takes no appends this frame
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *count_out = 0; stats[0] = 0; stats[3] = 0; }
+        return;
+    }
 
     // every tile count is staged in LDS once (one round of global loads per workgroup); the per-tile prefixes are
     // then summed out of LDS — a workgroup walks 2-8 tiles and used to pay a dependent global round trip for each
@@ -676,44 +699,73 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
     hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap);
 }
 
-void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
-                            const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
-                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                            float4 *clean_tex, const uint8_t *submap_active, int n_active, int what)
+void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
+                    uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active, int n_active)
 {
-    int P = cam.W * cam.H;
     uint32_t blocks = (count_ub + 255) / 256;   // zbuf is ZB_EMPTY on entry: launch_zbuf_reset once, k_resolve afterwards
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride the rest
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, count, zbuf, m.p1, submap_active,
+    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, sh, zbuf, m.p1, submap_active,
                        n_active);
+}
+void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
+                    uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
+                    float4 *clean_tex, int what, int rearm)
+{
+    const int P = cam.W * cam.H;
     if (!clean_tex) what &= ~RESOLVE_CLEAN;
-    hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, zbuf, idx, vertconf, colortime,
-                       normrad, curvmax, curvmin, clean_tex, what);
+    hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, rearm, zbuf, idx, vertconf,
+                       colortime, normrad, curvmax, curvmin, clean_tex, what);
+}
+
+// local stand-ins for the two collectives of a sharded projection (one process playing several shards): the same
+// reductions RCCL performs between ranks, so the zero-filling / ownership logic is exercised on one GPU
+__global__ void k_zbuf_min_merge(unsigned long long *__restrict__ dst, unsigned long long *__restrict__ src, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long a = dst[i], b = src[i];
+    if (b < a) dst[i] = b;
+    if (b != ZB_EMPTY) src[i] = ZB_EMPTY;
+}
+__global__ void k_add_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P)
+{
+    hipLaunchKernelGGL(k_zbuf_min_merge, dim3((P + 255) / 256), dim3(256), 0, s, dst, src_reset, P);
+}
+void launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, size_t n)
+{
+    hipLaunchKernelGGL(k_add_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
 }
 
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, uint32_t *stats, float curvThr)
+                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 5);   // [0..3] statistics, [4] force-full-check flag
     hipLaunchKernelGGL(k_associate, dim3((Q + 255) / 256), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
-                       rec_best, slot);
+                       rec_best, slot, sh);
     hipLaunchKernelGGL(k_apply_merges, dim3((Q + 255) / 256), dim3(256), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
-                       stats + 1, curvThr);
+                       sh, stats + 1, curvThr);
 }
 
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
-                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active)
+                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
+                  int n_records, int zero_records)
 {
-    int Q = (cam.W / 2) * (cam.H / 2);
+    const int Qfull = (cam.W / 2) * (cam.H / 2);
+    const int Q = n_records;   // records are appended by one shard only (the end of the global order)
     CleanParams cp;
     cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
     cp.nw = (int)(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
@@ -732,8 +784,9 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), sizeof(uint32_t) * (size_t)tiles, s, time, m, rec, Q, keep_flags, tile_count,
                        count_in, count_out, stats, cap, tile_done);
     if (e1) hipEventRecord(e1, s);
-    int nz = Q > (int)tiles ? Q : (int)tiles;
-    hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, Q, tile_count, tile_done, (int)tiles);
+    const int zq = zero_records ? Qfull : 0;
+    int nz = zq > (int)tiles ? zq : (int)tiles;
+    hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, zq, tile_count, tile_done, (int)tiles);
 }
 
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P)

@@ -5,6 +5,11 @@
 struct MapPlanes { float4 *p0, *p1, *p2, *p3, *p4; };
 typedef MapPlanes RecPlanes;
 
+// Map sharding (SURVEY §8e sharding 2).  The global surfel order is the concatenation of the G shards: shard k holds
+// the global ids [off_k, off_k + n_k) with off_k = n_0 + ... + n_(k-1).  `counts` is the device array of the G live
+// counts (all-gathered after every clean); a single-GPU context is G = 1, k = 0, off = 0.
+struct ShardRef { const uint32_t *counts; int k, G; };
+
 // device-resident pose block: written by the odometry epilogue, read by every map kernel, so a
 // frame needs no host round trip (the reference syncs ~40x per frame)
 struct DevPose {
@@ -31,22 +36,30 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
                        const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
                        int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
                        uint32_t cap, uint32_t *count);
-void launch_predict_indices(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m,
-                            const uint32_t *count, uint32_t count_ub, unsigned long long *zbuf, uint32_t *idx,
-                            float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                            float4 *clean_tex /* nullable: packed texels for the clean test */,
-                            const uint8_t *submap_active /* nullable: KeyFrameIDMap */, int n_active,
-                            int what /* 1 geometry images | 2 attribute images | 4 clean texels */);
+// projection = launch_project (z-buffer of packed keys) + launch_resolve (winner gather).  With a sharded map the
+// z-buffers are min-reduced between the two and the resolved images sum-reduced afterwards (a pixel has one owner,
+// every other shard writes zeros); `rearm` lets the last local shard leave the z-buffer empty for the next pass.
+void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
+                    uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active /* nullable: KeyFrameIDMap */,
+                    int n_active);
+void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
+                    uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
+                    float4 *clean_tex /* nullable: packed texels for the clean test */,
+                    int what /* 1 geometry images | 2 attribute images | 4 clean texels */, int rearm);
+void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P);   // local stand-in for allReduce(min)
+void launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, size_t n);                          // local stand-in for allReduce(sum)
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, uint32_t *stats, float curvThr);
+                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr);
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
-                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active);
+                  uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
+                  int n_records /* Q on the shard that takes the appends (the last one), else 0 */,
+                  int zero_records /* re-arm the record flags at the end */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);

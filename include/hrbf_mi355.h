@@ -260,6 +260,28 @@ int hrbf_icp_step(hrbf_handle h, const float Rcurr[9], const float tcurr[3],
 int hrbf_comm_unique_id(uint8_t out128[128]);
 int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
 
+/* multi-GPU (sharding 2): the surfel map itself is cut over the ranks of the communicator above.  The
+ * global surfel order — the order GlobalModel holds on one GPU (GlobalModel.cpp:551-688: stable compaction, new
+ * surfels appended) — is split into `world` contiguous ranges, one per rank; ids in the index map stay global, so the
+ * z-test ties, the association, the merges and the order of the map are the single-GPU ones bit for bit.  Per
+ * projection (three per frame) the ranks exchange: ncclAllReduce(min) over the W*H packed u64 z-buffer keys, then
+ * ncclAllReduce(sum, as uint32) over the resolved attribute images (one owner per pixel, zeros elsewhere: exact);
+ * after the clean pass one ncclAllGather of the `world` live counts.  Association is replicated (it reads images
+ * only); merges are applied by the owner; the streaming clean + compaction pass — the HBM-bound part — runs on every
+ * rank over its own range only.  New surfels are appended at the end of the order = on the last rank;
+ * hrbf_map_rebalance() re-cuts the ranges evenly (synchronous, ncclSend/ncclRecv of the pieces that change owner).
+ *   hrbf_map_shard_init(h, 1)  requires hrbf_comm_init and an empty map; with the virtual communicator
+ *                              (rank < 0) this one process plays all shards and local kernels stand in for the
+ *                              collectives — the test mode, bit-identical to the single-GPU map.
+ *   hrbf_upload_map            always takes the WHOLE map; a rank keeps its slice.
+ *   hrbf_surfel_count          global count; hrbf_local_surfel_count / hrbf_download_map: the local range(s).
+ *   hrbf_rebalance_plan        the host-side arithmetic of the re-cut (pure function, no device needed):
+ *                              moves5[i] = {src shard, dst shard, offset in src, offset in dst, length}, <= 2*G - 1. */
+int hrbf_map_shard_init(hrbf_handle h, int enable);
+int hrbf_map_rebalance(hrbf_handle h);
+int hrbf_rebalance_plan(const uint32_t *counts, int n_shards, uint32_t *new_counts, uint32_t *moves5, int *n_moves);
+uint32_t hrbf_local_surfel_count(hrbf_handle h);
+
 #ifdef __cplusplus
 }
 #endif

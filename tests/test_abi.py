@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from hrbffusion3d_amd import api
@@ -84,3 +86,23 @@ def test_product_path_never_imports_the_oracle():
                     if re.search(r"oracle_lib|liboracle|\borc_[a-z_]+\s*\(|#include\s*[\"<][^\">]*oracle|import\s+.*oracle", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_rebalance_plan_is_an_exact_recut():
+    """hrbf_rebalance_plan (pure host arithmetic of hrbf_map_rebalance): applying the moves to G contiguous shards
+    gives G near-equal contiguous shards holding the same global sequence."""
+    from hrbffusion3d_amd import api
+    rng = np.random.default_rng(5)
+    for G in (1, 2, 3, 4, 8):
+        for _ in range(20):
+            counts = rng.integers(0, 50, G).astype(np.uint32)
+            if rng.random() < 0.3:
+                counts[:-1] = 0                                  # everything on the last shard (after seeding)
+            seq = np.arange(int(counts.sum()))
+            shards = np.split(seq, np.cumsum(counts)[:-1])
+            new, moves = api.rebalance_plan(counts)
+            assert new.sum() == counts.sum() and new.max() - new.min() <= 1 and len(moves) <= 2 * G - 1 + (G == 1)
+            out = [np.full(int(n), -1) for n in new]
+            for a, b, so, do, ln in moves:
+                out[b][do:do + ln] = shards[a][so:so + ln]
+            assert np.array_equal(np.concatenate(out) if out else seq, seq)

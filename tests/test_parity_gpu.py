@@ -314,6 +314,70 @@ def test_row_sharded_registration(pair, mode):
     assert_same_state(o, g, mode + " back to single")
 
 
+@pytest.mark.parametrize("G", [2, 3])
+def test_sharded_map_from_an_empty_map(pair, G):
+    """SURVEY §8e sharding 2: the surfel map cut into G contiguous ranges of the global order, one process playing all
+    shards (projection under global ids -> min-reduce of the z-buffer keys -> owner gathers, others write zeros ->
+    integer sum-reduce; merges by the owner; clean + compaction per shard; appends on the last shard).  Every image,
+    the concatenated map, the fuse statistics and the pose stay bit-identical to the oracle's single map — before and
+    after re-cutting the ranges (frame 0 seeds everything on the last shard)."""
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    g.comm_init(-1, G); g.map_shard_init(True)
+    for k in range(7):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "G=%d frame %d" % (G, k))
+        if k > 0:
+            assert np.array_equal(o.fuse_stats(), g.fuse_stats()), k
+        if k in (0, 3):
+            g.map_rebalance()
+            assert_same_state(o, g, "G=%d after rebalance at %d" % (G, k))
+    assert g.local_surfel_count() == g.surfel_count() == o.surfel_count()
+
+
+def test_sharded_map_rccl_world1(pair):
+    """the real-mode code path on the one GPU a test box has: an RCCL communicator of world size 1, so every
+    collective of the sharded map (allReduce min over u64 keys, grouped allReduce sum over the images as uint32,
+    allGather of the counts, in place on the context's stream) is actually issued through librccl"""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    g.comm_init(0, 1, HRBFFusion.comm_unique_id()); g.map_shard_init(True)
+    for k in range(4):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "rccl1 frame %d" % k)
+    g.map_rebalance()
+    assert_same_state(o, g, "rccl1 after rebalance")
+
+
+def test_sharded_map_uploaded_and_tracked(pair):
+    """the same at QVGA against an uploaded 150 k-surfel map cut into 4 slices (several fuse tiles per shard, most of
+    the view's winners owned by different shards), tracked and noisy, with the sparse-ICP option on top"""
+    W, H, G = 320, 240, 4
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    seed = synth.seed_map(150_000, width=W)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=seed.shape[0] + 300_000, use_sparse_icp=1)   # capacity per shard
+    o, g = pair(p)
+    g.comm_init(-1, G); g.map_shard_init(True)
+    rgb, d, T = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
+    for k in range(1, 6):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "sharded upload frame %d" % k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+        if k == 3:
+            g.map_rebalance()
+            assert_same_state(o, g, "after rebalance")
+
+
 @pytest.mark.parametrize("sharded", [False, True])
 def test_sparse_icp_with_outlier_slab(pair, sharded):
     """SURVEY §8f-4, use_sparse_icp: the ADMM variant of icpStep (multiplier image, shrink step, updateLambdaMap folded
