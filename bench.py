@@ -16,6 +16,7 @@ One JSON line on rank 0, with `roofline` (fuse streaming kernel, HIP events on t
 stream) and `cpu_baseline` (the CPU oracle on a bounded sample; baseline, not target).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -41,6 +42,13 @@ def parse():
     ap.add_argument("--shard-odometry", action="store_true",
                     help="N > 1: all ranks track ONE sequence, registration reductions row-sharded + RCCL all-reduce "
                          "(SURVEY §8e sharding 1; strong scaling, a latency cost at VGA). Default: independent replicas")
+    ap.add_argument("--shard-map", action="store_true",
+                    help="all ranks track ONE sequence against ONE surfel map cut into contiguous ranges over the ranks "
+                         "(SURVEY §8e sharding 2, implies --shard-odometry's communicator; strong scaling; pays off "
+                         "for maps far beyond 1 M surfels). Default: independent replicas")
+    ap.add_argument("--virtual-shards", type=int, default=0,
+                    help="single process: play G map shards in turn on one GPU (measures the sharded path's extra "
+                         "kernels without any interconnect); not a benchmark configuration")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -105,13 +113,19 @@ def main():
     cap += (W // 2) * (H // 2) * min(nframes, 64)
     p = default_params(W, H, fx, fy, cx, cy, max_surfels=cap)
     fus = HRBFFusion(p, device=local_rank)
-    if args.shard_odometry:
+    one_sequence = args.shard_odometry or args.shard_map
+    if args.virtual_shards > 1:
+        fus.comm_init(-1, args.virtual_shards)
+        fus.map_shard_init(True)
+    elif one_sequence:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = torch.tensor(list(HRBFFusion.comm_unique_id()), dtype=torch.uint8, device="cuda")
         if dist is not None:
             dist.broadcast(uid, src=0)
         fus.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+        if args.shard_map:
+            fus.map_shard_init(True)       # every rank then keeps its slice of the uploaded map
     fus.upload_map(seed)
     fus.set_pose(poses[0])
     fus.bootstrap(frames[0][0], frames[0][1])
@@ -199,14 +213,16 @@ def main():
     if rank == 0:
         out = {
             "metric": "frames/sec at 640x480, 1M-surfel map, 1 MI355X",
-            "value": (K if args.shard_odometry else world * K) / dt, "unit": "frames/s", "n_gpus": world, "steps": K,
+            "value": (K if one_sequence else world * K) / dt, "unit": "frames/s", "n_gpus": world, "steps": K,
             "warmup": Wm, "ms_per_step": 1000.0 * dt / K, "higher_is_better": True,
-            "scaling": "strong" if args.shard_odometry else "weak",
+            "scaling": "strong" if one_sequence else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGB-D stream (room+sphere+relief, Lissajous path, seed 12345), "
                                    "map pre-seeded to %d surfels, full processFrame per step" % (W, H, seed.shape[0]),
                        "surfels_start": int(count0), "surfels_end": int(count1),
-                       "parallelism": ("row-sharded registration x%d (RCCL int64 all-reduce)" % world) if args.shard_odometry
+                       "parallelism": ("surfel map in %d contiguous shards + row-sharded registration (RCCL)" % world) if args.shard_map
+                                      else ("row-sharded registration x%d (RCCL int64 all-reduce)" % world) if args.shard_odometry
+                                      else ("%d virtual map shards on one GPU" % args.virtual_shards) if args.virtual_shards > 1
                                       else ("replicas x%d" % world if world > 1 else "single GPU"),
                        "final_translation_error_mm": err_mm, "pcie_inclusive_fps": pcie_fps,
                        "update_model": update_model,
@@ -228,7 +244,15 @@ def main():
                                    "sample": "skipped (rank 0 at N=1 only)"}
         if args.verbose:
             sys.stderr.write("gen %.1fs, timed %.3fs, fuse kernel %.4f ms, %s\n" % (t_gen, dt, fuse_ms, st[-1]))
-        print(json.dumps(out))
+    # RCCL prints a version banner through C stdio when a communicator is created; when stdout is a pipe it would be
+    # flushed at exit, i.e. AFTER the JSON line.  Push everything out first, print the line, then silence fd 1.
+    libc = C.CDLL(None)
+    sys.stdout.flush(); libc.fflush(None)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out)); sys.stdout.flush()
+    barrier()
+    devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 1)
     fus.close()
     if dist is not None:
         dist.destroy_process_group()

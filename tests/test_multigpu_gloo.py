@@ -76,6 +76,82 @@ def test_limb_allreduce_is_exact_and_timing_is_max_over_ranks(oracle_lib_built):
     assert _combine(part) == out.value
 
 
+def _shard_worker(rank, world, port, q):
+    """the exchange protocol of the sharded surfel map (csrc/abi.hip st_indices / hrbf_map_rebalance) on two real
+    processes: global ids in the z-buffer keys, MIN over the keys, integer SUM over the owner-filled images,
+    all-gather of the counts, and the re-cut of the ranges with the moves of hrbf_rebalance_plan as send / recv."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hrbffusion3d_amd import api
+    rng = np.random.default_rng(11)
+    N, P = 5000, 64 * 48
+    pix = rng.integers(0, P, N); depth = rng.integers(1, 200, N).astype(np.float32) * 0.01   # many exact depth ties
+    attr = rng.standard_normal((N, 4)).astype(np.float32); attr[::7] = -0.0                   # -0.0 must survive the sum
+    counts = np.array([1200, 3800], np.int64)                                                  # uneven on purpose
+    off = int(counts[:rank].sum()); n = int(counts[rank])
+    EMPTY = np.iinfo(np.int64).max
+    z = np.full(P, EMPTY, np.int64)
+    keys = (depth[off:off + n].view(np.uint32).astype(np.int64) << 32) | np.arange(off, off + n, dtype=np.int64)
+    np.minimum.at(z, pix[off:off + n], keys)
+    zt = torch.from_numpy(z); dist.all_reduce(zt, op=dist.ReduceOp.MIN)
+    win = zt.numpy() & 0xFFFFFFFF
+    hit = zt.numpy() != EMPTY
+    img = np.zeros((P, 4), np.float32)
+    own = hit & (win >= off) & (win < off + n)
+    img[own] = attr[win[own]]
+    it = torch.from_numpy(img.view(np.int32)); dist.all_reduce(it, op=dist.ReduceOp.SUM)
+    # counts all-gather + even re-cut
+    mine = torch.tensor([n], dtype=torch.int64); allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    cnt = np.array([int(t.item()) for t in allc], np.uint32)
+    new, moves = api.rebalance_plan(cnt)
+    shard = np.arange(off, off + n, dtype=np.int64)
+    out = np.full(int(new[rank]), -1, np.int64)
+    reqs = []
+    for a, b, so, do, ln in moves:
+        if a == rank and b == rank:
+            out[do:do + ln] = shard[so:so + ln]
+        elif a == rank:
+            reqs.append(dist.isend(torch.from_numpy(shard[so:so + ln].copy()), dst=b))
+        elif b == rank:
+            t = torch.zeros(ln, dtype=torch.int64); dist.recv(t, src=a); out[do:do + ln] = t.numpy()
+    for r in reqs:
+        r.wait()
+    q.put((rank, zt.numpy().copy(), it.numpy().copy(), out, [int(v) for v in new]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_map_exchange_protocol_world2():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r = q.get(timeout=120); got[r[0]] = r[1:]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: one z-buffer over all surfels, ties -> lower global id, direct gather
+    rng = np.random.default_rng(11)
+    N, P = 5000, 64 * 48
+    pix = rng.integers(0, P, N); depth = rng.integers(1, 200, N).astype(np.float32) * 0.01
+    attr = rng.standard_normal((N, 4)).astype(np.float32); attr[::7] = -0.0
+    EMPTY = np.iinfo(np.int64).max
+    z = np.full(P, EMPTY, np.int64)
+    np.minimum.at(z, pix, (depth.view(np.uint32).astype(np.int64) << 32) | np.arange(N, dtype=np.int64))
+    img = np.zeros((P, 4), np.float32); hit = z != EMPTY; img[hit] = attr[(z & 0xFFFFFFFF)[hit]]
+    for r in (0, 1):
+        zr, ir, out, new = got[r]
+        assert np.array_equal(zr, z) and np.array_equal(ir, img.view(np.int32))      # bit-exact incl. -0.0
+    assert got[0][3] == [2500, 2500]
+    assert np.array_equal(np.concatenate([got[0][2], got[1][2]]), np.arange(N))
+
+
 def test_bench_json_contract_fields():
     """static check of the bench line's keys (the values need a GPU)"""
     src = open(os.path.join(ROOT, "bench.py")).read()
