@@ -44,10 +44,12 @@ class GlobalModel {
 public:
     explicit GlobalModel(hrbf_handle h) : h_(h) {}
     unsigned int lastCount() const { return hrbf_surfel_count(h_); }
-    /* caller-owned array of lastCount()*20 floats (= Eigen::Vector4f[count*5]); delete[] it */
+    /* surfels held by THIS process: == lastCount() unless the map is sharded over ranks (hrbf_map_shard_init) */
+    unsigned int localCount() const { return hrbf_local_surfel_count(h_); }
+    /* caller-owned array of localCount()*20 floats (= Eigen::Vector4f[count*5]); delete[] it */
     float *downloadMap() const
     {
-        const unsigned int n = lastCount();
+        const unsigned int n = localCount();
         float *out = new float[(size_t)(n ? n : 1) * 20];
         if (n && hrbf_download_map(h_, out, n) != HRBF_OK) { delete[] out; throw std::runtime_error(hrbf_last_error()); }
         return out;
@@ -62,6 +64,11 @@ public:
     void setActiveSubmaps(const unsigned char *active, int n)
     {
         if (hrbf_set_active_submaps(h_, active, n) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
+    /* sharded map only: re-cut the ranges evenly over the ranks (new surfels land on the last rank) */
+    void rebalance()
+    {
+        if (hrbf_map_rebalance(h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
     }
 private:
     hrbf_handle h_;
@@ -195,11 +202,18 @@ public:
     void setDepthCutoff(const float &val) { hrbf_set_depth_cutoff(h_, val); }
     bool getImage(int which, void *out, size_t bytes) { return hrbf_get_image(h_, which, out, bytes) == HRBF_OK; }
     hrbf_handle handle() { return h_; }
+    /* more than one GPU, one process per GPU sharing ONE sequence: join the communicator whose id
+       rank 0 obtained from hrbf_comm_unique_id; shardMap additionally cuts the (still empty) surfel map over the ranks */
+    void joinRanks(int rank, int world, const unsigned char id128[128], bool shardMap)
+    {
+        if (hrbf_comm_init(h_, rank, world, id128) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+        if (shardMap && hrbf_map_shard_init(h_, 1) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
 
     /* binary little-endian PLY, 13 properties (HRBFFusion.cpp:1737-1853) */
     void savePly(const std::string &filename, float confThreshold = 0.0f)
     {
-        const unsigned int n = model_->lastCount();
+        const unsigned int n = model_->localCount();
         float *map = model_->downloadMap();
         int valid = 0;
         for (unsigned int i = 0; i < n; ++i) valid += map[(size_t)i * 20 + 3] > confThreshold;
