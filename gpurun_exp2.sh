@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 300 python bench.py --cpu-frames 0 --shard-map > gpurun_out/o1.txt 2> gpurun_out/e1.txt; tail -1 gpurun_out/o1.txt | cut -c1-80; wc -l gpurun_out/o1.txt
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 30 --warmup 5 > gpurun_out/o2.txt 2> gpurun_out/e2.txt; tail -1 gpurun_out/o2.txt | cut -c1-80; wc -l gpurun_out/o2.txt; head -3 gpurun_out/o2.txt | cut -c1-80
-timeout 300 python bench.py > gpurun_out/o3.txt 2> gpurun_out/e3.txt; tail -1 gpurun_out/o3.txt | cut -c1-120; wc -l gpurun_out/o3.txt
+for o in "--surfels 4200000" "--surfels 8400000" "--surfels 4200000 --virtual-shards 4"; do
+echo "== $o"; timeout 600 python bench.py --cpu-frames 0 --steps 40 --warmup 10 $o 2>/dev/null | tail -1 | python -c "
+import sys, json
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['parallelism'], d['config']['surfels_end'], d['config']['final_translation_error_mm'], d['roofline']['frac'], d['roofline']['avg_kernel_ms'], d['config']['last_frame_region_ms'])"
+done
