@@ -44,7 +44,7 @@ def parse():
                          "(SURVEY §8e sharding 1; strong scaling, a latency cost at VGA). Default: independent replicas")
     ap.add_argument("--shard-map", action="store_true",
                     help="all ranks track ONE sequence against ONE surfel map cut into contiguous ranges over the ranks "
-                         "(SURVEY §8e sharding 2, implies --shard-odometry's communicator; strong scaling; pays off "
+                         "(SURVEY §8e sharding 2; add --shard-odometry for the row-sharded registration too; strong scaling; pays off "
                          "for maps far beyond 1 M surfels). Default: independent replicas")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="single process: play G map shards in turn on one GPU (measures the sharded path's extra "
@@ -126,6 +126,7 @@ def main():
         fus.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
         if args.shard_map:
             fus.map_shard_init(True)       # every rank then keeps its slice of the uploaded map
+            fus.set_row_sharding(args.shard_odometry)   # the 39 registration all-reduces only when asked for
     fus.upload_map(seed)
     fus.set_pose(poses[0])
     fus.bootstrap(frames[0][0], frames[0][1])
@@ -220,7 +221,7 @@ def main():
             "config": {"workload": "synthetic %dx%d RGB-D stream (room+sphere+relief, Lissajous path, seed 12345), "
                                    "map pre-seeded to %d surfels, full processFrame per step" % (W, H, seed.shape[0]),
                        "surfels_start": int(count0), "surfels_end": int(count1),
-                       "parallelism": ("surfel map in %d contiguous shards + row-sharded registration (RCCL)" % world) if args.shard_map
+                       "parallelism": ("surfel map in %d contiguous shards%s (RCCL)" % (world, " + row-sharded registration" if args.shard_odometry else "")) if args.shard_map
                                       else ("row-sharded registration x%d (RCCL int64 all-reduce)" % world) if args.shard_odometry
                                       else ("%d virtual map shards on one GPU" % args.virtual_shards) if args.virtual_shards > 1
                                       else ("replicas x%d" % world if world > 1 else "single GPU"),

@@ -27,7 +27,7 @@ EXPORTS = [
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
     "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
-    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
+    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
 
 
@@ -79,6 +79,7 @@ def load_library():
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
+    lib.hrbf_set_row_sharding.argtypes = [vp, i32]
     lib.hrbf_rebalance_plan.argtypes = [vp, i32, vp, vp, vp]
     lib.hrbf_local_surfel_count.argtypes = [vp]; lib.hrbf_local_surfel_count.restype = C.c_uint32
     _lib = lib
@@ -190,6 +191,9 @@ class HRBFFusion:
     def map_shard_init(self, enable=True):
         """cut the surfel map over the ranks of comm_init (SURVEY §8e sharding 2); the map must be empty"""
         self._check(self.lib.hrbf_map_shard_init(self.h, int(bool(enable))))
+
+    def set_row_sharding(self, enable):
+        self._check(self.lib.hrbf_set_row_sharding(self.h, int(bool(enable))))
 
     def map_rebalance(self):
         self._check(self.lib.hrbf_map_rebalance(self.h))

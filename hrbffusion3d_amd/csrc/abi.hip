@@ -82,6 +82,7 @@ struct hrbf_context {
     int G;                      // global shard count (1 = the map is not sharded)
     int shard_first;            // global index of sh[0] (the rank in real mode)
     int shard_real;             // one shard per rank, reductions through RCCL
+    int rows_replicated;        // communicator present but registration NOT row-sharded (hrbf_set_row_sharding(h, 0))
     ShardScratch x;
     int target;                 // index of the live row of d_counts (ping-pong)
     int map_dirty;              // map uploaded from outside since the last fuse pass -> full curvature re-check
@@ -577,7 +578,7 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
         launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
     OdoSources src = make_sources(c);
     OdoConfig cfg = make_cfg(c);
-    const bool sharded = c->comm.comm != nullptr || c->comm.virtual_world > 1;
+    const bool sharded = (c->comm.comm != nullptr || c->comm.virtual_world > 1) && !c->rows_replicated;
     launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier);
 }
 
@@ -1163,6 +1164,15 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
     HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->ev_pending = false;
+    return HRBF_OK;
+}
+
+// with a communicator present, choose whether the registration reductions are row-sharded + all-reduced (default) or
+// every rank reduces the whole image itself (no registration collectives; the map may still be sharded)
+extern "C" int hrbf_set_row_sharding(hrbf_handle c, int enable)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    c->rows_replicated = enable ? 0 : 1;
     return HRBF_OK;
 }
 

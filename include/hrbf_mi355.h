@@ -278,6 +278,7 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  *   hrbf_rebalance_plan        the host-side arithmetic of the re-cut (pure function, no device needed):
  *                              moves5[i] = {src shard, dst shard, offset in src, offset in dst, length}, <= 2*G - 1. */
 int hrbf_map_shard_init(hrbf_handle h, int enable);
+int hrbf_set_row_sharding(hrbf_handle h, int enable);   /* 0: keep the communicator (sharded map) but let every rank reduce the whole image: no registration collectives */
 int hrbf_map_rebalance(hrbf_handle h);
 int hrbf_rebalance_plan(const uint32_t *counts, int n_shards, uint32_t *new_counts, uint32_t *moves5, int *n_moves);
 uint32_t hrbf_local_surfel_count(hrbf_handle h);

@@ -354,6 +354,10 @@ def test_sharded_map_rccl_world1(pair):
         assert_same_state(o, g, "rccl1 frame %d" % k)
     g.map_rebalance()
     assert_same_state(o, g, "rccl1 after rebalance")
+    g.set_row_sharding(False)                               # sharded map, replicated registration
+    rgb, d, _ = synth.frame(4, W, H, noise=True)
+    o.process_frame(rgb, d); g.process_frame(rgb, d)
+    assert_same_state(o, g, "rccl1 rows replicated")
 
 
 def test_sharded_map_uploaded_and_tracked(pair):
