@@ -2,6 +2,7 @@
 import struct
 
 import numpy as np
+import pytest
 
 from hrbffusion3d_amd import io, synth
 
@@ -123,3 +124,24 @@ def test_run_cli_helpers(tmp_path):
     assert len(got) == 2 and got[0][1].shape == (48, 64, 3) and got[0][3].shape == (4, 4)
     pairs = run.match_groundtruth(np.array([0.00, 0.10, 0.50]), np.array([0.001, 0.095, 0.30]), [None] * 3)
     assert pairs == [(0, 0), (1, 1)]
+
+
+def test_run_cli_tum_directory_source(tmp_path):
+    """--tum: associations.txt (ts depth ts rgb, HRBFFusion.cpp:226-236) + 16-bit depth PNGs + RGB PNGs"""
+    Image = pytest.importorskip("PIL.Image")
+    from hrbffusion3d_amd import run
+    W, H = 32, 24
+    (tmp_path / "depth").mkdir(); (tmp_path / "rgb").mkdir()
+    lines = []
+    for k in range(3):
+        d = (np.arange(W * H, dtype=np.uint16).reshape(H, W) + 1000 * k)
+        Image.fromarray(d).save(str(tmp_path / "depth" / ("%d.png" % k)))
+        c = np.zeros((H, W, 3), np.uint8); c[..., 0] = 10 * k; c[..., 2] = 200
+        Image.fromarray(c).save(str(tmp_path / "rgb" / ("%d.png" % k)))
+        lines.append("%.6f depth/%d.png %.6f rgb/%d.png" % (1.5 + 0.033 * k, k, 1.5 + 0.033 * k + 0.001, k))
+    (tmp_path / "associations.txt").write_text("# comment\n" + "\n".join(lines) + "\n")
+    a = run.parse(["--tum", str(tmp_path), "--width", str(W), "--height", str(H)])
+    got = list(run.frame_source(a))
+    assert [g[0] for g in got] == [1500000, 1533000, 1566000]
+    assert got[2][2].dtype == np.uint16 and got[2][2][1, 1] == 2000 + W + 1
+    assert got[1][1].shape == (H, W, 3) and tuple(got[1][1][0, 0]) == (10, 0, 200)
