@@ -27,7 +27,8 @@ EXPORTS = [
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
     "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
-    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
+    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
+    "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
 
 
@@ -80,6 +81,9 @@ def load_library():
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
+    lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
+    lib.hrbf_predict_indices.argtypes = [vp, vp, i32, f32, i32]; lib.hrbf_fuse.argtypes = [vp, vp, i32, f32, i32]
+    lib.hrbf_clean.argtypes = [vp, vp, i32, f32, f32]
     lib.hrbf_rebalance_plan.argtypes = [vp, i32, vp, vp, vp]
     lib.hrbf_local_surfel_count.argtypes = [vp]; lib.hrbf_local_surfel_count.restype = C.c_uint32
     _lib = lib
@@ -188,6 +192,26 @@ class HRBFFusion:
         self._check(self.lib.hrbf_comm_init(self.h, int(rank), int(world), buf))
 
     # submap bookkeeping + rigid map correction (GlobalModel::updateModel), SURVEY §8f-3
+    # GlobalModel / IndexMap operators under the reference's names (explicit pose / time / cut-offs)
+    @staticmethod
+    def _pose_arg(T):
+        return None if T is None else _p(np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(-1)))
+
+    def initialise(self, init_pose=None):
+        self._check(self.lib.hrbf_initialise(self.h, self._pose_arg(init_pose)))
+
+    def predict_indices(self, pose=None, time=0, depth_cutoff=0.0, index_submap=-1):
+        self._check(self.lib.hrbf_predict_indices(self.h, self._pose_arg(pose), int(time), float(depth_cutoff), int(index_submap)))
+
+    def fuse(self, pose=None, time=0, depth_cutoff=0.0, index_submap=-1):
+        self._check(self.lib.hrbf_fuse(self.h, self._pose_arg(pose), int(time), float(depth_cutoff), int(index_submap)))
+
+    def clean(self, pose=None, time=0, conf_threshold=-1.0, max_depth=0.0):
+        self._check(self.lib.hrbf_clean(self.h, self._pose_arg(pose), int(time), float(conf_threshold), float(max_depth)))
+
+    def predict_hrbf(self):
+        self._check(self.lib.hrbf_predict_hrbf(self.h))
+
     def map_shard_init(self, enable=True):
         """cut the surfel map over the ranks of comm_init (SURVEY §8e sharding 2); the map must be empty"""
         self._check(self.lib.hrbf_map_shard_init(self.h, int(bool(enable))))

@@ -1084,6 +1084,64 @@ extern "C" int hrbf_icp_step(hrbf_handle c, const float Rcurr[9], const float tc
                         angle_thresh, use_weight, A_out, b_out, residual_out);
 }
 
+// ------------------------------------------------------------------------------------------ named operators
+// GlobalModel::{initialise,fuse,clean} (GlobalModel.h:50-107) and IndexMap::{predictIndices,predictHRBF}
+// (IndexMap.h:43-68) with the arguments the reference passes explicitly — pose, time, cut-offs — on the context's map
+// and images (the reference's GPUTexture arguments; fill them with hrbf_set_image / hrbf_upload_frame + stages).
+// The given pose / time / thresholds become the context's current ones, exactly as after the reference's call.
+static void op_set_pose_time(hrbf_context *c, const float pose16[16], int time)
+{
+    hipSetDevice(c->device);
+    if (pose16) launch_pose_set(c->stream, c->d_pose, pose16, 0);
+    if (time > 0) c->tick = time;
+}
+extern "C" int hrbf_initialise(hrbf_handle c, const float init_pose16[16])
+{
+    if (!c) return HRBF_ERR_INVALID;
+    op_set_pose_time(c, init_pose16, 0);
+    st_init(c);
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+extern "C" int hrbf_predict_indices(hrbf_handle c, const float pose16[16], int time, float depth_cutoff, int index_submap)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    op_set_pose_time(c, pose16, time);
+    if (depth_cutoff > 0.0f) c->prm.max_depth_processed = depth_cutoff;
+    if (index_submap >= 0) c->index_submap = index_submap;
+    st_indices(c);
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+extern "C" int hrbf_fuse(hrbf_handle c, const float pose16[16], int time, float depth_cutoff, int index_submap)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    op_set_pose_time(c, pose16, time);
+    if (depth_cutoff > 0.0f) c->prm.max_depth_processed = depth_cutoff;
+    if (index_submap >= 0) c->index_submap = index_submap;
+    st_fuse(c);
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+extern "C" int hrbf_clean(hrbf_handle c, const float pose16[16], int time, float conf_threshold, float max_depth)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    op_set_pose_time(c, pose16, time);
+    if (conf_threshold >= 0.0f) c->prm.confidence_threshold = conf_threshold;
+    if (max_depth > 0.0f) c->prm.max_depth_processed = max_depth;
+    st_clean(c);
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+extern "C" int hrbf_predict_hrbf(hrbf_handle c)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    st_predict(c);
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+
 extern "C" int hrbf_comm_unique_id(uint8_t out128[128])
 {
     if (!out128) return HRBF_ERR_INVALID;

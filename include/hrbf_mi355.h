@@ -234,6 +234,16 @@ int hrbf_upload_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth);
  * tick = 2, i.e. the state the reference is in after its first processFrame. */
 int hrbf_bootstrap(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth);
 int hrbf_run_stage(hrbf_handle h, int stage);
+/* the map / prediction operators under the reference's names and with the arguments it passes explicitly
+ * (GlobalModel.h:50-107 initialise / fuse / clean, IndexMap.h:43-68 predictIndices / predictHRBF).  They work on the
+ * context's map and images — the reference's GPUTexture arguments, filled by the pre-processing stages or
+ * hrbf_set_image.  pose16: column-major T_wc (NULL keeps the current pose); time <= 0, cut-offs <= 0 and
+ * index_submap < 0 keep the context's values.  What is passed becomes the context's current state. */
+int hrbf_initialise(hrbf_handle h, const float init_pose16[16]);
+int hrbf_predict_indices(hrbf_handle h, const float pose16[16], int time, float depth_cutoff, int index_submap);
+int hrbf_fuse(hrbf_handle h, const float pose16[16], int time, float depth_cutoff, int index_submap);
+int hrbf_clean(hrbf_handle h, const float pose16[16], int time, float conf_threshold, float max_depth);
+int hrbf_predict_hrbf(hrbf_handle h);
 int hrbf_set_tick(hrbf_handle h, int tick);
 int hrbf_set_weighting(hrbf_handle h, float w);
 

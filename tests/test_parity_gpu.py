@@ -253,6 +253,40 @@ def test_stage_seams_in_isolation(pair):
     assert g.fuse_stats()[2] == 0 and len(g.download_map()) <= len(before)
 
 
+def test_named_map_operators(pair):
+    """GlobalModel::{initialise,fuse,clean} / IndexMap::{predictIndices,predictHRBF} under their own names with the
+    explicit pose / time / cut-off arguments of the reference (GlobalModel.h:50-107, IndexMap.h:43-68) against the
+    oracle driven through set_pose / set_tick / run_stage: the map pipeline of one frame, operator by operator."""
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    pre = ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS", "CURVATURE", "CONFIDENCE")
+    rgb, d, T0 = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_frame(rgb, d)
+        for st in pre:
+            x.run_stage(st)
+    o.set_pose(T0); o.run_stage("INITIALISE")
+    g.initialise(T0)
+    assert_same_state(o, g, "initialise", ["INDEX"])
+    rgb, d, T1 = synth.frame(1, W, H, noise=True)
+    for x in (o, g):
+        x.upload_frame(rgb, d)
+        for st in pre:
+            x.run_stage(st)
+    o.set_pose(T1); o.set_tick(2)
+    o.run_stage("PREDICT_INDICES"); g.predict_indices(T1, 2, p.max_depth_processed, 0)
+    assert_same_state(o, g, "predictIndices", [n for n in IMAGES if n.startswith("INDEX")])
+    o.run_stage("FUSE"); g.fuse(T1, 2, p.max_depth_processed, 0)
+    o.run_stage("PREDICT_INDICES"); g.predict_indices(T1, 2)
+    o.run_stage("CLEAN"); g.clean(T1, 2, p.confidence_threshold, p.max_depth_processed)
+    assert np.array_equal(o.fuse_stats(), g.fuse_stats()) and g.fuse_stats()[1] > 0
+    o.run_stage("PREDICT_INDICES"); g.predict_indices()
+    o.run_stage("PREDICT_HRBF"); g.predict_hrbf()
+    assert_same_state(o, g, "operators", [n for n in IMAGES if n.startswith(("INDEX", "PRED"))])
+
+
 def test_update_model_and_submap_mask(pair):
     """SURVEY §8f-3: GlobalModel::updateModel and the active-submap mask, GPU vs oracle bit for bit, inside a
     tracked sequence (the corrected map is projected, fused, cleaned and predicted from afterwards)."""
