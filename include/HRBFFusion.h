@@ -65,10 +65,40 @@ public:
     {
         if (hrbf_set_active_submaps(h_, active, n) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
     }
+    /* GlobalModel::{initialise,fuse,clean} (GlobalModel.h:50-107) with the scalar arguments of the reference; the
+       GPUTexture arguments are the context's images.  pose: column-major 4x4 T_wc (Eigen::Matrix4f::data()). */
+    void initialise(const float *init_pose16)
+    {
+        if (hrbf_initialise(h_, init_pose16) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
+    void fuse(const float *pose16, const int &time, const float depthCutoff, const float indexsubmap = 0.f)
+    {
+        if (hrbf_fuse(h_, pose16, time, depthCutoff, (int)indexsubmap) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
+    void clean(const float *pose16, const int &time, const float confThreshold, const float maxDepth)
+    {
+        if (hrbf_clean(h_, pose16, time, confThreshold, maxDepth) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
     /* sharded map only: re-cut the ranges evenly over the ranks (new surfels land on the last rank) */
     void rebalance()
     {
         if (hrbf_map_rebalance(h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
+private:
+    hrbf_handle h_;
+};
+
+/* IndexMap::{predictIndices,predictHRBF} (IndexMap.h:43-68); the images are fetched with HRBFFusion::getImage */
+class IndexMap {
+public:
+    explicit IndexMap(hrbf_handle h) : h_(h) {}
+    void predictIndices(const float *pose16, const int &time, const float depthCutoff, const int indexSubmap = 0)
+    {
+        if (hrbf_predict_indices(h_, pose16, time, depthCutoff, indexSubmap) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+    }
+    void predictHRBF()
+    {
+        if (hrbf_predict_hrbf(h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
     }
 private:
     hrbf_handle h_;
@@ -161,9 +191,10 @@ public:
         p.fast_odom = fastOdom; p.so3 = so3; p.frame_to_frame_rgb = frameToFrameRGB; p.max_surfels = maxSurfels;
         if (hrbf_create(&p, device, &h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
         model_ = new GlobalModel(h_);
+        index_ = new IndexMap(h_);
         trajectory_manager = new TrajectoryManager();
     }
-    ~HRBFFusion() { delete trajectory_manager; delete model_; hrbf_destroy(h_); }
+    ~HRBFFusion() { delete trajectory_manager; delete index_; delete model_; hrbf_destroy(h_); }
     HRBFFusion(const HRBFFusion &) = delete;
     HRBFFusion &operator=(const HRBFFusion &) = delete;
 
@@ -189,6 +220,7 @@ public:
     const int getTick() { return hrbf_get_tick(h_); }
     void setTick(const int &val) { hrbf_set_tick(h_, val); }
     GlobalModel &getGlobalModel() { return *model_; }
+    IndexMap &getIndexMap() { return *index_; }
     float lastICPError() { float e, c; hrbf_last_icp(h_, &e, &c); return e; }
     float lastICPCount() { float e, c; hrbf_last_icp(h_, &e, &c); return c; }
     /* setters applied every GUI frame (GUI/src/HRBF_fusion.cpp:448-456) */
@@ -247,6 +279,7 @@ public:
 private:
     hrbf_handle h_;
     GlobalModel *model_;
+    IndexMap *index_;
     Pose curr_;
 };
 
