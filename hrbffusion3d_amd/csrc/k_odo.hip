@@ -1018,7 +1018,7 @@ __device__ __forceinline__ bool icp_pixel(const IcpArgs &A, const float *Rcurr, 
         d_cp = sub3(add3(d_cp, io->z), lm);
     }
     float weight = 1.0f;
-    if (A.use_weight) { float w = A.icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
+    if (A.use_weight) { float w = bx < 0 ? 0.0f : A.icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }   // bx < 0: see oracle/orc_odo.c
     float row[7];
     f3 cr = cross3(s_cp, n_cp);
     row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;

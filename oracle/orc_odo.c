@@ -420,7 +420,9 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
         sp->z[k] = z;
     }
     float weight = 1.0f;
-    if (use_weight) { float w = icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
+    /* every candidate can score NaN (flat patch: ckmax = 0): the reference then keeps corres = (-1,-1) and reads
+       uninitialised locals and icpWeight[-1][-1]; the products are all zero here (bv = bn = 0), the weight is defined 0 */
+    if (use_weight) { float w = bx < 0 ? 0.0f : icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
     float row[7];
     f3 cr = cross3(s_cp, n_cp);
     row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
