@@ -482,9 +482,50 @@ __device__ __forceinline__ bool in_view(const CleanParams &cp, const Rigid &tinv
     return lp.z < cp.maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)cam.W && y < (float)cam.H;
 }
 
+// the clean test of one item: surfel `idx` of the map or association record `idx`
+__device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &tinv, float ftime, const MapPlanes &m,
+                                           const RecPlanes &rec, bool is_surf, uint32_t idx,
+                                           const float4 *__restrict__ clean_tex)
+{
+    const float4 vp = is_surf ? m.p0[idx] : rec.p0[idx];
+    bool keep = true;
+    f3 lp; float x, y;
+    const bool inv = in_view(cp, tinv, vp, lp, x, y);
+    // color_time is needed for in-view items (init time, merged-this-frame), for unstable surfels (stale
+    // test) and for records; a stable surfel outside the frustum is decided by pos_conf alone (16 B)
+    const bool need_ct = inv || !is_surf || vp.w < cp.confThr || cp.full_check;
+    float4 vc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (need_ct) vc = is_surf ? m.p1[idx] : rec.p1[idx];
+    if (inv) {
+        const float4 vn = is_surf ? m.p2[idx] : rec.p2[idx];
+        keep = clean_window(cp, tinv, lp, x, y, vc.z, vc.y, vn, clean_tex);
+    }
+    if (!is_surf || cp.full_check || (need_ct && vc.w == ftime)) {
+        const float k1 = is_surf ? m.p3[idx].w : rec.p3[idx].w;
+        const float k2 = is_surf ? m.p4[idx].w : rec.p4[idx].w;
+        if (k1 < -cp.curvThr || k1 > cp.curvThr || k2 < -cp.curvThr || k2 > cp.curvThr) keep = false;
+    }
+    if (need_ct) {
+        float lastw = vc.w;
+        if (lastw == -2.0f) lastw = ftime;
+        if (lastw == -1.0f || ((ftime - lastw) > 200.0f && vp.w < cp.confThr)) keep = false;
+    }
+    return keep;
+}
+
 // Pass A: the clean test of every surfel and record -> one keep byte per item.  Embarrassingly
 // parallel, so the in-view minority (16 index-map samples each) is spread over the whole chip by the
 // hardware scheduler instead of stalling the scan tiles that happen to contain it.
+// The first ceil(Q / 256) workgroups take the records: every record is in view (18 texel gathers each), so they are
+// the first work the chip starts, and a wave takes an 8x8 tile of the quarter grid — its record loads are eight
+// 128-byte runs and its window gathers fall into ~18 image rows x a few lines, instead of 64 rows of one column,
+// which is what 64 consecutive record indices q (column-major draw order) would give.  Their keep counts reach the tile counters through an LDS histogram.
+#define CLEAN_HIST 256
+__host__ __device__ inline uint32_t clean_record_blocks(int W, int H)
+{
+    const uint32_t tiles = (((uint32_t)W / 2u + 7u) / 8u) * (((uint32_t)H / 2u + 7u) / 8u);   // 8x8 tiles of the quarter grid
+    return (tiles + 3u) / 4u;                                                                // 4 waves per workgroup
+}
 __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m, RecPlanes rec,
                                                      const int32_t *__restrict__ rec_flag, int Q,
                                                      const uint32_t *__restrict__ count_in,
@@ -493,45 +534,46 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
                                                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ stats)
 {
     const uint32_t N = *count_in;
-    const uint32_t total = N + (uint32_t)Q;
     const Rigid tinv = cp.dp->tinv;
     const float ftime = (float)cp.time;
     cp.full_check |= (int)stats[4];   // raised by k_apply_merges (see there)
-    const uint32_t total64 = (total + 63u) & ~63u;
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[2] = 0;   // appended counter, accumulated by pass B
+    const uint32_t nrb = Q > 0 ? clean_record_blocks(cp.cam.W, cp.cam.H) : 0u;
+    if (blockIdx.x < nrb) {
+        __shared__ uint32_t s_hist[CLEAN_HIST];
+        const uint32_t base_tile = N / FUSE_TILE;
+        const uint32_t ntile = (N + (uint32_t)Q - 1u) / FUSE_TILE - base_tile + 1u;
+        const bool use_hist = ntile <= CLEAN_HIST;
+        s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        // one wave = one 8x8 tile of the quarter grid; 8 consecutive lanes walk down a column = 8 consecutive q
+        const uint32_t QW = (uint32_t)cp.cam.W / 2u, QH = (uint32_t)cp.cam.H / 2u;
+        const uint32_t tiles_x = (QW + 7u) / 8u;
+        const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+        const uint32_t qx = (tile % tiles_x) * 8u + (lane >> 3), qy = (tile / tiles_x) * 8u + (lane & 7u);
+        if (qx < QW && qy < QH) {
+            const uint32_t q = qx * QH + qy;
+            const bool keep = rec_flag[q] != 0 && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex);
+            keep_flags[N + q] = keep ? 1 : 0;
+            if (keep) {
+                const uint32_t tl = (N + q) / FUSE_TILE;
+                if (use_hist) atomicAdd(&s_hist[tl - base_tile], 1u);
+                else atomicAdd(&tile_count[(size_t)tl * TC_STRIDE], 1u);
+            }
+        }
+        __syncthreads();
+        if (use_hist && threadIdx.x < ntile && s_hist[threadIdx.x])
+            atomicAdd(&tile_count[(size_t)(base_tile + threadIdx.x) * TC_STRIDE], s_hist[threadIdx.x]);
+        return;
+    }
+    const uint32_t sb = blockIdx.x - nrb, sgrid = gridDim.x - nrb;
+    const uint32_t N64 = (N + 63u) & ~63u;
     // Plain round-robin grid-stride on purpose: the in-view minority (the expensive items) is clustered in the
     // array, and an XCD-contiguous chunking (one eighth of the array per XCD, better L2 locality for the clean
     // texels) measured 2x SLOWER because one or two XCDs then own all the heavy work (profiles/r01 notes).
-    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < total64; it += gridDim.x * blockDim.x) {
-        const bool is_surf = it < N;
-        const uint32_t q = it - N;
-        bool keep = false;
-        if (it < total && (is_surf || rec_flag[q] != 0)) {
-            const float4 vp = is_surf ? m.p0[it] : rec.p0[q];
-            keep = true;
-            f3 lp; float x, y;
-            const bool inv = in_view(cp, tinv, vp, lp, x, y);
-            // color_time is needed for in-view items (init time, merged-this-frame), for unstable surfels (stale
-            // test) and for records; a stable surfel outside the frustum is decided by pos_conf alone (16 B)
-            const bool need_ct = inv || !is_surf || vp.w < cp.confThr || cp.full_check;
-            float4 vc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (need_ct) vc = is_surf ? m.p1[it] : rec.p1[q];
-            if (inv) {
-                const float4 vn = is_surf ? m.p2[it] : rec.p2[q];
-                keep = clean_window(cp, tinv, lp, x, y, vc.z, vc.y, vn, clean_tex);
-            }
-            if (!is_surf || cp.full_check || (need_ct && vc.w == ftime)) {
-                const float k1 = is_surf ? m.p3[it].w : rec.p3[q].w;
-                const float k2 = is_surf ? m.p4[it].w : rec.p4[q].w;
-                if (k1 < -cp.curvThr || k1 > cp.curvThr || k2 < -cp.curvThr || k2 > cp.curvThr) keep = false;
-            }
-            if (need_ct) {
-                float lastw = vc.w;
-                if (lastw == -2.0f) lastw = ftime;
-                if (lastw == -1.0f || ((ftime - lastw) > 200.0f && vp.w < cp.confThr)) keep = false;
-            }
-        }
-        if (it < total) keep_flags[it] = keep ? 1 : 0;
+    for (uint32_t it = sb * blockDim.x + threadIdx.x; it < N64; it += sgrid * blockDim.x) {
+        const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex);
+        if (it < N) keep_flags[it] = keep ? 1 : 0;
         // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
         const unsigned long long bal = __ballot(keep);
         if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&tile_count[(size_t)(it / FUSE_TILE) * TC_STRIDE], (uint32_t)__popcll(bal));
@@ -774,9 +816,10 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     uint32_t tiles = (items_ub + FUSE_TILE - 1) / FUSE_TILE;
     if (tiles > max_tiles) tiles = max_tiles;
     if (e0) hipEventRecord(e0, s);
-    uint32_t fblocks = (items_ub + 255) / 256;
+    uint32_t fblocks = (count_ub + 255) / 256;            // surfel workgroups (grid-stride) ...
     if (fblocks > 256u * 16u) fblocks = 256u * 16u;
     if (fblocks == 0) fblocks = 1;
+    if (Q > 0) fblocks += clean_record_blocks(cam.W, cam.H);   // ... behind the record workgroups
     hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
                        keep_flags, tile_count, stats);
     uint32_t blocks = tiles < 256u ? tiles : 256u;   // co-resident: ONE 512-thread workgroup per CU (132 VGPR -> 12 waves/CU)
