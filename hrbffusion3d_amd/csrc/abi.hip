@@ -95,7 +95,8 @@ struct hrbf_context {
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
     uint32_t *d_init_flags, *d_init_offs;
     uint32_t max_tiles;
-    float4 *d_clean_tex;        // 2 x float4 per pixel: packed index-map texels for the clean test
+    float4 *d_clean_tex;        // packed index-map texels + update mask for the clean test (k_resolve)
+    float clean_thr; int clean_time;   // the threshold and time baked into them
     DevPose *d_pose;
     int index_submap;           // submap id stamped on new surfels (HRBFFusion::indexSubmap)
     uint8_t *d_submap_active; int n_submap_active;   // KeyFrameIDMap (null = all active)
@@ -218,7 +219,7 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     DA(c->d_rec_flag, c->Q); DA(c->d_rec_best, c->Q);
     DA(c->d_init_flags, P); DA(c->d_init_offs, P);
     DA(c->d_pose, 1);
-    DA(c->d_clean_tex, 2 * P);
+    DA(c->d_clean_tex, clean_tex_elems((int)P));
     e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * HRBF_MAX_SHARDS, hipHostMallocDefault);
     if (e != hipSuccess) { hrbf_set_error("hipHostMalloc: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     c->h_count_pinned[0] = 0;
@@ -453,7 +454,7 @@ static int what_images(hrbf_context *c, bool primary, bool for_clean, int what, 
         out[n++] = {primary ? c->d_im_colortime : c->x.colortime, P * 4}; out[n++] = {primary ? c->d_im_curvmax : c->x.curvmax, P * 4};
         out[n++] = {primary ? c->d_im_curvmin : c->x.curvmin, P * 4};
     }
-    if ((what & 4) && for_clean) out[n++] = {primary ? c->d_clean_tex : c->x.clean_tex, P * 8};
+    if ((what & 4) && for_clean) out[n++] = {primary ? c->d_clean_tex : c->x.clean_tex, clean_tex_elems(c->P) * 4};
     return n;
 }
 
@@ -477,11 +478,13 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
 {
     const float maxd = c->prm.max_depth_processed;
     float4 *ctex = for_clean ? c->d_clean_tex : nullptr;
+    if (for_clean && (what & 4)) { c->clean_thr = c->prm.confidence_threshold; c->clean_time = c->tick; }
     if (c->G == 1 && !c->shard_real) {
         launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[0].map, shard_ref(c, 0), c->sh[0].count_ub, c->d_zbuf,
                        c->d_submap_active, c->n_submap_active);
         launch_resolve(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), c->d_zbuf, c->d_idx, c->d_im_vertconf,
-                       c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctex, what, 1);
+                       c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctex, what, 1,
+                       c->clean_thr, c->clean_time);
         return;
     }
     // sharded map: every shard projects its own surfels under GLOBAL ids -> min-reduce of the packed keys -> every
@@ -501,7 +504,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
                        p0 ? c->d_im_vertconf : c->x.vertconf, p0 ? c->d_im_colortime : c->x.colortime,
                        p0 ? c->d_im_normrad : c->x.normrad, p0 ? c->d_im_curvmax : c->x.curvmax,
                        p0 ? c->d_im_curvmin : c->x.curvmin, for_clean ? (p0 ? c->d_clean_tex : c->x.clean_tex) : nullptr, what,
-                       k == c->nsh - 1 ? 1 : 0);
+                       k == c->nsh - 1 ? 1 : 0, c->clean_thr, c->clean_time);
         if (!p0) {
             what_images(c, false, for_clean, what, scr);
             for (int t = 0; t < ni; ++t) launch_add_u32(c->stream, (uint32_t *)prim[t].p, (const uint32_t *)scr[t].p, prim[t].words);
@@ -526,6 +529,9 @@ static void st_fuse(hrbf_context *c)
 }
 static void st_clean(hrbf_context *c)
 {
+    // the clean texels carry the confidence threshold and the time they were resolved with; a caller that changed
+    // either since (stage API / named operators) gets a fresh projection instead of a stale test
+    if (c->clean_thr != c->prm.confidence_threshold || c->clean_time != c->tick) st_indices(c, true, 7);
     const bool ring = c->timing && c->G == 1;
     for (int k = 0; k < c->nsh; ++k) {
         const int gk = c->shard_first + k;
@@ -1211,7 +1217,7 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
         if (!r) r = dalloc(&c->x.normrad, P);
         if (!r) r = dalloc(&c->x.curvmax, P);
         if (!r) r = dalloc(&c->x.curvmin, P);
-        if (!r) r = dalloc(&c->x.clean_tex, 2 * P);
+        if (!r) r = dalloc(&c->x.clean_tex, clean_tex_elems((int)P));
         if (r) return r;
         HIP_CHECK(hipDeviceSynchronize());
         launch_zbuf_reset(c->stream, c->x.zbuf, c->P);

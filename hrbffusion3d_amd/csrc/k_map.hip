@@ -146,52 +146,67 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
 #define RESOLVE_GEOM 1
 #define RESOLVE_ATTR 2
 #define RESOLVE_CLEAN 4
+// The clean test's view of the index map (pass A of the fuse): ONE 16-byte texel per pixel {winner position in the
+// camera frame, winner's init time} — zero when there is no winner, when it is surfel 0 (the reference's
+// `current > 0U` gate, copy_unstable.vert:111) or when its confidence is not above the threshold (both predicates of
+// the test need it) — followed by one bit per pixel: "the winner was updated this frame".  A zero texel has z = 0 and
+// fails every `vcf.z > lp.z` of the test, so validity costs no extra flag.  4.9 MB + 38 KB at VGA instead of the
+// 9.8 MB of two float4 per pixel: it stays in L2 and the window needs 9 + 3 loads instead of 18.
+__host__ __device__ inline size_t clean_tex_float4s(int P) { return (size_t)P + (size_t)P / 128 + 4; }   // texels + bit words (+ slack)
+__device__ __forceinline__ const uint32_t *clean_bits(const float4 *clean_tex, int P)
+{
+    return reinterpret_cast<const uint32_t *>(clean_tex + P);
+}
+
 __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m, ShardRef sh, int rearm,
                                                  unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
                                                  float4 *__restrict__ curvmax, float4 *__restrict__ curvmin,
-                                                 float4 *__restrict__ clean_tex, int what)
+                                                 float4 *__restrict__ clean_tex, int what, float clean_conf_thr,
+                                                 int clean_time)
 {
+    const int P = cam.W * cam.H;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cam.W * cam.H) return;
+    if (i >= P) return;   // P is a multiple of 64: whole waves leave
     unsigned long long key = zbuf[i];
     const Rigid tinv = dp->tinv;
     const float4 z4 = make_float4(0, 0, 0, 0);
-    if (key == ZB_EMPTY) {
-        idx[i] = 0;
-        if (what & RESOLVE_GEOM) { vertconf[i] = z4; normrad[i] = z4; }
-        if (what & RESOLVE_ATTR) { colortime[i] = z4; curvmax[i] = z4; curvmin[i] = z4; }
-        if (what & RESOLVE_CLEAN) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
-        return;
+    uint32_t sg = 0u, s = 0u;
+    bool owned = false;
+    if (key != ZB_EMPTY) {
+        if (rearm) zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
+        sg = (uint32_t)(key & 0xFFFFFFFFull);   // global id of the winner
+        s = sg - shard_offset(sh);
+        owned = s < sh.counts[sh.k];   // else the winner lives on another shard: contribute zeros to the sum-reduction
     }
-    if (rearm) zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
-    const uint32_t sg = (uint32_t)(key & 0xFFFFFFFFull);   // global id of the winner
     idx[i] = sg;
-    const uint32_t s = sg - shard_offset(sh);
-    if (s >= sh.counts[sh.k]) {   // the winner lives on another shard: contribute zeros to the sum-reduction
-        if (what & RESOLVE_GEOM) { vertconf[i] = z4; normrad[i] = z4; }
-        if (what & RESOLVE_ATTR) { colortime[i] = z4; curvmax[i] = z4; curvmin[i] = z4; }
-        if (what & RESOLVE_CLEAN) { clean_tex[2 * i] = z4; clean_tex[2 * i + 1] = z4; }
-        return;
-    }
-    const float4 p = m.p0[s];
-    const f3 h = xform(tinv, xyz(p));
-    if (what & RESOLVE_GEOM) {
-        const float4 nr = m.p2[s];
-        const f3 n = normalize3(rot_mul(tinv, xyz(nr)));
-        vertconf[i] = make_float4(h.x, h.y, h.z, p.w);
-        normrad[i] = make_float4(n.x, n.y, n.z, nr.w);
-    }
-    if (what & (RESOLVE_ATTR | RESOLVE_CLEAN)) {
-        const float4 ct = m.p1[s];
-        if (what & RESOLVE_ATTR) { colortime[i] = ct; curvmax[i] = m.p3[s]; curvmin[i] = m.p4[s]; }
-        // packed texel for the clean test (pass A of the fuse): 32 contiguous bytes instead of three gathers;
-        // .w of the second half = the reference's `current > 0U` gate (copy_unstable.vert:111)
-        if (what & RESOLVE_CLEAN) {
-            clean_tex[2 * i] = make_float4(h.x, h.y, h.z, p.w);
-            clean_tex[2 * i + 1] = make_float4(ct.z, ct.w, sg > 0u ? 1.0f : 0.0f, 0.0f);
+    float4 o_vc = z4, o_nr = z4, o_ct = z4, o_c1 = z4, o_c2 = z4, o_clean = z4;
+    bool updated = false;
+    if (owned) {
+        const float4 p = m.p0[s];
+        const f3 h = xform(tinv, xyz(p));
+        if (what & RESOLVE_GEOM) {
+            const float4 nr = m.p2[s];
+            const f3 n = normalize3(rot_mul(tinv, xyz(nr)));
+            o_vc = make_float4(h.x, h.y, h.z, p.w);
+            o_nr = make_float4(n.x, n.y, n.z, nr.w);
         }
+        if (what & (RESOLVE_ATTR | RESOLVE_CLEAN)) {
+            const float4 ct = m.p1[s];
+            if (what & RESOLVE_ATTR) { o_ct = ct; o_c1 = m.p3[s]; o_c2 = m.p4[s]; }
+            if ((what & RESOLVE_CLEAN) && sg > 0u && p.w > clean_conf_thr) {
+                o_clean = make_float4(h.x, h.y, h.z, ct.z);
+                updated = ct.w == (float)clean_time;
+            }
+        }
+    }
+    if (what & RESOLVE_GEOM) { vertconf[i] = o_vc; normrad[i] = o_nr; }
+    if (what & RESOLVE_ATTR) { colortime[i] = o_ct; curvmax[i] = o_c1; curvmin[i] = o_c2; }
+    if (what & RESOLVE_CLEAN) {
+        clean_tex[i] = o_clean;
+        const unsigned long long bal = __ballot(updated);   // a wave = 64 consecutive pixels = one 8-byte word of the mask
+        if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(clean_tex + P)[i >> 6] = bal;
     }
 }
 
@@ -404,9 +419,12 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
     const bool nz_ok = hd_fabsf(ln.z) > 0.85f && own_active;
     const float rad14 = vn.w * 1.4f;
     const float ftime = (float)cp.time;
+    const int P = cam.W * cam.H;
+    const uint32_t *bits = clean_bits(clean_tex, P);
+    (void)ftime;
     if (cp.nw == 4) {
         // the 4 samples of an axis are non-decreasing with steps <= 1: values s0, s0+1, s0+2 with multiplicities.
-        // All (<= 9) distinct texels are requested in one batch (18 independent 16-B loads), then evaluated.
+        // All (<= 9) distinct texels and the three mask rows are requested in one batch, then evaluated.
         int sxk[4], syk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -419,28 +437,32 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
             mx[j] = (sxk[0] == sxk[0] + j) + (sxk[1] == sxk[0] + j) + (sxk[2] == sxk[0] + j) + (sxk[3] == sxk[0] + j);
             my[j] = (syk[0] == syk[0] + j) + (syk[1] == syk[0] + j) + (syk[2] == syk[0] + j) + (syk[3] == syk[0] + j);
         }
-        float4 ta[9], tb[9];
+        float4 ta[9];
+        uint32_t upd[3];   // bit jx of upd[jy]: the winner at (sx0 + jx, sy0 + jy) was updated this frame
 #pragma unroll
-        for (int jx = 0; jx < 3; ++jx)
-#pragma unroll
-            for (int jy = 0; jy < 3; ++jy) {
-                const int wgt = mx[jx] * my[jy];
-                const int si = (syk[0] + jy) * cam.W + (sxk[0] + jx);
-                ta[jx * 3 + jy] = make_float4(0, 0, 0, 0); tb[jx * 3 + jy] = make_float4(0, 0, 0, 0);
-                if (wgt > 0) { ta[jx * 3 + jy] = clean_tex[2 * si]; tb[jx * 3 + jy] = clean_tex[2 * si + 1]; }
+        for (int jy = 0; jy < 3; ++jy) {
+            upd[jy] = 0u;
+            if (my[jy] > 0) {   // rows outside the visit pattern may lie outside the image: not read
+                const uint32_t bi = (uint32_t)((syk[0] + jy) * cam.W + sxk[0]);
+                const uint32_t lo = bits[bi >> 5], hi = bits[(bi >> 5) + 1];   // one word of slack behind the mask
+                upd[jy] = (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (bi & 31u)) & 7u;
             }
 #pragma unroll
+            for (int jx = 0; jx < 3; ++jx) {
+                ta[jx * 3 + jy] = make_float4(0, 0, 0, 0);
+                if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = clean_tex[(syk[0] + jy) * cam.W + (sxk[0] + jx)];
+            }
+        }
+#pragma unroll
         for (int jx = 0; jx < 3; ++jx)
 #pragma unroll
             for (int jy = 0; jy < 3; ++jy) {
                 const int wgt = mx[jx] * my[jy];
-                const float4 vcf = ta[jx * 3 + jy], tt = tb[jx * 3 + jy];
-                if (wgt > 0 && tt.z > 0.0f) {
+                const float4 vcf = ta[jx * 3 + jy];   // {winner xyz, winner init time}; all zero = no usable winner
+                if (wgt > 0 && vcf.z > lp.z) {
                     float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
-                    if (tt.x < init_time && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
-                        hd_sqrtf(dx * dx + dy * dy) < rad14)
-                        count += wgt;
-                    if (tt.y == ftime && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f && nz_ok) zCount += wgt;
+                    if (vcf.w < init_time && vcf.z - lp.z < 0.01f && hd_sqrtf(dx * dx + dy * dy) < rad14) count += wgt;
+                    if (((upd[jy] >> jx) & 1u) && vcf.z - lp.z > 0.01f && nz_ok) zCount += wgt;
                 }
             }
         return !(count > 8 || zCount > 4);
@@ -456,13 +478,11 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
                 if (sy != prev_sy) {
                     prev_sy = sy; c1 = 0; z1 = 0;
                     const int si = sy * cam.W + sx;
-                    const float4 vcf = clean_tex[2 * si], tt = clean_tex[2 * si + 1];
-                    if (tt.z > 0.0f) {
+                    const float4 vcf = clean_tex[si];
+                    if (vcf.z > lp.z) {
                         float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
-                        if (tt.x < init_time && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z < 0.01f &&
-                            hd_sqrtf(dx * dx + dy * dy) < rad14)
-                            c1 = 1;
-                        if (tt.y == ftime && vcf.w > cp.confThr && vcf.z > lp.z && vcf.z - lp.z > 0.01f && nz_ok) z1 = 1;
+                        if (vcf.w < init_time && vcf.z - lp.z < 0.01f && hd_sqrtf(dx * dx + dy * dy) < rad14) c1 = 1;
+                        if (((bits[si >> 5] >> (si & 31)) & 1u) && vcf.z - lp.z > 0.01f && nz_ok) z1 = 1;
                     }
                 }
                 colc += c1; colz += z1;
@@ -752,12 +772,12 @@ void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxD
 }
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                    float4 *clean_tex, int what, int rearm)
+                    float4 *clean_tex, int what, int rearm, float clean_conf_thr, int clean_time)
 {
     const int P = cam.W * cam.H;
     if (!clean_tex) what &= ~RESOLVE_CLEAN;
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, rearm, zbuf, idx, vertconf,
-                       colortime, normrad, curvmax, curvmin, clean_tex, what);
+                       colortime, normrad, curvmax, curvmin, clean_tex, what, clean_conf_thr, clean_time);
 }
 
 // local stand-ins for the two collectives of a sharded projection (one process playing several shards): the same
@@ -842,6 +862,7 @@ void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
 }
 
 uint32_t fuse_tile_items() { return FUSE_TILE; }
+size_t clean_tex_elems(int P) { return clean_tex_float4s(P); }
 uint32_t fuse_tile_count_stride() { return TC_STRIDE; }
 
 // ------------------------------------------------------------------------------------------------

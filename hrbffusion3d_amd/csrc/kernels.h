@@ -44,8 +44,10 @@ void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxD
                     int n_active);
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                    float4 *clean_tex /* nullable: packed texels for the clean test */,
-                    int what /* 1 geometry images | 2 attribute images | 4 clean texels */, int rearm);
+                    float4 *clean_tex /* nullable: packed texels + update mask for the clean test (clean_tex_elems) */,
+                    int what /* 1 geometry images | 2 attribute images | 4 clean texels */, int rearm,
+                    float clean_conf_thr, int clean_time /* baked into the clean texels */);
+size_t clean_tex_elems(int P);   // float4 elements of the clean-texel buffer (texels + one bit per pixel)
 void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P);   // local stand-in for allReduce(min)
 void launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, size_t n);                          // local stand-in for allReduce(sum)
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
