@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--noise", action="store_true", help="Kinect-style depth noise + 3%% drop-outs")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle sample, ~10 s of host time (0 = skip)")
     ap.add_argument("--shard-odometry", action="store_true",
                     help="N > 1: all ranks track ONE sequence, registration reductions row-sharded + RCCL all-reduce "
                          "(SURVEY §8e sharding 1; strong scaling, a latency cost at VGA). Default: independent replicas")
