@@ -162,17 +162,26 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
 
 
 @pytest.mark.parametrize("variant", ["gauss_filter", "central_diff_normals", "no_so3_no_pyramid", "conf_eval", "rgb_only",
-                                     "icp_only", "corr_search", "sparse_icp_corr_search"])
+                                     "icp_only", "corr_search", "sparse_icp_corr_search", "clean_window_1", "clean_window_4",
+                                     "frame_to_frame_rgb", "rgb_grad_weight", "icp_unweighted", "predict_small",
+                                     "curv_window_2", "thresholds"])
 def test_parameter_variants(pair, variant):
     W, H = 160, 120
     fx, fy, cx, cy = synth.intrinsics(W, H)
     kw = {"gauss_filter": dict(use_bilateral=0), "central_diff_normals": dict(normal_estimation_pca=0.0),
           "no_so3_no_pyramid": dict(so3=0, pyramid=0, fast_odom=1), "conf_eval": dict(use_conf_eval=1),
           "rgb_only": dict(rgb_only=1), "icp_only": dict(icp_weight=100.0), "corr_search": dict(icp_use_corr_search=1),
-          "sparse_icp_corr_search": dict(use_sparse_icp=1, icp_use_corr_search=1)}[variant]
+          "sparse_icp_corr_search": dict(use_sparse_icp=1, icp_use_corr_search=1),
+          "clean_window_1": dict(clean_window_multiplier=1.0), "clean_window_4": dict(clean_window_multiplier=4.0),
+          "frame_to_frame_rgb": dict(frame_to_frame_rgb=1), "rgb_grad_weight": dict(rgb_use_grad_weight=1),
+          "icp_unweighted": dict(icp_use_weighted=0),
+          "predict_small": dict(predict_window_multiplier=2.0, predict_min_neighbors=4, predict_max_neighbors=6),
+          "curv_window_2": dict(curv_estimation_window=2.0),
+          "thresholds": dict(confidence_threshold=2.0, depth_cutoff=2.5, curv_valid_threshold=150.0, dense_enough_thresh=0.99,
+                             predict_conf_threshold=1.0, init_radius_multiplier=3.0)}[variant]
     p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17, **kw)
     o, g = pair(p)
-    for k in range(4):
+    for k in range(5):
         rgb, d, _ = synth.frame(k, W, H, noise=True)
         o.process_frame(rgb, d); g.process_frame(rgb, d)
         assert_same_state(o, g, "%s frame %d" % (variant, k))
