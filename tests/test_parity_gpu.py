@@ -219,6 +219,23 @@ def test_edge_cases_empty_and_invalid_depth(pair):
     assert g.surfel_count() > 0
 
 
+@pytest.mark.parametrize("cap", [9000, 20000])
+def test_map_at_capacity(pair, cap):
+    """maximum size: a map whose capacity is hit by the seed frame (cap 9000 < first frame's surfels) or by the
+    appends of later frames (cap 20000): the count saturates at the capacity, nothing is written past it, and images,
+    map and pose stay bit-identical to the oracle, which applies the same clamp"""
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=cap)
+    o, g = pair(p)
+    for k in range(8):
+        rgb, d, _ = synth.frame(3 * k, W, H, noise=True)     # larger steps: more new surface per frame
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "cap %d frame %d" % (cap, k))
+        assert g.surfel_count() <= cap
+    assert g.surfel_count() > 0.9 * cap if cap == 9000 else True
+
+
 def test_stage_seams_in_isolation(pair):
     """operator-level seams: each stage run alone on injected inputs"""
     W, H = 160, 120
