@@ -210,6 +210,13 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
     }
 }
 
+// workgroups (4 waves) needed to give every 8x8 tile of the quarter grid one wave (k_associate, record part of k_clean_flags)
+__host__ __device__ inline uint32_t quarter_tile_blocks(int W, int H)
+{
+    const uint32_t tiles = (((uint32_t)W / 2u + 7u) / 8u) * (((uint32_t)H / 2u + 7u) / 8u);
+    return (tiles + 3u) / 4u;
+}
+
 // ------------------------------------------------------------------------------------------
 // F1: data association (data.vert:63-198) over the quarter grid; record q = (px/2)*(H/2) + py/2
 // preserves the reference's column-major draw order among active pixels.
@@ -225,13 +232,14 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                                                    uint32_t *__restrict__ slot, ShardRef sh)
 {
     const int QW = cam.W / 2, QH = cam.H / 2;
-    // Threads walk the quarter grid ROW-major so that a wave reads 64 neighbouring pixels of one image row (the
-    // per-pixel loads and the 16 index-map samples coalesce); the record index q stays the reference's COLUMN-major
-    // draw order (data.vert), which decides "first primitive wins" and the append order.  Only the five record
-    // stores are strided by this.
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= QW * QH) return;
-    const int qx = t % QW, qy = t / QW;
+    // One wave = one 8x8 tile of the quarter grid (a 16x16 pixel block: the per-pixel loads and the index-map samples
+    // share cache lines); 8 consecutive lanes walk down a column, so they own 8 consecutive record indices q — the
+    // reference's COLUMN-major draw order (data.vert), which decides "first primitive wins" and the append order — and
+    // the five record stores are 128-byte runs (row-major threads made them 64 separate lines each).
+    const int tiles_x = (QW + 7) / 8;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qx = (tile % tiles_x) * 8 + (lane >> 3), qy = (tile / tiles_x) * 8 + (lane & 7);
+    if (qx >= QW || qy >= QH) return;
     const int q = qx * QH + qy;
     const Rigid pose = dp->pose;
     const int tpar = tick % 2;
@@ -541,11 +549,6 @@ __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &t
 // 128-byte runs and its window gathers fall into ~18 image rows x a few lines, instead of 64 rows of one column,
 // which is what 64 consecutive record indices q (column-major draw order) would give.  Their keep counts reach the tile counters through an LDS histogram.
 #define CLEAN_HIST 256
-__host__ __device__ inline uint32_t clean_record_blocks(int W, int H)
-{
-    const uint32_t tiles = (((uint32_t)W / 2u + 7u) / 8u) * (((uint32_t)H / 2u + 7u) / 8u);   // 8x8 tiles of the quarter grid
-    return (tiles + 3u) / 4u;                                                                // 4 waves per workgroup
-}
 __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m, RecPlanes rec,
                                                      const int32_t *__restrict__ rec_flag, int Q,
                                                      const uint32_t *__restrict__ count_in,
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     const float ftime = (float)cp.time;
     cp.full_check |= (int)stats[4];   // raised by k_apply_merges (see there)
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[2] = 0;   // appended counter, accumulated by pass B
-    const uint32_t nrb = Q > 0 ? clean_record_blocks(cp.cam.W, cp.cam.H) : 0u;
+    const uint32_t nrb = Q > 0 ? quarter_tile_blocks(cp.cam.W, cp.cam.H) : 0u;
     if (blockIdx.x < nrb) {
         __shared__ uint32_t s_hist[CLEAN_HIST];
         const uint32_t base_tile = N / FUSE_TILE;
@@ -812,7 +815,7 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 5);   // [0..3] statistics, [4] force-full-check flag
-    hipLaunchKernelGGL(k_associate, dim3((Q + 255) / 256), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
+    hipLaunchKernelGGL(k_associate, dim3(quarter_tile_blocks(cam.W, cam.H)), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
                        rec_best, slot, sh);
     hipLaunchKernelGGL(k_apply_merges, dim3((Q + 255) / 256), dim3(256), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
@@ -839,7 +842,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     uint32_t fblocks = (count_ub + 255) / 256;            // surfel workgroups (grid-stride) ...
     if (fblocks > 256u * 16u) fblocks = 256u * 16u;
     if (fblocks == 0) fblocks = 1;
-    if (Q > 0) fblocks += clean_record_blocks(cam.W, cam.H);   // ... behind the record workgroups
+    if (Q > 0) fblocks += quarter_tile_blocks(cam.W, cam.H);   // ... behind the record workgroups
     hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
                        keep_flags, tile_count, stats);
     uint32_t blocks = tiles < 256u ? tiles : 256u;   // co-resident: ONE 512-thread workgroup per CU (132 VGPR -> 12 waves/CU)
