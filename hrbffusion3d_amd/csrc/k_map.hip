@@ -852,7 +852,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     if (e1) hipEventRecord(e1, s);
     const int zq = zero_records ? Qfull : 0;
     int nz = zq > (int)tiles ? zq : (int)tiles;
-    hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, zq, tile_count, tile_done, (int)tiles);
+    if (nz > 0)   // an empty shard that takes no appends has nothing to re-arm
+        hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, zq, tile_count, tile_done, (int)tiles);
 }
 
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P)

@@ -392,7 +392,7 @@ def test_sharded_map_from_an_empty_map(pair, G):
         assert_same_state(o, g, "G=%d frame %d" % (G, k))
         if k > 0:
             assert np.array_equal(o.fuse_stats(), g.fuse_stats()), k
-        if k in (0, 3):
+        if k in (1, 4):                                     # frames 0-1 run with every shard but the last one empty
             g.map_rebalance()
             assert_same_state(o, g, "G=%d after rebalance at %d" % (G, k))
     assert g.local_surfel_count() == g.surfel_count() == o.surfel_count()
