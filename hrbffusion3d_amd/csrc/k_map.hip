@@ -617,8 +617,9 @@ __device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, cons
     if (sl.it < N) { sl.a = m.p0[sl.it]; sl.b = m.p1[sl.it]; sl.c = m.p2[sl.it]; sl.d = m.p3[sl.it]; sl.e = m.p4[sl.it]; }
     else {
         const uint32_t q = sl.it - N;
-        sl.a = rec.p0[q]; sl.b = rec.p1[q]; sl.c = rec.p2[q]; sl.d = rec.p3[q]; sl.e = rec.p4[q];
-        if (sl.b.w == -2.0f) sl.b.w = ftime;     // copy_unstable.vert:155-158
+        const float4 ct = rec.p1[q];
+        sl.a = rec.p0[q]; sl.c = rec.p2[q]; sl.d = rec.p3[q]; sl.e = rec.p4[q];
+        sl.b = make_float4(ct.x, ct.y, ct.z, ct.w == -2.0f ? ftime : ct.w);     // copy_unstable.vert:155-158
     }
 }
 __device__ __forceinline__ uint32_t move_store(const MoveSlot &sl, const MapPlanes &m, uint32_t N, uint32_t cap)
