@@ -26,7 +26,7 @@ EXPORTS = [
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
-    "hrbf_icp_step", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
+    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
 ]
@@ -78,6 +78,8 @@ def load_library():
     lib.hrbf_get_fuse_ring.argtypes = [vp, i32, vp, vp]; lib.hrbf_reset_fuse_ring.argtypes = [vp]
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
+    lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
+    lib.hrbf_update_lambda_map.argtypes = [vp] + [vp] * 9 + [i32, i32]
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]

@@ -1087,7 +1087,34 @@ extern "C" int hrbf_icp_step(hrbf_handle c, const float Rcurr[9], const float tc
     hipSetDevice(c->device);
     return run_icp_step(c->stream, Rcurr, tcurr, vmap_curr, nmap_curr, ck1_curr, ck2_curr, Rprev_inv, tprev, fx, fy, cx,
                         cy, vmap_g_prev, nmap_g_prev, ck1_g_prev, ck2_g_prev, icp_weight_prev, rows, cols, dist_thresh,
-                        angle_thresh, use_weight, A_out, b_out, residual_out);
+                        angle_thresh, use_weight, A_out, b_out, residual_out, nullptr, nullptr, nullptr);
+}
+
+// icpStep with useSparse = true (reduce.cu:302-315,455-492): lambda_map in, z_map (z_thrinkMap) and corres (corresICP)
+// out — device images, 3 interleaved floats / 2 int32 per pixel — and updateLambdaMap (cudafuncs.cu:1030-1111)
+extern "C" int hrbf_icp_step_sparse(hrbf_handle c, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                                    const float *nmap_curr, const float *ck1_curr, const float *ck2_curr,
+                                    const float Rprev_inv[9], const float tprev[3], float fx, float fy, float cx, float cy,
+                                    const float *vmap_g_prev, const float *nmap_g_prev, const float *ck1_g_prev,
+                                    const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
+                                    float dist_thresh, float angle_thresh, int use_weight, const float *lambda_map,
+                                    float *z_map_out, int32_t *corres_out, double A_out[36], double b_out[6],
+                                    double residual_out[2])
+{
+    if (!c || !lambda_map || !z_map_out || !corres_out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    return run_icp_step(c->stream, Rcurr, tcurr, vmap_curr, nmap_curr, ck1_curr, ck2_curr, Rprev_inv, tprev, fx, fy, cx,
+                        cy, vmap_g_prev, nmap_g_prev, ck1_g_prev, ck2_g_prev, icp_weight_prev, rows, cols, dist_thresh,
+                        angle_thresh, use_weight, A_out, b_out, residual_out, lambda_map, z_map_out, corres_out);
+}
+extern "C" int hrbf_update_lambda_map(hrbf_handle c, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                                      const float Rprev_inv[9], const float tprev[3], const float *vmap_g_prev,
+                                      const int32_t *corres, const float *z_map, float *lambda_map, int rows, int cols)
+{
+    if (!c || !corres || !z_map || !lambda_map) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    return run_update_lambda_map(c->stream, Rcurr, tcurr, vmap_curr, Rprev_inv, tprev, vmap_g_prev, corres, z_map, lambda_map,
+                                 rows, cols);
 }
 
 // ------------------------------------------------------------------------------------------ named operators

@@ -1712,12 +1712,72 @@ __global__ __launch_bounds__(RB) void k_icp_only(IcpArgs A, Rigid cur, Rigid pre
     block_reduce_exact<29>(out, valid, part);
 }
 
+// the sparse (ADMM) form of the seam: lambdaMap in, z_thrinkMap and corresICP out (reduce.cu:455-492); all three are
+// device images, lambda / z as 3 interleaved floats per pixel, corres as 2 int32 per pixel ((-1,-1) = no match)
+__global__ __launch_bounds__(RB) void k_icp_only_sparse(IcpArgs A, Rigid cur, Rigid prevInv_and_tprev,
+                                                        long long *__restrict__ part, const float *__restrict__ lambda3,
+                                                        float *__restrict__ z3, int32_t *__restrict__ corres2)
+{
+    float out[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+    bool valid = false;
+    const int i = blockIdx.x * RB + threadIdx.x;
+    if (i < A.rows * A.cols) {
+        const int y = i / A.cols, x = i - y * A.cols;
+        SparseIo io;
+        io.lambda = mk3(lambda3[3 * i], lambda3[3 * i + 1], lambda3[3 * i + 2]);
+        io.z = mk3(0, 0, 0); io.bx = -1; io.by = -1;
+        valid = icp_pixel<true>(A, cur.r, mk3(cur.t[0], cur.t[1], cur.t[2]), prevInv_and_tprev.r,
+                                mk3(prevInv_and_tprev.t[0], prevInv_and_tprev.t[1], prevInv_and_tprev.t[2]), x, y, out, &io);
+        z3[3 * i] = io.z.x; z3[3 * i + 1] = io.z.y; z3[3 * i + 2] = io.z.z;
+        corres2[2 * i] = io.bx; corres2[2 * i + 1] = io.by;
+    }
+    block_reduce_exact<29>(out, valid, part);
+}
+
+// updateLambdaMapKernel (cudafuncs.cu:1030-1080) as its own launch, on caller-owned device images
+__global__ void k_update_lambda(int rows, int cols, Rigid cur, Rigid prevInv_and_tprev, const float *__restrict__ vmap_c,
+                                const float *__restrict__ vmap_g, const int32_t *__restrict__ corres2,
+                                const float *__restrict__ z3, float *__restrict__ lambda3)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int ux = corres2[2 * i], uy = corres2[2 * i + 1];
+    if (ux <= 0) return;   // the reference tests corresp.x > 0
+    const int y = i / cols, x = i - y * cols;
+    const f3 tcurr = mk3(cur.t[0], cur.t[1], cur.t[2]), tprev = mk3(prevInv_and_tprev.t[0], prevInv_and_tprev.t[1], prevInv_and_tprev.t[2]);
+    const f3 vcur = mk3(PLN(vmap_c, 0, rows, cols, y, x), PLN(vmap_c, 1, rows, cols, y, x), PLN(vmap_c, 2, rows, cols, y, x));
+    const f3 vlp = m33_mul(prevInv_and_tprev.r, sub3(add3(m33_mul(cur.r, vcur), tcurr), tprev));
+    const f3 vp = m33_mul(prevInv_and_tprev.r, sub3(mk3(PLN(vmap_g, 0, rows, cols, uy, ux), PLN(vmap_g, 1, rows, cols, uy, ux),
+                                                         PLN(vmap_g, 2, rows, cols, uy, ux)), tprev));
+    const f3 d = sub3(sub3(vlp, vp), mk3(z3[3 * i], z3[3 * i + 1], z3[3 * i + 2]));
+    lambda3[3 * i] = lambda3[3 * i] + HD_SPARSE_MU * d.x;
+    lambda3[3 * i + 1] = lambda3[3 * i + 1] + HD_SPARSE_MU * d.y;
+    lambda3[3 * i + 2] = lambda3[3 * i + 2] + HD_SPARSE_MU * d.z;
+}
+
+int run_update_lambda_map(hipStream_t s, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                          const float Rprev_inv[9], const float tprev[3], const float *vmap_g_prev, const int32_t *corres,
+                          const float *z_map, float *lambda_map, int rows, int cols)
+{
+    Rigid cur, prv;
+    for (int k = 0; k < 9; ++k) { cur.r[k] = Rcurr[k]; prv.r[k] = Rprev_inv[k]; }
+    for (int k = 0; k < 3; ++k) { cur.t[k] = tcurr[k]; prv.t[k] = tprev[k]; }
+    const int n = rows * cols;
+    hipLaunchKernelGGL(k_update_lambda, dim3((n + 255) / 256), dim3(256), 0, s, rows, cols, cur, prv, vmap_curr, vmap_g_prev,
+                       corres, z_map, lambda_map);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { hrbf_set_error("update_lambda_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    return HRBF_OK;
+}
+
 int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
                  const float *nmap_curr, const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9],
                  const float tprev[3], float fx, float fy, float cx, float cy, const float *vmap_g_prev,
                  const float *nmap_g_prev, const float *ck1_g_prev, const float *ck2_g_prev, const float *icpw, int rows,
                  int cols, float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
-                 double residual_out[2])
+                 double residual_out[2], const float *lambda_map, float *z_map_out, int32_t *corres_out)
 {
     IcpArgs A;
     A.vmap_c = vmap_curr; A.nmap_c = nmap_curr; A.ck1_c = ck1_curr; A.ck2_c = ck2_curr;
@@ -1734,7 +1794,10 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
     const size_t bytes = sizeof(long long) * 87 * ODO_SLOTS;
     HIP_CHECK(hipMalloc(&part, bytes));
     hipError_t e = hipMemsetAsync(part, 0, bytes, s);
-    hipLaunchKernelGGL(k_icp_only, dim3(nb), dim3(RB), 0, s, A, cur, prv, part);
+    if (lambda_map)
+        hipLaunchKernelGGL(k_icp_only_sparse, dim3(nb), dim3(RB), 0, s, A, cur, prv, part, lambda_map, z_map_out, corres_out);
+    else
+        hipLaunchKernelGGL(k_icp_only, dim3(nb), dim3(RB), 0, s, A, cur, prv, part);
     long long *h = (long long *)malloc(bytes);
     if (e == hipSuccess) e = hipMemcpyAsync(h, part, bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -162,7 +162,11 @@ int run_icp_step(hipStream_t s, const float Rcurr[9], const float tcurr[3], cons
                  const float tprev[3], float fx, float fy, float cx, float cy, const float *vmap_g_prev,
                  const float *nmap_g_prev, const float *ck1_g_prev, const float *ck2_g_prev, const float *icpw, int rows,
                  int cols, float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
-                 double residual_out[2]);
+                 double residual_out[2], const float *lambda_map /* nullable: sparse variant */, float *z_map_out,
+                 int32_t *corres_out);
+int run_update_lambda_map(hipStream_t s, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                          const float Rprev_inv[9], const float tprev[3], const float *vmap_g_prev, const int32_t *corres,
+                          const float *z_map, float *lambda_map, int rows, int cols);
 
 // standalone so3Step / computeRgbResidual / rgbStep seams (device images, host matrices)
 int run_so3_step(hipStream_t s, const uint8_t *last_image, const uint8_t *next_image, int rows, int cols,

@@ -257,6 +257,20 @@ int hrbf_icp_step(hrbf_handle h, const float Rcurr[9], const float tcurr[3],
                   const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
                   float dist_thresh, float angle_thresh, int use_weight,
                   double A_out[36], double b_out[6], double residual_out[2]);
+/* the same with useSparse = true (reduce.cu:302-315,455-492) and updateLambdaMap (cudafuncs.cu:1030-1111): lambda_map
+ * (lambdaMap, in) and z_map_out (z_thrinkMap) are DEVICE images of 3 interleaved floats per pixel, corres_out
+ * (corresICP) 2 int32 per pixel, (-1, -1) = no match */
+int hrbf_icp_step_sparse(hrbf_handle h, const float Rcurr[9], const float tcurr[3],
+                         const float *vmap_curr, const float *nmap_curr, const float *ck1_curr, const float *ck2_curr,
+                         const float Rprev_inv[9], const float tprev[3], float fx, float fy, float cx, float cy,
+                         const float *vmap_g_prev, const float *nmap_g_prev, const float *ck1_g_prev,
+                         const float *ck2_g_prev, const float *icp_weight_prev, int rows, int cols,
+                         float dist_thresh, float angle_thresh, int use_weight,
+                         const float *lambda_map, float *z_map_out, int32_t *corres_out,
+                         double A_out[36], double b_out[6], double residual_out[2]);
+int hrbf_update_lambda_map(hrbf_handle h, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                           const float Rprev_inv[9], const float tprev[3], const float *vmap_g_prev,
+                           const int32_t *corres, const float *z_map, float *lambda_map, int rows, int cols);
 
 /* multi-GPU (sharding 1): one process per GPU joins an RCCL communicator (librccl is loaded on first use);
  * afterwards every rank still runs the whole frame on its own full map, but the registration reductions (SO3, RGB

@@ -514,6 +514,43 @@ int orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_c
     return 0;
 }
 
+/* icpStep with useSparse = true and updateLambdaMap as stand-alone operators on host images (lambda / z: 3 interleaved
+   floats per pixel, corres: 2 int32 per pixel) — the seam hrbf_icp_step_sparse / hrbf_update_lambda_map is checked against */
+int orc_icp_step_sparse(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                        const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9], const float tprev[3],
+                        float fx, float fy, float cx, float cy, const float *vmap_g_prev, const float *nmap_g_prev,
+                        const float *ck1_g_prev, const float *ck2_g_prev, const float *icp_weight_prev, int rows,
+                        int cols, float dist_thresh, float angle_thresh, int use_weight, const float *lambda_map,
+                        float *z_map_out, int32_t *corres_out, double A_out[36], double b_out[6], double residual_out[2])
+{
+    orc_planar vc = {rows, cols, (float *)vmap_curr}, nc = {rows, cols, (float *)nmap_curr};
+    orc_planar k1c = {rows, cols, (float *)ck1_curr}, k2c = {rows, cols, (float *)ck2_curr};
+    orc_planar vg = {rows, cols, (float *)vmap_g_prev}, ng = {rows, cols, (float *)nmap_g_prev};
+    orc_planar k1g = {rows, cols, (float *)ck1_g_prev}, k2g = {rows, cols, (float *)ck2_g_prev};
+    orc_sparse sp = {(f3 *)lambda_map, (f3 *)z_map_out, corres_out, NULL};
+    double s[29];
+    icp_step(Rcurr, v3(tcurr[0], tcurr[1], tcurr[2]), &vc, &nc, &k1c, &k2c, Rprev_inv,
+             v3(tprev[0], tprev[1], tprev[2]), fx, fy, cx, cy, &vg, &ng, &k1g, &k2g, icp_weight_prev,
+             dist_thresh, angle_thresh, 0, 0, use_weight, &sp, s);
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            double v = s[shift++];
+            if (j == 6) b_out[i] = v; else A_out[j * 6 + i] = A_out[i * 6 + j] = v;
+        }
+    residual_out[0] = s[27]; residual_out[1] = s[28];
+    return 0;
+}
+int orc_update_lambda_map(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float Rprev_inv[9],
+                          const float tprev[3], const float *vmap_g_prev, const int32_t *corres, const float *z_map,
+                          float *lambda_map, int rows, int cols)
+{
+    orc_planar vc = {rows, cols, (float *)vmap_curr}, vg = {rows, cols, (float *)vmap_g_prev};
+    orc_sparse sp = {(f3 *)lambda_map, (f3 *)z_map, (int32_t *)corres, NULL};
+    sparse_update_lambda(Rcurr, v3(tcurr[0], tcurr[1], tcurr[2]), &vc, Rprev_inv, v3(tprev[0], tprev[1], tprev[2]), &vg, &sp);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ O3: RGBResidual reduce.cu:957-1154 */
 static void rgb_residual_core(int rows, int cols, const int16_t *dIdx, const int16_t *dIdy, const float *lastDepth,
                               const float *nextDepth, const uint8_t *lastImage, const uint8_t *nextImage, float minScale,

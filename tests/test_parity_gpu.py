@@ -522,6 +522,94 @@ def test_icp_step_seam(oracle_lib_built, gpu_available):
     g.close()
 
 
+def test_icp_step_sparse_seam(oracle_lib_built, gpu_available):
+    """hrbf_icp_step_sparse / hrbf_update_lambda_map (icpStep with useSparse, updateLambdaMap) on caller-owned device
+    images against the oracle: sums, z_thrinkMap, corresICP and the updated lambdaMap bit for bit, over three
+    iterations.  The multiplier image starts with random vectors of up to 1.5 m / mu so that both branches of the
+    shrink operator run; with lambda = 0 the first iteration equals the plain seam; an independent numpy evaluation
+    checks z and the multiplier update of the matched pixels."""
+    import torch
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    K = (132.0, 132.0, 80.0, 60.0)
+    z = scenes.corner_depth(W, H, *K)
+    r = scenes.pixel_rays(W, H, *K)
+    P = r * z[..., None]
+    dx = np.zeros_like(P); dy = np.zeros_like(P)
+    dx[:, 1:-1] = P[:, 2:] - P[:, :-2]; dy[1:-1] = P[2:] - P[:-2]
+    n = np.cross(dx, dy); ln = np.linalg.norm(n, axis=-1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-12), 0); n = np.where(n[..., 2:3] < 0, -n, n)
+    v = np.stack([P[..., 0], P[..., 1], P[..., 2], np.ones_like(z)]).astype(np.float32)
+    nn = np.stack([n[..., 0], n[..., 1], n[..., 2], np.ones_like(z)]).astype(np.float32)
+    v[0][z <= 0] = np.nan; nn[0][ln[..., 0] <= 0] = np.nan
+    kk = np.zeros_like(v); kk[3] = 0.5
+    rng = np.random.default_rng(9)
+    w = rng.uniform(0.1, 3.0, (H, W)).astype(np.float32)
+    Rc = np.eye(3, dtype=np.float32); Rc[0, 1] = -0.004; Rc[1, 0] = 0.004
+    tc = np.array([0.003, -0.002, 0.004], np.float32)
+    I3 = np.eye(3, dtype=np.float32); t0 = np.zeros(3, np.float32)
+    lib = oracle_lib_built.load()
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    g = HRBFFusion(default_params(W, H, *K, max_surfels=1024))
+    dv, dn, dk, dw = (torch.from_numpy(a).cuda() for a in (v, nn, kk, w))
+
+    def both(lam):
+        zo = np.full((H, W, 3), 7.0, np.float32); co = np.full((H, W, 2), 5, np.int32)
+        A0 = np.zeros(36); b0 = np.zeros(6); r0 = np.zeros(2)
+        lib.orc_icp_step_sparse(pp(Rc), pp(tc), pp(v), pp(nn), pp(kk), pp(kk), pp(I3), pp(t0), *K, pp(v), pp(nn), pp(kk),
+                                pp(kk), pp(w), H, W, 0.1, 0.342, 1, pp(lam), pp(zo), pp(co), pp(A0), pp(b0), pp(r0))
+        dl = torch.from_numpy(lam).cuda(); dz = torch.full((H, W, 3), 7.0, device="cuda"); dc = torch.full((H, W, 2), 5, dtype=torch.int32, device="cuda")
+        A1 = np.zeros(36); b1 = np.zeros(6); r1 = np.zeros(2)
+        rc = g.lib.hrbf_icp_step_sparse(g.h, pp(Rc), pp(tc), dp(dv), dp(dn), dp(dk), dp(dk), pp(I3), pp(t0), *K, dp(dv),
+                                        dp(dn), dp(dk), dp(dk), dp(dw), H, W, 0.1, 0.342, 1, dp(dl), dp(dz), dp(dc),
+                                        pp(A1), pp(b1), pp(r1))
+        assert rc == 0
+        assert np.array_equal(A0, A1) and np.array_equal(b0, b1) and np.array_equal(r0, r1)
+        assert np.array_equal(bits(zo), bits(dz.cpu().numpy())) and np.array_equal(co, dc.cpu().numpy())
+        lam_o = lam.copy()
+        lib.orc_update_lambda_map(pp(Rc), pp(tc), pp(v), pp(I3), pp(t0), pp(v), pp(co), pp(zo), pp(lam_o), H, W)
+        assert g.lib.hrbf_update_lambda_map(g.h, pp(Rc), pp(tc), dp(dv), pp(I3), pp(t0), dp(dv), dp(dc), dp(dz), dp(dl), H, W) == 0
+        assert np.array_equal(bits(lam_o), bits(dl.cpu().numpy()))
+        return (A0, b0, r0), zo, co, lam_o
+
+    # lambda = 0: the plain seam's system, z = 0 everywhere
+    A_p = np.zeros(36); b_p = np.zeros(6); r_p = np.zeros(2)
+    lib.orc_icp_step(pp(Rc), pp(tc), pp(v), pp(nn), pp(kk), pp(kk), pp(I3), pp(t0), *K, pp(v), pp(nn), pp(kk), pp(kk),
+                     pp(w), H, W, 0.1, 0.342, 1, pp(A_p), pp(b_p), pp(r_p))
+    (A0, b0, r0), zo, co, lam1 = both(np.zeros((H, W, 3), np.float32))
+    assert np.array_equal(A0, A_p) and np.array_equal(b0, b_p) and np.array_equal(r0, r_p) and not zo.any()
+    assert (co[..., 0] >= 0).sum() == int(r0[1])
+    # random multipliers: both shrink branches, then two more iterations fed with the updated multipliers
+    lam = (rng.standard_normal((H, W, 3)) * rng.uniform(0, 15.0, (H, W, 1))).astype(np.float32)
+    for it in range(3):
+        lam_in = lam
+        _, zo, co, lam = both(lam_in)
+        m = co[..., 0] >= 0
+        hit = np.linalg.norm(zo, axis=-1) > 0
+        if it == 0:
+            assert hit.sum() > 100 and (m & ~hit).sum() > 100
+        # independent fp64 check on the matched pixels: z = beta(|h|) h, lambda' = lambda + mu (s - d - z) where x > 0
+        Pm = np.moveaxis(v[:3].astype(np.float64), 0, -1)
+        s_ = Pm @ Rc.astype(np.float64).T + tc
+        d_ = Pm[np.clip(co[..., 1], 0, H - 1), np.clip(co[..., 0], 0, W - 1)]
+        h = s_ - d_ + lam_in.astype(np.float64) / 10.0
+        hn = np.linalg.norm(h, axis=-1)
+        alpha = 0.1 ** (2.0 / 3.0)
+        beta = (alpha / np.maximum(hn, 1e-30) + 1.0) / 2.0
+        for _ in range(3):
+            beta = 1.0 - 0.05 * np.maximum(hn, 1e-30) ** -1.5 * beta ** -0.5
+        beta = np.where(hn <= alpha + 0.05 / np.sqrt(alpha), 0.0, beta)
+        near = np.abs(hn - (alpha + 0.05 / np.sqrt(alpha))) < 1e-4          # fp32 / fp64 may disagree at the threshold
+        sel = m & ~near
+        np.testing.assert_allclose(zo[sel], (beta[..., None] * h)[sel], rtol=2e-4, atol=2e-5)
+        upd = sel & (co[..., 0] > 0)
+        np.testing.assert_allclose(lam[upd], (lam_in + 10.0 * (s_ - d_ - zo))[upd], rtol=2e-4, atol=2e-3)
+        keep = m & (co[..., 0] == 0)
+        assert np.array_equal(lam[keep], lam_in[keep]) and np.array_equal(lam[~m], lam_in[~m])
+    g.close()
+
+
 def test_rgb_and_so3_step_seams(oracle_lib_built, gpu_available):
     """hrbf_so3_step, hrbf_rgb_residual, hrbf_rgb_step on caller-owned device images == oracle: the correspondence
     image byte for byte, count / sigma and every normal-equation entry bit for bit."""
