@@ -419,3 +419,94 @@ def test_sparse_icp_tracks_and_downweights_an_outlier_slab(oracle_lib_built):
     gt = frames[3][2][:3, 3]
     e_plain, e_sparse = np.linalg.norm(res[0][1][:3, 3] - gt), np.linalg.norm(res[1][1][:3, 3] - gt)
     assert e_sparse <= e_plain + 1e-3, (e_plain, e_sparse)
+
+
+def test_preprocessing_on_a_fronto_parallel_plane(oracle_lib_built):
+    """P1-P3, P5 on a constant-depth frame, from the formulas alone: the bilateral filter of a constant is the constant
+    (depth_bilateral.frag:16-67), the metric depth is value * depthFactor, vertices are (x - cx) z / fx with x taken at
+    INTEGER pixel coordinates (depth_vertex_normal_radius.frag:25-29), the normal is the optical axis, the surfel
+    radius sqrt(2) z / f (surfels.glsl:19-32: min(2 r, r / |n_z|)) times the initial multiplier, and the confidence
+    exp(-(r / r_max)^2 / 0.72) (surfels.glsl:34-46)."""
+    W, H, f = 160, 120, 132.0
+    cx, cy = 80.0, 60.0
+    p = default_params(W, H, f, f, cx, cy, max_surfels=1 << 16)
+    o = oracle_lib_built.Oracle(p)
+    z0 = 1.25
+    d = np.full((H, W), int(round(z0 * 5000)), np.uint16)
+    o.upload_frame(scenes.gray_rgb(W, H), d)
+    for st in ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS", "CONFIDENCE"):
+        o.run_stage(st)
+    df = o.get_image("DEPTH_FILTERED")
+    assert np.abs(df - float(d[0, 0])).max() < 2e-2                      # raw units; fp32 sum of 169 equal weights
+    assert np.array_equal(o.get_image("DEPTH_METRIC"), np.full((H, W), np.float32(d[0, 0]) * np.float32(1.0 / 5000.0), np.float32))
+    vf = o.get_image("VERTEX_FILTERED"); n = o.get_image("NORMAL"); rad = o.get_image("RADIUS"); conf = o.get_image("CONFIDENCE")
+    ys, xs = np.mgrid[0:H, 0:W]
+    inner = (slice(8, H - 8), slice(8, W - 8))
+    zf = vf[..., 2][inner]
+    assert np.abs(zf - z0).max() < 1e-5
+    np.testing.assert_allclose(vf[..., 0][inner], ((xs - cx) * vf[..., 2] / f)[inner], atol=2e-6)
+    np.testing.assert_allclose(vf[..., 1][inner], ((ys - cy) * vf[..., 2] / f)[inner], atol=2e-6)
+    nz = n[..., :3][inner]
+    assert np.abs(np.abs(nz[..., 2]) - 1.0).max() < 1e-4 and np.abs(nz[..., :2]).max() < 1e-2
+    np.testing.assert_allclose(rad[inner], p.init_radius_multiplier * np.sqrt(2.0) * z0 / f, rtol=2e-4)
+    r = np.hypot(xs + 0.5 - cx, ys + 0.5 - cy) / np.hypot(W / 2.0, H / 2.0)
+    np.testing.assert_allclose(conf, np.exp(-r * r / 0.72), rtol=2e-5)
+    o.close()
+
+
+def test_depth_cuts(oracle_lib_built):
+    """depth_bilateral.frag / depth_metric_*.frag: raw values below 0.3 m or beyond the cut-off give no depth"""
+    W, H = 160, 120
+    p = default_params(W, H, 132.0, 132.0, 80.0, 60.0, max_surfels=1 << 16, depth_cutoff=3.0)
+    o = oracle_lib_built.Oracle(p)
+    d = np.full((H, W), 5000, np.uint16)
+    d[:, :40] = 1400          # 0.28 m: too near
+    d[:, 120:] = 15500        # 3.1 m: beyond the cut-off
+    d[50:60, 70:80] = 0       # invalid
+    o.upload_frame(scenes.gray_rgb(W, H), d)
+    o.run_stage("FILTER_DEPTH"); o.run_stage("METRICISE")
+    for name in ("DEPTH_METRIC", "DEPTH_METRIC_FILTERED"):
+        m = o.get_image(name)
+        assert not m[:, :40].any() and not m[:, 120:].any() and not m[50:60, 70:80].any(), name
+        assert np.abs(m[20:40, 50:65] - 1.0).max() < 1e-3, name
+    o.close()
+
+
+def test_clean_drops_stale_unstable_surfels_only(oracle_lib_built):
+    """copy_unstable.vert:143-153: an unstable surfel (confidence below the threshold) not updated for more than 200
+    ticks is dropped; a stable one of the same age, or an unstable one seen 200 ticks ago, stays.  All four are placed
+    behind the camera so that only the age rule can apply."""
+    W, H, f = 160, 120, 132.0
+    p = default_params(W, H, f, f, 80.0, 60.0, max_surfels=1 << 12)
+    o = oracle_lib_built.Oracle(p)
+    thr = p.confidence_threshold
+    m = np.zeros((4, 20), np.float32)
+    m[:, :3] = [[0, 0, -2.0], [0.1, 0, -2.0], [0.2, 0, -2.0], [0.3, 0, -2.0]]
+    m[:, 3] = [thr - 1, thr + 1, thr - 1, thr - 1]                  # conf
+    m[:, 6] = 1.0                                                    # init time
+    m[:, 7] = [99.0, 99.0, 100.0, 101.0]                             # last time: ages 201, 201, 200, 199 at tick 300
+    m[:, 8:11] = [0, 0, 1]; m[:, 11] = 0.01
+    o.upload_map(m)
+    o.set_tick(300)
+    o.run_stage("PREDICT_INDICES"); o.run_stage("CLEAN")
+    out = o.download_map()
+    assert out.shape[0] == 3
+    assert np.array_equal(out[:, 0], np.float32([0.1, 0.2, 0.3]))    # survivors keep their order
+    o.close()
+
+
+def test_velocity_weighting_formula(oracle_lib_built):
+    """HRBFFusion.cpp:1112-1123: weighting = max(1 - min(max(|dt|, |dtheta|), 0.01) / 0.01, 0.5) * weightMultiplier,
+    from the pose change of a frame whose poses are replayed (load_trajectory)"""
+    W, H, f = 160, 120, 132.0
+    p = default_params(W, H, f, f, 80.0, 60.0, max_surfels=1 << 16, load_trajectory=1)
+    z = scenes.plane_depth(W, H, f, f, 80.0, 60.0, (0.0, 0.0, 1.0), 1.5)
+    rgb, d = scenes.gray_rgb(W, H), scenes.to_u16(z)
+    for step, wmul, expect in ((0.0, 1.0, 1.0), (0.004, 1.0, 0.6), (0.004, 2.0, 1.2), (0.02, 1.0, 0.5)):
+        o = oracle_lib_built.Oracle(p)
+        T = np.eye(4, dtype=np.float32)
+        o.set_pose(T); o.process_frame(rgb, d)
+        T[0, 3] = step
+        o.set_pose(T); o.process_frame(rgb, d, weight_multiplier=wmul)
+        assert abs(o.get_weighting() - expect) < 2e-4, (step, wmul, o.get_weighting())
+        o.close()
