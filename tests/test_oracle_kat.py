@@ -510,3 +510,52 @@ def test_velocity_weighting_formula(oracle_lib_built):
         o.set_pose(T); o.process_frame(rgb, d, weight_multiplier=wmul)
         assert abs(o.get_weighting() - expect) < 2e-4, (step, wmul, o.get_weighting())
         o.close()
+
+
+def test_rgb_step_matches_an_fp64_evaluation(lib):
+    """rgbStep (reduce.cu:717-808) re-evaluated in fp64 numpy from the oracle's own correspondence image: robust weight
+    1 / (sigma + |diff|), Jacobian row from the Sobel gradients at the live pixel and the back-projected point at the
+    model pixel, A = sum w J^T J, b = sum w J^T r.  Agreement to fp32 rounding of the per-pixel rows."""
+    from hrbffusion3d_amd import synth
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    f0, f1 = synth.frame(3, W, H, noise=True), synth.frame(4, W, H, noise=True)
+    grey = lambda rgb: (0.114 * rgb[..., 0] + 0.299 * rgb[..., 1] + 0.587 * rgb[..., 2]).astype(np.uint8)
+    last_img, next_img = np.ascontiguousarray(grey(f0[0])), np.ascontiguousarray(grey(f1[0]))
+    dep = lambda d: np.where(d > 0, d.astype(np.float32) / 5000.0, np.nan).astype(np.float32)
+    last_d, next_d = dep(f0[1]), dep(f1[1])
+    gi = next_img.astype(np.int32)
+    dIdx = np.zeros((H, W), np.int16); dIdy = np.zeros((H, W), np.int16)
+    dIdx[:, 1:-1] = 4 * (gi[:, 2:] - gi[:, :-2]); dIdy[1:-1] = 4 * (gi[2:] - gi[:-2])
+    a = 0.01
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    krk = (K @ R @ np.linalg.inv(K)).astype(np.float32); kt = (K @ np.array([0.004, -0.002, 0.003])).astype(np.float32)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    z = np.nan_to_num(last_d, nan=0.0)
+    cloud = np.ascontiguousarray(np.stack([(xs - cx) * z / fx, (ys - cy) * z / fy, z], -1).astype(np.float32))
+    co = np.zeros((H * W, 6), np.int16); df = np.zeros(H * W, np.float32)
+    c0, s0 = C.c_longlong(), C.c_longlong()
+    lib.orc_rgb_residual(25.0, _p(dIdx), _p(dIdy), _p(last_d), _p(next_d), _p(last_img), _p(next_img), H, W, _p(kt), _p(krk),
+                         _p(co), _p(df), C.byref(c0), C.byref(s0))
+    ok = co[:, 4] != 0
+    assert ok.sum() == c0.value > 1000
+    # the residual itself: next intensity at the live pixel minus last intensity at the projected pixel
+    u0, v0, x1, y1 = (co[ok, k].astype(int) for k in range(4))
+    np.testing.assert_array_equal(df[ok], next_img[y1, x1].astype(np.float32) - last_img[v0, u0].astype(np.float32))
+    assert s0.value == int(np.rint((df[ok].astype(np.float64) ** 2).sum()))
+    for sigma, use_grad in ((float(np.sqrt(c0.value)), 0), (-1.0, 0)):
+        A = np.zeros(36); b = np.zeros(6); r = np.zeros(2)
+        lib.orc_rgb_step(_p(co), _p(df), sigma, _p(cloud), fx, fy, _p(dIdx), _p(dIdy), use_grad, H, W, _p(A), _p(b), _p(r))
+        d = df[ok].astype(np.float64)
+        w = 1.0 / (sigma + np.abs(d)) if sigma != -1.0 else np.ones_like(d)
+        cp = cloud[v0, u0].astype(np.float64)
+        gx = 0.125 * w * dIdx[y1, x1]; gy = 0.125 * w * dIdy[y1, x1]
+        iz = 1.0 / cp[:, 2]
+        j0 = gx * fx * iz; j1 = gy * fy * iz; j2 = -(j0 * cp[:, 0] + j1 * cp[:, 1]) * iz
+        J = np.stack([j0, j1, j2, -cp[:, 2] * j1 + cp[:, 1] * j2, cp[:, 2] * j0 - cp[:, 0] * j2, -cp[:, 1] * j0 + cp[:, 0] * j1], 1)
+        rr = -w * d
+        A_ref = J.T @ J; b_ref = J.T @ rr
+        np.testing.assert_allclose(A.reshape(6, 6), A_ref, rtol=1e-4, atol=1e-6 * np.abs(A_ref).max())
+        np.testing.assert_allclose(b, b_ref, rtol=1e-4, atol=1e-5 * np.abs(b_ref).max())
+        assert r[1] == c0.value and abs(r[0] - (rr * rr).sum()) <= 1e-4 * (rr * rr).sum()
