@@ -543,16 +543,15 @@ static void st_clean(hrbf_context *c)
                      counts_next(c) + gk, sh.count_ub, sh.d_stats, c->cap, c->d_clean_tex, sh.d_keep_flags, sh.d_tile_count,
                      sh.d_tile_done, c->max_tiles, ring ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
                      ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
-                     last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0);
+                     last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0,
+                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4 : nullptr);
         if (last) {
             const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
             sh.count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
         }
     }
     shard_allgather_counts(c, counts_next(c));
-    if (ring) {
-        hipMemcpyAsync(c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4, c->sh[0].d_stats, sizeof(uint32_t) * 4,
-                       hipMemcpyDeviceToDevice, c->stream);
+    if (ring) {   // the statistics were parked in the ring slot by the pass's own last kernel
         c->ring_head++;
         if (c->ring_valid < HRBF_RING) c->ring_valid++;
     }

@@ -739,11 +739,13 @@ __global__ void k_zero_u32(uint32_t *p, int n)
     if (i < n) p[i] = 0u;
 }
 // end of the fuse pass: re-arm the record flags, the tile counters and tile_done for the next frame
-__global__ void k_zero_flags(int32_t *p, int n, uint32_t *tile_count, uint32_t *tile_done, int ntiles)
+__global__ void k_zero_flags(int32_t *p, int n, uint32_t *tile_count, uint32_t *tile_done, int ntiles,
+                             const uint32_t *__restrict__ stats, uint32_t *__restrict__ stats_ring_slot)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
     if (i < ntiles) { tile_count[(size_t)i * TC_STRIDE] = 0; tile_done[i] = 0; }
+    if (stats_ring_slot && i < 4) stats_ring_slot[i] = stats[i];   // per-frame item statistics for the event ring
 }
 __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
@@ -828,7 +830,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
-                  int n_records, int zero_records)
+                  int n_records, int zero_records, uint32_t *stats_ring_slot)
 {
     const int Qfull = (cam.W / 2) * (cam.H / 2);
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
@@ -853,8 +855,10 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     if (e1) hipEventRecord(e1, s);
     const int zq = zero_records ? Qfull : 0;
     int nz = zq > (int)tiles ? zq : (int)tiles;
+    if (stats_ring_slot && nz < 4) nz = 4;
     if (nz > 0)   // an empty shard that takes no appends has nothing to re-arm
-        hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, zq, tile_count, tile_done, (int)tiles);
+        hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, zq, tile_count, tile_done, (int)tiles,
+                           stats, stats_ring_slot);
 }
 
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P)

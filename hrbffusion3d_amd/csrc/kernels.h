@@ -61,7 +61,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
                   int n_records /* Q on the shard that takes the appends (the last one), else 0 */,
-                  int zero_records /* re-arm the record flags at the end */);
+                  int zero_records /* re-arm the record flags at the end */,
+                  uint32_t *stats_ring_slot /* nullable: the pass's 4 item statistics are copied here by its last kernel */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
