@@ -161,6 +161,10 @@ static void free_scratch(ShardScratch &x)
     for (void *p : q) if (p) hipFree(p);
     memset(&x, 0, sizeof(x));
 }
+static float4 *map_plane(const MapPlanes &m, int k)
+{
+    switch (k) { case 0: return m.p0; case 1: return m.p1; case 2: return m.p2; case 3: return m.p3; default: return m.p4; }
+}
 static uint32_t *counts_live(hrbf_context *c) { return c->d_counts + (size_t)c->target * HRBF_MAX_SHARDS; }
 static uint32_t *counts_next(hrbf_context *c) { return c->d_counts + (size_t)(1 - c->target) * HRBF_MAX_SHARDS; }
 static ShardRef shard_ref(hrbf_context *c, int k) { ShardRef r = {counts_live(c), c->shard_first + k, c->G}; return r; }
@@ -1321,8 +1325,8 @@ extern "C" int hrbf_map_rebalance(hrbf_handle c)
         const size_t so = moves[5 * i + 2], d_o = moves[5 * i + 3], len = moves[5 * i + 4];
         const bool src_local = a >= first && a < first + c->nsh, dst_local = b >= first && b < first + c->nsh;
         for (int pl = 0; pl < 5; ++pl) {
-            float4 *sp = src_local ? (&c->sh[a - first].map.p0)[pl] + so : nullptr;
-            float4 *dp = dst_local ? (&tmp[b - first].p0)[pl] + d_o : nullptr;
+            float4 *sp = src_local ? map_plane(c->sh[a - first].map, pl) + so : nullptr;
+            float4 *dp = dst_local ? map_plane(tmp[b - first], pl) + d_o : nullptr;
             if (src_local && dst_local) hipMemcpyAsync(dp, sp, sizeof(float4) * len, hipMemcpyDeviceToDevice, c->stream);
             else if (src_local) g_rccl.Send(sp, len * 4, kNcclUint32, b, c->comm.comm, c->stream);
             else if (dst_local) g_rccl.Recv(dp, len * 4, kNcclUint32, a, c->comm.comm, c->stream);
