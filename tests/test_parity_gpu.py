@@ -219,6 +219,36 @@ def test_edge_cases_empty_and_invalid_depth(pair):
     assert g.surfel_count() > 0
 
 
+def test_two_contexts_interleaved(gpu_available):
+    """two contexts in one process (different resolutions, their own streams, graphs and maps) fed alternately give the
+    same bits as each of them run alone: nothing is shared between contexts but the library's constant tables"""
+    from hrbffusion3d_amd.api import HRBFFusion
+
+    def params(W, H):
+        fx, fy, cx, cy = synth.intrinsics(W, H)
+        return default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 18)
+
+    sizes = [(160, 120), (320, 240)]
+    frames = {sz: [synth.frame(k, sz[0], sz[1], noise=True) for k in range(6)] for sz in sizes}
+    alone = {}
+    for sz in sizes:
+        g = HRBFFusion(params(*sz))
+        for rgb, d, _ in frames[sz]:
+            g.process_frame(rgb, d)
+        alone[sz] = (g.get_pose(), g.download_map(), g.get_image("PRED_VERTEX"))
+        g.close()
+    gs = {sz: HRBFFusion(params(*sz)) for sz in sizes}
+    for k in range(6):
+        for sz in sizes:
+            gs[sz].process_frame(frames[sz][k][0], frames[sz][k][1])
+    for sz in sizes:
+        pose, m, pv = alone[sz]
+        assert np.array_equal(bits(pose), bits(gs[sz].get_pose()))
+        assert np.array_equal(bits(m), bits(gs[sz].download_map()))
+        assert np.array_equal(bits(pv), bits(gs[sz].get_image("PRED_VERTEX")))
+        gs[sz].close()
+
+
 @pytest.mark.parametrize("cap", [9000, 20000])
 def test_map_at_capacity(pair, cap):
     """maximum size: a map whose capacity is hit by the seed frame (cap 9000 < first frame's surfels) or by the
