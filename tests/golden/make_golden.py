@@ -44,7 +44,37 @@ def run(make):
     return out
 
 
+VARIANTS = {
+    "sparse_icp": dict(use_sparse_icp=1),
+    "corr_search": dict(icp_use_corr_search=1),
+    "rgb_only": dict(rgb_only=1),
+    "icp_only": dict(icp_weight=100.0),
+    "no_so3_no_pyramid": dict(so3=0, pyramid=0, fast_odom=1),
+    "gauss_central_diff": dict(use_bilateral=0, normal_estimation_pca=0.0),
+}
+
+
+def run_variants(make):
+    """the same pair under the registration / pre-processing options: pose, counts and a digest of the whole map"""
+    f = lambda n: np.array(Image.open(os.path.join(HERE, n + ".png")))
+    out = {}
+    for name, kw in VARIANTS.items():
+        o = make(default_params(max_surfels=1 << 20, **kw))
+        for c, d in (("1c", "1d"), ("2c", "2d")):
+            o.process_frame(f(c), f(d))
+        out[name + "_pose"] = o.get_pose()
+        out[name + "_stats"] = o.fuse_stats()
+        out[name + "_icp"] = np.array(o.last_icp(), np.float32)
+        out[name + "_map_sha"] = digest(o.download_map())
+        out[name + "_pred_sha"] = digest(o.get_image("PRED_VERTEX"))
+        o.close()
+    return out
+
+
 if __name__ == "__main__":
     out = run(lambda p: Oracle(p, omp=True))
     np.savez_compressed(os.path.join(HERE, "gputest_pair_expected.npz"), **out)
     print("wrote", len(out), "arrays; frame-2 pose:\n", out["f2_pose"])
+    var = run_variants(lambda p: Oracle(p, omp=True))
+    np.savez_compressed(os.path.join(HERE, "gputest_pair_variants.npz"), **var)
+    print("wrote", len(var), "variant arrays")

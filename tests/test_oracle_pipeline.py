@@ -21,6 +21,24 @@ def test_png_pair_end_to_end_matches_golden(oracle_lib_built, png_pair):
         assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
 
 
+def test_png_pair_variants_match_golden(oracle_lib_built, png_pair):
+    """the same pair under six registration / pre-processing options (sparse ICP, windowed search, RGB only, ICP only,
+    no SO3 / pyramid, Gauss filter + central-difference normals) against the committed digests"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(GOLD), "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    got = mg.run_variants(lambda p: oracle_lib_built.Oracle(p, omp=True))
+    exp = np.load(os.path.join(os.path.dirname(GOLD), "gputest_pair_variants.npz"))
+    assert set(got) == set(exp.files)
+    for k in exp.files:
+        a, b = np.asarray(got[k]), exp[k]
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
+    poses = [exp[n + "_pose"] for n in mg.VARIANTS]
+    assert len({p.tobytes() for p in poses}) == len(poses)        # every option really changes the result
+    for p in poses:
+        assert np.linalg.norm(p[:3, 3]) < 0.05
+
+
 def test_png_pair_sanity(oracle_lib_built):
     """Pass criteria of SURVEY §8d config 1: runs end to end, small motion, map not empty."""
     exp = np.load(GOLD)

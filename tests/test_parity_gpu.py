@@ -84,6 +84,29 @@ def test_png_pair_matches_oracle_and_golden(pair, png_pair):
                 assert np.array_equal(sha, exp[tag + "sha_" + name]), name
 
 
+def test_png_pair_variants_match_golden_digests(gpu_available, png_pair):
+    """the GPU path alone against the committed fixture tests/golden/gputest_pair_variants.npz (made by
+    tests/golden/make_golden.py from the oracle): six registration / pre-processing options on the reference's PNG pair"""
+    import hashlib
+    import importlib.util
+    from hrbffusion3d_amd.api import HRBFFusion
+    gdir = os.path.dirname(GOLD)
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    exp = np.load(os.path.join(gdir, "gputest_pair_variants.npz"))
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    for name, kw in mg.VARIANTS.items():
+        g = HRBFFusion(default_params(max_surfels=1 << 20, **kw))
+        for rgb, d in png_pair:
+            g.process_frame(rgb, d)
+        assert np.array_equal(bits(g.get_pose()), bits(exp[name + "_pose"])), name
+        assert np.array_equal(g.fuse_stats(), exp[name + "_stats"]), name
+        assert np.array_equal(bits(np.array(g.last_icp(), np.float32)), bits(exp[name + "_icp"])), name
+        assert np.array_equal(sha(g.download_map()), exp[name + "_map_sha"]), name
+        assert np.array_equal(sha(g.get_image("PRED_VERTEX")), exp[name + "_pred_sha"]), name
+        g.close()
+
+
 @pytest.mark.parametrize("noise", [False, True])
 def test_tracked_synthetic_stream(pair, noise):
     """QVGA synthetic stream against a pre-seeded map, tracking ON: 10 frames, every image, the map
