@@ -29,6 +29,7 @@ EXPORTS = [
     "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
+    "hrbf_get_fuse_ring_parts", "hrbf_get_status",
 ]
 
 
@@ -76,6 +77,7 @@ def load_library():
     lib.hrbf_upload_frame.argtypes = [vp, vp, vp]; lib.hrbf_run_stage.argtypes = [vp, i32]
     lib.hrbf_bootstrap.argtypes = [vp, vp, vp]
     lib.hrbf_get_fuse_ring.argtypes = [vp, i32, vp, vp]; lib.hrbf_reset_fuse_ring.argtypes = [vp]
+    lib.hrbf_get_fuse_ring_parts.argtypes = [vp, i32, vp, vp, vp]; lib.hrbf_get_status.argtypes = [vp, vp, i32]
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
@@ -288,6 +290,23 @@ class HRBFFusion:
         if n < 0:
             raise HrbfError("hrbf_get_fuse_ring failed")
         return ms[:n].copy(), st[:n].copy()
+
+    def fuse_ring_parts(self, max_frames=1024):
+        """(merge_ms, stream_ms, stats8) per frame: F2 = k_apply_merges, F3 = k_clean_flags + k_fuse_stream;
+        stats8 = {in, merged, appended, out, -, -, moved, status}"""
+        mm = np.zeros(max_frames, np.float32); ms = np.zeros(max_frames, np.float32); st = np.zeros((max_frames, 8), np.uint32)
+        n = self.lib.hrbf_get_fuse_ring_parts(self.h, max_frames, _p(mm), _p(ms), _p(st))
+        if n < 0:
+            raise HrbfError("hrbf_get_fuse_ring_parts failed")
+        return mm[:n].copy(), ms[:n].copy(), st[:n].copy()
+
+    STATUS_CAPACITY, STATUS_INTERNAL_BOUND, STATUS_SO3_TIMEOUT = 1, 2, 4
+
+    def status(self, clear=False):
+        """sticky condition bits (HRBF_STATUS_*); synchronises"""
+        v = np.zeros(1, np.uint32)
+        self._check(self.lib.hrbf_get_status(self.h, _p(v), int(bool(clear))))
+        return int(v[0])
 
     def reset_fuse_ring(self):
         self.lib.hrbf_reset_fuse_ring(self.h)

@@ -50,7 +50,10 @@ struct MapShard {
     uint32_t count_ub;          // host upper bound of this shard's surfel count
     uint32_t *d_slot;           // per-surfel merge slot (lowest draw-order record wins)
     uint32_t *d_stats;
-    uint32_t *d_tile_count; uint32_t *d_tile_done;
+    uint32_t *d_tile_count[2];  // per-tile keep counts, double buffered: a pass zeroes the buffer the next pass uses
+    uint32_t tile_dirty[2];     // entries of each buffer that may be non-zero
+    int tile_par;               // buffer the next pass accumulates into
+    uint32_t *d_tile_done; uint32_t epoch;   // tile_done holds the epoch (pass counter) of the pass that raised it
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
 };
 // private projection outputs of the virtual shards k >= 1 (reduced into the context's own images)
@@ -106,8 +109,11 @@ struct hrbf_context {
     OdoBuffers odo;
     // timing
     int timing; hipEvent_t ev[12]; float timings[8];
-    // per-frame ring: HIP events bracketing ONLY the k_fuse_stream launch + its item statistics
-    hipEvent_t *ring_e0, *ring_e1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid;
+    // per-frame ring: HIP events bracketing the fuse pass — F2 (k_apply_merges: m0..m1) and F3 (k_clean_flags +
+    // k_fuse_stream: e0..e1), nothing else — + its statistics words
+    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid;
+    uint32_t ring_merge_head;   // ring slot the last merge events went to (a clean without a fuse has no F2 part)
+    uint32_t status;            // sticky HRBF_STATUS_* bits folded from the device on blocking calls
 };
 
 template <typename T>
@@ -142,7 +148,9 @@ static int alloc_shard(hrbf_context *c, MapShard &sh)
     int r = alloc_planes(c, sh.map, c->cap);
     if (!r) r = dalloc(&sh.d_slot, c->cap);
     if (!r) r = dalloc(&sh.d_stats, 8);
-    if (!r) r = dalloc(&sh.d_tile_count, (size_t)c->max_tiles * fuse_tile_count_stride());
+    if (!r) r = dalloc(&sh.d_tile_count[0], (size_t)c->max_tiles * fuse_tile_count_stride());
+    if (!r) r = dalloc(&sh.d_tile_count[1], (size_t)c->max_tiles * fuse_tile_count_stride());
+    sh.tile_dirty[0] = sh.tile_dirty[1] = 0; sh.tile_par = 0; sh.epoch = 0;
     if (!r) r = dalloc(&sh.d_tile_done, c->max_tiles);
     if (!r) r = dalloc(&sh.d_keep_flags, (size_t)c->cap + (size_t)c->Q + 64);
     sh.count_ub = 0;
@@ -151,9 +159,9 @@ static int alloc_shard(hrbf_context *c, MapShard &sh)
 static void free_shard(MapShard &sh)
 {
     free_planes(sh.map);
-    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count, sh.d_tile_done, sh.d_keep_flags};
+    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count[0], sh.d_tile_count[1], sh.d_tile_done, sh.d_keep_flags};
     for (void *p : q) if (p) hipFree(p);
-    sh.d_slot = sh.d_stats = sh.d_tile_count = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr;
+    sh.d_slot = sh.d_stats = sh.d_tile_count[0] = sh.d_tile_count[1] = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr;
 }
 static void free_scratch(ShardScratch &x)
 {
@@ -194,7 +202,9 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
         hrbf_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return HRBF_ERR_NODEVICE;
     }
+    if (p->max_surfels <= 0) { hrbf_set_error("max_surfels must be positive"); return HRBF_ERR_INVALID; }
     hrbf_context *c = (hrbf_context *)calloc(1, sizeof(hrbf_context));
+    if (!c) { hrbf_set_error("out of host memory"); return HRBF_ERR_DEVICE; }
     c->prm = *p; c->device = device;
     c->W = p->width; c->H = p->height; c->P = c->W * c->H; c->Q = (c->W / 2) * (c->H / 2);
     c->tick = 1;
@@ -230,8 +240,11 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming);
     for (int i = 0; i < 12; ++i) hipEventCreate(&c->ev[i]);
     c->ring_e0 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t)); c->ring_e1 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t));
-    for (int i = 0; i < HRBF_RING; ++i) { hipEventCreate(&c->ring_e0[i]); hipEventCreate(&c->ring_e1[i]); }
-    DA(c->d_stats_ring, (size_t)HRBF_RING * 4);
+    c->ring_m0 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t)); c->ring_m1 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t));
+    for (int i = 0; i < HRBF_RING; ++i) {
+        hipEventCreate(&c->ring_e0[i]); hipEventCreate(&c->ring_e1[i]); hipEventCreate(&c->ring_m0[i]); hipEventCreate(&c->ring_m1[i]);
+    }
+    DA(c->d_stats_ring, (size_t)HRBF_RING * 8);
     // odometry buffers
     for (int i = 0; i < HRBF_NUM_PYRS; ++i) {
         OdoLevel &L = c->odo.lv[i];
@@ -362,8 +375,12 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     for (int k = 0; k < 3; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->ev_stage[k]) hipEventDestroy(c->ev_stage[k]); }
     if (c->ev_count) hipEventDestroy(c->ev_count);
     for (int i = 0; i < 12; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->ring_e0) for (int i = 0; i < HRBF_RING; ++i) { if (c->ring_e0[i]) hipEventDestroy(c->ring_e0[i]); if (c->ring_e1[i]) hipEventDestroy(c->ring_e1[i]); }
-    free(c->ring_e0); free(c->ring_e1);
+    hipEvent_t *rings[] = {c->ring_e0, c->ring_e1, c->ring_m0, c->ring_m1};
+    for (hipEvent_t *r : rings) {
+        if (!r) continue;
+        for (int i = 0; i < HRBF_RING; ++i) if (r[i]) hipEventDestroy(r[i]);
+        free(r);
+    }
     if (c->d_stats_ring) hipFree(c->d_stats_ring);
     if (c->comm.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm.comm);
     if (c->d_submap_active) hipFree(c->d_submap_active);
@@ -468,10 +485,11 @@ static void st_init(hrbf_context *c)
     const int kl = c->G - 1 - c->shard_first;
     if (c->G > 1) hipMemsetAsync(counts_live(c), 0, sizeof(uint32_t) * HRBF_MAX_SHARDS, c->stream);
     for (int k = 0; k < c->nsh; ++k) c->sh[k].count_ub = 0;
+    c->ev_pending = false; c->ub_growth_since = 0;   // a count read-back still in flight describes the map that is being replaced
     if (kl >= 0 && kl < c->nsh) {
         launch_initialise(c->stream, c->cam, c->d_pose, c->d_vertex_raw, c->d_normal, c->d_rgb, c->d_curv1, c->d_curv2,
                           c->d_gradmag, c->prm.use_conf_eval, c->prm.conf_eval_epsilon, c->prm.curv_valid_threshold,
-                          c->d_init_flags, c->d_init_offs, c->sh[kl].map, c->cap, counts_live(c) + (c->G - 1));
+                          c->d_init_flags, c->d_init_offs, c->sh[kl].map, c->cap, counts_live(c) + (c->G - 1), c->sh[kl].d_stats + 7);
         c->sh[kl].count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
     }
     shard_allgather_counts(c, counts_live(c));
@@ -524,12 +542,14 @@ static void st_fuse(hrbf_context *c)
 {
     // association is replicated (it reads images only); each shard keeps the merge slots of its own surfels and applies
     // the merges that land on them
+    const bool ring = c->timing && c->G == 1;
     for (int k = 0; k < c->nsh; ++k)
         launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, c->index_submap, c->d_depth_metric,
                     c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf,
                     c->d_im_normrad, c->rec, c->d_rec_flag, c->d_rec_best, c->sh[k].d_slot, c->sh[k].map, shard_ref(c, k),
-                    c->sh[k].d_stats, c->prm.curv_valid_threshold);
-    c->fuse_tick = c->tick;
+                    c->sh[k].d_stats, c->prm.curv_valid_threshold, ring ? c->ring_m0[c->ring_head % HRBF_RING] : nullptr,
+                    ring ? c->ring_m1[c->ring_head % HRBF_RING] : nullptr);
+    c->fuse_tick = c->tick; c->ring_merge_head = c->ring_head;
 }
 static void st_clean(hrbf_context *c)
 {
@@ -541,21 +561,29 @@ static void st_clean(hrbf_context *c)
         const int gk = c->shard_first + k;
         const bool last = gk == c->G - 1;   // new surfels are appended at the end of the global order
         MapShard &sh = c->sh[k];
+        const int cur = sh.tile_par;
+        uint32_t dirty[2] = {sh.tile_dirty[cur], sh.tile_dirty[1 - cur]};
         launch_clean(c->stream, c->cam, c->d_pose, c->prm.max_depth_processed, c->prm.confidence_threshold,
                      c->prm.curv_valid_threshold, c->tick, c->prm.clean_window_multiplier,
                      (c->map_dirty || c->fuse_tick != c->tick) ? 1 : 0, sh.map, c->rec, c->d_rec_flag, counts_live(c) + gk,
-                     counts_next(c) + gk, sh.count_ub, sh.d_stats, c->cap, c->d_clean_tex, sh.d_keep_flags, sh.d_tile_count,
-                     sh.d_tile_done, c->max_tiles, ring ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
+                     counts_next(c) + gk, sh.count_ub, sh.d_stats, c->cap, c->d_clean_tex, sh.d_keep_flags,
+                     sh.d_tile_count[cur], sh.d_tile_count[1 - cur], dirty, sh.d_tile_done, ++sh.epoch,
+                     c->max_tiles, ring ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
                      ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
                      last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0,
-                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 4 : nullptr);
+                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr);
+        sh.tile_dirty[cur] = dirty[0]; sh.tile_dirty[1 - cur] = dirty[1]; sh.tile_par = 1 - cur;
         if (last) {
             const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
             sh.count_ub = ub > c->cap ? c->cap : (uint32_t)ub;
         }
     }
     shard_allgather_counts(c, counts_next(c));
-    if (ring) {   // the statistics were parked in the ring slot by the pass's own last kernel
+    if (ring) {   // the statistics are parked in the ring slot behind the pass
+        if (c->ring_merge_head != c->ring_head || c->fuse_tick != c->tick) {   // no merge this frame: an empty F2 interval
+            hipEventRecord(c->ring_m0[c->ring_head % HRBF_RING], c->stream);
+            hipEventRecord(c->ring_m1[c->ring_head % HRBF_RING], c->stream);
+        }
         c->ring_head++;
         if (c->ring_valid < HRBF_RING) c->ring_valid++;
     }
@@ -885,6 +913,9 @@ extern "C" int hrbf_upload_map(hrbf_handle c, const float *in, size_t n)
     HIP_CHECK(hipMemcpyAsync(counts_live(c), cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->map_dirty = 1;
+    // a count read-back armed before the upload describes the OLD map: folding it into count_ub later would size the
+    // next fuse pass for fewer surfels than the device holds
+    c->ev_pending = false; c->ub_growth_since = 0;
     return HRBF_OK;
 }
 
@@ -971,23 +1002,37 @@ extern "C" int hrbf_get_timings(hrbf_handle c, float out[8])
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) out[6] = ms;   // first projection (+confidence)
     return HRBF_OK;
 }
-extern "C" int hrbf_get_fuse_ring(hrbf_handle c, int max_frames, float *kernel_ms, uint32_t *stats4)
+static int fuse_ring_read(hrbf_context *c, int max_frames, float *merge_ms, float *stream_ms, uint32_t *stats, int nstat)
 {
-    if (!c || !kernel_ms || !stats4) return -1;
     hipSetDevice(c->device);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
     int n = (int)c->ring_valid; if (n > max_frames) n = max_frames;
-    uint32_t *h = (uint32_t *)malloc(sizeof(uint32_t) * 4 * HRBF_RING);
-    if (hipMemcpy(h, c->d_stats_ring, sizeof(uint32_t) * 4 * HRBF_RING, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return -1; }
+    uint32_t *h = (uint32_t *)malloc(sizeof(uint32_t) * 8 * HRBF_RING);
+    if (hipMemcpy(h, c->d_stats_ring, sizeof(uint32_t) * 8 * HRBF_RING, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return -1; }
     for (int i = 0; i < n; ++i) {   // oldest first among the last n
         uint32_t slot = (c->ring_head - (uint32_t)n + (uint32_t)i) % HRBF_RING;
-        float ms = 0.0f;
+        float ms = 0.0f, mm = 0.0f;
         if (hipEventElapsedTime(&ms, c->ring_e0[slot], c->ring_e1[slot]) != hipSuccess) ms = -1.0f;
-        kernel_ms[i] = ms;
-        memcpy(&stats4[i * 4], &h[slot * 4], sizeof(uint32_t) * 4);
+        if (hipEventElapsedTime(&mm, c->ring_m0[slot], c->ring_m1[slot]) != hipSuccess) mm = -1.0f;
+        stream_ms[i] = ms; merge_ms[i] = mm;
+        memcpy(&stats[i * nstat], &h[slot * 8], sizeof(uint32_t) * (size_t)nstat);
     }
     free(h);
     return n;
+}
+extern "C" int hrbf_get_fuse_ring(hrbf_handle c, int max_frames, float *kernel_ms, uint32_t *stats4)
+{
+    if (!c || !kernel_ms || !stats4 || max_frames < 0) return -1;
+    float *mm = (float *)malloc(sizeof(float) * (size_t)(max_frames + 1));
+    const int n = fuse_ring_read(c, max_frames, mm, kernel_ms, stats4, 4);
+    for (int i = 0; i < n; ++i) kernel_ms[i] = (kernel_ms[i] < 0.0f || mm[i] < 0.0f) ? -1.0f : kernel_ms[i] + mm[i];   // F2 + F3
+    free(mm);
+    return n;
+}
+extern "C" int hrbf_get_fuse_ring_parts(hrbf_handle c, int max_frames, float *merge_ms, float *stream_ms, uint32_t *stats8)
+{
+    if (!c || !merge_ms || !stream_ms || !stats8 || max_frames < 0) return -1;
+    return fuse_ring_read(c, max_frames, merge_ms, stream_ms, stats8, 8);
 }
 extern "C" int hrbf_reset_fuse_ring(hrbf_handle c) { if (!c) return -1; c->ring_head = 0; c->ring_valid = 0; return 0; }
 extern "C" int hrbf_set_load_trajectory(hrbf_handle c, int v) { if (!c) return HRBF_ERR_INVALID; c->prm.load_trajectory = v; return HRBF_OK; }
@@ -1060,6 +1105,32 @@ extern "C" int hrbf_update_model(hrbf_handle c, const float *delta16_colmajor, i
         launch_update_model(c->stream, c->sh[k].map, counts_live(c) + c->shard_first + k, c->sh[k].count_ub, c->d_delta, n);
     c->map_dirty = 1;   // positions moved: the next clean re-checks everything
     HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
+
+// sticky status bits (include/hrbf_mi355.h HRBF_STATUS_*): folded from the device by this call (it synchronises)
+extern "C" int hrbf_get_status(hrbf_handle c, uint32_t *flags, int clear)
+{
+    if (!c || !flags) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    for (int k = 0; k < c->nsh; ++k) {
+        uint32_t v = 0;
+        HIP_CHECK(hipMemcpyAsync(&v, c->sh[k].d_stats + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (v & 1u) c->status |= HRBF_STATUS_INTERNAL_BOUND;
+        if (v & 2u) c->status |= HRBF_STATUS_CAPACITY;
+    }
+    {
+        const int so3 = odo_read_timeouts(c->stream, c->odo.state, clear);
+        if (so3 < 0) { hrbf_set_error("get_status: read-back failed"); return HRBF_ERR_DEVICE; }
+        if (so3 > 0) c->status |= HRBF_STATUS_SO3_TIMEOUT;
+    }
+    *flags = c->status;
+    if (clear) {
+        c->status = 0;
+        for (int k = 0; k < c->nsh; ++k) HIP_CHECK(hipMemsetAsync(c->sh[k].d_stats + 7, 0, sizeof(uint32_t), c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     return HRBF_OK;
 }
 

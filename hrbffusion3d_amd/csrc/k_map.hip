@@ -94,7 +94,10 @@ __global__ void k_init_scatter(Cam cam, const DevPose *__restrict__ dp, const fl
     out.p4[n] = curv2[i];
 }
 
-__global__ void k_clamp_count(uint32_t *count, uint32_t cap) { if (*count > cap) *count = cap; }
+__global__ void k_clamp_count(uint32_t *count, uint32_t cap, uint32_t *status)
+{
+    if (*count > cap) { *count = cap; if (status) atomicOr(status, 2u); }   // seed frame larger than the map: HRBF_STATUS_CAPACITY
+}
 
 // ------------------------------------------------------------------------------------------
 // M1: projection (index_map.vert:34-66 + GL point raster + GL_LESS z-test)
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
 }
 
 // F2: sparse in-place merge (update.vert:51-115): only the winning record of each surfel applies.
-__global__ __launch_bounds__(256) void k_apply_merges(int Q, int tick, RecPlanes rec,
+#define MERGE_THREADS 256
+__global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick, RecPlanes rec,
                                                       const int32_t *__restrict__ rec_flag,
                                                       const uint32_t *__restrict__ rec_best, uint32_t *__restrict__ slot,
                                                       MapPlanes m, ShardRef sh, uint32_t *__restrict__ merged, float curvThr)
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     const Rigid tinv = cp.dp->tinv;
     const float ftime = (float)cp.time;
     cp.full_check |= (int)stats[4];   // raised by k_apply_merges (see there)
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[2] = 0;   // appended counter, accumulated by pass B
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[2] = 0; stats[5] = 0; stats[6] = 0; }   // appended, tile ticket, moved: pass B
     const uint32_t nrb = Q > 0 ? quarter_tile_blocks(cp.cam.W, cp.cam.H) : 0u;
     if (blockIdx.x < nrb) {
         __shared__ uint32_t s_hist[CLEAN_HIST];
@@ -605,10 +609,16 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
 
 // Pass B: in-place leftward move of the survivors + append of the records (see header comment).
 // A tile's output offset = sum of the keep counts of all earlier tiles, summed directly by the tile
-// (<= a few thousand L2-resident words): no scan kernel, no look-back chain.
-// The grid is sized to be fully co-resident (<= 1 workgroup of 512 threads per CU) and every workgroup walks its
-// tiles in increasing order, so a writer only ever waits for tile_done of a tile that is finished or
-// owned by a running workgroup; raising tile_done needs no wait -> placement-independent, no deadlock.
+// (<= a few thousand L2-resident words staged in LDS): no scan kernel, no look-back chain.
+// Forward progress does NOT depend on co-residency: tiles are handed out by an atomic ticket in increasing order, so
+// a tile a writer waits for (tile_done of a tile its output range overlaps, always a LOWER tile) was claimed earlier
+// by a workgroup that is already running, and raising tile_done needs no wait at all (it follows the tile's own
+// loads) -> no wait can cycle, whatever else occupies the device (other contexts, RCCL kernels, a smaller grid).
+// tile_done holds the EPOCH of the pass that raised it (a per-shard launch counter), the tile counters are double
+// buffered (this pass zeroes the buffer the next pass accumulates into) and the record flags are re-armed by the
+// lanes that move the records: the pass needs no re-arm kernel.
+// Tiles before the first one whose survivors change place (first tile that is not completely kept, or the tile that
+// holds the end of the map) are never touched and never written into: the ticket starts there.
 struct MoveSlot { float4 a, b, c, d, e; uint32_t it, o; bool keep; };
 
 __device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, const RecPlanes &rec, uint32_t N, float ftime)
@@ -635,51 +645,80 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlane
                                                               const uint32_t *__restrict__ count_in,
                                                               uint32_t *__restrict__ count_out,
                                                               uint32_t *__restrict__ stats, uint32_t cap,
-                                                              uint32_t *__restrict__ tile_done)
+                                                              uint32_t *__restrict__ tile_done, uint32_t epoch,
+                                                              uint32_t lds_tiles, uint32_t *__restrict__ tile_count_next,
+                                                              uint32_t nzero_next, int32_t *__restrict__ rec_flag_rearm)
 {
     constexpr int NWAVE = FUSE_THREADS / 64;
     __shared__ uint32_t s_wcnt[FUSE_IPT][NWAVE];
     __shared__ uint32_t s_psum[NWAVE];
+    __shared__ uint32_t s_first[NWAVE];
+    __shared__ uint32_t s_ticket;
     const uint32_t N = *count_in;
     const uint32_t total = N + (uint32_t)Q;
     const uint32_t num_tiles = (total + FUSE_TILE - 1) / FUSE_TILE;
     const uint32_t surfel_tiles = (N + FUSE_TILE - 1) / FUSE_TILE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float ftime = (float)time;
+    // the other tile-counter buffer is the one the NEXT pass accumulates into: zero what its last use left behind
+    for (uint32_t t = blockIdx.x * FUSE_THREADS + threadIdx.x; t < nzero_next; t += gridDim.x * FUSE_THREADS)
+        tile_count_next[(size_t)t * TC_STRIDE] = 0u;
     if (num_tiles == 0) {   // an empty shard that takes no appends this frame
         if (blockIdx.x == 0 && threadIdx.x == 0) { *count_out = 0; stats[0] = 0; stats[3] = 0; }
         return;
     }
+    if (num_tiles > lds_tiles) {   // the host's bound on the item count was too small: refuse loudly instead of corrupting
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *count_out = N < cap ? N : cap; stats[0] = N; stats[3] = N; atomicOr(&stats[7], 1u); }
+        return;
+    }
 
     // every tile count is staged in LDS once (one round of global loads per workgroup); the per-tile prefixes are
-    // then summed out of LDS — a workgroup walks 2-8 tiles and used to pay a dependent global round trip for each
+    // then summed out of LDS
     extern __shared__ uint32_t s_cnt[];
-    for (uint32_t t = threadIdx.x; t < num_tiles; t += FUSE_THREADS) s_cnt[t] = tile_count[(size_t)t * TC_STRIDE];
+    uint32_t first = num_tiles - 1;   // the last tile always "moves" (it holds the end of the map and/or the records)
+    for (uint32_t t = threadIdx.x; t < num_tiles; t += FUSE_THREADS) {
+        const uint32_t c = tile_count[(size_t)t * TC_STRIDE];
+        s_cnt[t] = c;
+        if ((c != FUSE_TILE || (t + 1u) * FUSE_TILE > N) && t < first) first = t;
+    }
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_down(first, d); first = o < first ? o : first; }
+    if (lane == 0) s_first[wid] = first;
     __syncthreads();
-
-    for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        const uint32_t base = tile * FUSE_TILE;
-        uint32_t psum = 0;
-        for (uint32_t t = threadIdx.x; t < tile; t += FUSE_THREADS) psum += s_cnt[t];
-        for (int d = 32; d > 0; d >>= 1) psum += __shfl_down(psum, d);
-        if (lane == 0) s_psum[wid] = psum;
-        __syncthreads();
-        uint32_t prefix = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVE; ++w) prefix += s_psum[w];
+    for (int w = 0; w < NWAVE; ++w) first = s_first[w] < first ? s_first[w] : first;
+    first = __builtin_amdgcn_readfirstlane(first);
+
+    uint32_t done_upto = first, prefix = first * FUSE_TILE;   // every tile before `first` is full: prefix(first) = first * TILE
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&stats[5], 1u);
+        __syncthreads();
+        const uint32_t tile = first + s_ticket;
+        if (tile >= num_tiles) break;
+        const uint32_t base = tile * FUSE_TILE;
+        {   // prefix of this tile = prefix of the previous tile this workgroup took + the counts in between (tickets grow)
+            uint32_t psum = 0;
+            for (uint32_t t = done_upto + threadIdx.x; t < tile; t += FUSE_THREADS) psum += s_cnt[t];
+            for (int d = 32; d > 0; d >>= 1) psum += __shfl_down(psum, d);
+            if (lane == 0) s_psum[wid] = psum;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) prefix += s_psum[w];
+            done_upto = tile;
+        }
         const uint32_t tile_total = s_cnt[tile];
         if (tile == num_tiles - 1 && threadIdx.x == 0) {
             const uint32_t tot = prefix + tile_total;
             *count_out = tot > cap ? cap : tot;
             stats[0] = N; stats[3] = tot > cap ? cap : tot;
+            if (tot > cap) atomicOr(&stats[7], 2u);   // capacity reached: surfels were dropped (HRBF_ERR_CAPACITY on the next blocking call)
         }
         const bool tile_has_surfels = base < N;
         const uint32_t n_surf_here = N > base ? (N - base < FUSE_TILE ? N - base : FUSE_TILE) : 0u;
         const bool moves = (prefix != base) || (tile_total != n_surf_here) || (base + FUSE_TILE > N);
         if (!moves) {   // nothing in this tile changes place: no load, no store
             if (threadIdx.x == 0)
-                __hip_atomic_store(&tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
+                __hip_atomic_store(&tile_done[tile], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();   // s_ticket / s_psum reuse
             continue;
         }
         MoveSlot s0, s1, s2, s3;
@@ -712,24 +751,36 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlane
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tile_has_surfels && threadIdx.x == 0)
-            __hip_atomic_store(&tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // wait until the source tiles our output range overlaps have finished reading
+            __hip_atomic_store(&tile_done[tile], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // wait until the source tiles our output range overlaps have finished reading (all of them were claimed before
+        // this one; tiles before `first` are never claimed and never written into: prefix >= first * TILE)
         if (tile_total > 0 && threadIdx.x < 64) {
             const uint32_t t_lo = prefix / FUSE_TILE;
             const uint32_t t_hi = (prefix + tile_total - 1) / FUSE_TILE;
-            for (uint32_t t = t_lo + (uint32_t)lane; t <= t_hi && t < surfel_tiles; t += 64)
-                if (t != tile)
-                    while (__hip_atomic_load(&tile_done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-                        __builtin_amdgcn_s_sleep(1);
+            for (uint32_t t = t_lo + (uint32_t)lane; t <= t_hi && t < surfel_tiles && t < tile; t += 64)
+                while (__hip_atomic_load(&tile_done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
         uint32_t appended = move_store(s0, m, N, cap) + move_store(s1, m, N, cap) + move_store(s2, m, N, cap) +
                             move_store(s3, m, N, cap);
-        if (base + FUSE_TILE > N) {   // only tiles that contain records count appends
+        if (base + FUSE_TILE > N) {   // only tiles that contain records count appends; their lanes re-arm the record flags
+            if (rec_flag_rearm) {
+                if (s0.it >= N && s0.it < total) rec_flag_rearm[s0.it - N] = 0;
+                if (s1.it >= N && s1.it < total) rec_flag_rearm[s1.it - N] = 0;
+                if (s2.it >= N && s2.it < total) rec_flag_rearm[s2.it - N] = 0;
+                if (s3.it >= N && s3.it < total) rec_flag_rearm[s3.it - N] = 0;
+            }
             for (int d = 32; d > 0; d >>= 1) appended += __shfl_down(appended, d);
             if (lane == 0 && appended) atomicAdd(&stats[2], appended);
         }
-        __syncthreads();   // s_wcnt / s_psum reuse
+        if (tile_has_surfels) {   // statistics: surfels that really changed slot (real traffic = 160 B each)
+            uint32_t mv = (uint32_t)(s0.keep && s0.it < N && s0.o != s0.it) + (uint32_t)(s1.keep && s1.it < N && s1.o != s1.it) +
+                          (uint32_t)(s2.keep && s2.it < N && s2.o != s2.it) + (uint32_t)(s3.keep && s3.it < N && s3.o != s3.it);
+            for (int d = 32; d > 0; d >>= 1) mv += __shfl_down(mv, d);
+            if (lane == 0 && mv) atomicAdd(&stats[6], mv);
+        }
+        __syncthreads();   // s_wcnt / s_psum / s_ticket reuse
     }
 }
 
@@ -738,14 +789,15 @@ __global__ void k_zero_u32(uint32_t *p, int n)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
-// end of the fuse pass: re-arm the record flags, the tile counters and tile_done for the next frame
-__global__ void k_zero_flags(int32_t *p, int n, uint32_t *tile_count, uint32_t *tile_done, int ntiles,
-                             const uint32_t *__restrict__ stats, uint32_t *__restrict__ stats_ring_slot)
+// instrumentation only (timing ring on): park the pass's item statistics {in, merged, appended, out, -, -, moved, status}
+__global__ void k_copy_stats(const uint32_t *__restrict__ stats, uint32_t *__restrict__ slot)
+{
+    if (threadIdx.x < 8) slot[threadIdx.x] = stats[threadIdx.x];
+}
+__global__ void k_zero_i32(int32_t *p, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
-    if (i < ntiles) { tile_count[(size_t)i * TC_STRIDE] = 0; tile_done[i] = 0; }
-    if (stats_ring_slot && i < 4) stats_ring_slot[i] = stats[i];   // per-frame item statistics for the event ring
 }
 __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
@@ -757,14 +809,14 @@ __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const float4 *vertex_raw, const float4 *normal,
                        const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
                        int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
-                       uint32_t cap, uint32_t *count)
+                       uint32_t cap, uint32_t *count, uint32_t *status)
 {
     int P = cam.W * cam.H;
     hipLaunchKernelGGL(k_init_flags, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, normal, curv1, curv2, thr, flags);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, flags, offs, P, count);
     hipLaunchKernelGGL(k_init_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, vertex_raw, normal, rgb, curv1,
                        curv2, gradmag, use_conf_eval, eps, flags, offs, out, cap);
-    hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap);
+    hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap, status);
 }
 
 void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
@@ -814,21 +866,24 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr)
+                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr, hipEvent_t m0, hipEvent_t m1)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
-    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 5);   // [0..3] statistics, [4] force-full-check flag
+    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 7);   // [0..3] statistics, [4] force-full-check flag, [5] ticket, [6] moved; [7] = sticky status
     hipLaunchKernelGGL(k_associate, dim3(quarter_tile_blocks(cam.W, cam.H)), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
                        rec_best, slot, sh);
-    hipLaunchKernelGGL(k_apply_merges, dim3((Q + 255) / 256), dim3(256), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
+    if (m0) hipEventRecord(m0, s);   // F2 (update.vert) is part of the roofline-timed fuse: SURVEY §8d "F2+F3"
+    hipLaunchKernelGGL(k_apply_merges, dim3((Q + MERGE_THREADS - 1) / MERGE_THREADS), dim3(MERGE_THREADS), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
                        sh, stats + 1, curvThr);
+    if (m1) hipEventRecord(m1, s);
 }
 
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
-                  const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
+                  const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_count_next,
+                  uint32_t *tile_dirty /* [2]: entries this / the other buffer may hold */, uint32_t *tile_done, uint32_t epoch,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
                   int n_records, int zero_records, uint32_t *stats_ring_slot)
 {
@@ -848,17 +903,23 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     if (Q > 0) fblocks += quarter_tile_blocks(cam.W, cam.H);   // ... behind the record workgroups
     hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
                        keep_flags, tile_count, stats);
-    uint32_t blocks = tiles < 256u ? tiles : 256u;   // co-resident: ONE 512-thread workgroup per CU (132 VGPR -> 12 waves/CU)
+    // any grid size is safe (ticketed tiles); one 512-thread workgroup per CU keeps every CU's load/store pipes busy
+    uint32_t blocks = tiles < 256u ? tiles : 256u;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), sizeof(uint32_t) * (size_t)tiles, s, time, m, rec, Q, keep_flags, tile_count,
-                       count_in, count_out, stats, cap, tile_done);
+    const size_t lds = sizeof(uint32_t) * (size_t)(tiles ? tiles : 1);
+    static size_t lds_allowed = 48 * 1024;
+    if (lds > lds_allowed) {   // maps beyond ~25 M surfels per shard
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), lds, s, time, m, rec, Q, keep_flags, tile_count,
+                       count_in, count_out, stats, cap, tile_done, epoch, tiles, tile_count_next, tile_dirty[1],
+                       (zero_records && Q > 0) ? rec_flag : nullptr);
     if (e1) hipEventRecord(e1, s);
-    const int zq = zero_records ? Qfull : 0;
-    int nz = zq > (int)tiles ? zq : (int)tiles;
-    if (stats_ring_slot && nz < 4) nz = 4;
-    if (nz > 0)   // an empty shard that takes no appends has nothing to re-arm
-        hipLaunchKernelGGL(k_zero_flags, dim3((nz + 255) / 256), dim3(256), 0, s, rec_flag, zq, tile_count, tile_done, (int)tiles,
-                           stats, stats_ring_slot);
+    tile_dirty[0] = tiles; tile_dirty[1] = 0;   // this buffer now holds `tiles` counts, the other one is clean
+    if (zero_records && Q == 0)   // a rank of a sharded map that takes no appends still re-arms its (replicated) record flags
+        hipLaunchKernelGGL(k_zero_i32, dim3((Qfull + 255) / 256), dim3(256), 0, s, rec_flag, Qfull);
+    if (stats_ring_slot) hipLaunchKernelGGL(k_copy_stats, dim3(1), dim3(64), 0, s, stats, stats_ring_slot);
 }
 
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P)

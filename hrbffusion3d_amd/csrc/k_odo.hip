@@ -37,8 +37,10 @@ struct OdoState {
     float last_icp_error, last_icp_count;
     float sigmaVal;
     unsigned int ticket;              // last-workgroup election of the fused reduce+solve kernels
-    unsigned int bar;                 // arrival counter of the grid barrier (persistent SO3 kernel)
-    int bar_timeout;                  // set if a barrier spin ran into its bound (never expected)
+    // persistent SO3 kernel: per-iteration chunk tickets and completed-chunk counters, exit counter (publisher election)
+    unsigned int so3_ticket[12], so3_chunks_done[12], so3_exit;
+    int bar_timeout;                  // this frame: a bounded poll of the SO3 kernel gave up (never expected)
+    int bar_timeouts_total;           // sticky count of such frames (hrbf_get_status)
 };
 
 size_t odo_state_bytes() { return sizeof(OdoState); }
@@ -619,7 +621,10 @@ __device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__
     st->so3_done = cfg.so3 ? 0 : 1;
     st->gn_break = 0;
     st->res_icp[0] = st->res_icp[1] = 0.0f;
-    st->ticket = 0u; st->bar = 0u;
+    st->ticket = 0u;
+    for (int k = 0; k < 12; ++k) { st->so3_ticket[k] = 0u; st->so3_chunks_done[k] = 0u; }
+    st->so3_exit = 0u;
+    st->bar_timeouts_total += st->bar_timeout; st->bar_timeout = 0;
     if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
     if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
 }
@@ -812,26 +817,6 @@ __global__ __launch_bounds__(RB) void k_so3_reduce(OdoLevel L, OdoState *st, lon
     if (fused_solve && elect_last_workgroup(&st->ticket)) so3_solve_block(st, part, totals, 2, cfg, gn_level);
 }
 
-// Grid barrier of the persistent SO3 kernel (its grid is launched only when it fits the device at once).  Data crosses
-// it only through agent-scope atomics (the slot rows), so no cache maintenance is needed: wave 0 — the wave that
-// issued this workgroup's slot atomics — waits until they are performed, arrives with one relaxed atomic and polls.
-// The poll is bounded: a barrier that cannot complete sets bar_timeout and lets the kernel finish with wrong
-// numbers instead of hanging the device.
-__device__ __forceinline__ void grid_barrier(unsigned int *ctr, unsigned int target, int *timeout_flag)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 18)) { *timeout_flag = 1; break; }
-        }
-    }
-    __syncthreads();
-}
-
 // LDS copy of the SO3 part of the state: every workgroup of the persistent kernel advances its own copy with the
 // same deterministic arithmetic, so nothing but the slot sums has to be exchanged
 struct So3Local {
@@ -842,15 +827,26 @@ struct So3Local {
     float basis[9], kinv[9], krlr[9];
 };
 
-// all SO3 iterations in one launch: per iteration products -> slot set `it` -> grid barrier -> every
-// workgroup folds the set and takes the step on its LDS copy.  Stops as soon as the alignment has converged
-// (the per-iteration launches had to be issued regardless).  Workgroup 0 publishes the final state.
+// All SO3 iterations in one launch.  The level-2 image is cut into `nchunk` chunks of RB pixels; per iteration the
+// running workgroups draw chunks from a ticket, add their exact products into slot set `it` and count the chunk as
+// done; a workgroup then waits until all chunks of the iteration are done (claiming further chunks while any is
+// unclaimed), folds the set and takes the step on its LDS copy of the state.  Every chunk a waiter depends on was
+// claimed by a workgroup that is running and finishes it without waiting for anybody, so the kernel makes progress
+// with ANY number of resident workgroups — other contexts, RCCL kernels or a grid larger than the device cannot
+// deadlock it.  A workgroup that starts late replays the iterations from the retained slot sets (one set per
+// iteration) with the same deterministic arithmetic.  The ticket of iteration it+1 is drawn together with the
+// arrival of iteration it, so the usual (co-resident) case pays no extra round trip.  The loop ends at convergence
+// (typically 4 iterations).  The LAST workgroup to leave publishes the final state: by then every other workgroup
+// has read the initial one.
 __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st, long long *__restrict__ part,
-                                                       OdoConfig cfg, int gn_level)
+                                                       OdoConfig cfg, int gn_level, unsigned int nchunk)
 {
     __shared__ So3Local S;
     __shared__ long long s_tot[33];
+    __shared__ unsigned int s_chunk, s_next;
+    __shared__ int s_more;
     if (threadIdx.x == 0) {
+        s_chunk = __hip_atomic_fetch_add(&st->so3_ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int k = 0; k < 9; ++k) {
             S.resultR[k] = st->resultR[k]; S.lastResultR[k] = st->lastResultR[k]; S.R_lr[k] = st->R_lr[k];
             S.basis[k] = st->basis[k]; S.kinv[k] = st->kinv[k]; S.krlr[k] = st->krlr[k];
@@ -858,16 +854,44 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
         S.so3_lastError = st->so3_lastError; S.so3_lastCount = st->so3_lastCount; S.so3_done = st->so3_done;
     }
     __syncthreads();
-    const int i = blockIdx.x * RB + threadIdx.x;
+    unsigned int chunk = s_chunk;
     for (int it = 0; it < SO3_ITERS; ++it) {
         if (S.so3_done) break;                      // identical in every workgroup
         long long *set = part + (size_t)it * ODO_SLOTS * 33;
-        float row4[11];
+        bool drawn = false;
+        for (;;) {
+            if (chunk < nchunk) {
+                float row4[11];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
-        const bool valid = so3_pixel(L, &S, i, row4);
-        block_reduce_exact<11>(row4, valid, set);
-        grid_barrier(&st->bar, (unsigned int)(it + 1) * gridDim.x, &st->bar_timeout);
+                for (int k = 0; k < 11; ++k) row4[k] = 0.0f;
+                const bool valid = so3_pixel(L, &S, (int)(chunk * RB + threadIdx.x), row4);
+                block_reduce_exact<11>(row4, valid, set);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {   // wave 0 issued this workgroup's slot atomics: the release fence orders them first
+                if (chunk < nchunk) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_fetch_add(&st->so3_chunks_done[it], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!drawn) s_next = __hip_atomic_fetch_add(&st->so3_ticket[it + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int more = 0, spins = 0;
+                for (;;) {
+                    if (__hip_atomic_load(&st->so3_chunks_done[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nchunk) break;
+                    if (__hip_atomic_load(&st->so3_ticket[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunk) {
+                        const unsigned int c = __hip_atomic_fetch_add(&st->so3_ticket[it], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (c < nchunk) { s_chunk = c; more = 1; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) { st->bar_timeout = 1; break; }   // cannot happen by construction; loud if it does
+                }
+                s_more = more;
+            }
+            drawn = true;
+            __syncthreads();
+            if (!s_more) break;
+            chunk = s_chunk;
+            __syncthreads();   // s_chunk / s_more are rewritten by the next round
+        }
         if (threadIdx.x < 33) {
             long long v[ODO_SLOTS];
 #pragma unroll
@@ -878,11 +902,13 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
             for (int b = 0; b < ODO_SLOTS; ++b) t += v[b];
             s_tot[threadIdx.x] = t;
         }
+        chunk = s_next;
         __syncthreads();
         if (threadIdx.x == 0) so3_step(&S, s_tot, cfg);
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(&st->so3_exit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
         for (int k = 0; k < 9; ++k) {
             st->resultR[k] = S.resultR[k]; st->lastResultR[k] = S.lastResultR[k]; st->R_lr[k] = S.R_lr[k];
             st->basis[k] = S.basis[k]; st->kinv[k] = S.kinv[k]; st->krlr[k] = S.krlr[k];
@@ -1562,11 +1588,10 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         hipLaunchKernelGGL(k_odo_prepare, dim3((P + 255) / 256, HRBF_NUM_PYRS), dim3(256), 0, s, all, ob.state, dp, cfg, rgb,
                            cfg.so3 ? -1 : gn_level, ob.so3_part);
     }
-    // O2: SO3 pre-alignment on level 2: one persistent launch for all iterations when its grid fits the device at
-    // once (75 workgroups at VGA against 256 CUs; the stream is in-order, so nothing else is resident), else one
-    // launch per iteration whose last workgroup takes the step.  A plain launch on purpose:
-    // hipLaunchCooperativeKernel serialises against the whole device and cost 30 frames/s in the benchmark; the
-    // barrier polls are bounded, so a placement surprise cannot hang the GPU (it poisons the pose instead).
+    // O2: SO3 pre-alignment on level 2: one persistent launch for all iterations (75 chunks at VGA).  A plain launch on
+    // purpose: hipLaunchCooperativeKernel serialises against the whole device and cost 30 frames/s in the benchmark,
+    // and the kernel does not need co-residency (see k_so3_persistent).  The row-sharded multi-GPU path keeps one
+    // launch per iteration (the all-reduce sits between the reduction and the step).
     if (cfg.so3) {
         const OdoLevel &L = ob.lv[2];
         const int nb = (L.rows * L.cols + RB - 1) / RB;
@@ -1592,12 +1617,11 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(RB), 0, s, ob.state, ob.so3_part, ob.totals + 176, 0, cfg,
                                    it == SO3_ITERS - 1 ? gn_level : -1);
             }
-        } else if (2 * (long long)nb <= capacity)   // at most half of the slots: no dependence on the placement policy
-            hipLaunchKernelGGL(k_so3_persistent, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, cfg, gn_level);
-        else
-            for (int it = 0; it < SO3_ITERS; ++it)
-                hipLaunchKernelGGL(k_so3_reduce, dim3(nb), dim3(RB), 0, s, L, ob.state, ob.so3_part, ob.totals + 176, cfg, 1,
-                                   it == SO3_ITERS - 1 ? gn_level : -1, 0, L.rows * L.cols);
+        } else {   // any grid size is safe (ticketed chunks); one workgroup per chunk while the device can hold them all
+            const long long grid = capacity > 0 && nb > capacity ? capacity : nb;
+            hipLaunchKernelGGL(k_so3_persistent, dim3((unsigned)grid), dim3(RB), 0, s, L, ob.state, ob.so3_part, cfg, gn_level,
+                               (unsigned int)nb);
+        }
     }
     // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration.  On the single-GPU path the whole loop (57
     // launches whose arguments only depend on the configuration and on which of the two image-pointer parities is
@@ -1968,4 +1992,14 @@ int run_rgb_step(hipStream_t s, const int16_t *corres, const float *corres_diff,
         }
     residual_out[0] = sums[27]; residual_out[1] = sums[28];
     return HRBF_OK;
+}
+
+// sticky count of frames whose SO3 kernel ran into its poll bound (hrbf_get_status); synchronises the stream
+int odo_read_timeouts(hipStream_t s, OdoState *st, int clear)
+{
+    int v[2] = {0, 0};
+    if (hipMemcpyAsync(v, &st->bar_timeout, sizeof(v), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (clear) { const int z[2] = {0, 0}; hipMemcpyAsync(&st->bar_timeout, z, sizeof(z), hipMemcpyHostToDevice, s); hipStreamSynchronize(s); }
+    return v[0] + v[1];
 }

@@ -35,7 +35,7 @@ void launch_confidence(hipStream_t s, const Cam &cam, const float *gradmag, floa
 void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const float4 *vertex_raw, const float4 *normal,
                        const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
                        int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
-                       uint32_t cap, uint32_t *count);
+                       uint32_t cap, uint32_t *count, uint32_t *status /* nullable: |= 2 when the seed frame exceeds cap */);
 // projection = launch_project (z-buffer of packed keys) + launch_resolve (winner gather).  With a sharded map the
 // z-buffers are min-reduced between the two and the resolved images sum-reduced afterwards (a pixel has one owner,
 // every other shard writes zeros); `rearm` lets the last local shard leave the z-buffer empty for the next pass.
@@ -54,15 +54,20 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr);
+                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr,
+                 hipEvent_t m0, hipEvent_t m1 /* nullable: bracket the merge kernel (F2) */);
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
-                  const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_done,
+                  const float4 *clean_tex, uint8_t *keep_flags,
+                  uint32_t *tile_count /* this pass's counters (zero on entry) */,
+                  uint32_t *tile_count_next /* the other buffer: zeroed by this pass for the next one */,
+                  uint32_t *tile_dirty /* [2] host bookkeeping: entries {this, other} buffer may hold; updated */,
+                  uint32_t *tile_done, uint32_t epoch /* per-shard pass counter, > 0 */,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
                   int n_records /* Q on the shard that takes the appends (the last one), else 0 */,
                   int zero_records /* re-arm the record flags at the end */,
-                  uint32_t *stats_ring_slot /* nullable: the pass's 4 item statistics are copied here by its last kernel */);
+                  uint32_t *stats_ring_slot /* nullable (timing ring): the pass's 8 statistics words are copied here afterwards */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
@@ -137,6 +142,7 @@ struct OdoSources {   // images the odometry is initialised from (selected on de
 size_t odo_state_bytes();
 size_t odo_slot_bytes();
 void odo_release(OdoBuffers &ob);   // destroys the cached graphs
+int odo_read_timeouts(hipStream_t s, OdoState *st, int clear);   // frames whose SO3 kernel hit its poll bound (sticky)
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
 // full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
 // Row-sharded registration (SURVEY §8e sharding 1): every rank holds the full pyramids and reduces the image rows

@@ -202,13 +202,22 @@ int hrbf_update_model(hrbf_handle h, const float *delta16_colmajor, int n);
  * hrbf_enable_timing(h,2) records only the two events per frame that feed hrbf_get_fuse_ring. */
 int hrbf_enable_timing(hrbf_handle h, int on);
 int hrbf_get_timings(hrbf_handle h, float out_ms[8]);
-/* ring of the last <= 1024 frames (timing enabled): duration in ms of the fuse streaming kernel alone
- * (HIP events on the context's stream bracketing only that launch) and its {in, merged, appended, out}
- * surfel counts; returns the number of frames written, oldest first. */
+/* ring of the last <= 1024 frames (timing enabled): duration in ms of the fuse pass — F2 + F3 of SURVEY.md §8d:
+ * k_apply_merges (update.vert) + k_clean_flags + k_fuse_stream (copy_unstable.*), HIP events on the context's stream
+ * bracketing exactly those launches — and its {in, merged, appended, out} surfel counts; returns the number of
+ * frames written, oldest first.  hrbf_get_fuse_ring_parts gives the two parts separately and 8 statistics words:
+ * {in, merged, appended, out, -, -, moved (surfels that changed slot in the in-place compaction), status}. */
 int hrbf_get_fuse_ring(hrbf_handle h, int max_frames, float *kernel_ms, uint32_t *stats4);
+int hrbf_get_fuse_ring_parts(hrbf_handle h, int max_frames, float *merge_ms, float *stream_ms, uint32_t *stats8);
 int hrbf_reset_fuse_ring(hrbf_handle h);
 /* build-specific: toggle trajectory replay (globalInputLoadTrajectory) between frames */
 int hrbf_set_load_trajectory(hrbf_handle h, int v);
+/* sticky condition bits, folded from the device by this (synchronising) call; clear != 0 resets them.  The per-frame
+ * path never blocks, so conditions the reference would exit() on are reported here instead of from hrbf_process_frame. */
+#define HRBF_STATUS_CAPACITY 1u        /* the map reached max_surfels: new surfels were dropped (cf. HRBF_ERR_CAPACITY) */
+#define HRBF_STATUS_INTERNAL_BOUND 2u  /* a fuse pass was launched with a stale host bound on the surfel count and refused to run */
+#define HRBF_STATUS_SO3_TIMEOUT 4u     /* the SO3 pre-alignment kernel ran into its poll bound: that frame's pose is NaN */
+int hrbf_get_status(hrbf_handle h, uint32_t *flags, int clear);
 /* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
 int hrbf_get_fuse_stats(hrbf_handle h, uint32_t out[4]);
 
