@@ -18,9 +18,21 @@ RELIEF_AMP = 0.03
 RELIEF_LAMBDA = 0.40
 
 
-def intrinsics(width=640, height=480):
-    s = width / 640.0
-    return 528.0 * s, 528.0 * s, 320.0 * s, 240.0 * s
+# Intrinsics of BASELINE configs 2 / 3 (dataset documentation): fx != fy and an off-centre principal
+# point.  ICL-NUIM publishes fy = -480 (image y axis pointing up); most pipelines run it with +480.
+TUM_FR1 = (517.3, 516.5, 318.6, 255.3)
+ICL_NUIM = (481.2, 480.0, 319.5, 239.5)
+ICL_NUIM_NEG = (481.2, -480.0, 319.5, 239.5)
+KINECT2_512x424 = (366.1, 364.7, 258.3, 203.9)     # a non-4:3 sensor (512 x 424)
+
+
+def intrinsics(width=640, height=480, K=None):
+    """(fx, fy, cx, cy).  K = None: the synthetic default (528, 528, 320, 240) at 640 px width, scaled with the width.
+    K given: taken as is, in pixels of THIS resolution (no scaling)."""
+    if K is None:
+        s = width / 640.0
+        return 528.0 * s, 528.0 * s, 320.0 * s, 240.0 * s
+    return tuple(float(v) for v in K)
 
 
 def _rot_yx(yaw, pitch):
@@ -66,9 +78,10 @@ def _relief(x, y):
     return RELIEF_AMP * np.sin(2 * np.pi * x / RELIEF_LAMBDA) * np.sin(2 * np.pi * y / RELIEF_LAMBDA)
 
 
-def raycast(T_wc, width=640, height=480):
-    """Returns (t, hit point world, z-depth) for every pixel centre-of-texel ray through (x, y) integer coords."""
-    fx, fy, cx, cy = intrinsics(width, height)
+def raycast(T_wc, width=640, height=480, K=None):
+    """Returns (t, hit point world, z-depth) for every pixel centre-of-texel ray through (x, y) integer coords.
+    K = (fx, fy, cx, cy) in pixels of this resolution (None: the scaled synthetic default)."""
+    fx, fy, cx, cy = intrinsics(width, height, K)
     u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
     d_c = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], axis=-1)
     R, o = T_wc[:3, :3], T_wc[:3, 3]
@@ -99,10 +112,10 @@ def raycast(T_wc, width=640, height=480):
     return t, ph, t  # d_c.z == 1 -> z-depth equals t
 
 
-def frame(k, width=640, height=480, noise=False, depth_units=5000.0):
+def frame(k, width=640, height=480, noise=False, depth_units=5000.0, K=None):
     """(rgb uint8 HxWx3, depth uint16 HxW, T_wc float32 4x4) of frame k."""
     T = camera_pose(k)
-    _, ph, z = raycast(T, width, height)
+    _, ph, z = raycast(T, width, height, K)
     rgb = texture(ph)
     zz = z.copy()
     if noise:
@@ -144,14 +157,14 @@ def _surface_samples(spacing, rng):
     return np.concatenate(pts), np.concatenate(nrm), np.concatenate(k1), np.concatenate(k2)
 
 
-def seed_map(n_target=1_000_000, t_now=1, width=640):
+def seed_map(n_target=1_000_000, t_now=1, width=640, K=None):
     """AoS surfel array (N,20) float32 in the reference layout, N ~ n_target (>= n_target)."""
     rng = np.random.default_rng(SEED)
     area = 2 * (4 * HALF[0] * HALF[1] + 4 * HALF[0] * HALF[2] + 4 * HALF[1] * HALF[2]) + 4 * np.pi * SPH_R ** 2
     spacing = float(np.sqrt(area / (n_target * 1.01)))
     p, n, k1, k2 = _surface_samples(spacing, rng)
     N = p.shape[0]
-    fx = intrinsics(width)[0]
+    fx = intrinsics(width, K=K)[0]
     m = np.zeros((N, 20), np.float32)
     m[:, 0:3] = p
     m[:, 3] = rng.uniform(5.0, 20.0, N)

@@ -149,6 +149,64 @@ def test_tracked_vga_stream_against_large_map(pair):
     assert np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3]) < 0.02
 
 
+DATASET_K = {"tum_fr1": (synth.TUM_FR1, (640, 480)), "icl_nuim": (synth.ICL_NUIM, (640, 480)),
+             "icl_nuim_neg_fy": (synth.ICL_NUIM_NEG, (640, 480)), "kinect2_512x424": (synth.KINECT2_512x424, (512, 424))}
+
+
+@pytest.mark.parametrize("name", list(DATASET_K))
+def test_tracked_stream_with_dataset_intrinsics(pair, name):
+    """BASELINE configs 2 / 3 geometry: streams rendered with the TUM fr1 (517.3, 516.5, 318.6, 255.3) and ICL-NUIM
+    (481.2, +-480, 319.5, 239.5) intrinsics at 640x480 and with a non-4:3 sensor (512x424, fx != fy, off-centre) —
+    noisy depth, 32 tracked frames against a pre-seeded map.  Pose and surfel count bit-identical to the oracle after
+    EVERY frame, every image and the whole map (content and order) at frames 1, 2, 8, 16, 24 and 32, and the
+    trajectory stays near the analytic ground truth.  With fx == fy and a centred principal point (every other test)
+    a swapped fx/fy or cx/cy, or a W-for-H slip, would cancel; here it cannot (see also test_projection_site_kats)."""
+    K, (W, H) = DATASET_K[name]
+    seed = synth.seed_map(400_000, width=W, K=K)
+    p = default_params(W, H, *K, max_surfels=seed.shape[0] + 40 * (W // 2) * (H // 2))
+    o, g = pair(p)
+    rgb, d, T = synth.frame(0, W, H, noise=True, K=K)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
+    worst = 0.0
+    for k in range(1, 33):
+        rgb, d, T = synth.frame(k, W, H, noise=True, K=K)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert np.array_equal(bits(o.get_pose()), bits(g.get_pose())), "%s frame %d pose" % (name, k)
+        assert o.surfel_count() == g.surfel_count(), "%s frame %d count" % (name, k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+        if k in (1, 2, 8, 16, 24, 32):
+            assert_same_state(o, g, "%s frame %d" % (name, k))
+        worst = max(worst, float(np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3])))
+    assert worst < 0.03, worst
+    assert g.status() == 0
+
+
+@pytest.mark.parametrize("K", ["tum_quarter", "skewed"])
+def test_projection_site_kats(gpu_available, K):
+    """the HIP path against the independent numpy known answers of tests/kat_projection.py (the same checks pin the
+    oracle in tests/test_intrinsics_kat.py): back-projection, index-map projection and prediction rays with fx != fy and
+    an off-centre principal point; each must also DISAGREE with the expectation evaluated for swapped intrinsics."""
+    import kat_projection as kp
+    from hrbffusion3d_amd.api import HRBFFusion
+    K = kp.K_TUM_Q if K == "tum_quarter" else kp.K_SKEWED
+    W, H = 160, 120
+    g = HRBFFusion(default_params(W, H, *K, max_surfels=1 << 15))
+    out = kp.run_back_projection(g, W, H, K)
+    assert kp.back_projection_error(out, K, W, H) < 2e-6
+    assert kp.back_projection_error(out, kp.swapped(K), W, H) > 1e-2
+    T, m, px, py, pc = kp.make_projection_case(W, H, K)
+    out = kp.run_projection(g, T, m)
+    bad, err, hits = kp.projection_mismatch(out, T, m, K, W, H)
+    assert hits == px.size and bad == 0 and err < 5e-6
+    assert kp.projection_mismatch(out, T, m, kp.swapped(K), W, H)[0] > px.size // 2
+    out = kp.run_prediction_rays(g, W, H, K)
+    err, plane = kp.prediction_ray_error(out, K, W, H)
+    assert err < 2e-6 and plane < 1e-4
+    assert kp.prediction_ray_error(out, kp.swapped(K), W, H)[0] > 1e-2
+    g.close()
+
+
 def test_long_sequence_trajectory_and_determinism(gpu_available):
     """150 noisy QVGA frames from an empty map (frame 0 seeds it): the trajectory stays near the ground truth (ATE, the
     north star's other metric, against the stream's analytic poses) and a second run reproduces pose and map bit for
@@ -518,12 +576,13 @@ def test_sparse_icp_with_outlier_slab(pair, sharded):
     assert o.sparse_shrunk_count() > 1000
 
 
-def test_icp_step_seam(oracle_lib_built, gpu_available):
-    """hrbf_icp_step on caller-owned device maps == oracle (bit-exact sums) ~= fp64 numpy (1e-5)."""
+@pytest.mark.parametrize("K", [(132.0, 132.0, 80.0, 60.0), (129.325, 129.125, 79.65, 63.825), (141.0, 129.0, 71.5, 66.25)])
+def test_icp_step_seam(oracle_lib_built, gpu_available, K):
+    """hrbf_icp_step on caller-owned device maps == oracle (bit-exact sums) ~= fp64 numpy (1e-5); symmetric intrinsics,
+    TUM fr1 proportions and a set with fx, fy 9 % apart (reduce.cu:326-331 projects with fx, cx / fy, cy separately)."""
     import torch
     from hrbffusion3d_amd.api import HRBFFusion
     W, H = 160, 120
-    K = (132.0, 132.0, 80.0, 60.0)
     z = scenes.corner_depth(W, H, *K)
     r = scenes.pixel_rays(W, H, *K)
     P = r * z[..., None]
