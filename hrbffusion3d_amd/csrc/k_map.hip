@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
 }
 
 // F2: sparse in-place merge (update.vert:51-115): only the winning record of each surfel applies.
+#ifndef MERGE_THREADS
 #define MERGE_THREADS 256
+#endif
 __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick, RecPlanes rec,
                                                       const int32_t *__restrict__ rec_flag,
                                                       const uint32_t *__restrict__ rec_best, uint32_t *__restrict__ slot,
@@ -336,9 +338,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick,
     const float4 r0 = rec.p0[qs], r1 = rec.p1[qs], r2 = rec.p2[qs], r3 = rec.p3[qs], r4 = rec.p4[qs];
     const float4 vp = m.p0[s], vc = m.p1[s], vn = m.p2[s], c1 = m.p3[s], c2 = m.p4[s];
     act = act && winner == (uint32_t)q;
-    {   // merged count: one atomic per wave instead of one per merge on a single address
+    {   // merged count: ONE atomic per workgroup — same-address atomics from 1200 waves serialise at the memory side
+#ifndef MERGE_NO_COUNT
+        __shared__ uint32_t s_m[MERGE_THREADS / 64];
         const unsigned long long bal = __ballot(act);
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(merged, (uint32_t)__popcll(bal));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < MERGE_THREADS / 64; ++w) t += s_m[w];
+            if (t) atomicAdd(merged, t);
+        }
+#endif
     }
     if (!act) return;
     slot[s] = 0xFFFFFFFFu;   // re-arm for the next frame (only touched entries are reset)
@@ -392,10 +404,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick,
 //    writer polls tile_done of the tiles its output range overlaps.  tile_done never waits on
 //    another tile's writes, so there is no serial chain.
 #ifndef FUSE_THREADS
-#ifndef FUSE_THREADS
 #define FUSE_THREADS 512
 #endif
+#ifndef FUSE_WAVES_PER_EU   // register budget of pass B (second __launch_bounds__ argument of hipcc = waves per SIMD)
+#define FUSE_WAVES_PER_EU 3
 #endif
+// workgroups of pass B per CU: while one waits for its loads another one stores
+#define FUSE_WG_PER_CU ((FUSE_WAVES_PER_EU * 4) / (FUSE_THREADS / 64) > 0 ? (FUSE_WAVES_PER_EU * 4) / (FUSE_THREADS / 64) : 1)
 #define FUSE_IPT 4   // the move path below is written out for exactly 4 items per thread
 #define FUSE_TILE (FUSE_THREADS * FUSE_IPT)
 #define TC_STRIDE 32   // one tile counter per 128-byte line: wave atomics of different tiles never share a line
@@ -639,7 +654,7 @@ __device__ __forceinline__ uint32_t move_store(const MoveSlot &sl, const MapPlan
     return sl.it >= N ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlanes m, RecPlanes rec, int Q,
+__global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream(int time, MapPlanes m, RecPlanes rec, int Q,
                                                               const uint8_t *__restrict__ keep_flags,
                                                               const uint32_t *__restrict__ tile_count,
                                                               const uint32_t *__restrict__ count_in,
@@ -687,6 +702,10 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_stream(int time, MapPlane
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) first = s_first[w] < first ? s_first[w] : first;
     first = __builtin_amdgcn_readfirstlane(first);
+    // Only as many workgroups as there are tiles to process draw tickets (the ticket word is one address: every draw is
+    // serialised at the memory side); the others leave.  Those that stay still take tiles dynamically, so whichever of
+    // them runs makes progress — no assumption about which workgroups are resident.
+    if (blockIdx.x >= num_tiles - first) return;
 
     uint32_t done_upto = first, prefix = first * FUSE_TILE;   // every tile before `first` is full: prefix(first) = first * TILE
     for (;;) {
@@ -904,7 +923,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
                        keep_flags, tile_count, stats);
     // any grid size is safe (ticketed tiles); one 512-thread workgroup per CU keeps every CU's load/store pipes busy
-    uint32_t blocks = tiles < 256u ? tiles : 256u;
+    uint32_t blocks = tiles < 256u * FUSE_WG_PER_CU ? tiles : 256u * FUSE_WG_PER_CU;
     if (blocks == 0) blocks = 1;
     const size_t lds = sizeof(uint32_t) * (size_t)(tiles ? tiles : 1);
     static size_t lds_allowed = 48 * 1024;

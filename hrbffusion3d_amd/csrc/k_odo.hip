@@ -38,7 +38,10 @@ struct OdoState {
     float sigmaVal;
     unsigned int ticket;              // last-workgroup election of the fused reduce+solve kernels
     // persistent SO3 kernel: per-iteration chunk tickets and completed-chunk counters, exit counter (publisher election)
-    unsigned int so3_ticket[12], so3_chunks_done[12], so3_exit;
+    // word[it] = {chunks of iteration `it` done (low 32) | tickets of iteration it+1 drawn (high 32)}: one 64-bit atomic
+    // arrives at iteration it AND draws the chunk of iteration it+1; so3_ticket0 = tickets of iteration 0
+    unsigned long long so3_word[12];
+    unsigned int so3_ticket0, so3_exit;
     int bar_timeout;                  // this frame: a bounded poll of the SO3 kernel gave up (never expected)
     int bar_timeouts_total;           // sticky count of such frames (hrbf_get_status)
 };
@@ -622,8 +625,8 @@ __device__ inline void odo_begin_state(OdoState *st, const DevPose *__restrict__
     st->gn_break = 0;
     st->res_icp[0] = st->res_icp[1] = 0.0f;
     st->ticket = 0u;
-    for (int k = 0; k < 12; ++k) { st->so3_ticket[k] = 0u; st->so3_chunks_done[k] = 0u; }
-    st->so3_exit = 0u;
+    for (int k = 0; k < 12; ++k) st->so3_word[k] = 0ull;
+    st->so3_ticket0 = 0u; st->so3_exit = 0u;
     st->bar_timeouts_total += st->bar_timeout; st->bar_timeout = 0;
     if (cfg.so3) so3_set_operands(st, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
     if (gn_level >= 0) gn_begin_state(st, cfg, gn_level);
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
     __shared__ unsigned int s_chunk, s_next;
     __shared__ int s_more;
     if (threadIdx.x == 0) {
-        s_chunk = __hip_atomic_fetch_add(&st->so3_ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_chunk = __hip_atomic_fetch_add(&st->so3_ticket0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int k = 0; k < 9; ++k) {
             S.resultR[k] = st->resultR[k]; S.lastResultR[k] = st->lastResultR[k]; S.R_lr[k] = st->R_lr[k];
             S.basis[k] = st->basis[k]; S.kinv[k] = st->kinv[k]; S.krlr[k] = st->krlr[k];
@@ -869,16 +872,22 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
             }
             __syncthreads();
             if (threadIdx.x == 0) {   // wave 0 issued this workgroup's slot atomics: the release fence orders them first
-                if (chunk < nchunk) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __hip_atomic_fetch_add(&st->so3_chunks_done[it], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // one 64-bit atomic: +1 chunk done (if one was processed) and, the first time round, +1 ticket of it+1
+                const unsigned long long inc = (chunk < nchunk ? 1ull : 0ull) | (drawn ? 0ull : (1ull << 32));
+                if (inc) {
+                    if (chunk < nchunk) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    const unsigned long long old = __hip_atomic_fetch_add(&st->so3_word[it], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!drawn) s_next = (unsigned int)(old >> 32);
                 }
-                if (!drawn) s_next = __hip_atomic_fetch_add(&st->so3_ticket[it + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int more = 0, spins = 0;
                 for (;;) {
-                    if (__hip_atomic_load(&st->so3_chunks_done[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nchunk) break;
-                    if (__hip_atomic_load(&st->so3_ticket[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunk) {
-                        const unsigned int c = __hip_atomic_fetch_add(&st->so3_ticket[it], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)__hip_atomic_load(&st->so3_word[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nchunk) break;
+                    // chunks of this iteration nobody has claimed yet (only when fewer workgroups run than there are chunks)
+                    const unsigned int drawn_it = it == 0 ? __hip_atomic_load(&st->so3_ticket0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                          : (unsigned int)(__hip_atomic_load(&st->so3_word[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+                    if (drawn_it < nchunk) {
+                        const unsigned int c = it == 0 ? __hip_atomic_fetch_add(&st->so3_ticket0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : (unsigned int)(__hip_atomic_fetch_add(&st->so3_word[it - 1], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
                         if (c < nchunk) { s_chunk = c; more = 1; break; }
                     }
                     __builtin_amdgcn_s_sleep(1);

@@ -5,6 +5,9 @@
     python -m hrbffusion3d_amd.run --tum /data/rgbd_dataset_freiburg1_desk --fx 517.3 --fy 516.5 --cx 318.6 --cy 255.3 \
            --out traj.freiburg --groundtruth /data/.../groundtruth.txt
     python -m hrbffusion3d_amd.run --synthetic 200 --noise --out traj.freiburg        # the bench stream, with ATE
+    python -m hrbffusion3d_amd.run --config GlobalStateParam.txt --out traj.freiburg  # the reference's own settings:
+           # the parameter file (Core/src/Utils/parameterFile.h) names the data directory, the frame source (sensorType
+           # 2 = .klg, 3 = associations.txt) and the OpenCV camera YAML (intrinsics, resolution, DepthMapFactor)
 
 Frame sources: a .klg raw log (io.KlgReader), a TUM directory with associations.txt (PNG decoding needs Pillow), or the
 synthetic stream.  There is no CPU fallback: the HIP library and a gfx950 device are required.
@@ -24,13 +27,19 @@ from .params import default_params
 def parse(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     src = ap.add_mutually_exclusive_group(required=True)
+    src.add_argument("--config", help="the reference's GlobalStateParam.txt: frame source, camera YAML and every tunable "
+                                      "come from it (explicit flags below still override)")
     src.add_argument("--klg", help=".klg raw log (RawLogReader format)")
     src.add_argument("--tum", help="TUM RGB-D directory containing associations.txt (ts depth ts rgb)")
     src.add_argument("--synthetic", type=int, metavar="N", help="N frames of the synthetic stream")
-    ap.add_argument("--width", type=int, default=640); ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--fx", type=float, default=528.0); ap.add_argument("--fy", type=float, default=528.0)
-    ap.add_argument("--cx", type=float, default=320.0); ap.add_argument("--cy", type=float, default=240.0)
-    ap.add_argument("--depth-factor", type=float, default=5000.0, help="raw units per metre (DepthMapFactor)")
+    ap.add_argument("--camera", help="OpenCV camera YAML (Camera.fx/fy/cx/cy/width/height, DepthMapFactor), e.g. TUM1.yaml; "
+                                      "with --config the file it names is used unless this is given")
+    ap.add_argument("--data-dir", help="with --config: where the data lives on THIS machine when currentWorkingDirectory "
+                                        "of the parameter file does not exist here")
+    ap.add_argument("--width", type=int, default=None); ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--fx", type=float, default=None); ap.add_argument("--fy", type=float, default=None)
+    ap.add_argument("--cx", type=float, default=None); ap.add_argument("--cy", type=float, default=None)
+    ap.add_argument("--depth-factor", type=float, default=None, help="raw units per metre (DepthMapFactor)")
     ap.add_argument("--flip-colors", action="store_true", help=".klg stored BGR")
     ap.add_argument("--noise", action="store_true", help="synthetic: Kinect-style depth noise + drop-outs")
     ap.add_argument("--max-frames", type=int, default=0)
@@ -43,7 +52,49 @@ def parse(argv=None):
     ap.add_argument("--ply-confidence", type=float, default=0.0)
     ap.add_argument("--groundtruth", help="TUM-format ground truth: report the Horn-aligned ATE RMSE")
     ap.add_argument("--device", type=int, default=0)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    return apply_reference_config(args)
+
+
+def apply_reference_config(args):
+    """fill in what the reference's parameter file / camera YAML say; explicit flags win; then the plain defaults"""
+    from . import config as hcfg
+    args.param_overrides = {}
+    cam_file = args.camera
+    if args.config:
+        g = hcfg.load_global_state(args.config)
+        base = args.data_dir or os.path.dirname(os.path.abspath(args.config))
+        args.param_overrides = hcfg.hrbf_kwargs(g)
+        if cam_file is None and g.get("parameterFileCvFormat"):
+            cam_file = hcfg.resolve(g, "parameterFileCvFormat", base)
+        st = g.get("sensorType", 3)
+        if st == 2:
+            args.klg = hcfg.resolve(g, "klgFileName", base)
+        elif st == 3:
+            args.tum = os.path.dirname(hcfg.resolve(g, "AssociationFile", base)) or base
+            args.assoc_name = os.path.basename(g.get("AssociationFile", "associations.txt"))
+        else:
+            raise SystemExit("sensorType %r (live camera) has no counterpart here" % (st,))
+        if g.get("globalInputICLNUIMDataset"):
+            args.icl_nuim = True
+        if not args.max_frames and g.get("globalEndFrame", -1) > 0:
+            args.max_frames = int(g["globalEndFrame"])
+        if g.get("optimizationUseLocalBA") or g.get("optimizationUseGlobalBA"):
+            sys.stderr.write("note: optimizationUseLocalBA / GlobalBA are set in %s; the sparse ORB back-end is out of "
+                             "scope here (front-end only, as BASELINE configs 2 / 3 specify)\n" % args.config)
+    if cam_file:
+        cam = hcfg.camera_from_yaml(cam_file)
+        for k in ("width", "height", "fx", "fy", "cx", "cy"):
+            if getattr(args, k) is None:
+                setattr(args, k, cam[k])
+        if args.depth_factor is None:
+            args.depth_factor = 1.0 / cam["depth_scale"]
+        if not cam["rgb"]:
+            args.flip_colors = True
+    for k, v in (("width", 640), ("height", 480), ("fx", 528.0), ("fy", 528.0), ("cx", 320.0), ("cy", 240.0), ("depth_factor", 5000.0)):
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
 def frame_source(args):
@@ -55,7 +106,7 @@ def frame_source(args):
         r.close()
     elif args.tum:
         from PIL import Image
-        for td, fd, tr, fr in hio.load_associations(os.path.join(args.tum, "associations.txt")):
+        for td, fd, tr, fr in hio.load_associations(os.path.join(args.tum, getattr(args, "assoc_name", "associations.txt"))):
             depth = np.asarray(Image.open(os.path.join(args.tum, fd)), np.uint16)
             rgb = np.asarray(Image.open(os.path.join(args.tum, fr)).convert("RGB"), np.uint8)
             yield int(round(td * 1e6)), np.ascontiguousarray(rgb), np.ascontiguousarray(depth), None
@@ -84,7 +135,8 @@ def main(argv=None):
     from .api import HRBFFusion
     if args.synthetic is not None:
         args.fx, args.fy, args.cx, args.cy = synth.intrinsics(args.width, args.height)
-    kw = dict(max_surfels=args.max_surfels, depth_scale=1.0 / args.depth_factor)
+    kw = dict(args.param_overrides)
+    kw.update(max_surfels=args.max_surfels, depth_scale=1.0 / args.depth_factor)
     if args.icp_weight is not None:
         kw["icp_weight"] = args.icp_weight
     if args.rgb_only:

@@ -330,6 +330,70 @@ def test_two_contexts_interleaved(gpu_available):
         gs[sz].close()
 
 
+def test_two_contexts_concurrent_with_a_device_filling_co_runner(gpu_available):
+    """1000 iterations of two contexts enqueued back to back WITHOUT synchronisation (each on its own stream, inputs
+    resident in HBM, so their kernels really overlap on the device) while a third stream keeps every CU busy with
+    large GEMMs.  The fuse pass (ticketed tiles, tile_done epochs) and the persistent SO3 kernel (ticketed chunks) must
+    not depend on their workgroups being co-resident: no hang, no status bit, and poses / maps bit-identical to each
+    context run alone.  Noisy QVGA streams against 150 k-surfel maps: ~110 fuse tiles per frame, surfels removed in
+    mid-array on most frames (the in-place compaction's wait chain is exercised), 75 SO3 chunks."""
+    import torch
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 320, 240
+    K = synth.intrinsics(W, H)
+    NF, ITERS = 40, 1000
+    tri = lambda i: (i % (2 * NF - 2)) if (i % (2 * NF - 2)) < NF else (2 * NF - 2) - (i % (2 * NF - 2))    # 0..39..1 0..: continuous motion
+    streams = {}
+    for name, off in (("a", 0), ("b", 60)):
+        fr = [synth.frame(off + k, W, H, noise=True) for k in range(NF)]
+        streams[name] = dict(frames=fr, seed=synth.seed_map(150_000, width=W),
+                             dev=[(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1].view(np.int16)).cuda()) for f in fr])
+
+    def start(name):
+        st = streams[name]
+        g = HRBFFusion(default_params(W, H, *K, max_surfels=st["seed"].shape[0] + 600_000))
+        g.upload_map(st["seed"]); g.set_pose(st["frames"][0][2]); g.bootstrap(st["frames"][0][0], st["frames"][0][1])
+        return g
+
+    def feed(g, name, i):
+        d = streams[name]["dev"][tri(i)]
+        g.process_frame_device(d[0].data_ptr(), d[1].data_ptr(), i)
+
+    alone = {}
+    moved_frames = 0
+    for name in streams:
+        g = start(name)
+        g.enable_timing(2)
+        for i in range(1, ITERS + 1):
+            feed(g, name, i)
+        g.synchronize()
+        _, _, st8 = g.fuse_ring_parts(1024)
+        moved_frames += int((st8[:, 6] > 0).sum())
+        assert g.status() == 0
+        alone[name] = (g.get_pose(), g.download_map())
+        g.close()
+    assert moved_frames > 200      # the moving branch of the compaction ran on a good share of the frames
+    side = torch.cuda.Stream()
+    a = torch.randn(6144, 6144, device="cuda"); b = torch.randn(6144, 6144, device="cuda"); c = torch.empty_like(a)
+    gs = {name: start(name) for name in streams}
+    for i in range(1, ITERS + 1):
+        if i % 25 == 1:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    torch.mm(a, b, out=c)          # a few hundred workgroups with big LDS tiles: keeps the CUs occupied
+        for name in streams:
+            feed(gs[name], name, i)
+    for name in streams:
+        gs[name].synchronize()
+    torch.cuda.synchronize()
+    for name in streams:
+        assert gs[name].status() == 0
+        pose, m = alone[name]
+        assert np.array_equal(bits(pose), bits(gs[name].get_pose())), name
+        assert np.array_equal(bits(m), bits(gs[name].download_map())), name
+        gs[name].close()
+
+
 @pytest.mark.parametrize("cap", [9000, 20000])
 def test_map_at_capacity(pair, cap):
     """maximum size: a map whose capacity is hit by the seed frame (cap 9000 < first frame's surfels) or by the
