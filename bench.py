@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--worst-frac", type=float, default=0.05)
     ap.add_argument("--worst-samples", type=int, default=5)
     ap.add_argument("--only-worst", action="store_true", help="run only the worst-case fuse leg (profiling)")
+    ap.add_argument("--no-cpp-shim", action="store_true", help="skip the C++-class leg (g++ compile + run of tools/shim_bench.cpp)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -83,6 +84,33 @@ def cpu_baseline(args, seed, frames, poses):
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d frames of the same %dx%d stream against the same %d-surfel map (oracle, OpenMP)" %
                       (n, args.width, args.height, seed.shape[0])}
+
+
+def cpp_shim_leg(args, seed, frames, poses):
+    """frames/s through the C++ class (include/HRBFFusion.h -> tools/shim_bench.cpp, compiled here with g++): the
+    reference's call site, HRBFFusion::processFrame(host rgb, host depth, timestamp) per frame, nothing else"""
+    import subprocess
+    import tempfile
+    from hrbffusion3d_amd import build as hb
+    so = hb.build()
+    warm, steps = 5, min(40, len(frames) - 7)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "shim_bench")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tools", "shim_bench.cpp"), "-o", exe, so,
+                               "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+        with open(os.path.join(tmp, "frames.bin"), "wb") as f:
+            for rgb, d in frames[:2 + warm + steps]:
+                f.write(np.ascontiguousarray(rgb).tobytes()); f.write(np.ascontiguousarray(d).tobytes())
+        with open(os.path.join(tmp, "map.bin"), "wb") as f:
+            f.write(np.ascontiguousarray(seed, np.float32).tobytes())
+            f.write(np.ascontiguousarray(np.asarray(poses[0], np.float32).T).tobytes())
+        fx, fy, cx, cy = (str(v) for v in __import__("hrbffusion3d_amd.synth", fromlist=["x"]).intrinsics(args.width, args.height))
+        out = subprocess.run([exe, os.path.join(tmp, "frames.bin"), os.path.join(tmp, "map.bin"), str(args.width),
+                              str(args.height), fx, fy, cx, cy, str(warm), str(steps)], capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    return json.loads(out.stdout.strip().split("\n")[-1])
 
 
 def frustum_counts(m, T_wc, K, W, H, conf_thr, max_depth=20.0):
@@ -322,6 +350,13 @@ def main():
             break
         except Exception:
             traffic = None
+    shim = None
+    if rank == 0 and world == 1 and args.virtual_shards <= 1 and not one_sequence and not args.no_cpp_shim:
+        fus.synchronize()
+        try:
+            shim = cpp_shim_leg(args, seed, frames, poses)
+        except Exception as e:
+            shim = {"error": repr(e)}
     worst = None
     if rank == 0 and world == 1 and args.worst_surfels > 0 and args.virtual_shards <= 1 and not one_sequence:
         fus.synchronize()
@@ -345,6 +380,7 @@ def main():
                                       else ("%d virtual map shards on one GPU" % args.virtual_shards) if args.virtual_shards > 1
                                       else ("replicas x%d" % world if world > 1 else "single GPU"),
                        "final_translation_error_mm": err_mm, "pcie_inclusive_fps": pcie_fps,
+                       "cpp_shim": shim,
                        "update_model": update_model,
                        "last_frame_region_ms": {"Initialization": float(tm[0]), "Registration": float(tm[1]),
                                                 "Integration": float(tm[2]), "Prediction": float(tm[3]),

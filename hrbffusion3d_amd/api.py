@@ -29,7 +29,7 @@ EXPORTS = [
     "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
-    "hrbf_get_fuse_ring_parts", "hrbf_get_status",
+    "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
 ]
 
 
@@ -78,6 +78,9 @@ def load_library():
     lib.hrbf_bootstrap.argtypes = [vp, vp, vp]
     lib.hrbf_get_fuse_ring.argtypes = [vp, i32, vp, vp]; lib.hrbf_reset_fuse_ring.argtypes = [vp]
     lib.hrbf_get_fuse_ring_parts.argtypes = [vp, i32, vp, vp, vp]; lib.hrbf_get_status.argtypes = [vp, vp, i32]
+    lib.hrbf_frames_enqueued.argtypes = [vp]; lib.hrbf_frames_enqueued.restype = C.c_uint32
+    lib.hrbf_frames_completed.argtypes = [vp]; lib.hrbf_frames_completed.restype = C.c_uint32
+    lib.hrbf_get_pose_log.argtypes = [vp, C.c_uint32, C.c_uint32, vp, i32]
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
@@ -299,6 +302,20 @@ class HRBFFusion:
         if n < 0:
             raise HrbfError("hrbf_get_fuse_ring_parts failed")
         return mm[:n].copy(), ms[:n].copy(), st[:n].copy()
+
+    def frames_completed(self):
+        """frames whose pose has landed in the pinned trajectory ring (never blocks)"""
+        return int(self.lib.hrbf_frames_completed(self.h))
+
+    def pose_log(self, first=0, count=None, wait=True):
+        """poses (n, 4, 4) of frames [first, first + count) from the device-written trajectory ring"""
+        if count is None:
+            count = int(self.lib.hrbf_frames_enqueued(self.h)) - first
+        out = np.zeros((max(count, 1), 16), np.float32)
+        n = self.lib.hrbf_get_pose_log(self.h, first, count, _p(out), int(bool(wait)))
+        if n < 0:
+            raise HrbfError(self.lib.hrbf_last_error().decode())
+        return out[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy()
 
     STATUS_CAPACITY, STATUS_INTERNAL_BOUND, STATUS_SO3_TIMEOUT = 1, 2, 4
 

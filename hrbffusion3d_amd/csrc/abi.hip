@@ -114,6 +114,8 @@ struct hrbf_context {
     hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid;
     uint32_t ring_merge_head;   // ring slot the last merge events went to (a clean without a fuse has no F2 part)
     uint32_t status;            // sticky HRBF_STATUS_* bits folded from the device on blocking calls
+    PoseLog *h_pose_log, *d_pose_log_view;   // pinned host ring + its device-side address
+    uint32_t frames_enqueued;   // process_frame calls so far = index of the next frame in the pose log
 };
 
 template <typename T>
@@ -237,6 +239,10 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * HRBF_MAX_SHARDS, hipHostMallocDefault);
     if (e != hipSuccess) { hrbf_set_error("hipHostMalloc: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     c->h_count_pinned[0] = 0;
+    e = hipHostMalloc((void **)&c->h_pose_log, sizeof(PoseLog), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_pose_log_view, c->h_pose_log, 0);
+    if (e != hipSuccess) { hrbf_set_error("pose log: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
+    c->h_pose_log->completed = 0;
     hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming);
     for (int i = 0; i < 12; ++i) hipEventCreate(&c->ev[i]);
     c->ring_e0 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t)); c->ring_e1 = (hipEvent_t *)calloc(HRBF_RING, sizeof(hipEvent_t));
@@ -372,6 +378,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
         for (void *p : q) if (p) hipFree(p);
     }
     if (c->h_count_pinned) hipHostFree(c->h_count_pinned);
+    if (c->h_pose_log) hipHostFree(c->h_pose_log);
     for (int k = 0; k < 3; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->ev_stage[k]) hipEventDestroy(c->ev_stage[k]); }
     if (c->ev_count) hipEventDestroy(c->ev_count);
     for (int i = 0; i < 12; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -600,13 +607,14 @@ static void st_predict(hrbf_context *c)
                         c->d_pr_image, c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_time,
                         c->d_pr_icpw);
 }
-static void st_fillin(hrbf_context *c, bool end_of_frame = false)
+static void st_fillin(hrbf_context *c, bool end_of_frame = false, bool log_frame = false)
 {
     launch_fillin(c->stream, c->P, c->prm.curv_valid_threshold, c->prm.icp_curv_weight_lambda, c->prm.frame_to_frame_rgb,
                   c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_icpw, c->d_pr_image,
                   c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_fi_vertex,
                   c->d_fi_normal, c->d_fi_curv1, c->d_fi_curv2, c->d_fi_icpw, c->d_fi_image, c->cam,
-                  c->prm.dense_enough_thresh, end_of_frame ? c->d_pose : nullptr);
+                  c->prm.dense_enough_thresh, end_of_frame ? c->d_pose : nullptr, log_frame ? c->d_pose_log_view : nullptr,
+                  c->frames_enqueued);
     c->fill_flag_fresh = end_of_frame ? 1 : 0;
 }
 static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
@@ -652,10 +660,10 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     TIMER(7);
     st_predict(c);
     TIMER(8);
-    st_fillin(c, true);   // + shouldFillIn of the next frame + lastPose <- currPose
+    st_fillin(c, true, true);   // + shouldFillIn of the next frame + lastPose <- currPose + the pose log entry
     TIMER(9);
     request_count(c);
-    c->tick++;
+    c->tick++; c->frames_enqueued++;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hrbf_set_error("launch: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
     return HRBF_OK;
@@ -770,6 +778,33 @@ extern "C" int hrbf_get_pose(hrbf_handle c, float out[16])
     out[15] = 1.0f;
     return HRBF_OK;
 }
+// ---- trajectory without blocking: the pose of every processed frame sits in a pinned ring the device appends to
+extern "C" uint32_t hrbf_frames_enqueued(hrbf_handle c) { return c ? c->frames_enqueued : 0u; }
+extern "C" uint32_t hrbf_frames_completed(hrbf_handle c)
+{
+    if (!c || !c->h_pose_log) return 0u;
+    return __atomic_load_n(&c->h_pose_log->completed, __ATOMIC_ACQUIRE);
+}
+extern "C" int hrbf_get_pose_log(hrbf_handle c, uint32_t first_frame, uint32_t count, float *out16, int wait)
+{
+    if (!c || (count && !out16)) return HRBF_ERR_INVALID;
+    if (wait) { hipSetDevice(c->device); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    const uint32_t done = hrbf_frames_completed(c);
+    if (first_frame >= done) return 0;
+    if (done - first_frame > POSE_LOG_CAP || done > first_frame + POSE_LOG_CAP) {
+        const uint32_t oldest = done > POSE_LOG_CAP ? done - POSE_LOG_CAP : 0u;
+        if (first_frame < oldest) { hrbf_set_error("pose log: frame %u was overwritten (ring of %u)", first_frame, POSE_LOG_CAP); return HRBF_ERR_INVALID; }
+    }
+    uint32_t n = done - first_frame; if (n > count) n = count;
+    for (uint32_t k = 0; k < n; ++k) {
+        const Rigid r = c->h_pose_log->poses[(first_frame + k) % POSE_LOG_CAP];
+        float *out = out16 + (size_t)k * 16;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) out[j * 4 + i] = r.r[i * 3 + j]; out[12 + i] = r.t[i]; out[i * 4 + 3] = 0.0f; }
+        out[15] = 1.0f;
+    }
+    return (int)n;
+}
+
 extern "C" int hrbf_set_pose(hrbf_handle c, const float in[16])
 {
     if (!c || !in) return HRBF_ERR_INVALID;

@@ -532,9 +532,8 @@ __device__ __forceinline__ bool in_view(const CleanParams &cp, const Rigid &tinv
 // the clean test of one item: surfel `idx` of the map or association record `idx`
 __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &tinv, float ftime, const MapPlanes &m,
                                            const RecPlanes &rec, bool is_surf, uint32_t idx,
-                                           const float4 *__restrict__ clean_tex)
+                                           const float4 *__restrict__ clean_tex, const float4 vp /* pos_conf of the item */)
 {
-    const float4 vp = is_surf ? m.p0[idx] : rec.p0[idx];
     bool keep = true;
     f3 lp; float x, y;
     const bool inv = in_view(cp, tinv, vp, lp, x, y);
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
         const uint32_t qx = (tile % tiles_x) * 8u + (lane >> 3), qy = (tile / tiles_x) * 8u + (lane & 7u);
         if (qx < QW && qy < QH) {
             const uint32_t q = qx * QH + qy;
-            const bool keep = rec_flag[q] != 0 && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex);
+            const bool keep = rec_flag[q] != 0 && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex, rec.p0[q]);
             keep_flags[N + q] = keep ? 1 : 0;
             if (keep) {
                 const uint32_t tl = (N + q) / FUSE_TILE;
@@ -613,8 +612,15 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     // Plain round-robin grid-stride on purpose: the in-view minority (the expensive items) is clustered in the
     // array, and an XCD-contiguous chunking (one eighth of the array per XCD, better L2 locality for the clean
     // texels) measured 2x SLOWER because one or two XCDs then own all the heavy work (profiles/r01 notes).
-    for (uint32_t it = sb * blockDim.x + threadIdx.x; it < N64; it += sgrid * blockDim.x) {
-        const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex);
+    // the position plane of the NEXT round is requested before this round's item is tested: the streaming read (16 B
+    // per surfel, all most surfels need) never waits behind the dependent gathers of the in-view minority
+    const uint32_t stride = sgrid * blockDim.x;
+    uint32_t it = sb * blockDim.x + threadIdx.x;
+    float4 vp_next = it < N ? m.p0[it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (; it < N64; it += stride) {
+        const float4 vp = vp_next;
+        if (it + stride < N) vp_next = m.p0[it + stride];
+        const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp);
         if (it < N) keep_flags[it] = keep ? 1 : 0;
         // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
         const unsigned long long bal = __ballot(keep);
@@ -708,6 +714,9 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
     if (blockIdx.x >= num_tiles - first) return;
 
     uint32_t done_upto = first, prefix = first * FUSE_TILE;   // every tile before `first` is full: prefix(first) = first * TILE
+    // statistics are accumulated per lane over all tiles of the workgroup and added ONCE at the end: same-address
+    // atomics are serialised at the memory side (~8 ns each) and one per wave and tile made the pass atomic-bound
+    uint32_t acc_appended = 0, acc_moved = 0;
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(&stats[5], 1u);
         __syncthreads();
@@ -781,25 +790,29 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
                     __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
-        uint32_t appended = move_store(s0, m, N, cap) + move_store(s1, m, N, cap) + move_store(s2, m, N, cap) +
-                            move_store(s3, m, N, cap);
-        if (base + FUSE_TILE > N) {   // only tiles that contain records count appends; their lanes re-arm the record flags
-            if (rec_flag_rearm) {
-                if (s0.it >= N && s0.it < total) rec_flag_rearm[s0.it - N] = 0;
-                if (s1.it >= N && s1.it < total) rec_flag_rearm[s1.it - N] = 0;
-                if (s2.it >= N && s2.it < total) rec_flag_rearm[s2.it - N] = 0;
-                if (s3.it >= N && s3.it < total) rec_flag_rearm[s3.it - N] = 0;
-            }
-            for (int d = 32; d > 0; d >>= 1) appended += __shfl_down(appended, d);
-            if (lane == 0 && appended) atomicAdd(&stats[2], appended);
+        acc_appended += move_store(s0, m, N, cap) + move_store(s1, m, N, cap) + move_store(s2, m, N, cap) +
+                        move_store(s3, m, N, cap);
+        if (base + FUSE_TILE > N && rec_flag_rearm) {   // the lanes that handled records re-arm the record flags
+            if (s0.it >= N && s0.it < total) rec_flag_rearm[s0.it - N] = 0;
+            if (s1.it >= N && s1.it < total) rec_flag_rearm[s1.it - N] = 0;
+            if (s2.it >= N && s2.it < total) rec_flag_rearm[s2.it - N] = 0;
+            if (s3.it >= N && s3.it < total) rec_flag_rearm[s3.it - N] = 0;
         }
-        if (tile_has_surfels) {   // statistics: surfels that really changed slot (real traffic = 160 B each)
-            uint32_t mv = (uint32_t)(s0.keep && s0.it < N && s0.o != s0.it) + (uint32_t)(s1.keep && s1.it < N && s1.o != s1.it) +
-                          (uint32_t)(s2.keep && s2.it < N && s2.o != s2.it) + (uint32_t)(s3.keep && s3.it < N && s3.o != s3.it);
-            for (int d = 32; d > 0; d >>= 1) mv += __shfl_down(mv, d);
-            if (lane == 0 && mv) atomicAdd(&stats[6], mv);
-        }
+        // statistics: surfels that really changed slot (real traffic = 160 B each)
+        acc_moved += (uint32_t)(s0.keep && s0.it < N && s0.o != s0.it) + (uint32_t)(s1.keep && s1.it < N && s1.o != s1.it) +
+                     (uint32_t)(s2.keep && s2.it < N && s2.o != s2.it) + (uint32_t)(s3.keep && s3.it < N && s3.o != s3.it);
         __syncthreads();   // s_wcnt / s_psum / s_ticket reuse
+    }
+    // one atomic per workgroup and statistic (s_psum / s_first are free again: every path above ended with a barrier)
+    for (int d = 32; d > 0; d >>= 1) { acc_appended += __shfl_down(acc_appended, d); acc_moved += __shfl_down(acc_moved, d); }
+    if (lane == 0) { s_psum[wid] = acc_appended; s_first[wid] = acc_moved; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, mv = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { a += s_psum[w]; mv += s_first[w]; }
+        if (a) atomicAdd(&stats[2], a);
+        if (mv) atomicAdd(&stats[6], mv);
     }
 }
 

@@ -342,13 +342,21 @@ __global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb,
                          const uint8_t *__restrict__ rgb, float4 *__restrict__ fi_vertex,
                          float4 *__restrict__ fi_normal, float4 *__restrict__ fi_curv1, float4 *__restrict__ fi_curv2,
                          float *__restrict__ fi_icpw, uint8_t *__restrict__ fi_image, Cam cam, float dense_thresh,
-                         DevPose *dp /* nullable: end-of-frame bookkeeping rides along */)
+                         DevPose *dp /* nullable: end-of-frame bookkeeping rides along */,
+                         PoseLog *pose_log /* nullable: pinned host ring the frame's pose is appended to */, uint32_t frame_idx)
 {
     // end of frame: the next registration's shouldFillIn flag (Resize::vertex + denseEnough on the prediction
     // this kernel reads anyway) and lastPose <- currPose; one workgroup, no separate launches
     if (dp && blockIdx.x == 0) {
         should_fill_in_block(cam, pr_vertex, dense_thresh, &dp->should_fill_in);
-        if (threadIdx.x == 0) dp->prev = dp->pose;
+        if (threadIdx.x == 0) {
+            dp->prev = dp->pose;
+            if (pose_log) {   // trajectory without a host round trip: the caller reads the pinned ring whenever it wants
+                pose_log->poses[frame_idx % POSE_LOG_CAP] = dp->pose;
+                __threadfence_system();
+                __hip_atomic_store(&pose_log->completed, frame_idx + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -398,11 +406,12 @@ void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const
                    const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
                    const float4 *curv2, const float *confidence, const uint8_t *rgb, float4 *fi_vertex,
                    float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image,
-                   const Cam &cam, float dense_thresh, DevPose *dp_end_of_frame)
+                   const Cam &cam, float dense_thresh, DevPose *dp_end_of_frame, PoseLog *pose_log, uint32_t frame_idx)
 {
     hipLaunchKernelGGL(k_fillin, dim3((P + 255) / 256), dim3(256), 0, s, P, thr, lambda, f2f, pr_vertex, pr_normal,
                        pr_curv1, pr_curv2, pr_icpw, pr_image, vertex_filtered, normal, curv1, curv2, confidence, rgb,
-                       fi_vertex, fi_normal, fi_curv1, fi_curv2, fi_icpw, fi_image, cam, dense_thresh, dp_end_of_frame);
+                       fi_vertex, fi_normal, fi_curv1, fi_curv2, fi_icpw, fi_image, cam, dense_thresh, dp_end_of_frame,
+                       dp_end_of_frame ? pose_log : (PoseLog *)nullptr, frame_idx);
 }
 
 void launch_should_fill_in(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float thresh, int *flag)

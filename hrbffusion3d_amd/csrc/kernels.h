@@ -21,6 +21,15 @@ struct DevPose {
     int should_fill_in;
 };
 
+// trajectory log in pinned, device-mapped host memory: the end-of-frame kernel appends the frame's pose and publishes
+// the frame count with a system-scope release, so a caller can follow the trajectory without ever blocking the stream
+#define POSE_LOG_CAP 65536u
+struct PoseLog {
+    uint32_t completed;            // frames whose pose is in the ring (monotonic)
+    uint32_t pad[15];
+    Rigid poses[POSE_LOG_CAP];     // frame f at poses[f % POSE_LOG_CAP]
+};
+
 // ---- k_pre.hip
 void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, float *filtered, float *metric,
                           float *metric_f, float depthFactor, float maxD, int bilateral);
@@ -87,7 +96,8 @@ void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const
                    const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
                    const float4 *curv2, const float *confidence, const uint8_t *rgb, float4 *fi_vertex,
                    float4 *fi_normal, float4 *fi_curv1, float4 *fi_curv2, float *fi_icpw, uint8_t *fi_image,
-                   const Cam &cam, float dense_thresh, DevPose *dp_end_of_frame /* nullable */);
+                   const Cam &cam, float dense_thresh, DevPose *dp_end_of_frame /* nullable */,
+                   PoseLog *pose_log /* nullable, used with dp_end_of_frame */, uint32_t frame_idx);
 void launch_should_fill_in(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float thresh, int *flag);
 
 // ---- k_odo.hip

@@ -20,7 +20,12 @@
  *   - GL handles (model(), textures) do not exist: use downloadMap() / getImage();
  *   - downloadMap() returns the CURRENT map; the reference copies from vbos[renderSource]
  *     (GlobalModel.cpp:791), i.e. the buffer of the previous pass with the new count;
- *   - errors throw std::runtime_error instead of exit(0) (Core/src/Cuda/convenience.cuh:64-71).
+ *   - errors throw std::runtime_error instead of exit(0) (Core/src/Cuda/convenience.cuh:64-71);
+ *   - processFrame() only ENQUEUES the frame (no host synchronisation).  The reference pushes currPose into
+ *     trajectory_manager->poses inside processFrame (HRBFFusion.cpp:1058,1129-1133); here the device appends every
+ *     frame's pose to a pinned ring (hrbf_get_pose_log) and `poses` is brought up to date lazily — by
+ *     syncTrajectory(), by SaveTrajectoryToFile() and by getTrajectory().  A caller that reads
+ *     trajectory_manager->poses directly calls syncTrajectory() first.  getCurrPose() blocks, as it must.
  */
 #ifndef HRBF_MI355_HRBFFUSION_H_
 #define HRBF_MI355_HRBFFUSION_H_
@@ -30,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -106,13 +112,15 @@ private:
 
 class TrajectoryManager {
 public:
-    std::vector<Pose> poses;
+    std::vector<Pose> poses;         // complete up to the last syncTrajectory() (see the header comment)
     std::vector<int64_t> timstamp;   // (sic) reference member name
+    std::function<void()> sync;      // installed by HRBFFusion: pulls the poses the device has logged since
 
     /* format: "TUM" (ts tx ty tz qx qy qz qw; icl_nuim negates ty and prints an integer stamp),
        "zhou" (.log) or "lefloch" — TrajectoryManager.cpp:284-373 */
     bool SaveTrajectoryToFile(const std::string &type, const std::string &fname, bool icl_nuim = false) const
     {
+        if (sync) sync();
         if (type == "zhou") {
             FILE *f = fopen(fname.c_str(), "w");
             if (!f) return false;
@@ -182,7 +190,7 @@ public:
                const int countThresh = 35000, const float errThresh = 5e-05f, const float confidence = 10.0f,
                const float depthCut = 3.0f, const float icpThresh = 10.0f, const bool fastOdom = false,
                const bool so3 = true, const bool frameToFrameRGB = false, int maxSurfels = 4596 * 4596, int device = 0)
-        : h_(nullptr), model_(nullptr)
+        : h_(nullptr), model_(nullptr), load_trajectory_(false), synced_(0)
     {
         (void)countThresh; (void)errThresh;   // stored but never read on this path in the reference either
         hrbf_params p;
@@ -193,6 +201,7 @@ public:
         model_ = new GlobalModel(h_);
         index_ = new IndexMap(h_);
         trajectory_manager = new TrajectoryManager();
+        trajectory_manager->sync = [this]() { this->syncTrajectory(); };
     }
     ~HRBFFusion() { delete trajectory_manager; delete index_; delete model_; hrbf_destroy(h_); }
     HRBFFusion(const HRBFFusion &) = delete;
@@ -204,12 +213,45 @@ public:
         const int tick_before = hrbf_get_tick(h_);
         if (hrbf_process_frame(h_, rgb, depth, timestamp, weightMultiplier) != HRBF_OK)
             throw std::runtime_error(hrbf_last_error());
-        Pose p;
-        hrbf_get_pose(h_, p.m);
-        curr_ = p;
-        trajectory_manager->poses.push_back(p);                       /* HRBFFusion.cpp:1058,1129-1133 */
-        if (tick_before > 1) trajectory_manager->timstamp.push_back(timestamp);
+        /* HRBFFusion.cpp:1058,1129-1133: the first frame pushes the initial pose, every later frame currPose and its
+           time stamp — unless the trajectory is being replayed (globalInputLoadTrajectory).  No synchronisation here:
+           which frames push is recorded, the poses are pulled from the device-written ring on demand. */
+        const bool pushes = tick_before == 1 || !load_trajectory_;
+        pushes_.push_back(pushes);
+        if (tick_before > 1 && pushes) trajectory_manager->timstamp.push_back(timestamp);
     }
+    /* same, inputs already in device memory (HBM): nothing is copied and nothing blocks */
+    void processFrameDevice(const void *d_rgb, const void *d_depth, const int64_t &timestamp, const float weightMultiplier = 1.f)
+    {
+        const int tick_before = hrbf_get_tick(h_);
+        if (hrbf_process_frame_device(h_, d_rgb, d_depth, timestamp, weightMultiplier) != HRBF_OK)
+            throw std::runtime_error(hrbf_last_error());
+        const bool pushes = tick_before == 1 || !load_trajectory_;
+        pushes_.push_back(pushes);
+        if (tick_before > 1 && pushes) trajectory_manager->timstamp.push_back(timestamp);
+    }
+    /* bring trajectory_manager->poses up to date (blocks until every enqueued frame is done) */
+    void syncTrajectory()
+    {
+        const uint32_t n = hrbf_frames_enqueued(h_);
+        if (synced_ >= n) return;
+        std::vector<float> buf((size_t)(n - synced_) * 16);
+        const int got = hrbf_get_pose_log(h_, synced_, n - synced_, buf.data(), 1);
+        if (got < 0) throw std::runtime_error(hrbf_last_error());
+        for (int k = 0; k < got; ++k) {
+            if (synced_ + (uint32_t)k < pushes_.size() && !pushes_[synced_ + (uint32_t)k]) continue;
+            Pose p; memcpy(p.m, &buf[(size_t)k * 16], sizeof(p.m));
+            trajectory_manager->poses.push_back(p);
+        }
+        synced_ += (uint32_t)got;
+    }
+    const std::vector<Pose> &getTrajectory() { syncTrajectory(); return trajectory_manager->poses; }
+    /* frames whose pose has landed; never blocks (hrbf_frames_completed) */
+    unsigned int framesCompleted() { return hrbf_frames_completed(h_); }
+    void synchronize() { if (hrbf_synchronize(h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error()); }
+    /* globalInputLoadTrajectory: poses come from setPose() before each frame and nothing is pushed */
+    void setLoadTrajectory(bool on) { load_trajectory_ = on; hrbf_set_load_trajectory(h_, on ? 1 : 0); }
+    void setPose(const float *pose16) { if (hrbf_set_pose(h_, pose16) != HRBF_OK) throw std::runtime_error(hrbf_last_error()); }
 
     const float *getCurrPoseData() { hrbf_get_pose(h_, curr_.m); return curr_.m; }
 #ifdef EIGEN_CORE_H
@@ -281,6 +323,9 @@ private:
     GlobalModel *model_;
     IndexMap *index_;
     Pose curr_;
+    bool load_trajectory_;
+    std::vector<bool> pushes_;   // per processed frame: does it contribute to trajectory_manager->poses
+    uint32_t synced_;            // frames already folded into trajectory_manager->poses
 };
 
 }  // namespace hrbf_mi355

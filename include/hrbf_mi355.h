@@ -111,6 +111,14 @@ int hrbf_synchronize(hrbf_handle h);
 /* getters the reference's caller uses (GUI/src/HRBF_fusion.cpp:235-497) ---------------------- */
 int hrbf_get_pose(hrbf_handle h, float out16[16]);          /* getCurrPose(), column-major T_wc */
 int hrbf_set_pose(hrbf_handle h, const float in16[16]);     /* trajectory replay (HRBFFusion.cpp:1105-1108) */
+/* The trajectory WITHOUT blocking (trajectory_manager->poses, Core/src/HRBFFusion.h:383-384): every processed frame's
+ * pose is appended by the device to a pinned host ring of 65536 entries.  hrbf_frames_enqueued = process_frame calls so
+ * far; hrbf_frames_completed = frames whose pose has landed (never blocks); hrbf_get_pose_log copies the poses of frames
+ * [first, first + count) that have landed (column-major 4x4 each) and returns how many — wait != 0 drains the stream
+ * first.  hrbf_get_pose remains the blocking getCurrPose(). */
+uint32_t hrbf_frames_enqueued(hrbf_handle h);
+uint32_t hrbf_frames_completed(hrbf_handle h);
+int hrbf_get_pose_log(hrbf_handle h, uint32_t first_frame, uint32_t count, float *out16_each, int wait);
 int hrbf_get_tick(hrbf_handle h);                           /* getTick() */
 uint32_t hrbf_surfel_count(hrbf_handle h);                  /* getGlobalModel().lastCount() */
 int hrbf_download_map(hrbf_handle h, float *out, size_t cap_surfels); /* GlobalModel::downloadMap (GlobalModel.cpp:775-804) */

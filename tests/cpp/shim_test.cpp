@@ -38,6 +38,16 @@ int main(int argc, char **argv)
         printf("tick %d count %u pose t = %g %g %g\n", f.getTick(), f.getGlobalModel().lastCount(), f.getCurrPoseData()[12],
                f.getCurrPoseData()[13], f.getCurrPoseData()[14]);
         if (f.getTick() != 3 || f.getGlobalModel().lastCount() == 0) return 20;
+        // the trajectory is pulled lazily from the device-written ring: nothing was synchronised by processFrame itself
+        if (f.getTrajectory().size() != 2 || f.trajectory_manager->timstamp.size() != 1) return 22;
+        if (memcmp(f.getTrajectory()[1].m, f.getCurrPoseData(), sizeof(float) * 16) != 0) return 23;
+        if (f.framesCompleted() != 2) return 24;
+        // replayed trajectory (globalInputLoadTrajectory): the frame is processed at the given pose and pushes nothing
+        f.setLoadTrajectory(true);
+        f.setPose(f.getCurrPoseData());
+        f.processFrame(rgb.data(), d.data(), 66666);
+        if (f.getTrajectory().size() != 2 || f.trajectory_manager->timstamp.size() != 1 || f.framesCompleted() != 3) return 25;
+        f.setLoadTrajectory(false);
         f.savePly(base + "/m.ply");
         f.trajectory_manager->SaveTrajectoryToFile("TUM", base + "/run.freiburg");
         printf("GPU-OK\n");

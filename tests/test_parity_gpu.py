@@ -905,6 +905,57 @@ def test_full_size_properties_1M(gpu_available):
     assert np.array_equal(idx, idx2)
 
 
+def test_full_size_forced_early_removals_1M(gpu_available):
+    """The in-place compaction at BASELINE size when it has to move the WHOLE map: 3 % of a 1.05 M-surfel map is unstable
+    and stale (copy_unstable.vert:159-165 drops unstable surfels not seen for 200 frames), spread from index 0, noisy
+    input.  Properties: every unmerged stale surfel is gone, the survivors keep their relative order and their bits
+    (they were re-read and written `shift` slots to the left across ~520 ticketed tiles), counts add up, the pass
+    reports that it moved (nearly) everything, and a second run reproduces map and pose bit for bit."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 640, 480
+    K = synth.intrinsics(W, H)
+    seed = synth.seed_map(1_050_000)
+    n = len(seed)
+    stale = np.zeros(n, bool)
+    stale[np.random.default_rng(7).choice(n, int(0.03 * n), replace=False)] = True
+    stale[0:64:3] = True
+    seed[stale, 3] = 1.0
+    tag = {r.tobytes(): i for i, r in enumerate(np.ascontiguousarray(seed[:, 0:3]))}
+    assert len(tag) == n
+    p = default_params(W, H, *K, max_surfels=n + 600_000)
+
+    def run():
+        g = HRBFFusion(p)
+        g.enable_timing(2)
+        g.upload_map(seed); g.set_pose(synth.camera_pose(0))
+        rgb, d, _ = synth.frame(0, W, H, noise=True); g.bootstrap(rgb, d)
+        g.set_tick(300)
+        stats = []
+        for k in range(1, 4):
+            rgb, d, T = synth.frame(k, W, H, noise=True)
+            g.process_frame(rgb, d)
+            stats.append(g.fuse_stats().astype(np.int64))
+        _, _, st8 = g.fuse_ring_parts(3)
+        out = (g.download_map(), stats, st8.astype(np.int64), g.get_pose(), g.status())
+        g.close()
+        return out
+
+    m, stats, st8, pose, status = run()
+    assert status == 0
+    removed1 = stats[0][0] + stats[0][2] - stats[0][3]
+    assert stats[0][0] == n and removed1 > 0.8 * stale.sum()
+    assert st8[0][6] > 0.9 * n                       # the first frame moved (nearly) the whole map
+    assert stats[-1][3] == len(m)
+    old = m[m[:, 7] == 1.0]                          # never merged, never appended
+    assert not np.any(old[:, 3] == 1.0)              # no stale unstable surfel survived unmerged
+    where = np.array([tag[r.tobytes()] for r in np.ascontiguousarray(old[:, 0:3])])
+    assert np.all(np.diff(where) > 0)                # order preserved over the whole map, not a sample
+    assert np.array_equal(bits(old), bits(seed[where]))
+    assert len(old) > 0.85 * n
+    m2, stats2, _, pose2, _ = run()
+    assert np.array_equal(bits(m), bits(m2)) and np.array_equal(bits(pose), bits(pose2))
+
+
 def test_run_cli_over_a_klg_log(gpu_available, tmp_path):
     """The caller's side (`python -m hrbffusion3d_amd.run`, the MainController/RawLogReader loop without the GUI):
     a synthetic QVGA stream written as a .klg log, replayed through process_frame; the trajectory file and the PLY are
