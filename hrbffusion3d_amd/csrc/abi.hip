@@ -239,7 +239,7 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
     e = hipHostMalloc((void **)&c->h_count_pinned, sizeof(uint32_t) * HRBF_MAX_SHARDS, hipHostMallocDefault);
     if (e != hipSuccess) { hrbf_set_error("hipHostMalloc: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     c->h_count_pinned[0] = 0;
-    e = hipHostMalloc((void **)&c->h_pose_log, sizeof(PoseLog), hipHostMallocMapped);
+    e = hipHostMalloc((void **)&c->h_pose_log, sizeof(PoseLog), hipHostMallocMapped | hipHostMallocCoherent);   // fine-grained: device stores bypass L2
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_pose_log_view, c->h_pose_log, 0);
     if (e != hipSuccess) { hrbf_set_error("pose log: %s", hipGetErrorString(e)); hrbf_destroy(c); return HRBF_ERR_DEVICE; }
     c->h_pose_log->completed = 0;
@@ -797,7 +797,16 @@ extern "C" int hrbf_get_pose_log(hrbf_handle c, uint32_t first_frame, uint32_t c
     }
     uint32_t n = done - first_frame; if (n > count) n = count;
     for (uint32_t k = 0; k < n; ++k) {
-        const Rigid r = c->h_pose_log->poses[(first_frame + k) % POSE_LOG_CAP];
+        const volatile PoseRecord *rec = &c->h_pose_log->poses[(first_frame + k) % POSE_LOG_CAP];
+        // the tag is written after the pose; `completed` after the tag.  A record whose tag has not landed although
+        // `completed` says so would mean the device's posted writes were reordered: wait for it (bounded), never return junk
+        int spins = 0;
+        while (__atomic_load_n(&rec->tag, __ATOMIC_ACQUIRE) != first_frame + k + 1u) {
+            if (++spins > 1000000) { hrbf_set_error("pose log: record %u never landed", first_frame + k); return HRBF_ERR_DEVICE; }
+        }
+        Rigid r;
+        for (int i = 0; i < 9; ++i) r.r[i] = rec->pose.r[i];
+        for (int i = 0; i < 3; ++i) r.t[i] = rec->pose.t[i];
         float *out = out16 + (size_t)k * 16;
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) out[j * 4 + i] = r.r[i * 3 + j]; out[12 + i] = r.t[i]; out[i * 4 + 3] = 0.0f; }
         out[15] = 1.0f;

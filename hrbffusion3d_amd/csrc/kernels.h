@@ -24,10 +24,11 @@ struct DevPose {
 // trajectory log in pinned, device-mapped host memory: the end-of-frame kernel appends the frame's pose and publishes
 // the frame count with a system-scope release, so a caller can follow the trajectory without ever blocking the stream
 #define POSE_LOG_CAP 65536u
+struct PoseRecord { Rigid pose; uint32_t tag; uint32_t pad[3]; };   // tag = frame index + 1, written after the pose
 struct PoseLog {
-    uint32_t completed;            // frames whose pose is in the ring (monotonic)
+    uint32_t completed;                 // frames whose pose is in the ring (monotonic)
     uint32_t pad[15];
-    Rigid poses[POSE_LOG_CAP];     // frame f at poses[f % POSE_LOG_CAP]
+    PoseRecord poses[POSE_LOG_CAP];     // frame f at poses[f % POSE_LOG_CAP]
 };
 
 // ---- k_pre.hip
