@@ -362,6 +362,15 @@ def main():
         fus.synchronize()
         try:
             worst = worst_case_leg(args, local_rank)
+            try:    # HBM bytes of this very leg from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process)
+                with open(os.path.join(ROOT, "profiles", "r02_fuse_traffic.json")) as f:
+                    tw = float(json.load(f)["worst_case_leg_4.34M_surfels_all_moved"]["traffic_bytes_per_launch"])
+                if args.worst_surfels == 4_300_000 and abs(args.worst_frac - 0.05) < 1e-9 and (W, H) == (640, 480):
+                    worst["traffic"] = tw
+                    worst["achieved_traffic"] = tw / (worst["avg_kernel_ms"] * 1e-3) / 1e9
+                    worst["traffic_source"] = "profiles/r02_fuse_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --only-worst`)"
+            except Exception:
+                pass
         except Exception as e:   # the second leg must never take the bench line down
             worst = {"error": repr(e)}
 

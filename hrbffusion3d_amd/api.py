@@ -30,6 +30,7 @@ EXPORTS = [
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
+    "hrbf_probe_single_workgroup_iteration",
 ]
 
 
@@ -81,6 +82,7 @@ def load_library():
     lib.hrbf_frames_enqueued.argtypes = [vp]; lib.hrbf_frames_enqueued.restype = C.c_uint32
     lib.hrbf_frames_completed.argtypes = [vp]; lib.hrbf_frames_completed.restype = C.c_uint32
     lib.hrbf_get_pose_log.argtypes = [vp, C.c_uint32, C.c_uint32, vp, i32]
+    lib.hrbf_probe_single_workgroup_iteration.argtypes = [vp, i32, i32, vp]
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
@@ -302,6 +304,12 @@ class HRBFFusion:
         if n < 0:
             raise HrbfError("hrbf_get_fuse_ring_parts failed")
         return mm[:n].copy(), ms[:n].copy(), st[:n].copy()
+
+    def probe_single_workgroup_iteration(self, level=2, iters=4):
+        """ms one 256-thread workgroup needs for the pixel work of `iters` Gauss-Newton iterations of `level`"""
+        ms = C.c_float()
+        self._check(self.lib.hrbf_probe_single_workgroup_iteration(self.h, level, iters, C.byref(ms)))
+        return ms.value
 
     def frames_completed(self):
         """frames whose pose has landed in the pinned trajectory ring (never blocks)"""

@@ -56,10 +56,14 @@ struct MapShard {
     uint32_t *d_tile_done; uint32_t epoch;   // tile_done holds the epoch (pass counter) of the pass that raised it
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
 };
-// private projection outputs of the virtual shards k >= 1 (reduced into the context's own images)
+// sharded map: the private z-buffer of the virtual shards k >= 1 and the winner records ("winners' attributes
+// gathered only for hit pixels"): `send` = the records this shard packed, `recv` = those of the other ranks (real mode)
 struct ShardScratch {
-    unsigned long long *zbuf; uint32_t *idx;
-    float4 *vertconf, *colortime, *normrad, *curvmax, *curvmin, *clean_tex;
+    unsigned long long *zbuf;
+    uint32_t *rec_count;        // [HRBF_MAX_SHARDS]: records packed by each rank (slot `rank` = own count; all-gathered)
+    uint32_t *send_idx, *recv_idx;
+    float4 *send_f, *recv_f;    // 6 planes of P float4 each
+    uint32_t *h_counts;         // pinned: the all-gathered counts (sizes of the variable-length exchange)
 };
 
 struct hrbf_context {
@@ -167,8 +171,9 @@ static void free_shard(MapShard &sh)
 }
 static void free_scratch(ShardScratch &x)
 {
-    void *q[] = {x.zbuf, x.idx, x.vertconf, x.colortime, x.normrad, x.curvmax, x.curvmin, x.clean_tex};
+    void *q[] = {x.zbuf, x.rec_count, x.send_idx, x.recv_idx, x.send_f, x.recv_f};
     for (void *p : q) if (p) hipFree(p);
+    if (x.h_counts) hipHostFree(x.h_counts);
     memset(&x, 0, sizeof(x));
 }
 static float4 *map_plane(const MapPlanes &m, int k)
@@ -472,20 +477,6 @@ static void shard_allgather_counts(hrbf_context *c, uint32_t *row)
 {
     if (c->shard_real && c->comm.comm) rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
 }
-struct ImgRef { void *p; size_t words; };
-static int what_images(hrbf_context *c, bool primary, bool for_clean, int what, ImgRef out[6])
-{
-    const size_t P = (size_t)c->P;
-    int n = 0;
-    if (what & 1) { out[n++] = {primary ? c->d_im_vertconf : c->x.vertconf, P * 4}; out[n++] = {primary ? c->d_im_normrad : c->x.normrad, P * 4}; }
-    if (what & 2) {
-        out[n++] = {primary ? c->d_im_colortime : c->x.colortime, P * 4}; out[n++] = {primary ? c->d_im_curvmax : c->x.curvmax, P * 4};
-        out[n++] = {primary ? c->d_im_curvmin : c->x.curvmin, P * 4};
-    }
-    if ((what & 4) && for_clean) out[n++] = {primary ? c->d_clean_tex : c->x.clean_tex, clean_tex_elems(c->P) * 4};
-    return n;
-}
-
 static void st_init(hrbf_context *c)
 {
     // the seed goes to the end of the global order = the last shard; every other shard starts empty
@@ -517,7 +508,8 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
         return;
     }
     // sharded map: every shard projects its own surfels under GLOBAL ids -> min-reduce of the packed keys -> every
-    // shard gathers the winners it owns and writes zeros elsewhere -> sum-reduce of the images (as integers: exact).
+    // shard gathers the winners it owns (zeros elsewhere) and packs them as winner records -> the records of the other
+    // shards are exchanged (variable length: 4 + 16..80 bytes per HIT pixel instead of dense images) and scattered.
     for (int k = 0; k < c->nsh; ++k) {
         unsigned long long *zb = k == 0 ? c->d_zbuf : c->x.zbuf;
         launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[k].map, shard_ref(c, k), c->sh[k].count_ub, zb,
@@ -525,24 +517,59 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
         if (k > 0) launch_zbuf_min_merge(c->stream, c->d_zbuf, c->x.zbuf, c->P);
     }
     if (c->shard_real && c->comm.comm) rccl_allreduce_min_u64(c->comm.comm, c->d_zbuf, (size_t)c->P, c->stream);
-    ImgRef prim[6], scr[6];
-    const int ni = what_images(c, true, for_clean, what, prim);
-    for (int k = 0; k < c->nsh; ++k) {
-        const bool p0 = k == 0;
-        launch_resolve(c->stream, c->cam, c->d_pose, c->sh[k].map, shard_ref(c, k), c->d_zbuf, p0 ? c->d_idx : c->x.idx,
-                       p0 ? c->d_im_vertconf : c->x.vertconf, p0 ? c->d_im_colortime : c->x.colortime,
-                       p0 ? c->d_im_normrad : c->x.normrad, p0 ? c->d_im_curvmax : c->x.curvmax,
-                       p0 ? c->d_im_curvmin : c->x.curvmin, for_clean ? (p0 ? c->d_clean_tex : c->x.clean_tex) : nullptr, what,
-                       k == c->nsh - 1 ? 1 : 0, c->clean_thr, c->clean_time);
-        if (!p0) {
-            what_images(c, false, for_clean, what, scr);
-            for (int t = 0; t < ni; ++t) launch_add_u32(c->stream, (uint32_t *)prim[t].p, (const uint32_t *)scr[t].p, prim[t].words);
+    const uint32_t cap = (uint32_t)c->P;
+    float4 *ctx_clean = for_clean ? c->d_clean_tex : nullptr;
+    if (!c->shard_real) {
+        // one process plays all shards in turn: shard 0 writes the images (zeros where it owns nothing), every further
+        // shard packs its winners and they are scattered right away — the data flow of the exchange without a wire
+        for (int k = 0; k < c->nsh; ++k) {
+            uint32_t *cnt = c->x.rec_count + k;
+            if (k > 0) hipMemsetAsync(cnt, 0, sizeof(uint32_t), c->stream);
+            launch_resolve(c->stream, c->cam, c->d_pose, c->sh[k].map, shard_ref(c, k), c->d_zbuf, c->d_idx, c->d_im_vertconf,
+                           c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean, what,
+                           k == c->nsh - 1 ? 1 : 0, c->clean_thr, c->clean_time, k > 0 ? cnt : nullptr,
+                           k > 0 ? c->x.send_idx : nullptr, c->x.send_f, cap, k == 0 ? 1 : 0);
+            if (k > 0)
+                launch_winner_unpack(c->stream, c->P, cnt, 0, cap, c->x.send_idx, c->x.send_f, cap, what, c->d_im_vertconf,
+                                     c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
         }
+        return;
     }
-    if (c->shard_real && c->comm.comm) {
-        g_rccl.GroupStart();
-        for (int t = 0; t < ni; ++t) rccl_allreduce_sum_u32(c->comm.comm, (uint32_t *)prim[t].p, prim[t].words, c->stream);
-        g_rccl.GroupEnd();
+    // one shard per rank
+    const int me = c->comm.rank, G = c->G;
+    uint32_t *cnt = c->x.rec_count + me;
+    hipMemsetAsync(cnt, 0, sizeof(uint32_t), c->stream);
+    launch_resolve(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), c->d_zbuf, c->d_idx, c->d_im_vertconf,
+                   c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean, what, 1, c->clean_thr,
+                   c->clean_time, cnt, c->x.send_idx, c->x.send_f, cap, 1);
+    if (!c->comm.comm || G == 1) return;
+    // sizes of the variable-length exchange: all-gather of the record counts, read back (the one host round trip of the pass)
+    rccl_allgather_u32(c->comm.comm, cnt, c->x.rec_count, 1, c->stream);
+    hipMemcpyAsync(c->x.h_counts, c->x.rec_count, sizeof(uint32_t) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+    const uint32_t n_me = c->x.h_counts[me] < cap ? c->x.h_counts[me] : cap;
+    int planes[6], np = 0;
+    if (what & 1) { planes[np++] = 0; planes[np++] = 1; }
+    if (what & 2) { planes[np++] = 2; planes[np++] = 3; planes[np++] = 4; }
+    if ((what & 4) && for_clean) planes[np++] = 5;
+    g_rccl.GroupStart();
+    uint32_t off = 0;
+    for (int p = 0; p < G; ++p) {
+        if (p == me) continue;
+        const uint32_t n_p = c->x.h_counts[p];
+        if (off + n_p > cap) break;   // cannot happen: a pixel has one owner, so the counts of all ranks add up to <= P
+        if (n_me) g_rccl.Send(c->x.send_idx, n_me, kNcclUint32, p, c->comm.comm, c->stream);
+        if (n_p) g_rccl.Recv(c->x.recv_idx + off, n_p, kNcclUint32, p, c->comm.comm, c->stream);
+        for (int t = 0; t < np; ++t) {
+            if (n_me) g_rccl.Send(c->x.send_f + (size_t)planes[t] * cap, (size_t)n_me * 4, kNcclUint32, p, c->comm.comm, c->stream);
+            if (n_p) g_rccl.Recv(c->x.recv_f + (size_t)planes[t] * cap + off, (size_t)n_p * 4, kNcclUint32, p, c->comm.comm, c->stream);
+        }
+        off += n_p;
+    }
+    g_rccl.GroupEnd();
+    if (off) {
+        launch_winner_unpack(c->stream, c->P, nullptr, 0, off, c->x.recv_idx, c->x.recv_f, cap, what,
+                             c->d_im_vertconf, c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
     }
 }
 static void st_fuse(hrbf_context *c)
@@ -1178,6 +1205,15 @@ extern "C" int hrbf_get_status(hrbf_handle c, uint32_t *flags, int clear)
     return HRBF_OK;
 }
 
+// measurement probe: one Gauss-Newton iteration's pixel work of pyramid `level` in ONE workgroup
+extern "C" int hrbf_probe_single_workgroup_iteration(hrbf_handle c, int level, int iters, float *ms_out)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    OdoConfig cfg = make_cfg(c);
+    return odo_probe_single_wg(c->stream, c->odo, cfg, level, iters, ms_out);
+}
+
 extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
 {
     if (!c || !out) return HRBF_ERR_INVALID;
@@ -1353,21 +1389,20 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
             HIP_CHECK(hipDeviceSynchronize());   // dalloc zero-fills on the null stream
             launch_fill_u32(c->stream, c->sh[k].d_slot, c->cap, 0xFFFFFFFFu);
         }
-    if (nsh > 1 && !c->x.zbuf) {
+    free_scratch(c->x);
+    if (nsh > 1 || real) {
         const size_t P = (size_t)c->P;
-        int r = dalloc(&c->x.zbuf, P);
-        if (!r) r = dalloc(&c->x.idx, P);
-        if (!r) r = dalloc(&c->x.vertconf, P);
-        if (!r) r = dalloc(&c->x.colortime, P);
-        if (!r) r = dalloc(&c->x.normrad, P);
-        if (!r) r = dalloc(&c->x.curvmax, P);
-        if (!r) r = dalloc(&c->x.curvmin, P);
-        if (!r) r = dalloc(&c->x.clean_tex, clean_tex_elems((int)P));
+        int r = dalloc(&c->x.rec_count, HRBF_MAX_SHARDS);
+        if (!r) r = dalloc(&c->x.send_idx, P);
+        if (!r) r = dalloc(&c->x.send_f, 6 * P);
+        if (!r && nsh > 1) r = dalloc(&c->x.zbuf, P);
+        if (!r && real) r = dalloc(&c->x.recv_idx, P);
+        if (!r && real) r = dalloc(&c->x.recv_f, 6 * P);
         if (r) return r;
+        if (real) HIP_CHECK(hipHostMalloc((void **)&c->x.h_counts, sizeof(uint32_t) * HRBF_MAX_SHARDS, hipHostMallocDefault));
         HIP_CHECK(hipDeviceSynchronize());
-        launch_zbuf_reset(c->stream, c->x.zbuf, c->P);
+        if (c->x.zbuf) launch_zbuf_reset(c->stream, c->x.zbuf, c->P);
     }
-    if (nsh == 1) free_scratch(c->x);
     c->G = G; c->nsh = nsh; c->shard_first = first; c->shard_real = real;
     for (int k = 0; k < nsh; ++k) c->sh[k].count_ub = 0;
     HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));

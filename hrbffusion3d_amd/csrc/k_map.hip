@@ -161,13 +161,19 @@ __device__ __forceinline__ const uint32_t *clean_bits(const float4 *clean_tex, i
     return reinterpret_cast<const uint32_t *>(clean_tex + P);
 }
 
+// Sharded map: instead of reducing dense images between the ranks, a rank packs ONE record per pixel whose
+// winner it owns — the pixel index (bit 31: "updated this frame", for the clean mask) and the winner's attributes the
+// next consumer reads — into compact arrays that are exchanged (all-gather-v) and scattered by k_winner_unpack.
+// rec.f holds six planes of `cap` float4: 0 vertconf, 1 normrad, 2 colortime, 3 curvmax, 4 curvmin, 5 clean texel.
+struct WinnerRecords { uint32_t *count; uint32_t *idx; float4 *f; uint32_t cap; };
+
 __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m, ShardRef sh, int rearm,
                                                  unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
                                                  float4 *__restrict__ curvmax, float4 *__restrict__ curvmin,
                                                  float4 *__restrict__ clean_tex, int what, float clean_conf_thr,
-                                                 int clean_time)
+                                                 int clean_time, WinnerRecords rec, int dense)
 {
     const int P = cam.W * cam.H;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
         s = sg - shard_offset(sh);
         owned = s < sh.counts[sh.k];   // else the winner lives on another shard: contribute zeros to the sum-reduction
     }
-    idx[i] = sg;
+    if (dense) idx[i] = sg;
     float4 o_vc = z4, o_nr = z4, o_ct = z4, o_c1 = z4, o_c2 = z4, o_clean = z4;
     bool updated = false;
     if (owned) {
@@ -204,12 +210,58 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
             }
         }
     }
-    if (what & RESOLVE_GEOM) { vertconf[i] = o_vc; normrad[i] = o_nr; }
-    if (what & RESOLVE_ATTR) { colortime[i] = o_ct; curvmax[i] = o_c1; curvmin[i] = o_c2; }
-    if (what & RESOLVE_CLEAN) {
-        clean_tex[i] = o_clean;
-        const unsigned long long bal = __ballot(updated);   // a wave = 64 consecutive pixels = one 8-byte word of the mask
-        if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(clean_tex + P)[i >> 6] = bal;
+    if (dense) {
+        if (what & RESOLVE_GEOM) { vertconf[i] = o_vc; normrad[i] = o_nr; }
+        if (what & RESOLVE_ATTR) { colortime[i] = o_ct; curvmax[i] = o_c1; curvmin[i] = o_c2; }
+        if (what & RESOLVE_CLEAN) {
+            clean_tex[i] = o_clean;
+            const unsigned long long bal = __ballot(updated);   // a wave = 64 consecutive pixels = one 8-byte word of the mask
+            if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(clean_tex + P)[i >> 6] = bal;
+        }
+    }
+    if (rec.idx) {   // pack the owned winners: one position per workgroup from a single atomic (same-address atomics serialise)
+        __shared__ uint32_t s_n[4], s_base;
+        const unsigned long long bal = __ballot(owned);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (lane == 0) s_n[wid] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t n = s_n[0] + s_n[1] + s_n[2] + s_n[3]; s_base = n ? atomicAdd(rec.count, n) : 0u; }
+        __syncthreads();
+        if (owned) {
+            uint32_t pos = s_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wid; ++w) pos += s_n[w];
+            if (pos < rec.cap) {
+                rec.idx[pos] = (uint32_t)i | (updated ? 0x80000000u : 0u);
+                const size_t cap = rec.cap;
+                if (what & RESOLVE_GEOM) { rec.f[pos] = o_vc; rec.f[cap + pos] = o_nr; }
+                if (what & RESOLVE_ATTR) { rec.f[2 * cap + pos] = o_ct; rec.f[3 * cap + pos] = o_c1; rec.f[4 * cap + pos] = o_c2; }
+                if (what & RESOLVE_CLEAN) rec.f[5 * cap + pos] = o_clean;
+            }
+        }
+    }
+}
+
+// scatter the winner records of other shards into the dense images (the pixels they cover were written as zeros by this
+// rank's own k_resolve: one owner per pixel)
+__global__ __launch_bounds__(256) void k_winner_unpack(int P, const uint32_t *__restrict__ count /* nullable */, uint32_t n_fixed, uint32_t first, const uint32_t *__restrict__ ridx,
+                                                       const float4 *__restrict__ rf, uint32_t cap, int what,
+                                                       float4 *__restrict__ vertconf, float4 *__restrict__ colortime,
+                                                       float4 *__restrict__ normrad, float4 *__restrict__ curvmax,
+                                                       float4 *__restrict__ curvmin, float4 *__restrict__ clean_tex)
+{
+    const uint32_t n = count ? *count : n_fixed;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const uint32_t pos = first + r;
+        const uint32_t w = ridx[pos];
+        const uint32_t i = w & 0x7FFFFFFFu;
+        if (i >= (uint32_t)P) continue;
+        const size_t c = cap;
+        if (what & RESOLVE_GEOM) { vertconf[i] = rf[pos]; normrad[i] = rf[c + pos]; }
+        if (what & RESOLVE_ATTR) { colortime[i] = rf[2 * c + pos]; curvmax[i] = rf[3 * c + pos]; curvmin[i] = rf[4 * c + pos]; }
+        if (what & RESOLVE_CLEAN) {
+            clean_tex[i] = rf[5 * c + pos];
+            if (w & 0x80000000u) atomicOr(reinterpret_cast<uint32_t *>(clean_tex + P) + (i >> 5), 1u << (i & 31u));
+        }
     }
 }
 
@@ -862,12 +914,25 @@ void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxD
 }
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                    float4 *clean_tex, int what, int rearm, float clean_conf_thr, int clean_time)
+                    float4 *clean_tex, int what, int rearm, float clean_conf_thr, int clean_time, uint32_t *rec_count,
+                    uint32_t *rec_idx, float4 *rec_f, uint32_t rec_cap, int dense)
 {
     const int P = cam.W * cam.H;
     if (!clean_tex) what &= ~RESOLVE_CLEAN;
+    WinnerRecords rec = {rec_count, rec_idx, rec_f, rec_cap};
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, rearm, zbuf, idx, vertconf,
-                       colortime, normrad, curvmax, curvmin, clean_tex, what, clean_conf_thr, clean_time);
+                       colortime, normrad, curvmax, curvmin, clean_tex, what, clean_conf_thr, clean_time, rec, dense);
+}
+void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
+                          const float4 *rf, uint32_t cap, int what, float4 *vertconf, float4 *colortime, float4 *normrad,
+                          float4 *curvmax, float4 *curvmin, float4 *clean_tex)
+{
+    if (!clean_tex) what &= ~RESOLVE_CLEAN;
+    uint32_t blocks = (n_ub + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_winner_unpack, dim3(blocks), dim3(256), 0, s, P, count, n_ub, first, ridx, rf, cap, what, vertconf, colortime,
+                       normrad, curvmax, curvmin, clean_tex);
 }
 
 // local stand-ins for the two collectives of a sharded projection (one process playing several shards): the same
@@ -880,18 +945,9 @@ __global__ void k_zbuf_min_merge(unsigned long long *__restrict__ dst, unsigned 
     if (b < a) dst[i] = b;
     if (b != ZB_EMPTY) src[i] = ZB_EMPTY;
 }
-__global__ void k_add_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
-}
 void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P)
 {
     hipLaunchKernelGGL(k_zbuf_min_merge, dim3((P + 255) / 256), dim3(256), 0, s, dst, src_reset, P);
-}
-void launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, size_t n)
-{
-    hipLaunchKernelGGL(k_add_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
 }
 
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,

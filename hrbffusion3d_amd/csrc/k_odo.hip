@@ -2012,3 +2012,82 @@ int odo_read_timeouts(hipStream_t s, OdoState *st, int clear)
     if (clear) { const int z[2] = {0, 0}; hipMemcpyAsync(&st->bar_timeout, z, sizeof(z), hipMemcpyHostToDevice, s); hipStreamSynchronize(s); }
     return v[0] + v[1];
 }
+
+// ------------------------------------------------------------------------------------------ measurement probe
+// The per-iteration pixel work of ONE pyramid level done by ONE workgroup (the "single-workgroup Gauss-Newton loop"
+// question): the ICP pixel + exact reduction over all pixels, then the RGB products + exact reduction
+// over the correspondences the last frame left behind.  Same pixel functions, same limbs; scratch slot rows.  Returns
+// the kernel time in ms of `iters` such passes (one launch), for comparison with the three launches of an iteration.
+__global__ __launch_bounds__(RB) void k_probe_single_wg_iteration(OdoLevel L, IcpArgs A, const OdoState *__restrict__ st, float fx,
+                                                                  float fy, int use_grad, const int16_t *__restrict__ corres,
+                                                                  long long *__restrict__ scratch, int iters)
+{
+    const int n = L.rows * L.cols;
+    for (int it = 0; it < iters; ++it) {
+        for (int base = 0; base < n; base += RB) {
+            float out[29];
+#pragma unroll
+            for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+            bool valid = false;
+            const int i = base + threadIdx.x;
+            if (i < n) {
+                const int y = i / A.cols, x = i - y * A.cols;
+                valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
+                                  mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
+            }
+            block_reduce_exact<29>(out, valid, scratch);
+            __syncthreads();
+        }
+        for (int base = 0; base < n; base += RB) {
+            float out[29];
+#pragma unroll
+            for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+            bool valid = false;
+            const int k = base + threadIdx.x;
+            if (k < n) {
+                const int2 rec = reinterpret_cast<const int2 *>(corres)[k];
+                if (rec.x != -1) {
+                    // the records were left by the last level-0 iteration: fold their coordinates into this level (timing only)
+                    const int u0 = (rec.x & 0xffff) % L.cols, v0 = (int)((uint32_t)rec.x >> 16) % L.rows;
+                    {
+                        const float4 cp = L.cloud4[(size_t)v0 * L.cols + u0];
+                        const int g = L.dIxy[k];
+                        rgb_products_core(__int_as_float(rec.y), cp.x, cp.y, cp.z, (int)(int16_t)(g & 0xffff), (int)(int16_t)((uint32_t)g >> 16),
+                                          10.0f, fx, fy, use_grad, out);
+                        valid = true;
+                    }
+                }
+            }
+            block_reduce_exact<29>(out, valid, scratch + ODO_SLOTS * 87);
+            __syncthreads();
+        }
+    }
+}
+
+int odo_probe_single_wg(hipStream_t s, OdoBuffers &ob, const OdoConfig &cfg, int level, int iters, float *ms_out)
+{
+    if (level < 0 || level >= HRBF_NUM_PYRS || iters < 1 || !ms_out) return HRBF_ERR_INVALID;
+    const OdoLevel &L = ob.lv[level];
+    IcpArgs A = make_icp_args(L, cfg, level);
+    long long *scratch = nullptr;
+    HIP_CHECK(hipMalloc(&scratch, sizeof(long long) * 87 * ODO_SLOTS * 2));
+    HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(long long) * 87 * ODO_SLOTS * 2, s));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int div = 1 << level;
+    // the correspondence records of the LAST frame's final level-0 iteration are laid out for level 0; any level's pixel
+    // count indexes a valid prefix of them, which is all a timing probe needs (indices are range-checked above)
+    hipLaunchKernelGGL(k_probe_single_wg_iteration, dim3(1), dim3(RB), 0, s, L, A, ob.state, cfg.fx / div, cfg.fy / div, cfg.rgb_use_grad,
+                       ob.corres, scratch, 1);   // warm-up (code + L2)
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(k_probe_single_wg_iteration, dim3(1), dim3(RB), 0, s, L, A, ob.state, cfg.fx / div, cfg.fy / div, cfg.rgb_use_grad,
+                       ob.corres, scratch, iters);
+    hipEventRecord(e1, s);
+    hipError_t e = hipStreamSynchronize(s);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(scratch);
+    if (e != hipSuccess) { hrbf_set_error("probe: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    *ms_out = ms;
+    return HRBF_OK;
+}

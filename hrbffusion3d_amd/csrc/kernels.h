@@ -47,8 +47,9 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
                        int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
                        uint32_t cap, uint32_t *count, uint32_t *status /* nullable: |= 2 when the seed frame exceeds cap */);
 // projection = launch_project (z-buffer of packed keys) + launch_resolve (winner gather).  With a sharded map the
-// z-buffers are min-reduced between the two and the resolved images sum-reduced afterwards (a pixel has one owner,
-// every other shard writes zeros); `rearm` lets the last local shard leave the z-buffer empty for the next pass.
+// z-buffers are min-reduced between the two; every shard then resolves the winners it owns (zeros elsewhere), packs
+// them as compact winner records and the records of the other shards are scattered into the images
+// (launch_winner_unpack); `rearm` lets the last local shard leave the z-buffer empty for the next pass.
 void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
                     uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active /* nullable: KeyFrameIDMap */,
                     int n_active);
@@ -56,10 +57,16 @@ void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes 
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
                     float4 *clean_tex /* nullable: packed texels + update mask for the clean test (clean_tex_elems) */,
                     int what /* 1 geometry images | 2 attribute images | 4 clean texels */, int rearm,
-                    float clean_conf_thr, int clean_time /* baked into the clean texels */);
+                    float clean_conf_thr, int clean_time /* baked into the clean texels */,
+                    uint32_t *rec_count = nullptr, uint32_t *rec_idx = nullptr /* nullable: pack the owned winners */,
+                    float4 *rec_f = nullptr /* 6 planes of rec_cap float4 */, uint32_t rec_cap = 0,
+                    int dense = 1 /* 0: records only (a virtual shard behind the first) */);
+// sharded map: scatter `*count` (or, with count == null, n_ub) winner records, starting at record `first`, into the dense images
+void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
+                          const float4 *rf, uint32_t cap, int what, float4 *vertconf, float4 *colortime, float4 *normrad,
+                          float4 *curvmax, float4 *curvmin, float4 *clean_tex);
 size_t clean_tex_elems(int P);   // float4 elements of the clean-texel buffer (texels + one bit per pixel)
 void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P);   // local stand-in for allReduce(min)
-void launch_add_u32(hipStream_t s, uint32_t *dst, const uint32_t *src, size_t n);                          // local stand-in for allReduce(sum)
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
@@ -153,7 +160,8 @@ struct OdoSources {   // images the odometry is initialised from (selected on de
 size_t odo_state_bytes();
 size_t odo_slot_bytes();
 void odo_release(OdoBuffers &ob);   // destroys the cached graphs
-int odo_read_timeouts(hipStream_t s, OdoState *st, int clear);   // frames whose SO3 kernel hit its poll bound (sticky)
+int odo_read_timeouts(hipStream_t s, OdoState *st, int clear);
+int odo_probe_single_wg(hipStream_t s, OdoBuffers &ob, const OdoConfig &cfg, int level, int iters, float *ms_out);   // measurement probe   // frames whose SO3 kernel hit its poll bound (sticky)
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);
 // full registration: pyramids + SO3 pre-alignment + 3-level Gauss-Newton; updates *dp (pose, weighting inputs)
 // Row-sharded registration (SURVEY §8e sharding 1): every rank holds the full pyramids and reduces the image rows

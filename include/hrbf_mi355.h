@@ -218,6 +218,10 @@ int hrbf_get_timings(hrbf_handle h, float out_ms[8]);
 int hrbf_get_fuse_ring(hrbf_handle h, int max_frames, float *kernel_ms, uint32_t *stats4);
 int hrbf_get_fuse_ring_parts(hrbf_handle h, int max_frames, float *merge_ms, float *stream_ms, uint32_t *stats8);
 int hrbf_reset_fuse_ring(hrbf_handle h);
+/* measurement probe (not part of the path): the pixel work of `iters` Gauss-Newton iterations of pyramid `level` (ICP
+ * products + RGB products, exact reductions) executed by ONE 256-thread workgroup; kernel time in ms.  Call after at
+ * least two processed frames.  DESIGN.md §6 compares it with the three launches an iteration takes. */
+int hrbf_probe_single_workgroup_iteration(hrbf_handle h, int level, int iters, float *ms_out);
 /* build-specific: toggle trajectory replay (globalInputLoadTrajectory) between frames */
 int hrbf_set_load_trajectory(hrbf_handle h, int v);
 /* sticky condition bits, folded from the device by this (synchronising) call; clear != 0 resets them.  The per-frame

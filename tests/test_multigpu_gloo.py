@@ -78,8 +78,10 @@ def test_limb_allreduce_is_exact_and_timing_is_max_over_ranks(oracle_lib_built):
 
 def _shard_worker(rank, world, port, q):
     """the exchange protocol of the sharded surfel map (csrc/abi.hip st_indices / hrbf_map_rebalance) on two real
-    processes: global ids in the z-buffer keys, MIN over the keys, integer SUM over the owner-filled images,
-    all-gather of the counts, and the re-cut of the ranges with the moves of hrbf_rebalance_plan as send / recv."""
+    processes: global ids in the z-buffer keys, MIN over the keys, then the WINNER-RECORD exchange (every rank packs
+    {pixel index | updated bit, attributes} of the pixels whose winner it owns, the record counts are all-gathered, the
+    records travel as variable-length send / recv and are scattered into the zero-filled images), all-gather of the
+    counts, and the re-cut of the ranges with the moves of hrbf_rebalance_plan as send / recv."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hrbffusion3d_amd import api
@@ -98,8 +100,34 @@ def _shard_worker(rank, world, port, q):
     hit = zt.numpy() != EMPTY
     img = np.zeros((P, 4), np.float32)
     own = hit & (win >= off) & (win < off + n)
-    img[own] = attr[win[own]]
-    it = torch.from_numpy(img.view(np.int32)); dist.all_reduce(it, op=dist.ReduceOp.SUM)
+    img[own] = attr[win[own]]                      # the rank's own k_resolve: its winners, zeros elsewhere
+    # pack (k_resolve's record branch): pixel index with the "updated" flag in bit 31 + one attribute plane
+    updated = (win % 5 == 0) & own
+    order = rng.permutation(np.nonzero(own)[0])    # the pack order is arbitrary on the GPU (one atomic per workgroup)
+    rec_idx = (order.astype(np.uint32) | (updated[order].astype(np.uint32) << 31)).astype(np.int64)
+    rec_f = attr[win[order]].copy()
+    cnt_t = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(cnt_t, torch.tensor([len(order)], dtype=torch.int64))
+    counts_rec = [int(t.item()) for t in cnt_t]
+    mask = np.zeros(P, bool); mask[np.nonzero(updated)[0]] = True
+    reqs = []
+    for p in range(world):
+        if p == rank:
+            continue
+        if counts_rec[rank]:
+            reqs.append(dist.isend(torch.from_numpy(rec_idx.copy()), dst=p))
+            reqs.append(dist.isend(torch.from_numpy(rec_f.view(np.int32).copy()), dst=p))
+        if counts_rec[p]:
+            ridx = torch.zeros(counts_rec[p], dtype=torch.int64); dist.recv(ridx, src=p)
+            rf = torch.zeros((counts_rec[p], 4), dtype=torch.int32); dist.recv(rf, src=p)
+            pix_r = (ridx.numpy() & 0x7FFFFFFF).astype(np.int64)
+            assert not own[pix_r].any()            # one owner per pixel: a received record never lands on an own winner
+            img[pix_r] = rf.numpy().view(np.float32)          # k_winner_unpack
+            mask[pix_r[(ridx.numpy() >> 31) & 1 == 1]] = True
+    for r in reqs:
+        r.wait()
+    it = torch.from_numpy(np.concatenate([img.view(np.int32), mask.astype(np.int32)[:, None]], 1))
+    assert sum(counts_rec) == int(hit.sum())       # every hit pixel has exactly one record
     # counts all-gather + even re-cut
     mine = torch.tensor([n], dtype=torch.int64); allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(allc, mine)
@@ -147,7 +175,8 @@ def test_sharded_map_exchange_protocol_world2():
     img = np.zeros((P, 4), np.float32); hit = z != EMPTY; img[hit] = attr[(z & 0xFFFFFFFF)[hit]]
     for r in (0, 1):
         zr, ir, out, new = got[r]
-        assert np.array_equal(zr, z) and np.array_equal(ir, img.view(np.int32))      # bit-exact incl. -0.0
+        assert np.array_equal(zr, z) and np.array_equal(ir[:, :4], img.view(np.int32))      # bit-exact incl. -0.0
+        assert np.array_equal(ir[:, 4] != 0, hit & ((z & 0xFFFFFFFF) % 5 == 0))               # the "updated" mask
     assert got[0][3] == [2500, 2500]
     assert np.array_equal(np.concatenate([got[0][2], got[1][2]]), np.arange(N))
 
