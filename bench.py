@@ -295,14 +295,7 @@ def main():
     merge_ms = float(mm[ok].mean()) if ok.any() else 0.0
     count1 = fus.surfel_count()
     P_end = fus.get_pose()
-    status = fus.status()
-    real_bytes = None
-    if world == 1 and ok.any() and args.virtual_shards <= 1:
-        m_now = fus.download_map()
-        n_view, n_unst_out = frustum_counts(m_now, P_end, (fx, fy, cx, cy), W, H, p.confidence_threshold)
-        sm = st[ok].astype(np.float64).mean(axis=0)
-        real_bytes = fuse_real_bytes(sm[0], n_view, n_unst_out, sm[1], sm[2], sm[6], (W // 2) * (H // 2), W * H)
-        del m_now
+    m_timed = fus.download_map() if (world == 1 and args.virtual_shards <= 1) else None   # for the real-bytes model below
     tm = np.zeros(8, np.float32)
     # PCIe-inclusive rate of the host-pointer entry point (never `value`): 1.5 MB upload + sync per frame
     pcie_fps = None
@@ -310,7 +303,7 @@ def main():
     if world == 1:
         nh = min(20, K)
         fus.enable_timing(False)
-        for k in range(1 + Wm, 1 + Wm + min(3, K)):      # first use allocates the pinned staging ring
+        for k in range(1 + Wm, 1 + Wm + min(6, K)):      # first use allocates the pinned staging ring; clocks back up after the read-back
             fus.process_frame(frames[k][0], frames[k][1], k)
         fus.synchronize()
         t1 = time.perf_counter()
@@ -335,6 +328,14 @@ def main():
         n_now = fus.surfel_count()
         update_model = {"ms_per_call_incl_upload": um_ms, "surfels": int(n_now),
                         "algorithmic_GBps_160B_per_surfel": 160.0 * n_now / (um_ms * 1e-3) / 1e9}
+    status = fus.status()
+    real_bytes = None
+    if m_timed is not None and ok.any():
+        m_now = m_timed
+        n_view, n_unst_out = frustum_counts(m_now, P_end, (fx, fy, cx, cy), W, H, p.confidence_threshold)
+        sm = st[ok].astype(np.float64).mean(axis=0)
+        real_bytes = fuse_real_bytes(sm[0], n_view, n_unst_out, sm[1], sm[2], sm[6], (W // 2) * (H // 2), W * H)
+        del m_now
     err_mm = float(1000.0 * np.linalg.norm(P_end[:3, 3] - poses[Wm + K][:3, 3]))
 
     # HBM traffic of the fuse pass: PMC counters cannot be collected from inside this process; the figure is the

@@ -472,7 +472,7 @@ struct CleanParams {
     const DevPose *dp;
     float maxDepth, confThr, curvThr;
     int time;
-    int nw;        // samples per axis = 2 * clean_window_multiplier
+    int nw;        // samples per axis = ceil(2 * clean_window_multiplier) (copy_unstable.vert:106-108, half-pixel steps)
     float w0;      // clean_window_multiplier * 0.5
     int full_check;
     const uint8_t *submap_active;   // nullable: KeyFrameIDMap (copy_unstable.vert:98-101)
@@ -979,7 +979,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
     CleanParams cp;
     cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
-    cp.nw = (int)(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
+    cp.nw = (int)ceilf(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
     cp.submap_active = submap_active; cp.n_active = n_active;
     const uint32_t items_ub = count_ub + (uint32_t)Q;
     uint32_t tiles = (items_ub + FUSE_TILE - 1) / FUSE_TILE;

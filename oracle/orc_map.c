@@ -229,7 +229,10 @@ static int clean_test(const orc_ctx *c, const float *tinv, f4 vp, f4 *vcol, f4 v
     if (lp.z < maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)W && y < (float)H) {
         /* half-pixel steps over [x - w/2, x + w/2) px (copy_unstable.vert:84-108 with FACTOR = 1):
            samples at x + (k - w)*0.5, k = 0 .. 2w-1 */
-        int nw = (int)(2.0f * c->prm.clean_window_multiplier);
+        /* copy_unstable.vert:106-108 steps i from x - wm/2 while i < x + wm/2 in half pixels: ceil(2 wm) samples per axis in exact
+           arithmetic (the shader accumulates i in fp32 texture coordinates; whether rounding ever adds a sample there is
+           driver arithmetic and stays unpinned) */
+        int nw = (int)ceilf(2.0f * c->prm.clean_window_multiplier);
         float w0 = c->prm.clean_window_multiplier * 0.5f;
         for (int a = 0; a < nw; ++a) {
             int sx = clampi((int)floorf(x + ((float)a * 0.5f - w0)), 0, W - 1);

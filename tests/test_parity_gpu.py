@@ -243,7 +243,7 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
 
 
 @pytest.mark.parametrize("variant", ["gauss_filter", "central_diff_normals", "no_so3_no_pyramid", "conf_eval", "rgb_only",
-                                     "icp_only", "corr_search", "sparse_icp_corr_search", "clean_window_1", "clean_window_4",
+                                     "icp_only", "corr_search", "sparse_icp_corr_search", "clean_window_1", "clean_window_4", "clean_window_2_25",
                                      "frame_to_frame_rgb", "rgb_grad_weight", "icp_unweighted", "predict_small",
                                      "curv_window_2", "thresholds"])
 def test_parameter_variants(pair, variant):
@@ -254,6 +254,7 @@ def test_parameter_variants(pair, variant):
           "rgb_only": dict(rgb_only=1), "icp_only": dict(icp_weight=100.0), "corr_search": dict(icp_use_corr_search=1),
           "sparse_icp_corr_search": dict(use_sparse_icp=1, icp_use_corr_search=1),
           "clean_window_1": dict(clean_window_multiplier=1.0), "clean_window_4": dict(clean_window_multiplier=4.0),
+          "clean_window_2_25": dict(clean_window_multiplier=2.25),      # 2 wm not an integer: ceil(4.5) = 5 samples per axis
           "frame_to_frame_rgb": dict(frame_to_frame_rgb=1), "rgb_grad_weight": dict(rgb_use_grad_weight=1),
           "icp_unweighted": dict(icp_use_weighted=0),
           "predict_small": dict(predict_window_multiplier=2.0, predict_min_neighbors=4, predict_max_neighbors=6),
