@@ -512,6 +512,37 @@ def test_velocity_weighting_formula(oracle_lib_built):
         o.close()
 
 
+def test_velocity_weighting_of_a_rotation_matches_the_svd_form(oracle_lib_built):
+    """HRBFFusion::rodrigues2 (HRBFFusion.cpp:2004-2050) first re-orthonormalises the relative rotation with a JacobiSVD
+    (R <- U V^T); the oracle (and the HIP path) skip the SVD — a documented deviation.  Known answer
+    from the reference's formula evaluated WITH the SVD (in fp64 numpy) on a slightly non-orthonormal fp32 rotation.
+    The angle is acos((trace - 1) / 2), ill-conditioned near zero: entry errors of 3e-7 — fp32 rounding level — move a
+    3 mrad angle by ~5e-5 rad, so the two forms differ by up to ~0.01 in the weighting (1 - theta / 0.01); the
+    reference's own fp32 SVD carries the same kind of noise.  The bound below is what the deviation may cost."""
+    W, H, f = 160, 120, 132.0
+    p = default_params(W, H, f, f, 80.0, 60.0, max_surfels=1 << 16, load_trajectory=1)
+    z = scenes.plane_depth(W, H, f, f, 80.0, 60.0, (0.0, 0.0, 1.0), 1.5)
+    rgb, d = scenes.gray_rgb(W, H), scenes.to_u16(z)
+    for angle in (0.0031, 0.0062, 0.0087):
+        ax = np.array([0.3, -0.5, 0.81]); ax /= np.linalg.norm(ax)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = (np.eye(3) + np.sin(angle) * Kx + (1 - np.cos(angle)) * Kx @ Kx).astype(np.float32)
+        R[0, 0] += 3e-7; R[1, 2] -= 2e-7                       # not exactly orthonormal, like a product of fp32 rotations
+        o = oracle_lib_built.Oracle(p)
+        T = np.eye(4, dtype=np.float32)
+        o.set_pose(T); o.process_frame(rgb, d)
+        T[:3, :3] = R
+        o.set_pose(T); o.process_frame(rgb, d)
+        # reference semantics: diff = currPose^-1 * lastPose, SVD re-orthonormalisation, angle from trace / skew part
+        dR = np.linalg.inv(T.astype(np.float64))[:3, :3]
+        U, _, Vt = np.linalg.svd(dR)
+        Ro = U @ Vt
+        theta = np.arccos(np.clip((np.trace(Ro) - 1.0) / 2.0, -1.0, 1.0))
+        expect = max(1.0 - min(theta, 0.01) / 0.01, 0.5)
+        assert abs(o.get_weighting() - expect) < 0.02, (angle, o.get_weighting(), expect)
+        o.close()
+
+
 def test_rgb_step_matches_an_fp64_evaluation(lib):
     """rgbStep (reduce.cu:717-808) re-evaluated in fp64 numpy from the oracle's own correspondence image: robust weight
     1 / (sigma + |diff|), Jacobian row from the Sobel gradients at the live pixel and the back-projected point at the
