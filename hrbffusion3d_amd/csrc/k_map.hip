@@ -124,22 +124,39 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
 {
     const uint32_t n = sh.counts[sh.k], off = shard_offset(sh);   // ids in the keys are GLOBAL
     const Rigid tinv = dp->tinv;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-        float4 p = pos[s];
-        if (submap_active) {   // index_map.vert:41-45: surfels of inactive submaps are not drawn
-            const uint32_t sm = (uint32_t)color_time[s].y;
-            if (sm >= (uint32_t)n_active || submap_active[sm] == 0) continue;
+    // PROJECT_UNROLL position loads are in flight per lane before the first one is consumed: the kernel is a 16 B/surfel
+    // stream with a short dependent tail (transform, two divisions, one atomic for the in-view minority)
+#ifndef PROJECT_UNROLL
+#define PROJECT_UNROLL 4
+#endif
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x; s0 < n; s0 += PROJECT_UNROLL * stride) {
+        float4 pk[PROJECT_UNROLL];
+#pragma unroll
+        for (int k = 0; k < PROJECT_UNROLL; ++k) {
+            const uint32_t s = s0 + (uint32_t)k * stride;
+            pk[k] = s < n ? pos[s] : make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // z < 0: culled below
         }
-        f3 h = xform(tinv, xyz(p));
-        if (h.z > maxDepth || h.z < 0.0f) continue;
-        float u = ((cam.fx * h.x) / h.z) + cam.cx;
-        float v = ((cam.fy * h.y) / h.z) + cam.cy;
-        if (!(u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H)) continue;
-        int ix = (int)hd_floorf(u), iy = (int)hd_floorf(v);
-        unsigned long long key = ((unsigned long long)hd_f2u(h.z) << 32) | (unsigned long long)(off + s);
-        unsigned long long *cell = &zbuf[iy * cam.W + ix];
-        // cheap pre-filter: keys only ever decrease, so a stale larger-or-equal read is conclusive
-        if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell, key);
+#pragma unroll
+        for (int k = 0; k < PROJECT_UNROLL; ++k) {
+            const uint32_t s = s0 + (uint32_t)k * stride;
+            if (s >= n) continue;
+            const float4 p = pk[k];
+            if (submap_active) {   // index_map.vert:41-45: surfels of inactive submaps are not drawn
+                const uint32_t sm = (uint32_t)color_time[s].y;
+                if (sm >= (uint32_t)n_active || submap_active[sm] == 0) continue;
+            }
+            f3 h = xform(tinv, xyz(p));
+            if (h.z > maxDepth || h.z < 0.0f) continue;
+            float u = ((cam.fx * h.x) / h.z) + cam.cx;
+            float v = ((cam.fy * h.y) / h.z) + cam.cy;
+            if (!(u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H)) continue;
+            int ix = (int)hd_floorf(u), iy = (int)hd_floorf(v);
+            unsigned long long key = ((unsigned long long)hd_f2u(h.z) << 32) | (unsigned long long)(off + s);
+            unsigned long long *cell = &zbuf[iy * cam.W + ix];
+            // cheap pre-filter: keys only ever decrease, so a stale larger-or-equal read is conclusive
+            if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell, key);
+        }
     }
 }
 
@@ -673,10 +690,14 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
         const float4 vp = vp_next;
         if (it + stride < N) vp_next = m.p0[it + stride];
         const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp);
+#ifndef CLEAN_NO_STORE
         if (it < N) keep_flags[it] = keep ? 1 : 0;
+#endif
         // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
         const unsigned long long bal = __ballot(keep);
+#ifndef CLEAN_NO_ATOMIC
         if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&tile_count[(size_t)(it / FUSE_TILE) * TC_STRIDE], (uint32_t)__popcll(bal));
+#endif
     }
 }
 

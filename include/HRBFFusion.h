@@ -203,6 +203,16 @@ public:
         trajectory_manager = new TrajectoryManager();
         trajectory_manager->sync = [this]() { this->syncTrajectory(); };
     }
+    /* every tunable at once: `p` as filled from GlobalStateParam (hrbf_default_params + the fields of
+       GUI/GlobalStateParam.txt:20-81; tools/hrbf_run.cpp shows the mapping) */
+    explicit HRBFFusion(const hrbf_params &p, int device = 0) : h_(nullptr), model_(nullptr), load_trajectory_(p.load_trajectory != 0), synced_(0)
+    {
+        if (hrbf_create(&p, device, &h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+        model_ = new GlobalModel(h_);
+        index_ = new IndexMap(h_);
+        trajectory_manager = new TrajectoryManager();
+        trajectory_manager->sync = [this]() { this->syncTrajectory(); };
+    }
     ~HRBFFusion() { delete trajectory_manager; delete index_; delete model_; hrbf_destroy(h_); }
     HRBFFusion(const HRBFFusion &) = delete;
     HRBFFusion &operator=(const HRBFFusion &) = delete;

@@ -78,6 +78,31 @@ HD_FN float hd_expf(float x0)
     return is_nan ? x0 : (over ? hd_u2f(0x7f800000u) : (under ? 0.0f : core));
 }
 
+/* hd_expf for arguments known to be <= 0 and not NaN (the bilateral weights, 169 per pixel): the NaN / overflow selects
+   of hd_expf can never fire there, so they are dropped; every other step — and therefore every result bit — is hd_expf's */
+HD_FN float hd_expf_nonpos(float x0)
+{
+    const int under = x0 < -103.9f;
+    const float x = under ? -103.9f : x0;
+    float kf = hd_rintf(x * 1.44269504088896341f);
+    float r = hd_fmaf(kf, -0.693359375f, x);
+    r = hd_fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.3981999507e-3f;
+    p = hd_fmaf(p, r, 8.3334519073e-3f);
+    p = hd_fmaf(p, r, 4.1665795894e-2f);
+    p = hd_fmaf(p, r, 1.6666665459e-1f);
+    p = hd_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    p = hd_fmaf(p, r2, r);
+    p = p + 1.0f;
+    int k = (int)kf;
+    int k1 = k / 2, k2 = k - k1;
+    float s1 = hd_u2f((uint32_t)(k1 + 127) << 23);
+    float s2 = hd_u2f((uint32_t)(k2 + 127) << 23);
+    const float core = (p * s1) * s2;
+    return under ? 0.0f : core;
+}
+
 /* ---------------------------------------------------------------- asin/acos (float) */
 HD_FN float hd_asin_kernel(float x, float z) /* asin(x) for |x|<=0.5, z=x*x */
 {

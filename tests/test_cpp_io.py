@@ -1,0 +1,137 @@
+"""include/hrbf_io.h + tools/hrbf_run.cpp: the C++ twins of hrbffusion3d_amd/config.py and io.py.  CPU: the C++ parsers
+(ParameterFile rules, camera YAML, association file, PNG decoder for 8-bit RGB and 16-bit grey, .klg with zlib depth)
+agree with the Python ones on the same files — the decoded first frame byte for byte.  GPU: the C++ caller loop replays
+a sequence through HRBFFusion::processFrame and writes the same trajectory as the Python runner, bit for bit."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hrbffusion3d_amd import config as hcfg
+from hrbffusion3d_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PARAM = '''##comment
+currentWorkingDirectory = "/nonexistent/on/this/machine";
+sensorType = %d;
+klgFileName = "seq.klg";
+AssociationFile = "associations.txt";
+parameterFileCvFormat = "cam.yaml";
+optimizationUseLocalBA = false;
+optimizationUseGlobalBA = false;
+preprocessingUsebilateralFilter = true;      //keep
+registrationPreAlignSO3 = true;
+registrationJointICPWeight = 10.0;
+registrationICPNeighborSearchRadius = 2.0;
+preictionMinNeighbors = 6.0;
+globalConfidenceThreshold = 5.0;
+globalDepthCutoff = 3.5;
+globalInputICLNUIMDataset = false;
+'''
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in np.frombuffer(b, np.uint8).tolist():
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def _build(tmp):
+    from hrbffusion3d_amd import build
+    so = build.build()
+    exe = os.path.join(tmp, "hrbf_run")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "hrbf_run.cpp"),
+                           "-o", exe, so, "-lz", "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _write_sequence(d, W, H, K, n, sensor):
+    from PIL import Image
+    from hrbffusion3d_amd.io import write_klg
+    frames = [synth.frame(k, W, H, noise=True, K=K) for k in range(n)]
+    os.makedirs(os.path.join(d, "rgb"), exist_ok=True); os.makedirs(os.path.join(d, "depth"), exist_ok=True)
+    with open(os.path.join(d, "associations.txt"), "w") as f:
+        f.write("# timestamp depth timestamp rgb\n")
+        for k, (rgb, dep, _) in enumerate(frames):
+            t = 1305031102.175304 + k / 30.0
+            Image.fromarray(rgb, "RGB").save(os.path.join(d, "rgb", "%04d.png" % k))
+            Image.fromarray(dep).save(os.path.join(d, "depth", "%04d.png" % k))       # 16-bit grey ("I;16")
+            f.write("%.6f depth/%04d.png %.6f rgb/%04d.png\n" % (t, k, t, k))
+    write_klg(os.path.join(d, "seq.klg"), [(k * 33333, f[0], f[1]) for k, f in enumerate(frames)], compress_depth=True)
+    with open(os.path.join(d, "cam.yaml"), "w") as f:
+        f.write("%%YAML:1.0\n# camera\nCamera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.width: %d\nCamera.height: %d\n"
+                "Camera.RGB: 1\nDepthMapFactor: 5000.0\n" % (K[0], K[1], K[2], K[3], W, H))
+    with open(os.path.join(d, "GlobalStateParam.txt"), "w") as f:
+        f.write(PARAM % sensor)
+    return frames
+
+
+@pytest.mark.parametrize("sensor", [3, 2])
+def test_cpp_readers_agree_with_the_python_ones(tmp_path, sensor):
+    exe = _build(str(tmp_path))
+    W, H = 160, 120
+    K = (129.325, 129.125, 79.65, 63.825)
+    frames = _write_sequence(str(tmp_path), W, H, K, 3, sensor)
+    out = subprocess.run([exe, "--selftest", "--config", str(tmp_path / "GlobalStateParam.txt")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    j = json.loads(out.stdout)
+    g = hcfg.load_global_state(str(tmp_path / "GlobalStateParam.txt"))
+    cam = hcfg.camera_from_yaml(str(tmp_path / "cam.yaml"))
+    assert j["sensorType"] == g["sensorType"] == sensor and j["frames"] == 3
+    assert (j["width"], j["height"]) == (cam["width"], cam["height"]) == (W, H)
+    for k in ("fx", "fy", "cx", "cy"):
+        assert j[k] == pytest.approx(np.float32(cam[k]), rel=1e-7)
+    assert j["depth_scale"] == pytest.approx(np.float32(1 / 5000.0), rel=1e-6) and j["rgb_order"] == 1
+    assert j["confidence"] == 5.0 and j["depth_cutoff"] == 3.5 and j["icp_weight"] == 10.0 and j["so3"] == 1 and j["bilateral"] == 1
+    assert j["min_neighbors"] == 6 and j["search_radius"] == 2 and j["icl"] == 0        # "6.0" / "2.0" read as ints
+    # the first frame, decoded in C++ (own PNG decoder / zlib), equals the arrays the files were written from
+    assert j["rgb_fnv"] == _fnv(frames[0][0].tobytes()) and j["depth_fnv"] == _fnv(frames[0][1].tobytes())
+    assert j["timestamp0"] == (int(round(1305031102.175304 * 1e6)) if sensor == 3 else 0)
+
+
+def test_cpp_png_decoder_on_the_reference_fixture(tmp_path, png_pair):
+    """the reference's GPUTest PNGs (RGB 8-bit, grey 16-bit; written by another encoder, other filter choices)"""
+    exe = _build(str(tmp_path))
+    import shutil
+    for n in ("1c", "1d"):
+        shutil.copy(os.path.join(ROOT, "tests", "golden", n + ".png"), tmp_path / (n + ".png"))
+    (tmp_path / "associations.txt").write_text("0.000000 1d.png 0.000000 1c.png\n")
+    (tmp_path / "cam.yaml").write_text("%YAML:1.0\nCamera.fx: 528.0\nCamera.fy: 528.0\nCamera.cx: 320.0\nCamera.cy: 240.0\n"
+                                       "Camera.width: 640\nCamera.height: 480\nCamera.RGB: 1\nDepthMapFactor: 5000.0\n")
+    (tmp_path / "GlobalStateParam.txt").write_text(PARAM % 3)
+    out = subprocess.run([exe, "--selftest", "--config", str(tmp_path / "GlobalStateParam.txt")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    j = json.loads(out.stdout)
+    rgb, d = png_pair[0]
+    assert j["rgb_fnv"] == _fnv(np.ascontiguousarray(rgb[..., :3]).tobytes()) and j["depth_fnv"] == _fnv(np.ascontiguousarray(d, np.uint16).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor", [3, 2])
+def test_cpp_caller_loop_matches_the_python_runner(tmp_path, gpu_available, sensor):
+    """tools/hrbf_run.cpp (GlobalStateParam.txt -> camera YAML -> PNG / .klg frames -> HRBFFusion::processFrame -> TUM
+    trajectory + PLY) against `python -m hrbffusion3d_amd.run --config` on the same files: same poses, same map size"""
+    from hrbffusion3d_amd import run
+    from hrbffusion3d_amd.io import load_trajectory_tum
+    exe = _build(str(tmp_path))
+    W, H = 320, 240
+    K = tuple(v / 2 for v in synth.TUM_FR1)
+    _write_sequence(str(tmp_path), W, H, K, 12, sensor)
+    cfg = str(tmp_path / "GlobalStateParam.txt")
+    out = subprocess.run([exe, "--config", cfg, "--out", str(tmp_path / "cpp.freiburg"), "--ply", str(tmp_path / "cpp.ply"),
+                          "--max-surfels", str(1 << 20)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    assert j["frames"] == 12 and j["poses"] == 12 and j["surfels"] > 0.5 * W * H
+    rep = run.main(["--config", cfg, "--out", str(tmp_path / "py.freiburg"), "--max-surfels", str(1 << 20)])
+    sa, pa = load_trajectory_tum(str(tmp_path / "cpp.freiburg")); sb, pb = load_trajectory_tum(str(tmp_path / "py.freiburg"))
+    assert len(pa) == len(pb) == 12
+    for a, b in zip(pa, pb):
+        assert np.allclose(a, b, atol=2e-6)          # both files print %g: six significant digits of the same poses
+    assert rep["surfels"] == j["surfels"]
+    head = open(tmp_path / "cpp.ply", "rb").read(400).split(b"end_header")[0]
+    assert b"element vertex" in head

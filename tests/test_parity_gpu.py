@@ -618,6 +618,54 @@ def test_sharded_map_uploaded_and_tracked(pair):
             assert_same_state(o, g, "after rebalance")
 
 
+@pytest.mark.parametrize("cfg", ["config4_vga_4M_4_shards", "config5_1280x960_8M_8_shards"])
+def test_baseline_config_4_and_5_geometry_sharded_equals_single(gpu_available, cfg):
+    """BASELINE configs 4 / 5 at their full sizes on the one GPU a test box has: a 640x480 stream against 4.3 M surfels
+    cut into 4 shards, and a 1280x960 stream against 8.7 M surfels cut into 8 — every shard played in turn by one
+    process with the winner-record exchange between them (key min-merge, pack, scatter).  The oracle cannot run these
+    sizes in test time, so the property is sharded == unsharded on the same library, bit for bit: pose, fuse statistics
+    and the whole concatenated map (content and order) over tracked noisy frames with a stale-surfel purge in frame 1
+    (so that the shards' in-place compactions really move their ranges), then again after a re-cut of the ranges."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H, n_seed, G = (640, 480, 4_300_000, 4) if cfg.startswith("config4") else (1280, 960, 8_700_000, 8)
+    K = synth.intrinsics(W, H)
+    seed = synth.seed_map(n_seed, width=W)
+    n = len(seed)
+    stale = np.zeros(n, bool)
+    stale[np.random.default_rng(3).choice(n, n // 50, replace=False)] = True
+    stale[0:64:3] = True
+    seed[stale, 3] = 1.0
+    frames = [synth.frame(k, W, H, noise=True) for k in range(4)]
+    Q = (W // 2) * (H // 2)
+
+    def run(shards):
+        g = HRBFFusion(default_params(W, H, *K, max_surfels=(n // max(shards, 1)) + 8 * Q + 200_000 if shards else n + 8 * Q))
+        if shards:
+            g.comm_init(-1, shards); g.map_shard_init(True)
+        g.upload_map(seed); g.set_pose(frames[0][2]); g.bootstrap(frames[0][0], frames[0][1])
+        g.set_tick(300)
+        out = []
+        for k in range(1, 4):
+            g.process_frame(frames[k][0], frames[k][1])
+            out.append((g.get_pose(), g.fuse_stats(), g.surfel_count()))
+            if shards and k == 2:
+                g.map_rebalance()
+        m = g.download_map()
+        status = g.status()
+        g.close()
+        return out, m, status
+
+    ref, m_ref, st_ref = run(0)
+    got, m_got, st_got = run(G)
+    assert st_ref == 0 and st_got == 0
+    assert ref[0][1][0] + ref[0][1][2] - ref[0][1][3] > 0.8 * stale.sum()      # the purge happened
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(bits(a[0]), bits(b[0])), "%s frame %d pose" % (cfg, k + 1)
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2], "%s frame %d counts" % (cfg, k + 1)
+    assert np.array_equal(bits(m_ref), bits(m_got))
+    assert np.linalg.norm(got[-1][0][:3, 3] - frames[3][2][:3, 3]) < 0.03
+
+
 @pytest.mark.parametrize("sharded", [False, True])
 def test_sparse_icp_with_outlier_slab(pair, sharded):
     """SURVEY §8f-4, use_sparse_icp: the ADMM variant of icpStep (multiplier image, shrink step, updateLambdaMap folded
