@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
 {
     const uint32_t n = sh.counts[sh.k], off = shard_offset(sh);   // ids in the keys are GLOBAL
     const Rigid tinv = dp->tinv;
-    // PROJECT_UNROLL position loads are in flight per lane before the first one is consumed: the kernel is a 16 B/surfel
-    // stream with a short dependent tail (transform, two divisions, one atomic for the in-view minority)
+    // PROJECT_UNROLL position loads in flight per lane.  Measured at 4.3 M surfels (69.5 MB stream): 1 / 2 / 4 / 8 loads in
+    // flight = 25.3 / 26.1 / 25.4 / 28.3 us — the kernel is not latency-bound, more loads in flight buy nothing
 #ifndef PROJECT_UNROLL
-#define PROJECT_UNROLL 4
+#define PROJECT_UNROLL 1
 #endif
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x; s0 < n; s0 += PROJECT_UNROLL * stride) {
@@ -681,23 +681,32 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     // Plain round-robin grid-stride on purpose: the in-view minority (the expensive items) is clustered in the
     // array, and an XCD-contiguous chunking (one eighth of the array per XCD, better L2 locality for the clean
     // texels) measured 2x SLOWER because one or two XCDs then own all the heavy work (profiles/r01 notes).
-    // the position plane of the NEXT round is requested before this round's item is tested: the streaming read (16 B
-    // per surfel, all most surfels need) never waits behind the dependent gathers of the in-view minority
+    // CLEAN_UNROLL position loads per lane in flight before the first item is tested.  Measured at 4.3 M surfels:
+    // 1 / 2 / 4 / 8 = 36 / 38 / 38 / 43 us (and neither the keep-byte stores nor the tile-count atomics show up when
+    // compiled out): the pass is bound by the in-view minority's window gathers, not by the stream's latency
+#ifndef CLEAN_UNROLL
+#define CLEAN_UNROLL 1
+#endif
     const uint32_t stride = sgrid * blockDim.x;
-    uint32_t it = sb * blockDim.x + threadIdx.x;
-    float4 vp_next = it < N ? m.p0[it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (; it < N64; it += stride) {
-        const float4 vp = vp_next;
-        if (it + stride < N) vp_next = m.p0[it + stride];
-        const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp);
+    for (uint32_t it0 = sb * blockDim.x + threadIdx.x; it0 < N64; it0 += CLEAN_UNROLL * stride) {
+        float4 vp[CLEAN_UNROLL];
+#pragma unroll
+        for (int k = 0; k < CLEAN_UNROLL; ++k) {
+            const uint32_t it = it0 + (uint32_t)k * stride;
+            vp[k] = it < N ? m.p0[it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < CLEAN_UNROLL; ++k) {
+            const uint32_t it = it0 + (uint32_t)k * stride;
+            if (it >= N64) break;          // wave-uniform: N64 and the strides are multiples of 64
+            const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k]);
 #ifndef CLEAN_NO_STORE
-        if (it < N) keep_flags[it] = keep ? 1 : 0;
+            if (it < N) keep_flags[it] = keep ? 1 : 0;
 #endif
-        // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
-        const unsigned long long bal = __ballot(keep);
-#ifndef CLEAN_NO_ATOMIC
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&tile_count[(size_t)(it / FUSE_TILE) * TC_STRIDE], (uint32_t)__popcll(bal));
-#endif
+            // 64 consecutive items share a tile (FUSE_TILE % 64 == 0): one atomic per wave feeds the tile count
+            const unsigned long long bal = __ballot(keep);
+            if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&tile_count[(size_t)(it / FUSE_TILE) * TC_STRIDE], (uint32_t)__popcll(bal));
+        }
     }
 }
 

@@ -54,11 +54,8 @@ __global__ __launch_bounds__(256) void k_filter_metric(Cam cam, const uint16_t *
                     float color2 = dv * dv;
                     // Measured and rejected (round 2): the 169 taps fully unrolled with compile-time offsets (62.6 us) and
                     // rows looped / columns unrolled (70.4 us) against this plain clamped loop (57.4 us).
-#ifdef FILTER_EXP_NONPOS
+                    // the argument is <= 0 and finite: hd_expf without its NaN / overflow selects (57.8 -> 50.3 us; same bits)
                     float weight = hd_expf_nonpos(-(space2 * 0.024691358f + color2 * 0.000555556f));
-#else
-                    float weight = hd_expf(-(space2 * 0.024691358f + color2 * 0.000555556f));
-#endif
                     sum1 += tmp * weight;
                     sum2 += weight;
                 } else if (tmp > 300.0f && hd_fabsf(tmp - value) < 100.0f) {
