@@ -723,10 +723,10 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
 // Tiles before the first one whose survivors change place (first tile that is not completely kept, or the tile that
 // holds the end of the map) are never touched and never written into: the ticket starts there.
 struct MoveSlot { float4 a, b, c, d, e; uint32_t it, o; bool keep; };
-
 __device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, const RecPlanes &rec, uint32_t N, float ftime)
 {
     if (!sl.keep) return;
+    // (non-temporal loads / stores measured: 195 vs 187 us for the whole pass at 4.3 M surfels — plain accesses stay)
     if (sl.it < N) { sl.a = m.p0[sl.it]; sl.b = m.p1[sl.it]; sl.c = m.p2[sl.it]; sl.d = m.p3[sl.it]; sl.e = m.p4[sl.it]; }
     else {
         const uint32_t q = sl.it - N;

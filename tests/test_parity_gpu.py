@@ -395,6 +395,30 @@ def test_two_contexts_concurrent_with_a_device_filling_co_runner(gpu_available):
         gs[name].close()
 
 
+def test_upload_of_a_larger_map_after_frames_ran(pair):
+    """a count read-back armed by earlier frames must not survive hrbf_upload_map / initialise — it
+    describes the OLD map, and folding it into the host bound later would size the next fuse pass (LDS tile counts,
+    tile counters) for fewer surfels than the device holds.  Frames from an empty map (small count), then a 60 k-surfel
+    map is uploaded into the running context, then more frames: bit-identical to the oracle, no status bit."""
+    W, H = 160, 120
+    K = synth.intrinsics(W, H)
+    p = default_params(W, H, *K, max_surfels=1 << 18)
+    o, g = pair(p)
+    for k in range(3):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)      # no synchronisation on the GPU side: read-backs stay armed
+    seed = synth.seed_map(60_000, width=W)
+    T = synth.frame(3, W, H)[2]
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T)
+    for k in range(3, 9):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+    assert_same_state(o, g, "after upload")
+    assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+    assert g.status() == 0 and g.surfel_count() > 60_000
+
+
 @pytest.mark.parametrize("cap", [9000, 20000])
 def test_map_at_capacity(pair, cap):
     """maximum size: a map whose capacity is hit by the seed frame (cap 9000 < first frame's surfels) or by the
