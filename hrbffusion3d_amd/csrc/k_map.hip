@@ -301,8 +301,11 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                                                    const float4 *__restrict__ vertconf,
                                                    const float4 *__restrict__ normrad, RecPlanes rec,
                                                    int32_t *__restrict__ rec_flag, uint32_t *__restrict__ rec_best,
-                                                   uint32_t *__restrict__ slot, ShardRef sh)
+                                                   uint32_t *__restrict__ slot, ShardRef sh, uint32_t *__restrict__ stats)
 {
+    // the pass's statistics words start from zero ([0..3] counts, [4] force-full-check, [5] ticket, [6] moved; [7] is the
+    // sticky status): nothing in this kernel reads them and the next kernel (k_apply_merges) is ordered behind it
+    if (blockIdx.x == 0 && threadIdx.x < 7) stats[threadIdx.x] = 0u;
     const int QW = cam.W / 2, QH = cam.H / 2;
     // One wave = one 8x8 tile of the quarter grid (a 16x16 pixel block: the per-pixel loads and the index-map samples
     // share cache lines); 8 consecutive lanes walk down a column, so they own 8 consecutive record indices q — the
@@ -898,11 +901,6 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
     }
 }
 
-__global__ void k_zero_u32(uint32_t *p, int n)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
-}
 // instrumentation only (timing ring on): park the pass's item statistics {in, merged, appended, out, -, -, moved, status}
 __global__ void k_copy_stats(const uint32_t *__restrict__ stats, uint32_t *__restrict__ slot)
 {
@@ -987,10 +985,9 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr, hipEvent_t m0, hipEvent_t m1)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
-    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, s, stats, 7);   // [0..3] statistics, [4] force-full-check flag, [5] ticket, [6] moved; [7] = sticky status
     hipLaunchKernelGGL(k_associate, dim3(quarter_tile_blocks(cam.W, cam.H)), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
-                       rec_best, slot, sh);
+                       rec_best, slot, sh, stats);
     if (m0) hipEventRecord(m0, s);   // F2 (update.vert) is part of the roofline-timed fuse: SURVEY §8d "F2+F3"
     hipLaunchKernelGGL(k_apply_merges, dim3((Q + MERGE_THREADS - 1) / MERGE_THREADS), dim3(MERGE_THREADS), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
                        sh, stats + 1, curvThr);

@@ -7,7 +7,10 @@
  * PARITY UNPINNED: the reference (YabinXuTUD/HRBFFusion3D) has no tests, no golden vectors and
  * cannot be built here (Pangolin/CUDA/Eigen/OpenCV/GL absent).  This oracle is a
  * line-by-line restatement of the reference's GLSL/CUDA/host semantics (each function cites the
- * file:line it follows); it is pinned only by analytic known-answer tests (tests/test_oracle_*.py).
+ * file:line it follows); it is pinned only by analytic known-answer tests (tests/test_oracle_*.py) and by
+ * independent numpy evaluations of every site where the camera intrinsics enter, with fx != fy and an off-centre
+ * principal point (tests/kat_projection.py, tests/test_intrinsics_kat.py).  tools/compare_reference_dump.py diffs it
+ * against the dump files the reference itself writes — the one-command way to pin it once a reference run exists.
  *
  * Plain C99, scalar, single-thread (OpenMP over pixels/surfels when built with -fopenmp; results
  * are identical because every reduction goes through the exact accumulator of hrbf_detmath.h).
