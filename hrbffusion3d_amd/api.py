@@ -325,7 +325,7 @@ class HRBFFusion:
             raise HrbfError(self.lib.hrbf_last_error().decode())
         return out[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy()
 
-    STATUS_CAPACITY, STATUS_INTERNAL_BOUND, STATUS_SO3_TIMEOUT = 1, 2, 4
+    STATUS_CAPACITY, STATUS_INTERNAL_BOUND, STATUS_SO3_TIMEOUT, STATUS_FUSE_TIMEOUT = 1, 2, 4, 8
 
     def status(self, clear=False):
         """sticky condition bits (HRBF_STATUS_*); synchronises"""

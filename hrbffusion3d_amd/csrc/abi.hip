@@ -1189,6 +1189,7 @@ extern "C" int hrbf_get_status(hrbf_handle c, uint32_t *flags, int clear)
         HIP_CHECK(hipMemcpyAsync(&v, c->sh[k].d_stats + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         if (v & 1u) c->status |= HRBF_STATUS_INTERNAL_BOUND;
+        if (v & 4u) c->status |= HRBF_STATUS_FUSE_TIMEOUT;
         if (v & 2u) c->status |= HRBF_STATUS_CAPACITY;
     }
     {

@@ -773,7 +773,12 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
         if (blockIdx.x == 0 && threadIdx.x == 0) { *count_out = 0; stats[0] = 0; stats[3] = 0; }
         return;
     }
-    if (num_tiles > lds_tiles) {   // the host's bound on the item count was too small: refuse loudly instead of corrupting
+    if (num_tiles > lds_tiles) {
+        // the host's bound on the item count was too small (cannot happen unless a count read-back is mis-tracked):
+        // refuse loudly instead of corrupting — the map is left as it is for this frame, the status bit is raised, and
+        // the counters pass A accumulated beyond what the host will re-arm are cleared here
+        for (uint32_t t = blockIdx.x * FUSE_THREADS + threadIdx.x; t < num_tiles; t += gridDim.x * FUSE_THREADS)
+            const_cast<uint32_t *>(tile_count)[(size_t)t * TC_STRIDE] = 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) { *count_out = N < cap ? N : cap; stats[0] = N; stats[3] = N; atomicOr(&stats[7], 1u); }
         return;
     }
@@ -870,9 +875,15 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
         if (tile_total > 0 && threadIdx.x < 64) {
             const uint32_t t_lo = prefix / FUSE_TILE;
             const uint32_t t_hi = (prefix + tile_total - 1) / FUSE_TILE;
-            for (uint32_t t = t_lo + (uint32_t)lane; t <= t_hi && t < surfel_tiles && t < tile; t += 64)
-                while (__hip_atomic_load(&tile_done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+            for (uint32_t t = t_lo + (uint32_t)lane; t <= t_hi && t < surfel_tiles && t < tile; t += 64) {
+                // every spin is bounded (MI355X_MICROARCH.md, correctness boundaries): the wait cannot cycle by
+                // construction, but a protocol bug must surface as a status bit, never as a hung device
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&tile_done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) { atomicOr(&stats[7], 4u); break; }
+                }
+            }
         }
         __syncthreads();
         acc_appended += move_store(s0, m, N, cap) + move_store(s1, m, N, cap) + move_store(s2, m, N, cap) +

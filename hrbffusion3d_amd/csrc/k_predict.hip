@@ -80,9 +80,11 @@ __device__ __forceinline__ void hrbf_value_term(const float4 a, const float4 b, 
     const float r = hd_sqrtf(d2 * b.w);
     const float s = 1.0f - r;
     const float s3 = s * s * s;
-    const float tt = -20.0f * s3 * b.w;
-    const bool nz = d2 != 0.0f;
-    const float gx = nz ? vx * tt : 0.0f, gy = nz ? vy * tt : 0.0f, gz = nz ? vz * tt : 0.0f;
+    // getWeightD returns the zero vector at d2 == 0 (hrbfbase.glsl:24-27).  There v = p - centre is exactly (+0, +0, +0)
+    // (x - x is +0 under round-to-nearest), so ONE select on the scalar factor gives the same three +0 products as
+    // three selects on the products — and keeps the T = 0 case (factor = -inf) away from 0 * inf
+    const float tt = d2 != 0.0f ? -20.0f * s3 * b.w : 0.0f;
+    const float gx = vx * tt, gy = vy * tt, gz = vz * tt;
     const float c = (gx * b.x + gy * b.y) + gz * b.z;
     value = in ? value - c : value;
     ns += in ? 1 : 0;

@@ -229,6 +229,7 @@ int hrbf_set_load_trajectory(hrbf_handle h, int v);
 #define HRBF_STATUS_CAPACITY 1u        /* the map reached max_surfels: new surfels were dropped (cf. HRBF_ERR_CAPACITY) */
 #define HRBF_STATUS_INTERNAL_BOUND 2u  /* a fuse pass was launched with a stale host bound on the surfel count and refused to run */
 #define HRBF_STATUS_SO3_TIMEOUT 4u     /* the SO3 pre-alignment kernel ran into its poll bound: that frame's pose is NaN */
+#define HRBF_STATUS_FUSE_TIMEOUT 8u    /* the in-place compaction ran into its (bounded) tile wait: the map of that frame is not trustworthy */
 int hrbf_get_status(hrbf_handle h, uint32_t *flags, int clear);
 /* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
 int hrbf_get_fuse_stats(hrbf_handle h, uint32_t out[4]);

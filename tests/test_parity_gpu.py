@@ -395,6 +395,37 @@ def test_two_contexts_concurrent_with_a_device_filling_co_runner(gpu_available):
         gs[name].close()
 
 
+def test_stale_surfel_purge_matches_oracle(pair):
+    """copy_unstable.vert:159-165 — unstable surfels not seen for 200 frames are dropped — against the oracle, with the
+    removals starting in the first tile so that every later tile of the in-place compaction moves: 6 % of a 150 k-surfel
+    map is unstable, the clock jumps by 300 frames after the bootstrap, five tracked noisy frames follow.  Images, map
+    (content and order), statistics and pose bit for bit; the pass reports that it moved (nearly) the whole map."""
+    W, H = 320, 240
+    K = synth.intrinsics(W, H)
+    seed = synth.seed_map(150_000, width=W)
+    n = len(seed)
+    stale = np.zeros(n, bool)
+    stale[np.random.default_rng(5).choice(n, int(0.06 * n), replace=False)] = True
+    stale[0:64:3] = True
+    seed[stale, 3] = 1.0
+    p = default_params(W, H, *K, max_surfels=n + 300_000)
+    o, g = pair(p)
+    g.enable_timing(2)
+    rgb, d, T = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d); x.set_tick(300)
+    for k in range(1, 6):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "purge frame %d" % k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+        if k == 1:
+            st = g.fuse_stats().astype(np.int64)
+            assert st[0] + st[2] - st[3] > 0.8 * stale.sum()
+    _, _, st8 = g.fuse_ring_parts(5)
+    assert st8[0][6] > 0.9 * n and g.status() == 0
+
+
 def test_upload_of_a_larger_map_after_frames_ran(pair):
     """a count read-back armed by earlier frames must not survive hrbf_upload_map / initialise — it
     describes the OLD map, and folding it into the host bound later would size the next fuse pass (LDS tile counts,
