@@ -222,3 +222,94 @@ def test_free_space_violation_removes_a_surfel_in_front_of_fresh_stable_ones(ora
         assert abs(len(m2) - (n0 + left)) < 0.05 * n0
         o2.close()
     o.close()
+
+
+def test_duplicate_rule_removes_newer_surfels_sitting_on_older_stable_ones(oracle_lib_built):
+    """copy_unstable.vert:116-124: a surfel is dropped when more than 8 of the 16 window samples show a stable surfel that
+    is OLDER (init time below its own), lies less than 1 cm behind it and within 1.4 radii in x / y.  A stable wall (one
+    surfel behind every pixel centre, uploaded: grown by fusion only the pixels with x % 2 == y % 2 would ever be
+    stable) and duplicates 5 mm in front of it: initialised later than the wall -> removed; initialised earlier ->
+    kept (the rule protects the first-comer)."""
+    W, H = 96, 72
+    f, cx, cy = 79.0, 48.0, 36.0
+    p = default_params(W, H, f, f, cx, cy, max_surfels=1 << 16)
+    z = scenes.plane_depth(W, H, f, f, cx, cy, (0.0, 0.0, 1.0), 2.0)
+    rgb, d = scenes.gray_rgb(W, H), scenes.to_u16(z)
+
+    def surfel(px, py, zz, conf, init, radius):
+        s = np.zeros(20, np.float32)
+        s[0:3] = ((px + 0.5 - cx) * zz / f, (py + 0.5 - cy) * zz / f, zz)
+        s[3] = conf; s[4] = 0x808080; s[6] = init; s[7] = 9
+        s[8:11] = (0, 0, 1); s[11] = radius; s[12] = 1; s[17] = 1
+        return s
+    wall = np.array([surfel(px, py, 2.0, 20.0, 5.0, 0.04) for px in range(W) for py in range(H)])
+    def dups(init_time):
+        return np.array([surfel(px, py, 1.995, 20.0, init_time, 0.08) for px in range(30, 66, 4) for py in range(20, 52, 4)])
+    for init_time, expect_removed in ((9.0, True), (2.0, False)):
+        o = oracle_lib_built.Oracle(p)
+        o.upload_map(np.concatenate([wall, dups(init_time)]))
+        o.upload_frame(rgb, d)
+        for st in ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS", "CURVATURE", "CONFIDENCE"):
+            o.run_stage(st)
+        o.set_tick(10)
+        o.run_stage("PREDICT_INDICES"); o.run_stage("CLEAN")          # the clean pass alone: no merge moves anything first
+        m2 = o.download_map()
+        left = int(((np.abs(m2[:, 2] - 1.995) < 1e-4) & (m2[:, 6] == init_time)).sum())
+        total = len(dups(init_time))
+        assert (left == 0) if expect_removed else (left == total), (init_time, left, total)
+        assert len(m2) == len(wall) + left
+        o.close()
+
+
+def test_bilateral_filter_on_a_step_edge_matches_fp64(oracle_lib_built):
+    """depth_bilateral.frag:16-67 on a 40 mm step: sum over the 13 x 13 window of d * w / sum w with
+    w = exp(-(dx^2 + dy^2) * 0.024691358 - (d - d0)^2 * 0.000555556), raw units (mm at factor 5000 -> value / 5)"""
+    W, H = 96, 72
+    p = default_params(W, H, 79.0, 79.0, 48.0, 36.0, max_surfels=1 << 12)
+    o = oracle_lib_built.Oracle(p)
+    rng = np.random.default_rng(1)
+    d = np.full((H, W), 5000, np.uint16); d[:, W // 2:] = 5200            # 1.00 m | 1.04 m
+    d = (d + rng.integers(-30, 31, d.shape)).astype(np.uint16)              # +- 6 mm of noise
+    o.upload_frame(scenes.gray_rgb(W, H), d); o.run_stage("FILTER_DEPTH")
+    got = o.get_image("DEPTH_FILTERED").astype(np.float64)
+    adj = 1.0 / ((1.0 / 5000.0) * 1000.0)                                     # depthFactor_adjustment
+    v = d.astype(np.float64) / adj
+    exp = np.zeros((H, W))
+    for y in range(8, H - 8):
+        for x in range(8, W - 8):
+            win = v[y - 6:y + 7, x - 6:x + 7]
+            dy, dx = np.mgrid[-6:7, -6:7]
+            w = np.exp(-((dx * dx + dy * dy) * 0.024691358 + (win - v[y, x]) ** 2 * 0.000555556))
+            exp[y, x] = (win * w).sum() / w.sum() * adj
+    inner = (slice(8, H - 8), slice(8, W - 8))
+    np.testing.assert_allclose(got[inner], exp[inner], rtol=2e-6)
+    # the range term works: pixels next to the step stay on their own side of the midpoint (sigma_color = 30 mm, step 40 mm)
+    assert got[30, W // 2 - 1] < 5085 and got[30, W // 2] > 5115
+    o.close()
+
+
+def test_pca_normal_and_radius_on_a_slanted_plane(oracle_lib_built):
+    """getNormalPCA (geometry.glsl:190-244) returns the plane's normal (oriented towards +z); getRadius
+    (surfels.glsl:19-32) = min(2 r, r / |n_z|) with r = sqrt(2) z / mean focal, times the initial multiplier"""
+    W, H = 160, 120
+    fx, fy, cx, cy = K_ASYM
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 12)
+    o = oracle_lib_built.Oracle(p)
+    nrm = np.array([0.35, -0.2, 1.0]); nrm /= np.linalg.norm(nrm)
+    z = scenes.plane_depth(W, H, fx, fy, cx, cy, nrm, 1.6)
+    # plane_depth renders through integer pixel coordinates; the PCA window back-projects through pixel CENTRES, so
+    # sample the plane there: z(x + .5, y + .5)
+    r = scenes.pixel_rays(W, H, fx, fy, cx, cy, half=0.5)
+    z = 1.6 / (r @ nrm)
+    o.upload_frame(scenes.gray_rgb(W, H), np.clip(np.rint(z * 5000), 0, 65535).astype(np.uint16))
+    for st in ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS"):
+        o.run_stage(st)
+    n = o.get_image("NORMAL_PCA"); vf = o.get_image("VERTEX_FILTERED")
+    inner = (slice(10, H - 10), slice(10, W - 10))
+    cosang = (n[..., :3][inner] @ nrm)
+    assert cosang.min() > 0.999            # 0.2 mm depth quantisation over a 7 x 7 window at 1.6 m
+    zz = vf[..., 2][inner].astype(np.float64)
+    rr = np.sqrt(2.0) * zz / (0.5 * (fx + fy))
+    expect = p.init_radius_multiplier * np.minimum(2 * rr, rr / np.abs(n[..., 2][inner]))
+    np.testing.assert_allclose(n[..., 3][inner], expect, rtol=1e-4)
+    o.close()
