@@ -313,3 +313,117 @@ def test_pca_normal_and_radius_on_a_slanted_plane(oracle_lib_built):
     expect = p.init_radius_multiplier * np.minimum(2 * rr, rr / np.abs(n[..., 2][inner]))
     np.testing.assert_allclose(n[..., 3][inner], expect, rtol=1e-4)
     o.close()
+
+
+def test_merge_formula_of_update_vert_both_branches(oracle_lib_built):
+    """update.vert:51-115 evaluated in fp64 per merged surfel: confidence-weighted averages of position, colour (decoded,
+    averaged, re-encoded with round()), normal (normalised after averaging), radius and both curvature vectors when the
+    live radius is below 1.5 x the model radius; otherwise only confidence and last-seen time change.  A wall with one
+    surfel behind every pixel centre, half of them with a radius small enough to take the second branch."""
+    W, H = 96, 72
+    f, cx, cy = 79.0, 48.0, 36.0
+    p = default_params(W, H, f, f, cx, cy, max_surfels=1 << 16)
+    r = scenes.pixel_rays(W, H, f, f, cx, cy)
+    nrm = np.array([0.1, -0.05, 1.0]); nrm /= np.linalg.norm(nrm)
+    z = 2.0 / (r @ nrm)
+    rgb = scenes.gray_rgb(W, H, seed=3); d = scenes.to_u16(z)
+    o = oracle_lib_built.Oracle(p)
+    o.upload_frame(rgb, d)
+    for st in ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS", "CURVATURE", "CONFIDENCE"):
+        o.run_stage(st)
+    dm = o.get_image("DEPTH_METRIC").astype(np.float64); npca = o.get_image("NORMAL_PCA").astype(np.float64)
+    conf = o.get_image("CONFIDENCE").astype(np.float64); k1 = o.get_image("CURV1").astype(np.float64); k2 = o.get_image("CURV2").astype(np.float64)
+    rng = np.random.default_rng(8)
+    surf = np.zeros((W * H, 20), np.float32)
+    ids = np.arange(W * H).reshape(W, H).T                       # id of the surfel behind pixel (px, py): column-major upload
+    k = 0
+    for px in range(W):
+        for py in range(H):
+            zz = dm[py, px] if dm[py, px] > 0 else 2.0
+            s = surf[k]; k += 1
+            s[0:3] = ((px + 0.5 - cx) * zz / f, (py + 0.5 - cy) * zz / f, zz + 0.002)       # 2 mm behind the measurement
+            s[3] = rng.uniform(6, 12)
+            col = rng.integers(10, 240, 3)
+            s[4] = (int(col[0]) << 16) + (int(col[1]) << 8) + int(col[2]); s[5] = 0; s[6] = 1; s[7] = 3
+            nn = nrm + rng.normal(0, 0.02, 3); nn /= np.linalg.norm(nn)
+            s[8:11] = nn
+            s[11] = 0.2 if (px // 2 + py // 2) % 2 == 0 else 0.005              # large radius: average; tiny radius: second branch
+            s[12:15] = (1, 0, 0); s[15] = rng.uniform(-5, 5); s[16:19] = (0, 1, 0); s[19] = rng.uniform(-5, 5)
+    o.upload_map(surf); o.set_tick(7)
+    o.run_stage("PREDICT_INDICES"); o.run_stage("FUSE")
+    m = o.download_map()
+    assert len(m) == len(surf)
+    merged = np.nonzero(m[:, 7] == 7.0)[0]
+    assert len(merged) > 0.15 * W * H
+    n_avg = n_keep = 0
+    for sid in merged[::7]:
+        px, py = sid // H, sid % H
+        assert px % 2 == 1 and py % 2 == 1                       # time 7: only odd / odd pixels are sampled (data.vert:103)
+        old = surf[sid].astype(np.float64)
+        a = conf[py, px]; c = old[3]
+        zz = dm[py, px]
+        vg = np.array([(px + 0.5 - cx) * zz / f, (py + 0.5 - cy) * zz / f, zz])
+        new_rad = npca[py, px, 3]
+        got = m[sid].astype(np.float64)
+        assert abs(got[3] - (c + a)) < 1e-5 and got[5] == 0 and got[6] == 1
+        if new_rad < 1.5 * old[11]:
+            n_avg += 1
+            np.testing.assert_allclose(got[0:3], (c * old[0:3] + a * vg) / (c + a), atol=2e-6)
+            oc = np.array([(int(old[4]) >> 16) & 255, (int(old[4]) >> 8) & 255, int(old[4]) & 255]) / 255.0
+            nc = rgb[py, px].astype(np.float64) / 255.0
+            avg = (c * oc + a * nc) / (c + a)
+            enc = (int(round(avg[0] * 255)) << 16) + (int(round(avg[1] * 255)) << 8) + int(round(avg[2] * 255))
+            assert abs(got[4] - enc) <= 0x010101 and got[4] == float(int(got[4]))      # each channel within one rounding step
+            nn = (c * old[8:11] + a * npca[py, px, :3]) / (c + a)
+            np.testing.assert_allclose(got[8:11], nn / np.linalg.norm(nn), atol=2e-6)
+            assert abs(got[11] - (c * old[11] + a * new_rad) / (c + a)) < 1e-6
+            np.testing.assert_allclose(got[12:16], (c * old[12:16] + a * k1[py, px]) / (c + a), atol=1e-5)
+            np.testing.assert_allclose(got[16:20], (c * old[16:20] + a * k2[py, px]) / (c + a), atol=1e-5)
+        else:
+            n_keep += 1
+            assert np.array_equal(got[0:3], old[0:3]) and got[4] == old[4] and np.array_equal(got[8:20], old[8:20])
+    assert n_avg > 20 and n_keep > 20
+    o.close()
+
+
+def test_fill_in_selects_and_icp_weight(oracle_lib_built):
+    """fill_vertex.frag:43-72, fill_normal.frag:36-49, fill_curvature.frag:35-51, fill_rgb.frag:29-37: where the prediction
+    is empty the live frame fills in — vertex only if the live curvatures are valid, with the ICP weight
+    (1 / z^2) (conf / 256 + exp(-lambda^2 / (2 kmax^2))) — elsewhere the prediction passes through unchanged"""
+    W, H = 96, 72
+    p = default_params(W, H, 79.0, 79.0, 48.0, 36.0, max_surfels=1 << 12)
+    o = oracle_lib_built.Oracle(p)
+    rng = np.random.default_rng(4)
+    f4 = lambda: rng.uniform(0.2, 2.0, (H, W, 4)).astype(np.float32)
+    pv, pn, pc1, pc2 = f4(), f4(), f4(), f4()
+    pn[..., :3] /= np.linalg.norm(pn[..., :3], axis=-1, keepdims=True)
+    hole = np.zeros((H, W), bool); hole[10:40, 20:70] = True
+    pv[hole] = 0; pn[hole] = 0
+    pc1[..., 3] = rng.uniform(-50, 50, (H, W)); pc2[..., 3] = rng.uniform(-50, 50, (H, W))
+    pc1[hole, 3] = 1000.0; pc2[hole, 3] = 1000.0                       # the prediction writes 1000 where it found nothing
+    pw = rng.uniform(0.1, 1.0, (H, W)).astype(np.float32)
+    pimg = rng.integers(1, 255, (H, W, 4)).astype(np.uint8); pimg[hole] = 0
+    lv, ln, lc1, lc2 = f4(), f4(), f4(), f4()
+    lc1[..., 3] = rng.uniform(-50, 50, (H, W)); lc2[..., 3] = rng.uniform(-50, 50, (H, W))
+    bad = np.zeros((H, W), bool); bad[15:20, 30:40] = True             # live curvature invalid: nothing to fill in with
+    lc1[bad, 3] = 400.0
+    lconf = rng.uniform(0.1, 1.0, (H, W)).astype(np.float32)
+    rgb = rng.integers(1, 255, (H, W, 3)).astype(np.uint8)
+    o.upload_frame(rgb, np.full((H, W), 5000, np.uint16))
+    for name, a in (("PRED_VERTEX", pv), ("PRED_NORMAL", pn), ("PRED_CURV1", pc1), ("PRED_CURV2", pc2), ("PRED_ICPWEIGHT", pw),
+                    ("PRED_IMAGE", pimg), ("VERTEX_FILTERED", lv), ("NORMAL", ln), ("CURV1", lc1), ("CURV2", lc2), ("CONFIDENCE", lconf)):
+        o.set_image(name, a)
+    o.run_stage("FILLIN")
+    fv, fn, fc1, fc2, fw, fi = (o.get_image(n) for n in ("FILL_VERTEX", "FILL_NORMAL", "FILL_CURV1", "FILL_CURV2", "FILL_ICPWEIGHT", "FILL_IMAGE"))
+    keep = ~hole
+    assert np.array_equal(fv[keep], pv[keep]) and np.array_equal(fw[keep], pw[keep]) and np.array_equal(fn[keep], pn[keep])
+    assert np.array_equal(fc1[keep], pc1[keep]) and np.array_equal(fc2[keep], pc2[keep]) and np.array_equal(fi[keep][:, :3], pimg[keep][:, :3])
+    fill = hole & ~bad
+    assert np.array_equal(fv[fill][:, :3], lv[fill][:, :3]) and np.array_equal(fv[fill][:, 3], lconf[fill])
+    kmax = np.maximum(np.abs(lc1[..., 3]), np.abs(lc2[..., 3])).astype(np.float64)
+    w = (1.0 / lv[..., 2].astype(np.float64) ** 2) * (lconf / 256.0 + np.exp(-0.5 * 100.0 / (kmax * kmax)))
+    np.testing.assert_allclose(fw[fill], w[fill], rtol=2e-5, atol=1e-30)
+    assert np.all(fv[hole & bad] == 0) and np.all(fw[hole & bad] == 0)
+    assert np.array_equal(fn[hole], ln[hole]) and np.array_equal(fc1[hole], lc1[hole]) and np.array_equal(fc2[hole], lc2[hole])
+    assert np.array_equal(fi[hole][:, :3], rgb[hole])
+    o.close()
