@@ -8,7 +8,7 @@
 // One thread per pixel, 16x16 tiles.  The GLSL gathers up to 49 neighbours into five private
 // vec4[100] arrays; here
 //   * the per-texel part of the implicit (centre, support radius^2 and its reciprocal, 10 n) is staged ONCE
-//     per tile in LDS (tile + 3-texel halo, 22x22 x 32 B = 15.5 KB), together with one validity bit per
+//     per tile in LDS (tile + 3-texel halo, two planes of 22x22 x 16 B = 15.5 KB), together with one validity bit per
 //     texel (the acceptance test of predict_hrbf.frag:85-92 depends on the texel only);
 //   * each thread walks the window in the shader's ring order with compile-time offsets and writes the LDS
 //     addresses of its accepted neighbours to a private column of an LDS list (<= 49 x 2 B per thread), so
@@ -17,12 +17,25 @@
 #include "common.h"
 #include "kernels.h"
 
-#define TB 16
+#ifndef PREDICT_TBX
+#define PREDICT_TBX 16
+#endif
+#ifndef PREDICT_TBY
+#define PREDICT_TBY 16
+#endif
+#define TBX PREDICT_TBX
+#define TBY PREDICT_TBY
 #define PR 3
-#define PTW (TB + 2 * PR)
-#define PNT (TB * TB)
+#define PTW (TBX + 2 * PR)
+#define PTH (TBY + 2 * PR)
+#define PNT (TBX * TBY)
 
-struct alignas(16) PTexel { float px, py, pz, T2, sx, sy, sz, invT2; };
+// per-texel part of the implicit in LDS, two planes of 16 B per texel (a wave's reads of neighbouring texels are then
+// contiguous — 32-byte records made every 16-byte read a two-way bank conflict, which showed once the arithmetic was packed):
+//   plane A: centre xyz, support radius^2        plane B (PLANE_B bytes behind): 10 n, 1 / radius^2
+#define PTEXEL_BYTES 16
+#define DUMMY_TEXEL (PTW * PTH)                       // support radius^2 = -1: in reach of nothing
+#define PLANE_B ((PTW * PTH + 1) * PTEXEL_BYTES)
 
 // ring visiting order of predict_hrbf.frag:75-80: rings i = 0..3, x offset outer, y offset inner,
 // ring-border texels only
@@ -45,6 +58,10 @@ constexpr RingEntry ring_entry(int slot)
 
 int predict_upload_tables() { return 0; }   // the ring table is a compile-time constant
 
+// The per-thread neighbour list: entry k of thread t is the 16-bit half (k & 1) of the 32-bit word [k / 2][t], so one 4-byte
+// read fetches the LDS offsets of the two neighbours a trip of hrbf_value evaluates.  `list` points at the thread's word 0.
+__device__ __forceinline__ int list_slot(int k) { return (k >> 1) * (2 * PNT) + (k & 1); }
+
 // neighbour gathering with the reference's "break only the innermost loop" behaviour
 template <int SLOT>
 __device__ __forceinline__ void gather_ring(const uint32_t (&wrow)[7], int nslots, int maxn, uint32_t lbase_bytes,
@@ -56,7 +73,7 @@ __device__ __forceinline__ void gather_ring(const uint32_t (&wrow)[7], int nslot
             if (e.newcol) skip = false;
             const bool acc = !skip && ((wrow[e.dy + 3] >> (e.dx + 3)) & 1u);
             if (acc) {
-                list[n * PNT] = (uint16_t)(lbase_bytes + (uint32_t)((e.dy * PTW + e.dx) * (int)sizeof(PTexel)));
+                list[list_slot(n)] = (uint16_t)(lbase_bytes + (uint32_t)((e.dy * PTW + e.dx) * PTEXEL_BYTES));
                 n++;
                 if (n > maxn) skip = true;
             }
@@ -65,56 +82,112 @@ __device__ __forceinline__ void gather_ring(const uint32_t (&wrow)[7], int nslot
     }
 }
 
-__device__ __forceinline__ float4 lds4(const PTexel *tile, uint32_t byte_off)
+__device__ __forceinline__ float4 lds4(const float4 *tile, uint32_t byte_off)
 {
     return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tile) + byte_off);
 }
 
-// one neighbour of hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34): branch-free, the contribution of a
-// neighbour whose support does not reach p is computed and discarded
-__device__ __forceinline__ void hrbf_value_term(const float4 a, const float4 b, const f3 p, bool live, float &value, int &ns)
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+// Keeps a scalar result scalar: without it the instruction selector turns a pair built from two scalar adds into a packed add
+// of two shuffled pairs (three v_mov per pair).  No instruction is emitted.
+__device__ __forceinline__ float opaque(float x)
 {
-    const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
-    const float d2 = (vx * vx + vy * vy) + vz * vz;
-    const bool in = live && !(a.w < d2);
-    const float r = hd_sqrtf(d2 * b.w);
-    const float s = 1.0f - r;
-    const float s3 = s * s * s;
-    // getWeightD returns the zero vector at d2 == 0 (hrbfbase.glsl:24-27).  There v = p - centre is exactly (+0, +0, +0)
-    // (x - x is +0 under round-to-nearest), so ONE select on the scalar factor gives the same three +0 products as
-    // three selects on the products — and keeps the T = 0 case (factor = -inf) away from 0 * inf
-    const float tt = d2 != 0.0f ? -20.0f * s3 * b.w : 0.0f;
-    const float gx = vx * tt, gy = vy * tt, gz = vz * tt;
-    const float c = (gx * b.x + gy * b.y) + gz * b.z;
-    value = in ? value - c : value;
-    ns += in ? 1 : 0;
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
-// hrbfvalue over the gathered list, two neighbours per trip; the offsets of the next pair are fetched while the
-// current pair is evaluated.  list[n .. n+2] hold a valid dummy offset.
-__device__ __forceinline__ float hrbf_value(const PTexel *__restrict__ tile, const uint16_t *__restrict__ list, int n,
+// Correctly rounded sqrt of two arguments that are zero or normal numbers: v_sqrt_f32 is within one ulp, and the two residual
+// tests (the ones the compiler's own expansion of sqrtf makes) move to the neighbouring float when that one is closer.  The
+// compiler's expansion also rescales arguments below 2^-96 and re-checks for 0 / inf; neither is needed here: the consumer is
+// 1 - r, which is exactly 1 for every r < 2^-25 whatever its last bit, a zero argument falls through both tests unchanged,
+// and arguments above 1 belong to neighbours whose term is discarded.
+__device__ __forceinline__ v2f sqrt_pair_for_unit_complement(const v2f x)
+{
+    v2f s;
+    s.x = __builtin_amdgcn_sqrtf(x.x); s.y = __builtin_amdgcn_sqrtf(x.y);
+    const v2i si = __builtin_bit_cast(v2i, s);
+    const v2f dn = __builtin_bit_cast(v2f, si - 1), up = __builtin_bit_cast(v2f, si + 1);
+    const v2f ed = __builtin_elementwise_fma(-dn, s, x), eu = __builtin_elementwise_fma(-up, s, x);
+    s.x = ed.x <= 0.0f ? dn.x : s.x; s.y = ed.y <= 0.0f ? dn.y : s.y;
+    s.x = eu.x > 0.0f ? up.x : s.x; s.y = eu.y > 0.0f ? up.y : s.y;
+    return s;
+}
+
+// hrbfvalue (hrbfbase.glsl:126-145) with getWeightD (:20-34) over the gathered list, TWO neighbours per trip with the
+// arithmetic written on float pairs (v_pk_add / v_pk_mul / v_pk_fma_f32: the same IEEE operations, half the issue slots —
+// this loop is VALU-issue bound).  x / y of one neighbour share a pair (they are adjacent in the LDS quad), the z
+// column and everything scalar per neighbour (d2, r, s, the factor) pair up ACROSS the two neighbours.  Branch-free: the
+// term of a neighbour whose support does not reach p is computed and discarded.  One 4-byte read fetches the offsets of the
+// next pair while the current one is evaluated; list entries n .. n+3 hold the offset of the dummy texel (support -1:
+// never reached).
+//
+// getWeightD returns the zero vector at d2 == 0 (hrbfbase.glsl:24-27).  There v = p - centre is exactly (+0, +0, +0)
+// (x - x is +0 under round-to-nearest), so ONE select on the scalar factor gives the same three +0 products as three selects
+// on the products — and keeps the T = 0 case (factor = -inf or NaN) away from 0 * inf.
+//
+// SAFE = false (every staged texel of the tile is finite and tame, tile_is_tame below) drops that select and folds the
+// support test into one select on the factor instead of one on the running sum:
+//   * d2 == 0 with a finite factor: the products are (+0) * factor = -0 or +0, their sum c is a zero, and value - (+-0)
+//     == value because the running sum is never -0 (it starts at +0 and x - x is +0);
+//   * a neighbour out of reach gets factor 0: v and 10 n are finite, so c is a zero again.
+// COUNT: the number of neighbours in reach is only consumed for the first sample of a ray (predict_hrbf.frag:139-141).
+template <bool SAFE, bool COUNT>
+__device__ __forceinline__ float hrbf_value(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n,
                                             f3 p, int &nsup)
 {
     float value = 0.0f;
     int ns = 0;
-    uint32_t o0 = list[0], o1 = list[PNT];
+    const v2f pxy = {p.x, p.y};
+    const uint32_t *pairs = reinterpret_cast<const uint32_t *>(list);
+    uint32_t oo = pairs[0];
     for (int k = 0; k < n; k += 2) {
-        const float4 a0 = lds4(tile, o0), b0 = lds4(tile, o0 + 16), a1 = lds4(tile, o1), b1 = lds4(tile, o1 + 16);
-        o0 = list[(k + 2) * PNT]; o1 = list[(k + 3) * PNT];
-        hrbf_value_term(a0, b0, p, true, value, ns);
-        hrbf_value_term(a1, b1, p, k + 1 < n, value, ns);
+        const uint32_t o0 = oo & 0xffffu, o1 = oo >> 16;
+        const float4 a0 = lds4(tile, o0), b0 = lds4(tile, o0 + PLANE_B), a1 = lds4(tile, o1), b1 = lds4(tile, o1 + PLANE_B);
+        pairs += PNT;
+        oo = pairs[0];
+        const v2f v0 = pxy - (v2f){a0.x, a0.y}, v1 = pxy - (v2f){a1.x, a1.y};
+        const v2f vz = {opaque(p.z - a0.z), opaque(p.z - a1.z)};
+        const v2f q0 = v0 * v0, q1 = v1 * v1;
+        const v2f d2 = (v2f){opaque(q0.x + q0.y), opaque(q1.x + q1.y)} + vz * vz;
+        const bool in0 = !(a0.w < d2.x), in1 = (!SAFE || k + 1 < n) && !(a1.w < d2.y);
+        const v2f inv = {b0.w, b1.w};
+        const v2f s = 1.0f - sqrt_pair_for_unit_complement(d2 * inv);
+        v2f tt = -20.0f * (s * s * s) * inv;
+        if (SAFE) { tt.x = d2.x != 0.0f ? tt.x : 0.0f; tt.y = d2.y != 0.0f ? tt.y : 0.0f; }
+        else { tt.x = in0 ? tt.x : 0.0f; tt.y = in1 ? tt.y : 0.0f; }
+        const v2f c0 = (v0 * tt.x) * (v2f){b0.x, b0.y}, c1 = (v1 * tt.y) * (v2f){b1.x, b1.y};
+        const v2f gz = vz * tt;
+        const v2f c = (v2f){opaque(c0.x + c0.y), opaque(c1.x + c1.y)} + (v2f){opaque(gz.x * b0.z), opaque(gz.y * b1.z)};
+        if (SAFE) {
+            value = in0 ? value - c.x : value;
+            value = in1 ? value - c.y : value;
+        } else {
+            value = value - c.x;
+            value = value - c.y;
+        }
+        if (COUNT) ns += (in0 ? 1 : 0) + (in1 ? 1 : 0);
     }
     nsup = ns;
     return value;
 }
 
+// A texel the shortcuts of hrbf_value<false> are exact for: centre below 1e15 in magnitude (squares and the march stay
+// finite), 10 n finite, 1 / T^2 below 1e30 (20 / T^2 finite).  NaNs fail every comparison.
+__device__ __forceinline__ bool texel_is_tame(const float4 ta, const float4 tb)
+{
+    return hd_fabsf(ta.x) < 1e15f && hd_fabsf(ta.y) < 1e15f && hd_fabsf(ta.z) < 1e15f && hd_fabsf(tb.x) < 1e30f &&
+           hd_fabsf(tb.y) < 1e30f && hd_fabsf(tb.z) < 1e30f && hd_fabsf(tb.w) < 1e30f;
+}
+
 // hrbfgradient (hrbfbase.glsl:147-166) with getWeightH (:37-69)
-__device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, const uint16_t *__restrict__ list, int n, f3 p)
+__device__ __forceinline__ f3 hrbf_gradient(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n, f3 p)
 {
     float grx = 0.0f, gry = 0.0f, grz = 0.0f;
     for (int k = 0; k < n; ++k) {
-        const uint32_t o = list[k * PNT];
-        const float4 a = lds4(tile, o), b = lds4(tile, o + 16);
+        const uint32_t o = list[list_slot(k)];
+        const float4 a = lds4(tile, o), b = lds4(tile, o + PLANE_B);
         const float sx = b.x, sy = b.y, sz = b.z;
         const float vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
         const float d2 = (vx * vx + vy * vy) + vz * vz;
@@ -142,102 +215,35 @@ __device__ __forceinline__ f3 hrbf_gradient(const PTexel *__restrict__ tile, con
     return mk3(grx, gry, grz);
 }
 
-// capacity of the per-thread neighbour list: once n exceeds maxn every later window column adds at most one
-// entry (15 columns can still follow), plus three dummy entries behind the list
-__host__ __device__ inline int predict_list_cap(int maxn)
+// Ray march + bisection of predict_hrbf.frag:150-260 as one loop with a single evaluation site: every trip
+// each live lane evaluates the implicit at the next sample of ITS OWN phase, so a wave needs
+// max_lane(total samples) trips instead of sum_phase(max_lane(samples of the phase)).
+//   first: value at `closest`               phase 1: 25 steps of 4 mm away from it until the sign flips
+//   phase 2: 10 steps of 0.4 mm back        phase 3: <= 10 bisections        phase 4: finished
+// The first coarse sample (i = 0) is `closest` itself: its value is v0, which cannot flip the sign, so the
+// march starts at i = 1.  Returns whether a surface point was found (in p_temp).
+template <bool SAFE>
+__device__ __forceinline__ bool ray_march(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n, int minn,
+                                          const f3 closest, const f3 ray, f3 &p_temp)
 {
-    int c = maxn + 1 + 15;
-    if (c > 49) c = 49;
-    if (c < 1) c = 1;
-    return c + 3;
-}
-
-__global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__restrict__ vertconf,
-                                                      const float4 *__restrict__ normrad,
-                                                      const float4 *__restrict__ colortime,
-                                                      const float4 *__restrict__ curvmax,
-                                                      const float4 *__restrict__ curvmin, int win, int minn, int maxn,
-                                                      float cthr, float lambda, uint8_t *__restrict__ pr_image,
-                                                      float4 *__restrict__ pr_vertex, float4 *__restrict__ pr_normal,
-                                                      float4 *__restrict__ pr_curv1, float4 *__restrict__ pr_curv2,
-                                                      uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw)
-{
-    __shared__ PTexel tile[PTW * PTW];
-    __shared__ uint32_t s_rowbits[PTW];
-    extern __shared__ uint16_t s_list[];   // predict_list_cap(maxn) x 256 entries
-    const int W = cam.W, H = cam.H;
-    const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
-    const int tid = threadIdx.y * TB + threadIdx.x;
-    if (tid < PTW) s_rowbits[tid] = 0u;
-    __syncthreads();
-    for (int i = tid; i < PTW * PTW; i += PNT) {
-        int tx = i % PTW, ty = i / PTW;
-        int gx = bx + tx - PR, gy = by + ty - PR;
-        PTexel t;
-        t.px = t.py = t.pz = t.T2 = t.sx = t.sy = t.sz = t.invT2 = 0.0f;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {   // outside the image: rejected like `j < 0 || j > 1` (:85)
-            float4 v = vertconf[gy * W + gx], n = normrad[gy * W + gx];
-            t.px = v.x; t.py = v.y; t.pz = v.z;
-            t.T2 = n.w * n.w; t.invT2 = 1.0f / t.T2;
-            t.sx = 10.0f * n.x; t.sy = 10.0f * n.y; t.sz = 10.0f * n.z;
-            if (!(v.z < 0.1f || len3(mk3(n.x, n.y, n.z)) < 0.1f || v.w < cthr || n.z < 0.0f))
-                atomicOr(&s_rowbits[ty], 1u << tx);
-        }
-        tile[i] = t;
-    }
-    __syncthreads();
-    const int px = bx + threadIdx.x, py = by + threadIdx.y;
-    if (px >= W || py >= H) return;
-    const int pi = py * W + px;
-    const uint32_t lbase_bytes = (uint32_t)(((threadIdx.y + PR) * PTW + threadIdx.x + PR) * (int)sizeof(PTexel));
-    uint16_t *list = s_list + tid;
-
-    int n = 0;
-    {
-        uint32_t wrow[7];
-#pragma unroll
-        for (int r = 0; r < 7; ++r) wrow[r] = s_rowbits[threadIdx.y + r] >> threadIdx.x;
-        bool skip = false;
-        gather_ring<0>(wrow, (2 * win + 1) * (2 * win + 1), maxn, lbase_bytes, list, n, skip);
-        list[n * PNT] = list[(n + 1) * PNT] = list[(n + 2) * PNT] = (uint16_t)lbase_bytes;   // dummies
-    }
-
-    const float x = (float)px + 0.5f, y = (float)py + 0.5f;
-    const float xl = (x - cam.cx) * cam.camz, yl = (y - cam.cy) * cam.camw;
-    const f3 ray = normalize3(mk3(xl, yl, 1.0f));
-
-    f3 closest = mk3(0, 0, 0);
-    {
-        float pmin = 1000000.0f;
-        for (int k = 0; k < n; ++k) {
-            const float4 a = lds4(tile, list[k * PNT]);
-            float pj = hd_fabsf(dot3(mk3(a.x, a.y, a.z), ray));
-            if (pj < pmin) { closest = scale3(ray, pj); pmin = pj; }
-        }
-    }
-
-    // Ray march + bisection of predict_hrbf.frag:150-260 as one loop with a single evaluation site: every trip
-    // each live lane evaluates the implicit at the next sample of ITS OWN phase, so a wave needs
-    // max_lane(total samples) trips instead of sum_phase(max_lane(samples of the phase)).
-    //   phase 0: value at `closest`            phase 1: 25 steps of 4 mm away from it until the sign flips
-    //   phase 2: 10 steps of 0.4 mm back       phase 3: <= 10 bisections        phase 4: finished
-    // The first coarse sample (i = 0) is `closest` itself: its value is v0, which cannot flip the sign, so the
-    // march starts at i = 1.
     bool found = false;
-    f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), p_temp = mk3(0, 0, 0), q = closest;
-    int phase = n > minn ? 0 : 4, it = 0;
+    f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), q = closest;
+    int phase = 4, it = 1;
     bool pos = false;   // sign class of v0
-    while (phase != 4) {
+    if (n > minn) {
         int nsup;
-        const float v = hrbf_value(tile, list, n, q, nsup);
-        if (phase == 0) {
-            if (nsup > minn) {
-                pos = v > 0.0f;
-                if (pos) ep = closest; else sp = closest;
-                phase = 1; it = 1;
-                q = pos ? sub3(ep, scale3(ray, 0.004f * (float)it)) : add3(sp, scale3(ray, 0.004f * (float)it));
-            } else phase = 4;
-        } else if (phase == 1) {
+        const float v0 = hrbf_value<SAFE, true>(tile, list, n, closest, nsup);
+        if (nsup > minn) {
+            pos = v0 > 0.0f;
+            if (pos) ep = closest; else sp = closest;
+            phase = 1;
+            q = pos ? sub3(ep, scale3(ray, 0.004f * (float)it)) : add3(sp, scale3(ray, 0.004f * (float)it));
+        }
+    }
+    while (phase != 4) {
+        int unused;
+        const float v = hrbf_value<SAFE, false>(tile, list, n, q, unused);
+        if (phase == 1) {
             if (pos ? v < 0.0f : v > 0.0f) {
                 if (pos) sp = q; else ep = q;
                 phase = 2; it = 1;
@@ -265,6 +271,94 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
             }
         }
     }
+    return found;
+}
+
+// capacity of the per-thread neighbour list: once n exceeds maxn every later window column adds at most one
+// entry (15 columns can still follow), plus four dummy entries behind the list (hrbf_value reads one pair ahead); even
+__host__ __device__ inline int predict_list_cap(int maxn)
+{
+    int c = maxn + 1 + 15;
+    if (c > 49) c = 49;
+    if (c < 1) c = 1;
+    return (c + 4 + 1) & ~1;
+}
+
+__global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__restrict__ vertconf,
+                                                      const float4 *__restrict__ normrad,
+                                                      const float4 *__restrict__ colortime,
+                                                      const float4 *__restrict__ curvmax,
+                                                      const float4 *__restrict__ curvmin, int win, int minn, int maxn,
+                                                      float cthr, float lambda, uint8_t *__restrict__ pr_image,
+                                                      float4 *__restrict__ pr_vertex, float4 *__restrict__ pr_normal,
+                                                      float4 *__restrict__ pr_curv1, float4 *__restrict__ pr_curv2,
+                                                      uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw)
+{
+    __shared__ float4 tile[2 * (PTW * PTH + 1)];
+    __shared__ uint32_t s_rowbits[PTH];
+    __shared__ uint32_t s_untame;
+    extern __shared__ uint16_t s_list[];   // predict_list_cap(maxn) x 256 entries
+    const int W = cam.W, H = cam.H;
+    const int bx = blockIdx.x * TBX, by = blockIdx.y * TBY;
+    const int tid = threadIdx.y * TBX + threadIdx.x;
+    if (tid < PTH) s_rowbits[tid] = 0u;
+    if (tid == 0) {
+        s_untame = 0u;
+        tile[DUMMY_TEXEL] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        tile[PTW * PTH + 1 + DUMMY_TEXEL] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    for (int i = tid; i < PTW * PTH; i += PNT) {
+        int tx = i % PTW, ty = i / PTW;
+        int gx = bx + tx - PR, gy = by + ty - PR;
+        float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = ta;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {   // outside the image: rejected like `j < 0 || j > 1` (:85)
+            float4 v = vertconf[gy * W + gx], n = normrad[gy * W + gx];
+            const float T2 = n.w * n.w;
+            ta = make_float4(v.x, v.y, v.z, T2);
+            tb = make_float4(10.0f * n.x, 10.0f * n.y, 10.0f * n.z, 1.0f / T2);
+            if (!(v.z < 0.1f || len3(mk3(n.x, n.y, n.z)) < 0.1f || v.w < cthr || n.z < 0.0f)) {
+                atomicOr(&s_rowbits[ty], 1u << tx);
+                if (!texel_is_tame(ta, tb)) s_untame = 1u;
+            }
+        }
+        tile[i] = ta; tile[PTW * PTH + 1 + i] = tb;
+    }
+    __syncthreads();
+    const int px = bx + threadIdx.x, py = by + threadIdx.y;
+    if (px >= W || py >= H) return;
+    const int pi = py * W + px;
+    const uint32_t lbase_bytes = (uint32_t)(((threadIdx.y + PR) * PTW + threadIdx.x + PR) * PTEXEL_BYTES);
+    uint16_t *list = s_list + 2 * tid;
+
+    int n = 0;
+    {
+        uint32_t wrow[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) wrow[r] = s_rowbits[threadIdx.y + r] >> threadIdx.x;
+        bool skip = false;
+        gather_ring<0>(wrow, (2 * win + 1) * (2 * win + 1), maxn, lbase_bytes, list, n, skip);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) list[list_slot(n + d)] = (uint16_t)(DUMMY_TEXEL * PTEXEL_BYTES);
+    }
+
+    const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    const float xl = (x - cam.cx) * cam.camz, yl = (y - cam.cy) * cam.camw;
+    const f3 ray = normalize3(mk3(xl, yl, 1.0f));
+
+    f3 closest = mk3(0, 0, 0);
+    {
+        float pmin = 1000000.0f;
+        for (int k = 0; k < n; ++k) {
+            const float4 a = lds4(tile, list[list_slot(k)]);
+            float pj = hd_fabsf(dot3(mk3(a.x, a.y, a.z), ray));
+            if (pj < pmin) { closest = scale3(ray, pj); pmin = pj; }
+        }
+    }
+
+    f3 p_temp = mk3(0, 0, 0);
+    const bool found = s_untame ? ray_march<true>(tile, list, n, minn, closest, ray, p_temp)
+                                : ray_march<false>(tile, list, n, minn, closest, ray, p_temp);
 
     uchar4 img = make_uchar4(0, 0, 0, 0);
     f3 p_surface = mk3(0, 0, 0), p_normal = mk3(0, 0, 0);
@@ -278,14 +372,14 @@ __global__ __launch_bounds__(256) void k_predict_hrbf(Cam cam, const float4 *__r
         float dsm = 1000000.0f;
         int best = -1;
         for (int k = 0; k < n; ++k) {
-            const uint32_t off = list[k * PNT];
+            const uint32_t off = list[list_slot(k)];
             const float4 a = lds4(tile, off);
             float dx = p_surface.x - a.x, dy = p_surface.y - a.y, dz = p_surface.z - a.z;
             float dist = hd_sqrtf((dx * dx + dy * dy) + dz * dz);
             if (dist < dsm) { dsm = dist; best = (int)off; }
         }
         if (best >= 0) {
-            const int ti = best / (int)sizeof(PTexel);
+            const int ti = best / PTEXEL_BYTES;
             const int gi = (by + ti / PTW - PR) * W + (bx + ti % PTW - PR);
             confidence = vertconf[gi].w; radius = normrad[gi].w;
             cmx = curvmax[gi]; cmn = curvmin[gi];
@@ -403,9 +497,9 @@ void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, 
                          int maxn, float cthr, float lambda, uint8_t *pr_image, float4 *pr_vertex, float4 *pr_normal,
                          float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw)
 {
-    dim3 g((cam.W + TB - 1) / TB, (cam.H + TB - 1) / TB);
+    dim3 g((cam.W + TBX - 1) / TBX, (cam.H + TBY - 1) / TBY);
     const size_t list_bytes = (size_t)predict_list_cap(maxn) * PNT * sizeof(uint16_t);
-    hipLaunchKernelGGL(k_predict_hrbf, g, dim3(TB, TB), list_bytes, s, cam, vertconf, normrad, colortime, curvmax, curvmin, win,
+    hipLaunchKernelGGL(k_predict_hrbf, g, dim3(TBX, TBY), list_bytes, s, cam, vertconf, normrad, colortime, curvmax, curvmin, win,
                        minn, maxn, cthr, lambda, pr_image, pr_vertex, pr_normal, pr_curv1, pr_curv2, pr_time, pr_icpw);
 }
 
