@@ -30,7 +30,7 @@ EXPORTS = [
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
-    "hrbf_probe_single_workgroup_iteration",
+    "hrbf_probe_single_workgroup_iteration", "hrbf_probe_sqrt_rounding",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library():
     lib.hrbf_frames_completed.argtypes = [vp]; lib.hrbf_frames_completed.restype = C.c_uint32
     lib.hrbf_get_pose_log.argtypes = [vp, C.c_uint32, C.c_uint32, vp, i32]
     lib.hrbf_probe_single_workgroup_iteration.argtypes = [vp, i32, i32, vp]
+    lib.hrbf_probe_sqrt_rounding.argtypes = [vp, vp]
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
@@ -310,6 +311,12 @@ class HRBFFusion:
         ms = C.c_float()
         self._check(self.lib.hrbf_probe_single_workgroup_iteration(self.h, level, iters, C.byref(ms)))
         return ms.value
+
+    def probe_sqrt_rounding(self):
+        """exhaustive device-side check of k_predict_hrbf's square-root shortcut, see hrbf_probe_sqrt_rounding"""
+        o = np.zeros(6, np.uint64)
+        self._check(self.lib.hrbf_probe_sqrt_rounding(self.h, _p(o)))
+        return o
 
     def frames_completed(self):
         """frames whose pose has landed in the pinned trajectory ring (never blocks)"""

@@ -1215,6 +1215,21 @@ extern "C" int hrbf_probe_single_workgroup_iteration(hrbf_handle c, int level, i
     return odo_probe_single_wg(c->stream, c->odo, cfg, level, iters, ms_out);
 }
 
+// test probe: k_predict_hrbf takes v_sqrt_f32 plus two residual tests for a correctly rounded root; this runs the check
+// of that shortcut over every non-negative finite float on the device it will run on
+extern "C" int hrbf_probe_sqrt_rounding(hrbf_handle c, uint64_t out[6])
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    unsigned long long *d = nullptr;
+    if (hipMalloc(&d, 6 * sizeof(unsigned long long)) != hipSuccess) return HRBF_ERR_DEVICE;
+    int rc = predict_probe_sqrt(c->stream, d) == 0 ? HRBF_OK : HRBF_ERR_DEVICE;
+    if (rc == HRBF_OK && hipMemcpyAsync(out, d, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = HRBF_ERR_DEVICE;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = HRBF_ERR_DEVICE;
+    hipFree(d);
+    return rc;
+}
+
 extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
 {
     if (!c || !out) return HRBF_ERR_INVALID;

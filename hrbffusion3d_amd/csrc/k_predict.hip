@@ -181,6 +181,36 @@ __device__ __forceinline__ bool texel_is_tame(const float4 ta, const float4 tb)
            hd_fabsf(tb.y) < 1e30f && hd_fabsf(tb.z) < 1e30f && hd_fabsf(tb.w) < 1e30f;
 }
 
+// Exhaustive check of what sqrt_pair_for_unit_complement relies on, over every non-negative finite float
+// (tests/test_parity_gpu.py::test_sqrt_shortcut_is_exhaustively_exact):
+//   out[0..3]  v_sqrt_f32 against the correctly rounded root: equal / one ulp low / one ulp high / anything else
+//   out[4]     arguments >= 2^-96 where the shortcut differs from the correctly rounded root
+//   out[5]     arguments <  2^-96 where 1 - shortcut differs from 1 - root (the only way the loop consumes it)
+__global__ void k_probe_sqrt(unsigned long long *out)
+{
+    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint64_t b = blockIdx.x * blockDim.x + threadIdx.x; b < 0x7f800000ull; b += stride) {
+        const float x = __builtin_bit_cast(float, (uint32_t)b);
+        const float exact = hd_sqrtf(x), raw = __builtin_amdgcn_sqrtf(x);
+        const int d = (int)(__builtin_bit_cast(uint32_t, raw) - __builtin_bit_cast(uint32_t, exact));
+        c[d == 0 ? 0 : d == -1 ? 1 : d == 1 ? 2 : 3]++;
+        const v2f r = sqrt_pair_for_unit_complement((v2f){x, x});
+        if (x >= 0x1p-96f) c[4] += (__builtin_bit_cast(uint32_t, r.x) != __builtin_bit_cast(uint32_t, exact)) ||
+                                   (__builtin_bit_cast(uint32_t, r.y) != __builtin_bit_cast(uint32_t, exact));
+        else c[5] += (1.0f - r.x != 1.0f - exact) || (1.0f - r.y != 1.0f - exact);
+    }
+    for (int i = 0; i < 6; ++i)
+        if (c[i]) atomicAdd(&out[i], c[i]);
+}
+
+int predict_probe_sqrt(hipStream_t s, unsigned long long *d_out6)
+{
+    if (hipMemsetAsync(d_out6, 0, 6 * sizeof(unsigned long long), s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_probe_sqrt, dim3(4096), dim3(256), 0, s, d_out6);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // hrbfgradient (hrbfbase.glsl:147-166) with getWeightH (:37-69)
 __device__ __forceinline__ f3 hrbf_gradient(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n, f3 p)
 {

@@ -222,6 +222,11 @@ int hrbf_reset_fuse_ring(hrbf_handle h);
  * products + RGB products, exact reductions) executed by ONE 256-thread workgroup; kernel time in ms.  Call after at
  * least two processed frames.  DESIGN.md §6 compares it with the three launches an iteration takes. */
 int hrbf_probe_single_workgroup_iteration(hrbf_handle h, int level, int iters, float *ms_out);
+/* test probe (not part of the path): exhaustive check, on the device, of the square-root shortcut k_predict_hrbf uses
+ * (v_sqrt_f32 + two residual tests).  out = {raw == root, raw one ulp low, raw one ulp high, raw further off,
+ * shortcut != correctly rounded root for x >= 2^-96, (1 - shortcut) != (1 - root) for x < 2^-96} over all
+ * non-negative finite floats; the last three must be 0. */
+int hrbf_probe_sqrt_rounding(hrbf_handle h, uint64_t out[6]);
 /* build-specific: toggle trajectory replay (globalInputLoadTrajectory) between frames */
 int hrbf_set_load_trajectory(hrbf_handle h, int v);
 /* sticky condition bits, folded from the device by this (synchronising) call; clear != 0 resets them.  The per-frame

@@ -510,6 +510,43 @@ def test_stage_seams_in_isolation(pair):
     assert g.fuse_stats()[2] == 0 and len(g.download_map()) <= len(before)
 
 
+def test_sqrt_shortcut_is_exhaustively_exact(gpu_available):
+    """k_predict_hrbf replaces the compiler's sqrtf expansion by v_sqrt_f32 + two residual tests (no rescaling of tiny
+    arguments, no 0 / inf re-check).  Checked here over EVERY non-negative finite float on the device under test."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    g = HRBFFusion(default_params(160, 120, *synth.intrinsics(160, 120), max_surfels=1 << 12))
+    h = g.probe_sqrt_rounding()
+    g.close()
+    assert int(h[:4].sum()) == 0x7f800000, h
+    assert h[3] <= 0x7fffff, h     # further off than one ulp only for (some of) the 2^23 - 1 denormal arguments: covered by h[5]
+    assert h[4] == 0 and h[5] == 0, h
+
+
+@pytest.mark.parametrize("radius", [0.0, float("nan"), 1e-25, 1e25, float("inf"), 0.02])
+def test_predict_with_degenerate_texels(pair, radius):
+    """The ray-cast kernel runs a select-free inner loop on tiles whose texels are all finite and tame and the literal one
+    otherwise.  Poisoned index-map texels: a texel ON the optical axis of the principal pixel (its first sample coincides
+    with the centre: d2 == 0, the getWeightD special case) with a zero / NaN / tiny / huge / infinite support radius, and
+    non-finite or huge positions and normals scattered over other tiles."""
+    W, H = 160, 120
+    p = default_params(W, H, 150.0, 150.0, 80.5, 60.5, max_surfels=1 << 17)
+    o, g = pair(p)
+    _, _, T = synth.frame(3, W, H)
+    seed = synth.seed_map(60_000, width=W)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.set_tick(5); x.run_stage("PREDICT_INDICES")
+    v = o.get_image("INDEX_VERTCONF").copy(); n = o.get_image("INDEX_NORMRAD").copy()
+    z0 = float(np.median(v[50:70, 70:90, 2][v[50:70, 70:90, 2] > 0.1]))
+    v[60, 80] = (0.0, 0.0, z0, 50.0); n[60, 80] = (0.0, 0.0, 1.0, radius)
+    v[61, 81, 3] = 50.0; n[61, 81, 3] = radius                                   # the same radius off the axis
+    v[20, 30, 0] = 1e20; v[25, 100, 1] = float("nan"); v[90, 40, 2] = float("inf"); v[100, 120, :3] *= 1e16
+    n[30, 130, :3] *= 1e35; n[95, 20, 0] = float("nan"); n[15, 75, 3] = -0.0
+    for x in (o, g):
+        x.set_image("INDEX_VERTCONF", v); x.set_image("INDEX_NORMRAD", n); x.run_stage("PREDICT_HRBF"); x.run_stage("FILLIN")
+    assert_same_state(o, g, "radius %r" % radius, [k for k in IMAGES if k.startswith(("PRED", "FILL"))])
+    assert (g.get_image("PRED_VERTEX")[..., 2] > 0).sum() > 1000               # the rest of the image is still predicted
+
+
 def test_named_map_operators(pair):
     """GlobalModel::{initialise,fuse,clean} / IndexMap::{predictIndices,predictHRBF} under their own names with the
     explicit pose / time / cut-off arguments of the reference (GlobalModel.h:50-107, IndexMap.h:43-68) against the
