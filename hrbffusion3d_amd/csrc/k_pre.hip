@@ -10,6 +10,80 @@
 
 #define TB 16   // tile edge; 256 threads = 4 wave64
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// (p * 2^k1) * 2^k2 with k1 = k / 2, k2 = k - k1 — hd_expf's two-step scaling — is one correctly rounded scaling by 2^k:
+// the first product is exact (no underflow for k >= -160), the second rounds once.  That is what v_ldexp_f32 computes;
+// checked bit for bit on the device for every p in [0.5, 2) and k in [-160, 0] by hrbf_probe_exp_scaling.
+__device__ __forceinline__ float exp_scale(float p, int k) { return __builtin_ldexpf(p, k); }
+
+// hd_expf_nonpos on two arguments at once (v_pk_mul / v_pk_fma_f32: the same IEEE operations per half)
+__device__ __forceinline__ v2f expf_nonpos_pair(const v2f x0)
+{
+    const bool u0 = x0.x < -103.9f, u1 = x0.y < -103.9f;
+    const v2f x = {u0 ? -103.9f : x0.x, u1 ? -103.9f : x0.y};
+    const v2f t = x * 1.44269504088896341f;
+    const v2f kf = {hd_rintf(t.x), hd_rintf(t.y)};
+    v2f r = __builtin_elementwise_fma(kf, (v2f)(-0.693359375f), x);
+    r = __builtin_elementwise_fma(kf, (v2f)(2.12194440e-4f), r);
+    v2f p = (v2f)(1.3981999507e-3f);
+    p = __builtin_elementwise_fma(p, r, (v2f)(8.3334519073e-3f));
+    p = __builtin_elementwise_fma(p, r, (v2f)(4.1665795894e-2f));
+    p = __builtin_elementwise_fma(p, r, (v2f)(1.6666665459e-1f));
+    p = __builtin_elementwise_fma(p, r, (v2f)(5.0000001201e-1f));
+    const v2f r2 = r * r;
+    p = __builtin_elementwise_fma(p, r2, r);
+    p = p + 1.0f;
+    v2f w;
+    w.x = u0 ? 0.0f : exp_scale(p.x, (int)kf.x);
+    w.y = u1 ? 0.0f : exp_scale(p.y, (int)kf.y);
+    return w;
+}
+
+// the scalar twin (odd tap at the end of a row)
+__device__ __forceinline__ float expf_nonpos_dev(const float x0)
+{
+    const bool under = x0 < -103.9f;
+    const float x = under ? -103.9f : x0;
+    const float kf = hd_rintf(x * 1.44269504088896341f);
+    float r = hd_fmaf(kf, -0.693359375f, x);
+    r = hd_fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.3981999507e-3f;
+    p = hd_fmaf(p, r, 8.3334519073e-3f);
+    p = hd_fmaf(p, r, 4.1665795894e-2f);
+    p = hd_fmaf(p, r, 1.6666665459e-1f);
+    p = hd_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    p = hd_fmaf(p, r2, r);
+    p = p + 1.0f;
+    return under ? 0.0f : exp_scale(p, (int)kf);
+}
+
+// test probe: exp_scale against hd_expf's two multiplications, every p in [0.5, 2) x every k in [-160, 0]
+__global__ void k_probe_exp_scaling(unsigned long long *out)
+{
+    unsigned long long bad = 0, total = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = 0x3f000000u + blockIdx.x * blockDim.x + threadIdx.x; b < 0x40000000u; b += stride) {
+        const float p = hd_u2f(b);
+        for (int k = -160; k <= 0; ++k) {
+            const int k1 = k / 2, k2 = k - k1;
+            const float ref = (p * hd_u2f((uint32_t)(k1 + 127) << 23)) * hd_u2f((uint32_t)(k2 + 127) << 23);
+            bad += hd_f2u(ref) != hd_f2u(exp_scale(p, k));
+            ++total;
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], total);
+}
+
+int pre_probe_exp_scaling(hipStream_t s, unsigned long long *d_out2)
+{
+    if (hipMemsetAsync(d_out2, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_probe_exp_scaling, dim3(4096), dim3(256), 0, s, d_out2);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // P1 + P2: bilateral (13x13) or gated Gaussian (9x9) on raw depth, plus both metric images.
 // LDS: (16+12)^2 raw depths as float-mm (value / adj precomputed once per texel).
@@ -42,26 +116,51 @@ __global__ __launch_bounds__(256) void k_filter_metric(Cam cam, const uint16_t *
         int x0 = x - R > 0 ? x - R : 0, x1 = x + R + 1 < W ? x + R + 1 : W;
         int y0 = y - R > 0 ? y - R : 0, y1 = y + R + 1 < H ? y + R + 1 : H;
         float sum1 = 0.0f, sum2 = 0.0f;
-        for (int cy = y0; cy < y1; ++cy) {
-            const float dy = (float)y - (float)cy;
-            const float *row = &tile[(cy - by + R) * TW + (R - bx)];
-            for (int cx = x0; cx < x1; ++cx) {
-                float tmp = row[cx];
-                float dx = (float)x - (float)cx;
-                if (BILATERAL) {
-                    float space2 = dx * dx + dy * dy;
-                    float dv = value - tmp;
-                    float color2 = dv * dv;
-                    // Measured and rejected (round 2): the 169 taps fully unrolled with compile-time offsets (62.6 us) and
-                    // rows looped / columns unrolled (70.4 us) against this plain clamped loop (57.4 us).
-                    // the argument is <= 0 and finite: hd_expf without its NaN / overflow selects (57.8 -> 50.3 us; same bits)
-                    float weight = hd_expf_nonpos(-(space2 * 0.024691358f + color2 * 0.000555556f));
+        if (BILATERAL) {
+            // Two taps per trip on float pairs (the loop is VALU-issue bound: 169 taps x ~37 instructions per pixel before).
+            // Same operations in the same order per tap; the sums take the taps left to right as before.
+            // Measured and rejected earlier: the 169 taps fully unrolled with compile-time offsets (62.6 us) and rows
+            // looped / columns unrolled (70.4 us) against the plain clamped loop (57.4 us; 50.3 with hd_expf_nonpos).
+            for (int cy = y0; cy < y1; ++cy) {
+                const float dy = (float)y - (float)cy;
+                const float dy2 = dy * dy;
+                const float *row = &tile[(cy - by + R) * TW + (R - bx)];
+                // dx = (float)x - (float)cx is a small integer: stepping it by 2 gives the same values as converting cx
+                const float *q = row + x0;
+                v2f dx = {(float)(x - x0), (float)(x - x0 - 1)};
+                int left = x1 - x0;
+                for (; left >= 2; left -= 2, q += 2, dx -= 2.0f) {
+                    const v2f tmp = {q[0], q[1]};
+                    const v2f space2 = dx * dx + dy2;
+                    const v2f dv = value - tmp;
+                    const v2f color2 = dv * dv;
+                    const v2f w = expf_nonpos_pair(-(space2 * 0.024691358f + color2 * 0.000555556f));
+                    const v2f tw = tmp * w;
+                    sum1 += tw.x; sum2 += w.x;
+                    sum1 += tw.y; sum2 += w.y;
+                }
+                if (left) {
+                    const float tmp = q[0];
+                    const float space2 = dx.x * dx.x + dy2;
+                    const float dv = value - tmp;
+                    const float color2 = dv * dv;
+                    const float weight = expf_nonpos_dev(-(space2 * 0.024691358f + color2 * 0.000555556f));
                     sum1 += tmp * weight;
                     sum2 += weight;
-                } else if (tmp > 300.0f && hd_fabsf(tmp - value) < 100.0f) {
-                    float weight = hd_expf(-((dx * dx + dy * dy) / (2.0f * 3.0f * 3.0f)));
-                    sum1 += tmp * weight;
-                    sum2 += weight;
+                }
+            }
+        } else {
+            for (int cy = y0; cy < y1; ++cy) {
+                const float dy = (float)y - (float)cy;
+                const float *row = &tile[(cy - by + R) * TW + (R - bx)];
+                for (int cx = x0; cx < x1; ++cx) {
+                    float tmp = row[cx];
+                    float dx = (float)x - (float)cx;
+                    if (tmp > 300.0f && hd_fabsf(tmp - value) < 100.0f) {
+                        float weight = hd_expf(-((dx * dx + dy * dy) / (2.0f * 3.0f * 3.0f)));
+                        sum1 += tmp * weight;
+                        sum2 += weight;
+                    }
                 }
             }
         }
@@ -228,6 +327,212 @@ __global__ __launch_bounds__(256) void k_vertex_normal_radius(Cam cam, const flo
 // (two of them divisions) for each of the <= 49 pixels a texel is a neighbour of
 struct alignas(16) NbTexel { float px, py, pz, valid, sx, sy, sz, T2, T2T2, s3, m20, pad; };
 
+// the nine running sums of a pixel: gradient (x, y | z) and the six Hessian entries the curvature consumes, paired the way
+// the packed arithmetic of curv_neighbour_fast produces them
+struct CurvSums { v2f grxy; float grz; v2f g04; float g1; v2f g25; float g8; };
+
+// One neighbour, literally: getWeightH (hrbfbase.glsl:37-69) and, inside the support, getWeightT (:72-124, only the 18
+// entries the Hessian consumes) — r = sqrt(d2 / T2) is formed once for both.
+__device__ __forceinline__ void curv_neighbour_literal(const NbTexel &me, const NbTexel &nb, CurvSums &a)
+{
+    const float sx = nb.sx, sy = nb.sy, sz = nb.sz;
+    const float vx = me.px - nb.px, vy = me.py - nb.py, vz = me.pz - nb.pz;
+    const float d2 = (vx * vx + vy * vy) + vz * vz;
+    const float T2 = nb.T2;
+    float h0, h1, h2, h4, h5, h8;
+    bool third = false;
+    float t0 = 0, t1_ = 0, t2_ = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, t13 = 0, t14 = 0, t16 = 0, t17 = 0, t26 = 0;
+    if (d2 > T2) { h0 = h1 = h2 = h4 = h5 = h8 = 0.0f; }
+    else if (d2 == 0.0f) { h0 = h4 = h8 = nb.m20; h1 = h2 = h5 = 0.0f; }
+    else {
+        const float r = hd_sqrtf(d2 / T2);
+        const float s = 1.0f - r;
+        {
+            float s2 = s * s;
+            float t1 = 20.0f * s2 / (nb.T2T2 * r);
+            float t2 = -r * s * T2;
+            h0 = t1 * (3.0f * (vx * vx) + t2);
+            h1 = t1 * 3.0f * vx * vy;
+            h2 = t1 * 3.0f * vx * vz;
+            h4 = t1 * (3.0f * (vy * vy) + t2);
+            h5 = t1 * 3.0f * vy * vz;
+            h8 = t1 * (3.0f * (vz * vz) + t2);
+        }
+        third = true;
+        float s2 = r - 2.0f + 1.0f / r;
+        float s3 = nb.s3;
+        float s4 = 1.0f / (r * r);
+        float prx = vx / (T2 * r), pry = vy / (T2 * r), prz = vz / (T2 * r);
+        float qx = prx - s4 * prx, qy = pry - s4 * pry, qz = prz - s4 * prz;
+        float tss = T2 * s * s;
+        t0 = s3 * (tss * prx + 2.0f * vx * s2 + vx * vx * qx);
+        t1_ = s3 * vy * (qx * vx + s2);
+        t2_ = s3 * vz * (qx * vx + s2);
+        t3 = s3 * (tss * pry + vx * vx * qy);
+        t4 = s3 * vx * (qy * vy + s2);
+        t5 = s3 * vx * vz * qy;
+        t6 = s3 * (tss * prz + vx * vx * qz);
+        t7 = s3 * vx * vy * qz;
+        t8 = s3 * vx * (qz * vz + s2);
+        t13 = s3 * (tss * pry + 2.0f * vy * s2 + vy * vy * qy);
+        t14 = s3 * vz * (qy * vy + s2);
+        t16 = s3 * (tss * prz + vy * vy * qz);
+        t17 = s3 * vy * (qz * vz + s2);
+        t26 = s3 * (tss * prz + 2.0f * vz * s2 + vz * vz * qz);
+    }
+    a.grxy.x -= (sx * h0 + sy * h1) + sz * h2;
+    a.grxy.y -= (sx * h1 + sy * h4) + sz * h5;
+    a.grz -= (sx * h2 + sy * h5) + sz * h8;
+    if (third) {
+        a.g04.x -= (sx * t0 + sy * t1_) + sz * t2_;
+        a.g1 -= (sx * t3 + sy * t4) + sz * t5;
+        a.g25.x -= (sx * t6 + sy * t7) + sz * t8;
+        a.g04.y -= (sx * t4 + sy * t13) + sz * t14;      // hw[12] = t[4]
+        a.g25.y -= (sx * t7 + sy * t16) + sz * t17;      // hw[15] = t[7]
+        a.g8 -= (sx * t8 + sy * t17) + sz * t26;         // hw[24] = t[8], hw[25] = t[17]
+    }
+    // outside the support the third derivatives are zero: "g -= 0" in the oracle, a no-op in IEEE
+}
+
+// ---- the same neighbour for TAME tiles (curv_texel_is_tame): identical IEEE operations, fewer instructions ----
+// Correctly rounded division without the range scaling and special-case fix-up of the compiler's expansion
+// (v_div_scale / v_div_fmas / v_div_fixup are identities when numerator, denominator and quotient are far from the ends of
+// the exponent range — guaranteed by the tame ranges below): reciprocal refined once, quotient refined twice, all in FMAs.
+__device__ __forceinline__ float rcp_refined(const float b)
+{
+    const float y = __builtin_amdgcn_rcpf(b);
+    return hd_fmaf(hd_fmaf(-b, y, 1.0f), y, y);
+}
+__device__ __forceinline__ float div_by(const float a, const float b, const float y /* rcp_refined(b) */)
+{
+    float q = a * y;
+    q = hd_fmaf(hd_fmaf(-b, q, a), y, q);
+    return hd_fmaf(hd_fmaf(-b, q, a), y, q);
+}
+__device__ __forceinline__ v2f div_by(const v2f a, const float b, const float y)
+{
+    const v2f nb = (v2f)(-b), yy = (v2f)(y);
+    v2f q = a * yy;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q, a), yy, q);
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q, a), yy, q);
+}
+// correctly rounded sqrt for arguments >= 2^-96 (hrbf_probe_sqrt_rounding checks every float): v_sqrt_f32 + the two
+// residual tests of the compiler's expansion, without its rescaling of tiny arguments and its 0 / inf re-check
+__device__ __forceinline__ float sqrt_normal(const float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = hd_u2f(hd_f2u(s) - 1u), up = hd_u2f(hd_f2u(s) + 1u);
+    const float ed = hd_fmaf(-dn, s, x), eu = hd_fmaf(-up, s, x);
+    const float t = ed <= 0.0f ? dn : s;
+    return eu > 0.0f ? up : t;
+}
+__device__ __forceinline__ float keep_scalar(float x)   // stops the selector from re-pairing two scalar results through v_mov
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ v2f swap2(const v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// What curv_neighbour_fast assumes of every texel that can take part (depth > 0.3): coordinates +0 or between 2^-20 and
+// 2^10 in magnitude (differences are then zero or >= 2^-43, squared distances zero or >= 2^-86), T^2 between 2^-26 and
+// 2^7, |10 n| below 2^10.  NaNs fail every comparison.
+__device__ __forceinline__ bool curv_coord_is_tame(const float c)
+{
+    const float m = hd_fabsf(c);
+    return hd_f2u(c) == 0u || (m >= 0x1p-20f && m < 0x1p10f);   // +0 only: differences of such coordinates are never -0
+}
+__device__ __forceinline__ bool curv_texel_is_tame(const NbTexel &t)
+{
+    return curv_coord_is_tame(t.px) && curv_coord_is_tame(t.py) && curv_coord_is_tame(t.pz) && t.T2 >= 0x1p-26f &&
+           t.T2 <= 0x1p7f && hd_fabsf(t.sx) < 0x1p10f && hd_fabsf(t.sy) < 0x1p10f && hd_fabsf(t.sz) < 0x1p10f;
+}
+
+// Main case (0 < d2 <= T2, r >= 2^-20) on float pairs: x / y entries share a register pair, z entries are scalar.
+// Every expression keeps the literal's association; a + b is written b + a in places (the same bits).
+__device__ __forceinline__ void curv_neighbour_fast(const v2f V, const float vz, const v2f SQ, const float vz2, const float qd,
+                                                    const NbTexel &nb, CurvSums &a)
+{
+    const v2f S = {nb.sx, nb.sy};
+    const float sz = nb.sz, T2 = nb.T2, s3 = nb.s3;
+    const float r = sqrt_normal(qd);
+    const float s = 1.0f - r;
+    const float yr = rcp_refined(r);
+    {
+        const float den = nb.T2T2 * r;
+        const float t1 = div_by(20.0f * (s * s), den, rcp_refined(den));
+        const float t2 = -r * s * T2;
+        const v2f H04 = t1 * (3.0f * SQ + t2);                   // h0, h4
+        const float h8 = t1 * (3.0f * vz2 + t2);
+        const v2f AB = (t1 * 3.0f) * V;
+        const float h1 = AB.x * V.y;
+        const v2f H25 = AB * vz;                                  // h2, h5
+        a.grxy -= (S * H04 + swap2(S) * h1) + sz * H25;
+        const v2f P = S * H25;
+        a.grz -= keep_scalar(P.x + P.y) + sz * h8;
+    }
+    const float s2 = (r - 2.0f) + div_by(1.0f, r, yr);
+    const float rr = r * r;
+    const float s4 = div_by(1.0f, rr, rcp_refined(rr));
+    const float D = T2 * r, yD = rcp_refined(D);
+    const v2f PR = div_by(V, D, yD);
+    const float prz = div_by(vz, D, yD);
+    const v2f Q = PR - s4 * PR;
+    const float qz = prz - s4 * prz;
+    const float tss = T2 * s * s;
+    const v2f TP = tss * PR;
+    const float tpz = tss * prz;
+    const v2f A = Q * V + s2;                                     // qx vx + s2, qy vy + s2
+    const float az = qz * vz + s2;
+    const v2f S3V = s3 * V;
+    const float s3vz = s3 * vz;
+    const v2f T0_13 = s3 * ((TP + (2.0f * V) * s2) + SQ * Q);     // t0, t13
+    const float t26 = s3 * ((tpz + (2.0f * vz) * s2) + vz2 * qz);
+    const v2f T6_16 = s3 * (tpz + SQ * qz);                       // t6, t16
+    const float t3 = s3 * (TP.y + SQ.x * Q.y);
+    const v2f T1_4 = swap2(S3V) * A;                              // t1 = (s3 vy)(qx vx + s2), t4 = (s3 vx)(qy vy + s2)
+    const v2f T2_14 = s3vz * A;                                   // t2, t14
+    const v2f T8_17 = S3V * az;                                   // t8, t17
+    const float t5 = (S3V.x * vz) * Q.y;
+    const float t7 = (S3V.x * V.y) * qz;
+    a.g04 -= (S * T0_13 + swap2(S) * T1_4) + sz * T2_14;
+    a.g1 -= (S.x * t3 + S.y * T1_4.y) + sz * t5;
+    a.g25 -= (S * T6_16 + swap2(S) * t7) + sz * T8_17;
+    const v2f P8 = S * T8_17;
+    a.g8 -= keep_scalar(P8.x + P8.y) + sz * t26;
+}
+
+template <bool TAME>
+__device__ __forceinline__ int curv_window(const NbTexel *__restrict__ tile, const NbTexel &me, int lx0, int lx1, int ly0,
+                                           int ly1, CurvSums &a)
+{
+    constexpr int RMAX = 3, TW = TB + 2 * RMAX;
+    int n = 0;
+    for (int lx = lx0; lx <= lx1; ++lx)
+        for (int ly = ly0; ly <= ly1; ++ly) {
+            const NbTexel nb = tile[ly * TW + lx];
+            const float vz = me.pz - nb.pz;
+            if (!(hd_fabsf(nb.pz - me.pz) < 0.10f && nb.valid > 0.0f)) continue;
+            n++;
+            if (!TAME) { curv_neighbour_literal(me, nb, a); continue; }
+            const v2f V = (v2f){me.px, me.py} - (v2f){nb.px, nb.py};
+            const v2f SQ = V * V;
+            const float vz2 = vz * vz;
+            const float d2 = keep_scalar(SQ.x + SQ.y) + vz2;
+            // outside the support: the literal subtracts (s * 0) sums — zeros, since 10 n is finite — from sums that are
+            // never -0 (they start at +0 and x - x is +0): nothing to do
+            if (d2 > nb.T2) continue;
+            if (d2 == 0.0f) {   // the pixel itself: h0 = h4 = h8 = -20 / T^2, the products with the zero entries vanish
+                a.grxy -= (v2f){nb.sx, nb.sy} * nb.m20;
+                a.grz -= nb.sz * nb.m20;
+                continue;
+            }
+            const float qd = div_by(d2, nb.T2, rcp_refined(nb.T2));
+            if (__builtin_amdgcn_ballot_w64(qd < 0x1p-40f) != 0ull) curv_neighbour_literal(me, nb, a);   // r < 2^-20: not tame
+            else curv_neighbour_fast(V, vz, SQ, vz2, qd, nb, a);
+        }
+    return n;
+}
+
 __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__restrict__ vertex_filtered,
                                                    const float4 *__restrict__ normal_in,
                                                    float4 *__restrict__ curv1, float4 *__restrict__ curv2,
@@ -236,8 +541,11 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
 {
     constexpr int RMAX = 3, TW = TB + 2 * RMAX;
     __shared__ NbTexel tile[TW * TW];
+    __shared__ uint32_t s_untame;
     const int W = cam.W, H = cam.H;
     const int bx = blockIdx.x * TB, by = blockIdx.y * TB;
+    if (threadIdx.x == 0 && threadIdx.y == 0) s_untame = 0u;
+    __syncthreads();
     for (int i = threadIdx.y * TB + threadIdx.x; i < TW * TW; i += TB * TB) {
         int tx = i % TW, ty = i / TW;
         int gx = bx + tx - RMAX, gy = by + ty - RMAX;
@@ -249,6 +557,8 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
             t.sx = 10.0f * n.x; t.sy = 10.0f * n.y; t.sz = 10.0f * n.z;
             t.T2 = n.w * n.w; t.T2T2 = t.T2 * t.T2; t.s3 = 60.0f / t.T2T2; t.m20 = -20.0f / t.T2;
             t.valid = (v.z > 0.3f && len3(mk3(n.x, n.y, n.z)) > 0.8f) ? 1.0f : 0.0f;
+            // a texel takes part as a neighbour (valid) or as the centre (depth > 0.3, |n| > 0.5)
+            if (v.z > 0.3f && len3(mk3(n.x, n.y, n.z)) > 0.5f && !curv_texel_is_tame(t)) s_untame = 1u;
         }
         tile[i] = t;
     }
@@ -265,75 +575,12 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
         f3 pmax = mk3(0, 0, 0), pmin = mk3(0, 0, 0);
         int x0 = px - win < 0 ? 0 : px - win, x1 = px + win > W - 1 ? W - 1 : px + win;
         int y0 = py - win < 0 ? 0 : py - win, y1 = py + win > H - 1 ? H - 1 : py + win;
-        int n = 0;
-        float grx = 0.0f, gry = 0.0f, grz = 0.0f;
-        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g4 = 0.0f, g5 = 0.0f, g8 = 0.0f;
-        for (int ix = x0; ix <= x1; ++ix)
-            for (int iy = y0; iy <= y1; ++iy) {
-                const NbTexel nb = tile[(iy - by + RMAX) * TW + (ix - bx + RMAX)];
-                if (!(hd_fabsf(nb.pz - me.pz) < 0.10f && nb.valid > 0.0f)) continue;
-                n++;
-                const float sx = nb.sx, sy = nb.sy, sz = nb.sz;
-                const float vx = me.px - nb.px, vy = me.py - nb.py, vz = me.pz - nb.pz;
-                const float d2 = (vx * vx + vy * vy) + vz * vz;
-                const float T2 = nb.T2;
-                // getWeightH (hrbfbase.glsl:37-69) and, inside the support, getWeightT (:72-124, only the 18 entries
-                // the Hessian consumes) — r = sqrt(d2 / T2) is formed once for both
-                float h0, h1, h2, h4, h5, h8;
-                bool third = false;
-                float t0 = 0, t1_ = 0, t2_ = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, t13 = 0, t14 = 0, t16 = 0, t17 = 0,
-                      t26 = 0;
-                if (d2 > T2) { h0 = h1 = h2 = h4 = h5 = h8 = 0.0f; }
-                else if (d2 == 0.0f) { h0 = h4 = h8 = nb.m20; h1 = h2 = h5 = 0.0f; }
-                else {
-                    const float r = hd_sqrtf(d2 / T2);
-                    const float s = 1.0f - r;
-                    {
-                        float s2 = s * s;
-                        float t1 = 20.0f * s2 / (nb.T2T2 * r);
-                        float t2 = -r * s * T2;
-                        h0 = t1 * (3.0f * (vx * vx) + t2);
-                        h1 = t1 * 3.0f * vx * vy;
-                        h2 = t1 * 3.0f * vx * vz;
-                        h4 = t1 * (3.0f * (vy * vy) + t2);
-                        h5 = t1 * 3.0f * vy * vz;
-                        h8 = t1 * (3.0f * (vz * vz) + t2);
-                    }
-                    third = true;
-                    float s2 = r - 2.0f + 1.0f / r;
-                    float s3 = nb.s3;
-                    float s4 = 1.0f / (r * r);
-                    float prx = vx / (T2 * r), pry = vy / (T2 * r), prz = vz / (T2 * r);
-                    float qx = prx - s4 * prx, qy = pry - s4 * pry, qz = prz - s4 * prz;
-                    float tss = T2 * s * s;
-                    t0 = s3 * (tss * prx + 2.0f * vx * s2 + vx * vx * qx);
-                    t1_ = s3 * vy * (qx * vx + s2);
-                    t2_ = s3 * vz * (qx * vx + s2);
-                    t3 = s3 * (tss * pry + vx * vx * qy);
-                    t4 = s3 * vx * (qy * vy + s2);
-                    t5 = s3 * vx * vz * qy;
-                    t6 = s3 * (tss * prz + vx * vx * qz);
-                    t7 = s3 * vx * vy * qz;
-                    t8 = s3 * vx * (qz * vz + s2);
-                    t13 = s3 * (tss * pry + 2.0f * vy * s2 + vy * vy * qy);
-                    t14 = s3 * vz * (qy * vy + s2);
-                    t16 = s3 * (tss * prz + vy * vy * qz);
-                    t17 = s3 * vy * (qz * vz + s2);
-                    t26 = s3 * (tss * prz + 2.0f * vz * s2 + vz * vz * qz);
-                }
-                grx -= (sx * h0 + sy * h1) + sz * h2;
-                gry -= (sx * h1 + sy * h4) + sz * h5;
-                grz -= (sx * h2 + sy * h5) + sz * h8;
-                if (third) {
-                    g0 -= (sx * t0 + sy * t1_) + sz * t2_;
-                    g1 -= (sx * t3 + sy * t4) + sz * t5;
-                    g2 -= (sx * t6 + sy * t7) + sz * t8;
-                    g4 -= (sx * t4 + sy * t13) + sz * t14;      // hw[12] = t[4]
-                    g5 -= (sx * t7 + sy * t16) + sz * t17;      // hw[15] = t[7]
-                    g8 -= (sx * t8 + sy * t17) + sz * t26;      // hw[24] = t[8], hw[25] = t[17]
-                }
-                // outside the support the third derivatives are zero: "g -= 0" in the oracle, a no-op in IEEE
-            }
+        CurvSums a;
+        a.grxy = (v2f)(0.0f); a.grz = 0.0f; a.g04 = (v2f)(0.0f); a.g1 = 0.0f; a.g25 = (v2f)(0.0f); a.g8 = 0.0f;
+        const int n = s_untame ? curv_window<false>(tile, me, x0 - bx + RMAX, x1 - bx + RMAX, y0 - by + RMAX, y1 - by + RMAX, a)
+                               : curv_window<true>(tile, me, x0 - bx + RMAX, x1 - bx + RMAX, y0 - by + RMAX, y1 - by + RMAX, a);
+        const float grx = a.grxy.x, gry = a.grxy.y, grz = a.grz;
+        const float g0 = a.g04.x, g1 = a.g1, g2 = a.g25.x, g4 = a.g04.y, g5 = a.g25.y, g8 = a.g8;
         if (n > 15) {
             float4 vn = normal_in[i];
             gmag = hd_fabsf((grx * vn.x + gry * vn.y) + grz * vn.z);

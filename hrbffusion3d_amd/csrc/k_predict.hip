@@ -254,15 +254,17 @@ __device__ __forceinline__ f3 hrbf_gradient(const float4 *__restrict__ tile, con
 // march starts at i = 1.  Returns whether a surface point was found (in p_temp).
 template <bool SAFE>
 __device__ __forceinline__ bool ray_march(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n, int minn,
-                                          const f3 closest, const f3 ray, f3 &p_temp)
+                                          const f3 closest, const f3 ray, f3 &p_temp, int &trips)
 {
     bool found = false;
+    trips = 0;
     f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), q = closest;
     int phase = 4, it = 1;
     bool pos = false;   // sign class of v0
     if (n > minn) {
         int nsup;
         const float v0 = hrbf_value<SAFE, true>(tile, list, n, closest, nsup);
+        trips = 1;
         if (nsup > minn) {
             pos = v0 > 0.0f;
             if (pos) ep = closest; else sp = closest;
@@ -273,6 +275,7 @@ __device__ __forceinline__ bool ray_march(const float4 *__restrict__ tile, const
     while (phase != 4) {
         int unused;
         const float v = hrbf_value<SAFE, false>(tile, list, n, q, unused);
+        ++trips;
         if (phase == 1) {
             if (pos ? v < 0.0f : v > 0.0f) {
                 if (pos) sp = q; else ep = q;
@@ -387,8 +390,9 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
     }
 
     f3 p_temp = mk3(0, 0, 0);
-    const bool found = s_untame ? ray_march<true>(tile, list, n, minn, closest, ray, p_temp)
-                                : ray_march<false>(tile, list, n, minn, closest, ray, p_temp);
+    int trips;   // samples of the implicit this ray took (statistics builds only; dead otherwise)
+    const bool found = s_untame ? ray_march<true>(tile, list, n, minn, closest, ray, p_temp, trips)
+                                : ray_march<false>(tile, list, n, minn, closest, ray, p_temp, trips);
 
     uchar4 img = make_uchar4(0, 0, 0, 0);
     f3 p_surface = mk3(0, 0, 0), p_normal = mk3(0, 0, 0);
@@ -428,6 +432,9 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
     pr_vertex[pi] = make_float4(p_surface.x, p_surface.y, p_surface.z, confidence);
     pr_normal[pi] = make_float4(p_normal.x, p_normal.y, p_normal.z, radius);
     pr_curv1[pi] = cmx; pr_curv2[pi] = cmn;
+#ifdef PREDICT_TRIP_STATS   // measurement build: samples | neighbours << 8 | found << 16 instead of the time stamp
+    tm = (uint32_t)trips | ((uint32_t)n << 8) | (found ? 1u << 16 : 0u);
+#endif
     pr_time[pi] = tm;
     pr_icpw[pi] = icpw;
 }

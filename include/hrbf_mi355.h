@@ -227,6 +227,9 @@ int hrbf_probe_single_workgroup_iteration(hrbf_handle h, int level, int iters, f
  * shortcut != correctly rounded root for x >= 2^-96, (1 - shortcut) != (1 - root) for x < 2^-96} over all
  * non-negative finite floats; the last three must be 0. */
 int hrbf_probe_sqrt_rounding(hrbf_handle h, uint64_t out[6]);
+/* test probe: the bilateral filter's exp scales its polynomial by 2^k with one v_ldexp_f32 where hd_expf (and the oracle)
+ * multiply by 2^(k/2) and 2^(k - k/2).  out = {mismatches, cases} over every p in [0.5, 2) and k in [-160, 0]. */
+int hrbf_probe_exp_scaling(hrbf_handle h, uint64_t out[2]);
 /* build-specific: toggle trajectory replay (globalInputLoadTrajectory) between frames */
 int hrbf_set_load_trajectory(hrbf_handle h, int v);
 /* sticky condition bits, folded from the device by this (synchronising) call; clear != 0 resets them.  The per-frame

@@ -522,6 +522,52 @@ def test_sqrt_shortcut_is_exhaustively_exact(gpu_available):
     assert h[4] == 0 and h[5] == 0, h
 
 
+def test_exp_scaling_shortcut_is_exhaustively_exact(gpu_available):
+    """the bilateral filter's exp scales by 2^k with v_ldexp_f32 instead of hd_expf's two multiplications: same bits for
+    every polynomial value in [0.5, 2) and every k the filter can produce"""
+    from hrbffusion3d_amd.api import HRBFFusion
+    g = HRBFFusion(default_params(160, 120, *synth.intrinsics(160, 120), max_surfels=1 << 12))
+    bad, total = g.probe_exp_scaling()
+    g.close()
+    assert total == (1 << 24) * 161 and bad == 0, (bad, total)
+
+
+@pytest.mark.parametrize("kind", ["tame_near_duplicates", "negative_zero", "tiny_coordinate", "huge_coordinate", "radius_zero",
+                                  "radius_tiny", "radius_huge", "radius_nan", "normal_huge", "position_nan"])
+def test_curvature_with_degenerate_texels(pair, kind):
+    """k_curvature runs packed arithmetic with unscaled divisions on tiles whose texels are all within tame ranges and the
+    literal code otherwise (and, inside a tame tile, for neighbours closer than 2^-20 support radii).  Each kind poisons
+    a few texels of the vertex / normal images the stage reads."""
+    W, H = 160, 120
+    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 12)
+    o, g = pair(p)
+    rgb, d, _ = synth.frame(3, W, H, noise=True)
+    for x in (o, g):
+        x.upload_frame(rgb, d)
+        for st in ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS"):
+            x.run_stage(st)
+    v = o.get_image("VERTEX_FILTERED").copy(); n = o.get_image("NORMAL").copy()
+    spots = [(30, 40), (31, 41), (60, 80), (61, 80), (90, 120), (100, 20), (17, 17), (64, 64), (65, 65)]
+    for (y, x) in spots:
+        if kind == "tame_near_duplicates":      # two texels one ulp apart at small coordinates: d2 / T^2 below 2^-40
+            v[y, x, :3] = (0.01, 0.01, v[y, x, 2] if v[y, x, 2] > 0.3 else 1.0)
+            v[y, x + 1, :3] = (np.nextafter(np.float32(0.01), np.float32(1)), 0.01, v[y, x, 2])
+            n[y, x + 1] = n[y, x]
+        elif kind == "negative_zero": v[y, x, 0] = -0.0
+        elif kind == "tiny_coordinate": v[y, x, 1] = 1e-30
+        elif kind == "huge_coordinate": v[y, x, 0] = 1e12
+        elif kind == "radius_zero": n[y, x, 3] = 0.0
+        elif kind == "radius_tiny": n[y, x, 3] = 1e-9
+        elif kind == "radius_huge": n[y, x, 3] = 1e5
+        elif kind == "radius_nan": n[y, x, 3] = float("nan")
+        elif kind == "normal_huge": n[y, x, :3] *= 1e20
+        elif kind == "position_nan": v[y, x, 2] = float("nan")
+    for x in (o, g):
+        x.set_image("VERTEX_FILTERED", v); x.set_image("NORMAL", n); x.run_stage("CURVATURE")
+    assert_same_state(o, g, kind, ["CURV1", "CURV2", "GRADIENT_MAG", "NORMAL"])
+    assert (np.abs(g.get_image("CURV1")[..., 3]) < 300).sum() > 1000      # the rest of the image has curvatures
+
+
 @pytest.mark.parametrize("radius", [0.0, float("nan"), 1e-25, 1e25, float("inf"), 0.02])
 def test_predict_with_degenerate_texels(pair, radius):
     """The ray-cast kernel runs a select-free inner loop on tiles whose texels are all finite and tame and the literal one
