@@ -1244,6 +1244,20 @@ extern "C" int hrbf_probe_exp_scaling(hrbf_handle c, uint64_t out[2])
     return rc;
 }
 
+// test probe: k_curvature divides without the range scaling of the compiler's expansion on tame tiles
+extern "C" int hrbf_probe_division(hrbf_handle c, uint64_t out[2])
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    unsigned long long *d = nullptr;
+    if (hipMalloc(&d, 2 * sizeof(unsigned long long)) != hipSuccess) return HRBF_ERR_DEVICE;
+    int rc = pre_probe_division(c->stream, d) == 0 ? HRBF_OK : HRBF_ERR_DEVICE;
+    if (rc == HRBF_OK && hipMemcpyAsync(out, d, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = HRBF_ERR_DEVICE;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = HRBF_ERR_DEVICE;
+    hipFree(d);
+    return rc;
+}
+
 extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
 {
     if (!c || !out) return HRBF_ERR_INVALID;

@@ -501,6 +501,36 @@ __device__ __forceinline__ void curv_neighbour_fast(const v2f V, const float vz,
     a.g8 -= keep_scalar(P8.x + P8.y) + sz * t26;
 }
 
+// test probe: div_by against the compiler's division on pseudo-random operands spread over the ranges curv_neighbour_fast
+// can meet (numerator 0 or 2^-103 < |a| < 2^24, denominator 2^-74 < b < 2^15); out = {mismatches, cases}
+__global__ void k_probe_division(unsigned long long *out, uint32_t rounds)
+{
+    unsigned long long bad = 0, total = 0;
+    uint64_t st = 0x9E3779B97F4A7C15ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+    for (uint32_t i = 0; i < rounds; ++i) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const uint32_t ra = (uint32_t)(st >> 32), rb = (uint32_t)st * 2654435761u ^ (uint32_t)(st >> 17);
+        const uint32_t ea = 127u - 102u + (ra >> 23) % 126u, eb = 127u - 73u + (rb >> 23) % 88u;
+        float x = hd_u2f((ra & 0x807fffffu) | (ea << 23));
+        const float y = hd_u2f((rb & 0x007fffffu) | (eb << 23));
+        if ((ra & 0x7f000000u) == 0u) x = 0.0f;                       // exact zeros now and then
+        const float ref = x / y, got = div_by(x, y, rcp_refined(y));
+        const v2f g2 = div_by((v2f){x, -x}, y, rcp_refined(y));
+        // (a -0 numerator comes out +0: tame coordinates exclude -0, so differences are never -0)
+        bad += hd_f2u(ref) != hd_f2u(got) || hd_f2u(g2.x) != hd_f2u(ref) || (x != 0.0f && hd_f2u(g2.y) != hd_f2u(-x / y));
+        ++total;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], total);
+}
+
+int pre_probe_division(hipStream_t s, unsigned long long *d_out2)
+{
+    if (hipMemsetAsync(d_out2, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_probe_division, dim3(4096), dim3(256), 0, s, d_out2, 4096u);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 template <bool TAME>
 __device__ __forceinline__ int curv_window(const NbTexel *__restrict__ tile, const NbTexel &me, int lx0, int lx1, int ly0,
                                            int ly1, CurvSums &a)

@@ -162,6 +162,7 @@ size_t odo_slot_bytes();
 void odo_release(OdoBuffers &ob);   // destroys the cached graphs
 int odo_read_timeouts(hipStream_t s, OdoState *st, int clear);
 int pre_probe_exp_scaling(hipStream_t s, unsigned long long *d_out2);   // exhaustive check of the exp scaling of the bilateral filter
+int pre_probe_division(hipStream_t s, unsigned long long *d_out2);      // unscaled FMA division of k_curvature against the compiler's
 int predict_probe_sqrt(hipStream_t s, unsigned long long *d_out6);   // exhaustive check of the sqrt shortcut of k_predict_hrbf
 int odo_probe_single_wg(hipStream_t s, OdoBuffers &ob, const OdoConfig &cfg, int level, int iters, float *ms_out);   // measurement probe   // frames whose SO3 kernel hit its poll bound (sticky)
 void launch_odo_first_rgb(hipStream_t s, const OdoBuffers &ob, const uint8_t *rgb);

@@ -230,6 +230,10 @@ int hrbf_probe_sqrt_rounding(hrbf_handle h, uint64_t out[6]);
 /* test probe: the bilateral filter's exp scales its polynomial by 2^k with one v_ldexp_f32 where hd_expf (and the oracle)
  * multiply by 2^(k/2) and 2^(k - k/2).  out = {mismatches, cases} over every p in [0.5, 2) and k in [-160, 0]. */
 int hrbf_probe_exp_scaling(hrbf_handle h, uint64_t out[2]);
+/* test probe: k_curvature's division on tame tiles (reciprocal refined once, quotient twice, no v_div_scale / v_div_fixup)
+ * against the compiler's correctly rounded division on 2^32 pseudo-random operand pairs spread over the tame ranges.
+ * out = {mismatches, cases}. */
+int hrbf_probe_division(hrbf_handle h, uint64_t out[2]);
 /* build-specific: toggle trajectory replay (globalInputLoadTrajectory) between frames */
 int hrbf_set_load_trajectory(hrbf_handle h, int v);
 /* sticky condition bits, folded from the device by this (synchronising) call; clear != 0 resets them.  The per-frame

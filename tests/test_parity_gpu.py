@@ -532,6 +532,16 @@ def test_exp_scaling_shortcut_is_exhaustively_exact(gpu_available):
     assert total == (1 << 24) * 161 and bad == 0, (bad, total)
 
 
+def test_unscaled_division_matches_the_compilers(gpu_available):
+    """2^32 pseudo-random operand pairs over the tame ranges of k_curvature: the FMA division without v_div_scale /
+    v_div_fixup gives the compiler's correctly rounded quotient every time (scalar and packed form)"""
+    from hrbffusion3d_amd.api import HRBFFusion
+    g = HRBFFusion(default_params(160, 120, *synth.intrinsics(160, 120), max_surfels=1 << 12))
+    bad, total = g.probe_division()
+    g.close()
+    assert total == 1 << 32 and bad == 0, (bad, total)
+
+
 @pytest.mark.parametrize("kind", ["tame_near_duplicates", "negative_zero", "tiny_coordinate", "huge_coordinate", "radius_zero",
                                   "radius_tiny", "radius_huge", "radius_nan", "normal_huge", "position_nan"])
 def test_curvature_with_degenerate_texels(pair, kind):
