@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--worst-samples", type=int, default=5)
     ap.add_argument("--only-worst", action="store_true", help="run only the worst-case fuse leg (profiling)")
     ap.add_argument("--no-cpp-shim", action="store_true", help="skip the C++-class leg (g++ compile + run of tools/shim_bench.cpp)")
+    ap.add_argument("--ring-stride", type=int, default=4,
+                    help="bracket the fuse pass with HIP events on every n-th frame of the timed region (each bracketed frame costs the stream ~22 us)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -269,7 +271,8 @@ def main():
         fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), k)
     fus.synchronize()
     count0 = fus.surfel_count()
-    fus.enable_timing(2)     # only the two events around the fuse pass (roofline); region events stay off
+    fus.enable_timing(2)     # only the events around the fuse pass (roofline); region events stay off
+    fus.set_fuse_ring_stride(max(1, args.ring_stride))
     fus.reset_fuse_ring()
 
     barrier(); torch.cuda.synchronize(); fus.synchronize()
@@ -399,6 +402,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_apply_merges + k_clean_flags + k_fuse_stream (F2 + F3, every kernel of the pass)",
                          "avg_kernel_ms": fuse_ms, "merge_ms": merge_ms, "clean_compact_ms": fuse_ms - merge_ms,
+                         "launches_timed": int(ok.sum()), "timed_every_nth_frame": max(1, args.ring_stride),
                          "bytes_per_launch": float(B[ok].mean()) if ok.any() else 0.0,
                          "real_bytes": real_bytes,
                          "achieved_real": (real_bytes / (fuse_ms * 1e-3) / 1e9) if real_bytes and fuse_ms > 0 else None,

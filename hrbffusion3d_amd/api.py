@@ -30,7 +30,7 @@ EXPORTS = [
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
-    "hrbf_probe_single_workgroup_iteration", "hrbf_probe_sqrt_rounding", "hrbf_probe_exp_scaling", "hrbf_probe_division",
+    "hrbf_probe_single_workgroup_iteration", "hrbf_probe_sqrt_rounding", "hrbf_probe_exp_scaling", "hrbf_probe_division", "hrbf_set_fuse_ring_stride",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library():
     lib.hrbf_probe_sqrt_rounding.argtypes = [vp, vp]
     lib.hrbf_probe_exp_scaling.argtypes = [vp, vp]
     lib.hrbf_probe_division.argtypes = [vp, vp]
+    lib.hrbf_set_fuse_ring_stride.argtypes = [vp, i32]
     lib.hrbf_set_load_trajectory.argtypes = [vp, i32]
     lib.hrbf_icp_step.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp]
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
@@ -325,6 +326,10 @@ class HRBFFusion:
         o = np.zeros(2, np.uint64)
         self._check(self.lib.hrbf_probe_exp_scaling(self.h, _p(o)))
         return o
+
+    def set_fuse_ring_stride(self, every_nth_frame):
+        """record the fuse ring (four event records + a statistics copy, ~22 us) only every n-th frame"""
+        self._check(self.lib.hrbf_set_fuse_ring_stride(self.h, int(every_nth_frame)))
 
     def probe_division(self):
         """(mismatches, cases) of k_curvature's unscaled division against the compiler's, see hrbf_probe_division"""

@@ -115,7 +115,7 @@ struct hrbf_context {
     int timing; hipEvent_t ev[12]; float timings[8];
     // per-frame ring: HIP events bracketing the fuse pass — F2 (k_apply_merges: m0..m1) and F3 (k_clean_flags +
     // k_fuse_stream: e0..e1), nothing else — + its statistics words
-    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid;
+    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid; uint32_t ring_stride;
     uint32_t ring_merge_head;   // ring slot the last merge events went to (a clean without a fuse has no F2 part)
     uint32_t status;            // sticky HRBF_STATUS_* bits folded from the device on blocking calls
     PoseLog *h_pose_log, *d_pose_log_view;   // pinned host ring + its device-side address
@@ -572,11 +572,17 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
                              c->d_im_vertconf, c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
     }
 }
+// whether this frame's fuse pass is bracketed by the ring's events: every record costs the stream ~4.6 us (a barrier
+// packet), four per frame plus the statistics copy are 2 % of a frame — a caller that only wants an average can sample
+static inline bool ring_frame(const hrbf_context *c)
+{
+    return c->timing && c->G == 1 && (c->ring_stride <= 1 || c->tick % c->ring_stride == 0);
+}
 static void st_fuse(hrbf_context *c)
 {
     // association is replicated (it reads images only); each shard keeps the merge slots of its own surfels and applies
     // the merges that land on them
-    const bool ring = c->timing && c->G == 1;
+    const bool ring = ring_frame(c);
     for (int k = 0; k < c->nsh; ++k)
         launch_fuse(c->stream, c->cam, c->d_pose, c->tick, c->prm.max_depth_processed, c->index_submap, c->d_depth_metric,
                     c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf,
@@ -590,7 +596,7 @@ static void st_clean(hrbf_context *c)
     // the clean texels carry the confidence threshold and the time they were resolved with; a caller that changed
     // either since (stage API / named operators) gets a fresh projection instead of a stale test
     if (c->clean_thr != c->prm.confidence_threshold || c->clean_time != c->tick) st_indices(c, true, 7);
-    const bool ring = c->timing && c->G == 1;
+    const bool ring = ring_frame(c);
     for (int k = 0; k < c->nsh; ++k) {
         const int gk = c->shard_first + k;
         const bool last = gk == c->G - 1;   // new surfels are appended at the end of the global order
@@ -1054,6 +1060,12 @@ extern "C" int hrbf_enable_timing(hrbf_handle c, int on)
 {
     if (!c) return HRBF_ERR_INVALID;
     c->timing = on == 2 ? 2 : (on ? 3 : 0);
+    return HRBF_OK;
+}
+extern "C" int hrbf_set_fuse_ring_stride(hrbf_handle c, int every_nth_frame)
+{
+    if (!c || every_nth_frame < 1) return HRBF_ERR_INVALID;
+    c->ring_stride = (uint32_t)every_nth_frame;
     return HRBF_OK;
 }
 extern "C" int hrbf_get_timings(hrbf_handle c, float out[8])

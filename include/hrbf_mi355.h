@@ -216,6 +216,10 @@ int hrbf_get_timings(hrbf_handle h, float out_ms[8]);
  * frames written, oldest first.  hrbf_get_fuse_ring_parts gives the two parts separately and 8 statistics words:
  * {in, merged, appended, out, -, -, moved (surfels that changed slot in the in-place compaction), status}. */
 int hrbf_get_fuse_ring(hrbf_handle h, int max_frames, float *kernel_ms, uint32_t *stats4);
+/* record the ring only on frames whose time stamp is a multiple of every_nth_frame (default 1: every frame).  The four
+ * event records and the statistics copy cost the stream about 22 us per recorded frame. */
+int hrbf_set_fuse_ring_stride(hrbf_handle h, int every_nth_frame);
+
 int hrbf_get_fuse_ring_parts(hrbf_handle h, int max_frames, float *merge_ms, float *stream_ms, uint32_t *stats8);
 int hrbf_reset_fuse_ring(hrbf_handle h);
 /* measurement probe (not part of the path): the pixel work of `iters` Gauss-Newton iterations of pyramid `level` (ICP
