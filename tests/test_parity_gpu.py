@@ -510,6 +510,25 @@ def test_stage_seams_in_isolation(pair):
     assert g.fuse_stats()[2] == 0 and len(g.download_map()) <= len(before)
 
 
+def test_fuse_ring_stride(gpu_available):
+    """hrbf_set_fuse_ring_stride: only frames whose time stamp is a multiple of the stride are bracketed by events"""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    g = HRBFFusion(default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 16))
+    g.enable_timing(2); g.set_fuse_ring_stride(3); g.reset_fuse_ring()
+    for k in range(12):
+        rgb, d, _ = synth.frame(k, W, H)
+        g.process_frame(rgb, d)
+    mm, ms, st = g.fuse_ring_parts(64)
+    assert len(ms) == 4 and (ms > 0).all() and (st[:, 3] > 0).all()       # frames 0 (first: initialise only) .. 11 -> ticks 3, 6, 9 (+ one of 0 / 12)
+    g.set_fuse_ring_stride(1); g.reset_fuse_ring()
+    for k in range(12, 16):
+        rgb, d, _ = synth.frame(k, W, H)
+        g.process_frame(rgb, d)
+    assert len(g.fuse_ring_parts(64)[1]) == 4
+    g.close()
+
+
 def test_sqrt_shortcut_is_exhaustively_exact(gpu_available):
     """k_predict_hrbf replaces the compiler's sqrtf expansion by v_sqrt_f32 + two residual tests (no rescaling of tiny
     arguments, no 0 / inf re-check).  Checked here over EVERY non-negative finite float on the device under test."""
