@@ -144,7 +144,8 @@ __device__ __forceinline__ void wave_reduce_limbs(const float *vals, bool valid,
         for (int i = lane; i < N * (5 - NL); i += 64) sums[5 * (i / (5 - NL)) + NL + i % (5 - NL)] = 0;
 }
 
-template <int N>
+// ZEROED: the caller guarantees that lanes with !valid hold exact zeros in vals (no select per value needed)
+template <int N, bool ZEROED = false>
 __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid, long long *__restrict__ slots)
 {
     constexpr int V = 5 * N;
@@ -156,10 +157,11 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
         uint32_t m = 0u;
 #pragma unroll
         for (int i = 0; i < N; ++i) { const uint32_t b = hd_f2u(vals[i]) & 0x7fffffffu; m = b > m ? b : m; }
-        if (!valid) m = 0u;
-        if (__ballot(m >= ((127u + 9u) << 23)) == 0ull) wave_reduce_limbs<N, 2>(vals, valid, lane, s_sum[wid]);
-        else if (__ballot(m >= ((127u + 34u) << 23)) == 0ull) wave_reduce_limbs<N, 3>(vals, valid, lane, s_sum[wid]);
-        else wave_reduce_limbs<N, 5>(vals, valid, lane, s_sum[wid]);
+        if (!ZEROED && !valid) m = 0u;
+        const bool use = ZEROED ? true : valid;
+        if (__ballot(m >= ((127u + 9u) << 23)) == 0ull) wave_reduce_limbs<N, 2>(vals, use, lane, s_sum[wid]);
+        else if (__ballot(m >= ((127u + 34u) << 23)) == 0ull) wave_reduce_limbs<N, 3>(vals, use, lane, s_sum[wid]);
+        else wave_reduce_limbs<N, 5>(vals, use, lane, s_sum[wid]);
     } else {
         for (int i = lane; i < V; i += 64) s_sum[wid][i] = 0;
     }
@@ -944,8 +946,35 @@ struct SparseIo { f3 lambda, z; int bx, by; };
 // pack_icp_texels: current pixel {v.xyz, valid} {n.xyz, -}, model pixel {v.xyz, icp weight} {n.xyz, valid} — two
 // 16-byte loads + two 16-byte gathers instead of eight 4-byte plane loads + nine 4-byte plane gathers per pixel
 // and iteration.  `valid` folds the four NaN tests of the planar version; every arithmetic step is the same.
+// the 27 upper-triangle products of the weighted row (JtJ | Jtr), the weighted squared residual and the count
+// (reduce.cu:374-395 / :764-786): what both Gauss-Newton terms hand to the exact reduction
+__device__ __forceinline__ void products29(const float (&row)[7], float weight, float *out)
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 7; ++j) out[k++] = weight * row[i] * row[j];
+    out[27] = weight * row[6] * row[6];
+    out[28] = 1.0f;
+}
+
+__device__ __forceinline__ bool icp_pixel_packed_rows(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                                      int x, int y, float (&row)[7], float &weight);
+
 __device__ __forceinline__ bool icp_pixel_packed(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
                                                  int x, int y, float *out)
+{
+    float row[7], weight;
+    if (!icp_pixel_packed_rows(A, Rcurr, tcurr, Rpi, tprev, x, y, row, weight)) return false;
+    products29(row, weight, out);
+    return true;
+}
+
+// ... returning the row and its weight instead of the 29 products: the Gauss-Newton kernel forms the products after the
+// control flow has merged (8 values to carry through the early exits instead of 29)
+__device__ __forceinline__ bool icp_pixel_packed_rows(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                                      int x, int y, float (&row)[7], float &weight)
 {
     const int rows = A.rows, cols = A.cols;
     const float4 c0 = A.cur_tex[2 * (y * cols + x)];
@@ -968,19 +997,11 @@ __device__ __forceinline__ bool icp_pixel_packed(const IcpArgs &A, const float *
     f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
     f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
     f3 n_cp = m33_mul(Rpi, bn);
-    float weight = 1.0f;
+    weight = 1.0f;
     if (A.use_weight) { float w = m0.w; weight = hd_isnanf(w) ? 0.0f : w; }
-    float row[7];
     f3 cr = cross3(s_cp, n_cp);
     row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
     row[6] = dot3(n_cp, sub3(s_cp, d_cp));
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 7; ++j) out[k++] = weight * row[i] * row[j];
-    out[27] = weight * row[6] * row[6];
-    out[28] = 1.0f;
     return true;
 }
 
@@ -1137,13 +1158,12 @@ __device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S
 }
 
 // RGBReduction::getProducts (reduce.cu:717-808) for one correspondence: operands already fetched
-__device__ __forceinline__ void rgb_products_core(float diff, float cpx, float cpy, float cpz, int gx_raw, int gy_raw,
-                                                  float sigma, float fx, float fy, int use_grad, float (&out)[29])
+__device__ __forceinline__ void rgb_row_core(float diff, float cpx, float cpy, float cpz, int gx_raw, int gy_raw,
+                                             float sigma, float fx, float fy, int use_grad, float (&row)[7], float &rw)
 {
     float w = sigma + hd_fabsf(diff);
     w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
     if (sigma == -1.0f) w = 1.0f;
-    float row[7];
     row[6] = -w * diff;
     float invz = 1.0f / cpz;
     float dIx = w * 0.125f * (float)gx_raw;
@@ -1154,18 +1174,18 @@ __device__ __forceinline__ void rgb_products_core(float diff, float cpx, float c
     row[3] = -cpz * v1 + cpy * v2;
     row[4] = cpz * v0 - cpx * v2;
     row[5] = -cpy * v0 + cpx * v1;
-    float rw = 1.0f;
+    rw = 1.0f;
     if (use_grad) {
         float gm = hd_sqrtf(dIx * dIx + dIy * dIy);
         rw = hd_expf(-0.5f * (10.0f / gm) * (10.0f / gm));
     }
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 7; ++j) out[q++] = rw * row[i] * row[j];
-    out[27] = rw * row[6] * row[6];
-    out[28] = 1.0f;
+}
+__device__ __forceinline__ void rgb_products_core(float diff, float cpx, float cpy, float cpz, int gx_raw, int gy_raw,
+                                                  float sigma, float fx, float fy, int use_grad, float (&out)[29])
+{
+    float row[7], rw;
+    rgb_row_core(diff, cpx, cpy, cpz, gx_raw, gy_raw, sigma, fx, fy, use_grad, row, rw);
+    products29(row, rw, out);
 }
 // the same on the seam layout: DataTerm as 6 x int16 + diff plane, cloud as 3 floats, gradients as two short planes
 __device__ __forceinline__ bool rgb_products_pixel(const OdoLevel &L, const RgbCorr &co, float sigma, float fx, float fy,
@@ -1198,12 +1218,23 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
             if (SPARSE)
                 valid = icp_pixel_sparse(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
                                          mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
-            else
+            else if (A.cur_tex && !A.use_search) {   // the usual case: packed operands, products formed after the early exits
+                float row[7], weight;
+                valid = icp_pixel_packed_rows(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
+                                              mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, row, weight);
+                if (!valid) {
+                    weight = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) row[k] = 0.0f;
+                }
+                products29(row, weight, out);          // a lane without a match contributes 0 * 0 * 0
+                out[28] = valid ? 1.0f : 0.0f;
+            } else
                 valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
                                   mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
         }
-        // icp_part rows are indexed by blockIdx.x in [0, nb)
-        block_reduce_exact<29>(out, valid, icp_part);
+        // icp_part rows are indexed by blockIdx.x in [0, nb); every path leaves exact zeros in the lanes it rejects
+        block_reduce_exact<29, true>(out, valid, icp_part);
     } else {
         __shared__ long long s_c[RB / 64], s_s[RB / 64];
         const int b = blockIdx.x - nb;
@@ -1390,9 +1421,7 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[174] = s_res[0]; totals[175] = s_res[1]; }
     const float sigma = s_sigma;
     const int brk = s_break;
-    float out[29];
-#pragma unroll
-    for (int k = 0; k < 29; ++k) out[k] = 0.0f;
+    float out[29], row[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rw = 0.0f;
     bool valid = false;
     const int k = p0 + blockIdx.x * RB + threadIdx.x;
     if (!brk && k < p1) {
@@ -1401,12 +1430,14 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
             const int u0 = rec.x & 0xffff, v0 = (int)((uint32_t)rec.x >> 16);
             const float4 cp = L.cloud4[(size_t)v0 * L.cols + u0];
             const int g = L.dIxy[k];
-            rgb_products_core(__int_as_float(rec.y), cp.x, cp.y, cp.z, (int)(int16_t)(g & 0xffff), (int)(int16_t)((uint32_t)g >> 16),
-                              sigma, fx, fy, use_grad, out);
+            rgb_row_core(__int_as_float(rec.y), cp.x, cp.y, cp.z, (int)(int16_t)(g & 0xffff), (int)(int16_t)((uint32_t)g >> 16),
+                         sigma, fx, fy, use_grad, row, rw);
             valid = true;
         }
     }
-    block_reduce_exact<29>(out, valid, rgb_part);
+    products29(row, rw, out);   // formed after the control flow has merged; a lane without a correspondence contributes zeros
+    out[28] = valid ? 1.0f : 0.0f;
+    block_reduce_exact<29, true>(out, valid, rgb_part);
 }
 
 // ---- row-sharded path: slot rows -> totals on every rank, all-reduce in between (launch_odometry)
