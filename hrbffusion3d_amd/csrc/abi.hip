@@ -631,14 +631,28 @@ static void st_clean(hrbf_context *c)
     c->map_dirty = 0;
     c->ub_growth_since += (uint32_t)c->Q;
 }
-static void st_predict(hrbf_context *c)
+// with_fill_in: the frame path — the ray-cast kernel fills in from the live frame as well (FILL_* images), so what is left
+// of FillIn is the end-of-frame bookkeeping (st_end_of_frame)
+static void st_predict(hrbf_context *c, bool with_fill_in = false)
 {
     c->fill_flag_fresh = 0;
+    FillIn f;
+    f.thr = c->prm.curv_valid_threshold; f.frame_to_frame_rgb = c->prm.frame_to_frame_rgb;
+    f.vertex_filtered = c->d_vertex_filtered; f.normal = c->d_normal; f.curv1 = c->d_curv1; f.curv2 = c->d_curv2;
+    f.confidence = c->d_confidence; f.rgb = c->d_rgb;
+    f.fi_vertex = c->d_fi_vertex; f.fi_normal = c->d_fi_normal; f.fi_curv1 = c->d_fi_curv1; f.fi_curv2 = c->d_fi_curv2;
+    f.fi_icpw = c->d_fi_icpw; f.fi_image = c->d_fi_image;
     launch_predict_hrbf(c->stream, c->cam, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax,
                         c->d_im_curvmin, (int)c->prm.predict_window_multiplier, c->prm.predict_min_neighbors,
                         c->prm.predict_max_neighbors, c->prm.predict_conf_threshold, c->prm.icp_curv_weight_lambda,
                         c->d_pr_image, c->d_pr_vertex, c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_pr_time,
-                        c->d_pr_icpw);
+                        c->d_pr_icpw, with_fill_in ? &f : nullptr);
+}
+static void st_end_of_frame(hrbf_context *c, bool log_frame)
+{
+    launch_end_of_frame(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, c->d_pose,
+                        log_frame ? c->d_pose_log_view : nullptr, c->frames_enqueued);
+    c->fill_flag_fresh = 1;
 }
 static void st_fillin(hrbf_context *c, bool end_of_frame = false, bool log_frame = false)
 {
@@ -691,9 +705,9 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     }
     st_indices(c, false, 3);             // prediction + the images a caller can fetch
     TIMER(7);
-    st_predict(c);
+    st_predict(c, true);        // ray cast + fill-in from the live frame
     TIMER(8);
-    st_fillin(c, true, true);   // + shouldFillIn of the next frame + lastPose <- currPose + the pose log entry
+    st_end_of_frame(c, true);   // shouldFillIn of the next frame + lastPose <- currPose + the pose log entry
     TIMER(9);
     request_count(c);
     c->tick++; c->frames_enqueued++;

@@ -317,6 +317,36 @@ __host__ __device__ inline int predict_list_cap(int maxn)
     return (c + 4 + 1) & ~1;
 }
 
+// one pixel of FillIn::{vertex,normal,curvature,image} (fill_vertex.frag:43-72, fill_normal.frag:36-49,
+// fill_curvature.frag:35-51, fill_rgb.frag:29-37) from the pixel's predicted values: shared by k_fillin (the stage) and
+// the tail of k_predict_hrbf<true> (the frame path: the prediction is still in registers, the live images are read while
+// the kernel's ALU work hides them)
+__device__ __forceinline__ void fill_pixel(int i, float thr, float lambda, int frame_to_frame_rgb, const float4 s,
+                                           const float4 n, const float4 k1, const float4 k2, const float icpw, uchar4 e,
+                                           const FillIn &f)
+{
+    if (s.z == 0.0f) {
+        float4 fv = f.vertex_filtered[i], r1 = f.curv1[i], r2 = f.curv2[i];
+        float4 outv = make_float4(0, 0, 0, 0);
+        float outw = 0.0f;
+        if (r1.w > -thr && r1.w < thr && r2.w > -thr && r2.w < thr) {
+            float vConf = f.confidence[i];
+            float a1 = hd_fabsf(r1.w), a2 = hd_fabsf(r2.w);
+            float cm = a1 > a2 ? a1 : a2;
+            outw = (1.0f / (fv.z * fv.z)) * (vConf / 256.0f + hd_expf(-0.5f * (lambda * lambda) / (cm * cm)));
+            outv = make_float4(fv.x, fv.y, fv.z, vConf);
+        }
+        f.fi_vertex[i] = outv; f.fi_icpw[i] = outw;
+    } else { f.fi_vertex[i] = s; f.fi_icpw[i] = icpw; }
+    f.fi_normal[i] = (len3(xyz(n)) < 0.8f) ? f.normal[i] : n;
+    if (k1.w > 300.0f || k2.w > 300.0f) { f.fi_curv1[i] = f.curv1[i]; f.fi_curv2[i] = f.curv2[i]; }
+    else { f.fi_curv1[i] = k1; f.fi_curv2[i] = k2; }
+    if ((int)e.x + (int)e.y + (int)e.z == 0 || frame_to_frame_rgb)
+        e = make_uchar4(f.rgb[i * 3], f.rgb[i * 3 + 1], f.rgb[i * 3 + 2], 255);
+    reinterpret_cast<uchar4 *>(f.fi_image)[i] = e;
+}
+
+template <bool FILL /* also fill in from the live frame (process_frame path) */>
 __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__restrict__ vertconf,
                                                       const float4 *__restrict__ normrad,
                                                       const float4 *__restrict__ colortime,
@@ -325,7 +355,7 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
                                                       float cthr, float lambda, uint8_t *__restrict__ pr_image,
                                                       float4 *__restrict__ pr_vertex, float4 *__restrict__ pr_normal,
                                                       float4 *__restrict__ pr_curv1, float4 *__restrict__ pr_curv2,
-                                                      uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw)
+                                                      uint32_t *__restrict__ pr_time, float *__restrict__ pr_icpw, FillIn fill)
 {
     __shared__ float4 tile[2 * (PTW * PTH + 1)];
     __shared__ uint32_t s_rowbits[PTH];
@@ -437,6 +467,9 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
 #endif
     pr_time[pi] = tm;
     pr_icpw[pi] = icpw;
+    if (FILL)
+        fill_pixel(pi, fill.thr, lambda, fill.frame_to_frame_rgb, make_float4(p_surface.x, p_surface.y, p_surface.z, confidence),
+                   make_float4(p_normal.x, p_normal.y, p_normal.z, radius), cmx, cmn, icpw, img, fill);
 }
 
 // Resize::vertex + denseEnough: *flag = 1 when the 20x20-cell thumbnail of the predicted vertex map
@@ -465,6 +498,35 @@ __device__ __forceinline__ void should_fill_in_block(const Cam &cam, const float
     }
 }
 
+// End of frame, one workgroup: the next registration's shouldFillIn flag (Resize::vertex + denseEnough on the finished
+// prediction), lastPose <- currPose, and the frame's pose appended to the pinned trajectory ring.
+__device__ __forceinline__ void end_of_frame_block(const Cam &cam, const float4 *__restrict__ pr_vertex, float dense_thresh,
+                                                   DevPose *dp, PoseLog *pose_log, uint32_t frame_idx)
+{
+    should_fill_in_block(cam, pr_vertex, dense_thresh, &dp->should_fill_in);
+    if (threadIdx.x == 0) {
+        dp->prev = dp->pose;
+        if (pose_log) {   // trajectory without a host round trip: the caller reads the pinned ring whenever it wants
+            // The ring is fine-grained (uncached) host memory: the stores go straight to the PCIe write queue, in
+            // order.  NO system-scope fence here — a release at system scope writes back the whole L2 (this frame's
+            // images) and cost 110 us per frame; the record carries its own frame tag for the reader to check.
+            PoseRecord *rec = &pose_log->poses[frame_idx % POSE_LOG_CAP];
+            rec->pose = dp->pose;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&rec->tag, frame_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&pose_log->completed, frame_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// the same bookkeeping alone, behind k_predict_hrbf<true> (which has filled in already)
+__global__ void k_end_of_frame(Cam cam, const float4 *__restrict__ pr_vertex, float dense_thresh, DevPose *dp, PoseLog *pose_log,
+                               uint32_t frame_idx)
+{
+    end_of_frame_block(cam, pr_vertex, dense_thresh, dp, pose_log, frame_idx);
+}
+
 // fill_vertex.frag:43-72, fill_normal.frag:36-49, fill_curvature.frag:35-51, fill_rgb.frag:29-37
 __global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb, const float4 *__restrict__ pr_vertex,
                          const float4 *__restrict__ pr_normal, const float4 *__restrict__ pr_curv1,
@@ -478,50 +540,15 @@ __global__ void k_fillin(int P, float thr, float lambda, int frame_to_frame_rgb,
                          DevPose *dp /* nullable: end-of-frame bookkeeping rides along */,
                          PoseLog *pose_log /* nullable: pinned host ring the frame's pose is appended to */, uint32_t frame_idx)
 {
-    // end of frame: the next registration's shouldFillIn flag (Resize::vertex + denseEnough on the prediction
-    // this kernel reads anyway) and lastPose <- currPose; one workgroup, no separate launches
-    if (dp && blockIdx.x == 0) {
-        should_fill_in_block(cam, pr_vertex, dense_thresh, &dp->should_fill_in);
-        if (threadIdx.x == 0) {
-            dp->prev = dp->pose;
-            if (pose_log) {   // trajectory without a host round trip: the caller reads the pinned ring whenever it wants
-                // The ring is fine-grained (uncached) host memory: the stores go straight to the PCIe write queue, in
-                // order.  NO system-scope fence here — a release at system scope writes back the whole L2 (this frame's
-                // images) and cost 110 us per frame; the record carries its own frame tag for the reader to check.
-                PoseRecord *rec = &pose_log->poses[frame_idx % POSE_LOG_CAP];
-                rec->pose = dp->pose;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&rec->tag, frame_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&pose_log->completed, frame_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
+    if (dp && blockIdx.x == 0) end_of_frame_block(cam, pr_vertex, dense_thresh, dp, pose_log, frame_idx);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    float4 s = pr_vertex[i];
-    if (s.z == 0.0f) {
-        float4 fv = vertex_filtered[i], r1 = curv1[i], r2 = curv2[i];
-        float4 outv = make_float4(0, 0, 0, 0);
-        float outw = 0.0f;
-        if (r1.w > -thr && r1.w < thr && r2.w > -thr && r2.w < thr) {
-            float vConf = confidence[i];
-            float a1 = hd_fabsf(r1.w), a2 = hd_fabsf(r2.w);
-            float cm = a1 > a2 ? a1 : a2;
-            outw = (1.0f / (fv.z * fv.z)) * (vConf / 256.0f + hd_expf(-0.5f * (lambda * lambda) / (cm * cm)));
-            outv = make_float4(fv.x, fv.y, fv.z, vConf);
-        }
-        fi_vertex[i] = outv; fi_icpw[i] = outw;
-    } else { fi_vertex[i] = s; fi_icpw[i] = pr_icpw[i]; }
-    float4 n = pr_normal[i];
-    fi_normal[i] = (len3(xyz(n)) < 0.8f) ? normal[i] : n;
-    float4 k1 = pr_curv1[i], k2 = pr_curv2[i];
-    if (k1.w > 300.0f || k2.w > 300.0f) { fi_curv1[i] = curv1[i]; fi_curv2[i] = curv2[i]; }
-    else { fi_curv1[i] = k1; fi_curv2[i] = k2; }
-    uchar4 e = reinterpret_cast<const uchar4 *>(pr_image)[i];
-    if ((int)e.x + (int)e.y + (int)e.z == 0 || frame_to_frame_rgb)
-        e = make_uchar4(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], 255);
-    reinterpret_cast<uchar4 *>(fi_image)[i] = e;
+    FillIn f;
+    f.thr = thr; f.frame_to_frame_rgb = frame_to_frame_rgb;
+    f.vertex_filtered = vertex_filtered; f.normal = normal; f.curv1 = curv1; f.curv2 = curv2; f.confidence = confidence; f.rgb = rgb;
+    f.fi_vertex = fi_vertex; f.fi_normal = fi_normal; f.fi_curv1 = fi_curv1; f.fi_curv2 = fi_curv2; f.fi_icpw = fi_icpw; f.fi_image = fi_image;
+    fill_pixel(i, thr, lambda, frame_to_frame_rgb, pr_vertex[i], pr_normal[i], pr_curv1[i], pr_curv2[i], pr_icpw[i],
+               reinterpret_cast<const uchar4 *>(pr_image)[i], f);
 }
 
 __global__ void k_should_fill_in(Cam cam, const float4 *__restrict__ pr_vertex, float thresh, int *flag)
@@ -532,12 +559,24 @@ __global__ void k_should_fill_in(Cam cam, const float4 *__restrict__ pr_vertex, 
 void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, const float4 *normrad,
                          const float4 *colortime, const float4 *curvmax, const float4 *curvmin, int win, int minn,
                          int maxn, float cthr, float lambda, uint8_t *pr_image, float4 *pr_vertex, float4 *pr_normal,
-                         float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw)
+                         float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw, const FillIn *fill)
 {
     dim3 g((cam.W + TBX - 1) / TBX, (cam.H + TBY - 1) / TBY);
     const size_t list_bytes = (size_t)predict_list_cap(maxn) * PNT * sizeof(uint16_t);
-    hipLaunchKernelGGL(k_predict_hrbf, g, dim3(TBX, TBY), list_bytes, s, cam, vertconf, normrad, colortime, curvmax, curvmin, win,
-                       minn, maxn, cthr, lambda, pr_image, pr_vertex, pr_normal, pr_curv1, pr_curv2, pr_time, pr_icpw);
+    if (fill)
+        hipLaunchKernelGGL(k_predict_hrbf<true>, g, dim3(TBX, TBY), list_bytes, s, cam, vertconf, normrad, colortime, curvmax,
+                           curvmin, win, minn, maxn, cthr, lambda, pr_image, pr_vertex, pr_normal, pr_curv1, pr_curv2, pr_time,
+                           pr_icpw, *fill);
+    else
+        hipLaunchKernelGGL(k_predict_hrbf<false>, g, dim3(TBX, TBY), list_bytes, s, cam, vertconf, normrad, colortime, curvmax,
+                           curvmin, win, minn, maxn, cthr, lambda, pr_image, pr_vertex, pr_normal, pr_curv1, pr_curv2, pr_time,
+                           pr_icpw, FillIn{});
+}
+
+void launch_end_of_frame(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float dense_thresh, DevPose *dp,
+                         PoseLog *pose_log, uint32_t frame_idx)
+{
+    hipLaunchKernelGGL(k_end_of_frame, dim3(1), dim3(256), 0, s, cam, pr_vertex, dense_thresh, dp, pose_log, frame_idx);
 }
 
 void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const float4 *pr_vertex,

@@ -95,10 +95,21 @@ uint32_t fuse_tile_count_stride();
 
 // ---- k_predict.hip
 int predict_upload_tables();
+// the live-frame side of FillIn::{vertex,normal,curvature,image}: inputs, parameters that are not the prediction's, outputs
+struct FillIn {
+    float thr; int frame_to_frame_rgb;
+    const float4 *vertex_filtered, *normal, *curv1, *curv2; const float *confidence; const uint8_t *rgb;
+    float4 *fi_vertex, *fi_normal, *fi_curv1, *fi_curv2; float *fi_icpw; uint8_t *fi_image;
+};
+// fill != null: the kernel also fills in from the live frame (the FILL_* images), pixel by pixel, from the prediction it
+// still holds in registers — the frame path; the stage API keeps prediction and fill-in apart (launch_fillin)
 void launch_predict_hrbf(hipStream_t s, const Cam &cam, const float4 *vertconf, const float4 *normrad,
                          const float4 *colortime, const float4 *curvmax, const float4 *curvmin, int win, int minn,
                          int maxn, float cthr, float lambda, uint8_t *pr_image, float4 *pr_vertex, float4 *pr_normal,
-                         float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw);
+                         float4 *pr_curv1, float4 *pr_curv2, uint32_t *pr_time, float *pr_icpw, const FillIn *fill);
+// end-of-frame bookkeeping alone (shouldFillIn of the next frame, lastPose <- currPose, pose ring entry)
+void launch_end_of_frame(hipStream_t s, const Cam &cam, const float4 *pr_vertex, float dense_thresh, DevPose *dp,
+                         PoseLog *pose_log, uint32_t frame_idx);
 void launch_fillin(hipStream_t s, int P, float thr, float lambda, int f2f, const float4 *pr_vertex,
                    const float4 *pr_normal, const float4 *pr_curv1, const float4 *pr_curv2, const float *pr_icpw,
                    const uint8_t *pr_image, const float4 *vertex_filtered, const float4 *normal, const float4 *curv1,
