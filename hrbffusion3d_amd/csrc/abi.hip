@@ -115,7 +115,7 @@ struct hrbf_context {
     int timing; hipEvent_t ev[12]; float timings[8];
     // per-frame ring: HIP events bracketing the fuse pass — F2 (k_apply_merges: m0..m1) and F3 (k_clean_flags +
     // k_fuse_stream: e0..e1), nothing else — + its statistics words
-    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid; uint32_t ring_stride;
+    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid; uint32_t ring_stride; bool level0_done;
     uint32_t ring_merge_head;   // ring slot the last merge events went to (a clean without a fuse has no F2 part)
     uint32_t status;            // sticky HRBF_STATUS_* bits folded from the device on blocking calls
     PoseLog *h_pose_log, *d_pose_log_view;   // pinned host ring + its device-side address
@@ -437,8 +437,21 @@ static void st_vnr(hrbf_context *c)
                                 c->d_vertex_filtered, c->d_normal, c->d_normal_pca, c->d_radius,
                                 c->prm.init_radius_multiplier, c->prm.normal_estimation_pca > 0.0f);
 }
-static void st_curv(hrbf_context *c)
+static OdoSources make_sources(hrbf_context *c);
+static OdoConfig make_cfg(hrbf_context *c);
+// with_level0: the frame path, when a registration follows and the shouldFillIn flag on the device is the current one —
+// level 0 of the registration pyramids is written from the tail of the curvature kernel (c->level0_done)
+static void st_curv(hrbf_context *c, bool with_level0 = false)
 {
+    c->level0_done = false;
+    if (with_level0) {
+        const OdoConfig cfg = make_cfg(c);
+        Level0Args l0;
+        l0.L = c->odo.lv[0]; l0.src = make_sources(c); l0.dp = c->d_pose; l0.f2f = cfg.frame_to_frame_rgb; l0.curv_thr = cfg.curv_thr;
+        launch_curvature_level0(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
+                                c->d_normal_opt, (int)c->prm.curv_estimation_window, l0);
+        c->level0_done = true;
+    } else
     launch_curvature(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
                      c->d_normal_opt, (int)c->prm.curv_estimation_window);
     // updateNormalRad: NORMAL <- NORMAL_OPT (HRBFFusion.cpp:1301-1310); the kernel rewrites every pixel, so the
@@ -671,7 +684,8 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
     OdoSources src = make_sources(c);
     OdoConfig cfg = make_cfg(c);
     const bool sharded = (c->comm.comm != nullptr || c->comm.virtual_world > 1) && !c->rows_replicated;
-    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier);
+    launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier, c->level0_done);
+    c->level0_done = false;
 }
 
 #define TIMER(i) do { if (c->timing & 1) hipEventRecord(c->ev[i], c->stream); } while (0)
@@ -681,7 +695,8 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     hipSetDevice(c->device);
     refresh_count_ub(c);
     TIMER(0);
-    st_filter(c); st_vnr(c); st_curv(c);
+    st_filter(c); st_vnr(c);
+    st_curv(c, c->tick > 1 && !c->prm.load_trajectory && c->fill_flag_fresh);
     TIMER(1);
     if (c->tick == 1) {
         st_init(c);

@@ -185,63 +185,16 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
 }
 
 // ------------------------------------------------------------------------------------------ O1: map building
-__device__ __forceinline__ uint8_t intensity_u8(int r, int g, int b)
-{
-    float v = (float)r * 0.114f;
-    v = v + (float)g * 0.299f;
-    v = v + (float)b * 0.587f;
-    return (uint8_t)(int)v;
-}
-
 // level 0 of every pyramid in one pass (copyMaps, copyCurvatureMap, copyicpWeightMap,
-// verticesToDepth, imageBGRToIntensity; cudafuncs.cu:344-470,874-911)
+// verticesToDepth, imageBGRToIntensity; cudafuncs.cu:344-470,874-911): odo_level0_pixel in kernels.h.  In the frame
+// path the pixel function runs at the tail of k_curvature (k_pre.hip), which has the live values in registers and ALU
+// work to hide the traffic behind; this kernel serves the stage API and the frames where that is not possible.
 __global__ void k_odo_level0(int P, OdoLevel L, OdoSources src, const DevPose *__restrict__ dp, int f2f, float curv_thr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const int fill = dp->should_fill_in;
-    const float4 *vtex = fill ? src.fi_vertex : src.pr_vertex;
-    const float4 *ntex = fill ? src.fi_normal : src.pr_normal;
-    const uint8_t *img = (fill || f2f) ? src.fi_image : src.pr_image;
-    const float4 *k1t = fill ? src.fi_curv1 : src.pr_curv1;
-    const float4 *k2t = fill ? src.fi_curv2 : src.pr_curv2;
-    const float *iwt = fill ? src.fi_icpw : src.pr_icpw;
-    const float qn = hd_nanf();
-    const size_t PP = (size_t)P;
-    // model
-    {
-        float4 v = vtex[i], n = ntex[i];
-        float4 vo = make_float4(qn, qn, qn, qn), no = vo;
-        if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
-        L.vmap_g[i] = vo.x; L.vmap_g[PP + i] = vo.y; L.vmap_g[2 * PP + i] = vo.z; L.vmap_g[3 * PP + i] = vo.w;
-        L.nmap_g[i] = no.x; L.nmap_g[PP + i] = no.y; L.nmap_g[2 * PP + i] = no.z; L.nmap_g[3 * PP + i] = no.w;
-        L.last_depth[i] = (v.z > 6.0f || v.z <= 0.0f) ? qn : v.z;
-        L.last_image[i] = intensity_u8(img[i * 4], img[i * 4 + 1], img[i * 4 + 2]);
-        float4 s = k1t[i], o = make_float4(qn, qn, qn, qn);
-        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
-        L.ck1_g[i] = o.x; L.ck1_g[PP + i] = o.y; L.ck1_g[2 * PP + i] = o.z; L.ck1_g[3 * PP + i] = o.w;
-        s = k2t[i]; o = make_float4(qn, qn, qn, qn);
-        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
-        L.ck2_g[i] = o.x; L.ck2_g[PP + i] = o.y; L.ck2_g[2 * PP + i] = o.z; L.ck2_g[3 * PP + i] = o.w;
-        float w = iwt[i];
-        L.icpw[i] = w > 0.0f ? w : qn;
-    }
-    // live frame
-    {
-        float4 v = src.vertex_filtered[i], n = src.normal[i];
-        float4 vo = make_float4(qn, qn, qn, qn), no = vo;
-        if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
-        L.vmap_c[i] = vo.x; L.vmap_c[PP + i] = vo.y; L.vmap_c[2 * PP + i] = vo.z; L.vmap_c[3 * PP + i] = vo.w;
-        L.nmap_c[i] = no.x; L.nmap_c[PP + i] = no.y; L.nmap_c[2 * PP + i] = no.z; L.nmap_c[3 * PP + i] = no.w;
-        L.next_depth[i] = (v.z > 6.0f || v.z <= 0.0f) ? qn : v.z;
-        L.next_image[i] = intensity_u8(src.rgb[i * 3], src.rgb[i * 3 + 1], src.rgb[i * 3 + 2]);
-        float4 s = src.curv1[i], o = make_float4(qn, qn, qn, qn);
-        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
-        L.ck1_c[i] = o.x; L.ck1_c[PP + i] = o.y; L.ck1_c[2 * PP + i] = o.z; L.ck1_c[3 * PP + i] = o.w;
-        s = src.curv2[i]; o = make_float4(qn, qn, qn, qn);
-        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
-        L.ck2_c[i] = o.x; L.ck2_c[PP + i] = o.y; L.ck2_c[2 * PP + i] = o.z; L.ck2_c[3 * PP + i] = o.w;
-    }
+    odo_level0_pixel(i, P, L, src, dp->should_fill_in, f2f, curv_thr, src.vertex_filtered[i], src.normal[i], src.curv1[i],
+                     src.curv2[i]);
 }
 
 // resizeMapKernel / resizeCMapKernel (cudafuncs.cu:526-674): validity plane = 0 (maps) or 3 (curvature)
@@ -1592,7 +1545,7 @@ static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
 }
 
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
-                     const OdoComm *oc, float weight_multiplier)
+                     const OdoComm *oc, float weight_multiplier, bool level0_done)
 {
     // sharded = the slot rows of this process do not hold the whole image: fold -> all-reduce -> stand-alone solve
     const bool sharded = oc != nullptr && (oc->comm != nullptr || oc->virtual_world > 1);
@@ -1610,8 +1563,9 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
     const int icp = !cfg.rgb_only && cfg.icp_weight > 0.0f;
     const int P = ob.lv[0].rows * ob.lv[0].cols;
     // O1: pyramids
-    hipLaunchKernelGGL(k_odo_level0, dim3((P + 255) / 256), dim3(256), 0, s, P, ob.lv[0], src, dp, cfg.frame_to_frame_rgb,
-                       cfg.curv_thr);
+    if (!level0_done)
+        hipLaunchKernelGGL(k_odo_level0, dim3((P + 255) / 256), dim3(256), 0, s, P, ob.lv[0], src, dp, cfg.frame_to_frame_rgb,
+                           cfg.curv_thr);
     for (int i = 1; i < HRBF_NUM_PYRS; ++i) {
         int n = ob.lv[i].rows * ob.lv[i].cols;
         hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256, ODO_DOWN_TASKS), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);

@@ -563,11 +563,12 @@ __device__ __forceinline__ int curv_window(const NbTexel *__restrict__ tile, con
     return n;
 }
 
+template <bool LEVEL0 /* also write level 0 of the registration pyramids for this pixel (frame path) */>
 __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__restrict__ vertex_filtered,
                                                    const float4 *__restrict__ normal_in,
                                                    float4 *__restrict__ curv1, float4 *__restrict__ curv2,
                                                    float *__restrict__ gradmag, float4 *__restrict__ normal_out,
-                                                   int win)
+                                                   int win, Level0Args l0)
 {
     constexpr int RMAX = 3, TW = TB + 2 * RMAX;
     __shared__ NbTexel tile[TW * TW];
@@ -646,6 +647,8 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
     }
     curv1[i] = pcmax; curv2[i] = pcmin; gradmag[i] = gmag;
     normal_out[i] = nopt;   // updateNormalRad: NORMAL <- NORMAL_OPT (HRBFFusion.cpp:1301-1310)
+    if (LEVEL0)   // what k_odo_level0 would read back for this pixel is what was just stored
+        odo_level0_pixel(i, W * H, l0.L, l0.src, l0.dp->should_fill_in, l0.f2f, l0.curv_thr, vertex_filtered[i], nopt, pcmax, pcmin);
 }
 
 // VertexConfidence (depth_confidence_evaluation.frag:37-50); weighting lives in device memory so
@@ -682,7 +685,13 @@ void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm,
 void launch_curvature(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
                       float *gradmag, float4 *normal_out, int win)
 {
-    hipLaunchKernelGGL(k_curvature, grid2d(cam), dim3(TB, TB), 0, s, cam, vf, normal_in, c1, c2, gradmag, normal_out, win);
+    hipLaunchKernelGGL(k_curvature<false>, grid2d(cam), dim3(TB, TB), 0, s, cam, vf, normal_in, c1, c2, gradmag, normal_out, win,
+                       Level0Args{});
+}
+void launch_curvature_level0(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
+                             float *gradmag, float4 *normal_out, int win, const Level0Args &l0)
+{
+    hipLaunchKernelGGL(k_curvature<true>, grid2d(cam), dim3(TB, TB), 0, s, cam, vf, normal_in, c1, c2, gradmag, normal_out, win, l0);
 }
 void launch_confidence(hipStream_t s, const Cam &cam, const float *gradmag, float *conf, const float *weighting,
                        int use_conf_eval, float eps)

@@ -167,6 +167,63 @@ struct OdoSources {   // images the odometry is initialised from (selected on de
     const float4 *vertex_filtered, *normal, *curv1, *curv2; const uint8_t *rgb;
 };
 
+// ---- level 0 of the registration pyramids, one pixel (shared by k_odo_level0 and the tail of k_curvature) ----
+__device__ __forceinline__ uint8_t intensity_u8(int r, int g, int b)
+{
+    float v = (float)r * 0.114f;
+    v = v + (float)g * 0.299f;
+    v = v + (float)b * 0.587f;
+    return (uint8_t)(int)v;
+}
+// v / n / k1 / k2: the live frame's filtered vertex, normal (after updateNormalRad) and curvature texels of pixel i
+__device__ __forceinline__ void odo_level0_pixel(int i, int P, const OdoLevel &L, const OdoSources &src, int fill, int f2f,
+                                                 float curv_thr, const float4 v_live, const float4 n_live,
+                                                 const float4 k1_live, const float4 k2_live)
+{
+    const float4 *vtex = fill ? src.fi_vertex : src.pr_vertex;
+    const float4 *ntex = fill ? src.fi_normal : src.pr_normal;
+    const uint8_t *img = (fill || f2f) ? src.fi_image : src.pr_image;
+    const float4 *k1t = fill ? src.fi_curv1 : src.pr_curv1;
+    const float4 *k2t = fill ? src.fi_curv2 : src.pr_curv2;
+    const float *iwt = fill ? src.fi_icpw : src.pr_icpw;
+    const float qn = hd_nanf();
+    const size_t PP = (size_t)P;
+    // model
+    {
+        float4 v = vtex[i], n = ntex[i];
+        float4 vo = make_float4(qn, qn, qn, qn), no = vo;
+        if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
+        L.vmap_g[i] = vo.x; L.vmap_g[PP + i] = vo.y; L.vmap_g[2 * PP + i] = vo.z; L.vmap_g[3 * PP + i] = vo.w;
+        L.nmap_g[i] = no.x; L.nmap_g[PP + i] = no.y; L.nmap_g[2 * PP + i] = no.z; L.nmap_g[3 * PP + i] = no.w;
+        L.last_depth[i] = (v.z > 6.0f || v.z <= 0.0f) ? qn : v.z;
+        L.last_image[i] = intensity_u8(img[i * 4], img[i * 4 + 1], img[i * 4 + 2]);
+        float4 s = k1t[i], o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck1_g[i] = o.x; L.ck1_g[PP + i] = o.y; L.ck1_g[2 * PP + i] = o.z; L.ck1_g[3 * PP + i] = o.w;
+        s = k2t[i]; o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck2_g[i] = o.x; L.ck2_g[PP + i] = o.y; L.ck2_g[2 * PP + i] = o.z; L.ck2_g[3 * PP + i] = o.w;
+        float w = iwt[i];
+        L.icpw[i] = w > 0.0f ? w : qn;
+    }
+    // live frame
+    {
+        const float4 v = v_live, n = n_live;
+        float4 vo = make_float4(qn, qn, qn, qn), no = vo;
+        if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
+        L.vmap_c[i] = vo.x; L.vmap_c[PP + i] = vo.y; L.vmap_c[2 * PP + i] = vo.z; L.vmap_c[3 * PP + i] = vo.w;
+        L.nmap_c[i] = no.x; L.nmap_c[PP + i] = no.y; L.nmap_c[2 * PP + i] = no.z; L.nmap_c[3 * PP + i] = no.w;
+        L.next_depth[i] = (v.z > 6.0f || v.z <= 0.0f) ? qn : v.z;
+        L.next_image[i] = intensity_u8(src.rgb[i * 3], src.rgb[i * 3 + 1], src.rgb[i * 3 + 2]);
+        float4 s = k1_live, o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck1_c[i] = o.x; L.ck1_c[PP + i] = o.y; L.ck1_c[2 * PP + i] = o.z; L.ck1_c[3 * PP + i] = o.w;
+        s = k2_live; o = make_float4(qn, qn, qn, qn);
+        if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
+        L.ck2_c[i] = o.x; L.ck2_c[PP + i] = o.y; L.ck2_c[2 * PP + i] = o.z; L.ck2_c[3 * PP + i] = o.w;
+    }
+}
+
 
 size_t odo_state_bytes();
 size_t odo_slot_bytes();
@@ -189,9 +246,16 @@ struct OdoComm {
     int virtual_world;
     int (*allreduce_i64)(void *comm, long long *buf, size_t count, hipStream_t s);
 };
-// weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well
+// weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well.
+// level0_done: launch_curvature_level0 has written level 0 of the pyramids for this frame already
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
-                     const OdoComm *oc /* nullable */, float weight_multiplier);
+                     const OdoComm *oc /* nullable */, float weight_multiplier, bool level0_done = false);
+// the curvature pass with level 0 of the registration pyramids written from its tail (odo_level0_pixel): the live values
+// are in registers there and the kernel is ALU-bound, so the 100 MB of level-0 traffic hide behind it.  Needs a valid
+// should_fill_in flag in *dp (set at the end of the previous frame).
+struct Level0Args { OdoLevel L; OdoSources src; const DevPose *dp; int f2f; float curv_thr; };
+void launch_curvature_level0(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
+                             float *gradmag, float4 *normal_out, int win, const Level0Args &l0);
 // pose bookkeeping
 void launch_pose_set(hipStream_t s, DevPose *dp, const float pose16_colmajor[16], int also_prev);
 void launch_frame_epilogue(hipStream_t s, DevPose *dp, float weight_multiplier, int tracked);
