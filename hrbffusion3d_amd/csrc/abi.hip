@@ -115,7 +115,7 @@ struct hrbf_context {
     int timing; hipEvent_t ev[12]; float timings[8];
     // per-frame ring: HIP events bracketing the fuse pass — F2 (k_apply_merges: m0..m1) and F3 (k_clean_flags +
     // k_fuse_stream: e0..e1), nothing else — + its statistics words
-    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid; uint32_t ring_stride; bool level0_done;
+    hipEvent_t *ring_e0, *ring_e1, *ring_m0, *ring_m1; uint32_t *d_stats_ring; uint32_t ring_head; uint32_t ring_valid; uint32_t ring_stride; int level0_done;
     uint32_t ring_merge_head;   // ring slot the last merge events went to (a clean without a fuse has no F2 part)
     uint32_t status;            // sticky HRBF_STATUS_* bits folded from the device on blocking calls
     PoseLog *h_pose_log, *d_pose_log_view;   // pinned host ring + its device-side address
@@ -443,14 +443,15 @@ static OdoConfig make_cfg(hrbf_context *c);
 // level 0 of the registration pyramids is written from the tail of the curvature kernel (c->level0_done)
 static void st_curv(hrbf_context *c, bool with_level0 = false)
 {
-    c->level0_done = false;
+    c->level0_done = 0;
     if (with_level0) {
         const OdoConfig cfg = make_cfg(c);
         Level0Args l0;
         l0.L = c->odo.lv[0]; l0.src = make_sources(c); l0.dp = c->d_pose; l0.f2f = cfg.frame_to_frame_rgb; l0.curv_thr = cfg.curv_thr;
+        l0.pack = (!cfg.use_search && !cfg.use_sparse) ? 1 : 0;   // the packed-operand registration reads nothing else of level 0's model maps
         launch_curvature_level0(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
                                 c->d_normal_opt, (int)c->prm.curv_estimation_window, l0);
-        c->level0_done = true;
+        c->level0_done = 1 + l0.pack;
     } else
     launch_curvature(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
                      c->d_normal_opt, (int)c->prm.curv_estimation_window);
@@ -685,7 +686,7 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
     OdoConfig cfg = make_cfg(c);
     const bool sharded = (c->comm.comm != nullptr || c->comm.virtual_world > 1) && !c->rows_replicated;
     launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier, c->level0_done);
-    c->level0_done = false;
+    c->level0_done = 0;
 }
 
 #define TIMER(i) do { if (c->timing & 1) hipEventRecord(c->ev[i], c->stream); } while (0)

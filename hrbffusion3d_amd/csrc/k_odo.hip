@@ -628,7 +628,7 @@ __device__ __forceinline__ void pack_icp_texels(const OdoLevel &L, int i)
 // (in place), Sobel + back-projected cloud of the live frame; workgroup (0,0) also resets the registration state
 struct OdoLevels { OdoLevel lv[HRBF_NUM_PYRS]; };
 __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg, int do_rgb,
-                              int gn_level, long long *__restrict__ so3_sets)
+                              int gn_level, long long *__restrict__ so3_sets, int level0_packed /* by odo_level0_pixel */)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) odo_begin_state(st, dp, cfg, gn_level);
     if (blockIdx.y == 0) {   // the per-iteration SO3 slot sets start from zero every frame
@@ -639,8 +639,10 @@ __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__rest
     const OdoLevel &L = all.lv[level];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.rows * L.cols) return;
-    transform_pixel(L, i, dp->pose);
-    pack_icp_texels(L, i);
+    if (!(level == 0 && level0_packed)) {
+        transform_pixel(L, i, dp->pose);
+        pack_icp_texels(L, i);
+    }
     if (do_rgb) {
         const int div = 1 << level;
         sobel_cloud_pixel(L, i, cfg.fx / div, cfg.fy / div, cfg.cx / div, cfg.cy / div);
@@ -1545,7 +1547,7 @@ static IcpArgs make_icp_args(const OdoLevel &L, const OdoConfig &cfg, int level)
 }
 
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
-                     const OdoComm *oc, float weight_multiplier, bool level0_done)
+                     const OdoComm *oc, float weight_multiplier, int level0_done)
 {
     // sharded = the slot rows of this process do not hold the whole image: fold -> all-reduce -> stand-alone solve
     const bool sharded = oc != nullptr && (oc->comm != nullptr || oc->virtual_world > 1);
@@ -1580,7 +1582,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         OdoLevels all;
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) all.lv[i] = ob.lv[i];
         hipLaunchKernelGGL(k_odo_prepare, dim3((P + 255) / 256, HRBF_NUM_PYRS), dim3(256), 0, s, all, ob.state, dp, cfg, rgb,
-                           cfg.so3 ? -1 : gn_level, ob.so3_part);
+                           cfg.so3 ? -1 : gn_level, ob.so3_part, level0_done == 2 ? 1 : 0);
     }
     // O2: SO3 pre-alignment on level 2: one persistent launch for all iterations (75 chunks at VGA).  A plain launch on
     // purpose: hipLaunchCooperativeKernel serialises against the whole device and cost 30 frames/s in the benchmark,

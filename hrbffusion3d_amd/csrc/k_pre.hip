@@ -648,7 +648,8 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
     curv1[i] = pcmax; curv2[i] = pcmin; gradmag[i] = gmag;
     normal_out[i] = nopt;   // updateNormalRad: NORMAL <- NORMAL_OPT (HRBFFusion.cpp:1301-1310)
     if (LEVEL0)   // what k_odo_level0 would read back for this pixel is what was just stored
-        odo_level0_pixel(i, W * H, l0.L, l0.src, l0.dp->should_fill_in, l0.f2f, l0.curv_thr, vertex_filtered[i], nopt, pcmax, pcmin);
+        odo_level0_pixel(i, W * H, l0.L, l0.src, l0.dp->should_fill_in, l0.f2f, l0.curv_thr, vertex_filtered[i], nopt, pcmax, pcmin,
+                         l0.pack ? &l0.dp->pose : nullptr);
 }
 
 // VertexConfidence (depth_confidence_evaluation.frag:37-50); weighting lives in device memory so

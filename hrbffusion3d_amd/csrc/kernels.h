@@ -175,10 +175,13 @@ __device__ __forceinline__ uint8_t intensity_u8(int r, int g, int b)
     v = v + (float)b * 0.587f;
     return (uint8_t)(int)v;
 }
-// v / n / k1 / k2: the live frame's filtered vertex, normal (after updateNormalRad) and curvature texels of pixel i
+// v / n / k1 / k2: the live frame's filtered vertex, normal (after updateNormalRad) and curvature texels of pixel i.
+// pack != null (packed-operand registration only): the level-0 part of k_odo_prepare's transform + pack_icp_texels is done
+// here as well, from registers — the model texel goes into the global frame with the pose *pack and both packed texels
+// are written; the planar level-0 model maps then stay in the camera frame (only the pyramid's next level reads them).
 __device__ __forceinline__ void odo_level0_pixel(int i, int P, const OdoLevel &L, const OdoSources &src, int fill, int f2f,
                                                  float curv_thr, const float4 v_live, const float4 n_live,
-                                                 const float4 k1_live, const float4 k2_live)
+                                                 const float4 k1_live, const float4 k2_live, const Rigid *pack = nullptr)
 {
     const float4 *vtex = fill ? src.fi_vertex : src.pr_vertex;
     const float4 *ntex = fill ? src.fi_normal : src.pr_normal;
@@ -200,11 +203,23 @@ __device__ __forceinline__ void odo_level0_pixel(int i, int P, const OdoLevel &L
         float4 s = k1t[i], o = make_float4(qn, qn, qn, qn);
         if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
         L.ck1_g[i] = o.x; L.ck1_g[PP + i] = o.y; L.ck1_g[2 * PP + i] = o.z; L.ck1_g[3 * PP + i] = o.w;
+        const float k1w = o.w;
         s = k2t[i]; o = make_float4(qn, qn, qn, qn);
         if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
         L.ck2_g[i] = o.x; L.ck2_g[PP + i] = o.y; L.ck2_g[2 * PP + i] = o.z; L.ck2_g[3 * PP + i] = o.w;
         float w = iwt[i];
-        L.icpw[i] = w > 0.0f ? w : qn;
+        w = w > 0.0f ? w : qn;
+        L.icpw[i] = w;
+        if (pack) {   // tranformMapsKernel / tranformCurvMapsKernel on this pixel (a NaN x marks an empty texel), then the pack
+            const Rigid &T = *pack;
+            f3 vg = mk3(vo.x, vo.y, vo.z), ng = mk3(no.x, no.y, no.z);
+            if (!hd_isnanf(vo.x)) { vg = rot_mul(T, vg); vg = mk3(vg.x + T.t[0], vg.y + T.t[1], vg.z + T.t[2]); }
+            if (!hd_isnanf(no.x)) ng = rot_mul(T, ng);
+            // the curvature directions are rotated too, but only their w (the curvature, untouched) enters the validity
+            const bool ok = !(hd_isnanf(vg.x) || hd_isnanf(ng.x) || hd_isnanf(k1w) || hd_isnanf(o.w));
+            L.icp_model[2 * i] = make_float4(vg.x, vg.y, vg.z, w);
+            L.icp_model[2 * i + 1] = make_float4(ng.x, ng.y, ng.z, ok ? 1.0f : 0.0f);
+        }
     }
     // live frame
     {
@@ -218,9 +233,15 @@ __device__ __forceinline__ void odo_level0_pixel(int i, int P, const OdoLevel &L
         float4 s = k1_live, o = make_float4(qn, qn, qn, qn);
         if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
         L.ck1_c[i] = o.x; L.ck1_c[PP + i] = o.y; L.ck1_c[2 * PP + i] = o.z; L.ck1_c[3 * PP + i] = o.w;
+        const float k1w = o.w;
         s = k2_live; o = make_float4(qn, qn, qn, qn);
         if (s.w < curv_thr && s.w > -curv_thr && !hd_isnanf(s.w)) o = s;
         L.ck2_c[i] = o.x; L.ck2_c[PP + i] = o.y; L.ck2_c[2 * PP + i] = o.z; L.ck2_c[3 * PP + i] = o.w;
+        if (pack) {
+            const bool ok = !(hd_isnanf(vo.x) || hd_isnanf(no.x) || hd_isnanf(k1w) || hd_isnanf(o.w));
+            L.icp_cur[2 * i] = make_float4(vo.x, vo.y, vo.z, ok ? 1.0f : 0.0f);
+            L.icp_cur[2 * i + 1] = make_float4(no.x, no.y, no.z, 0.0f);
+        }
     }
 }
 
@@ -247,13 +268,14 @@ struct OdoComm {
     int (*allreduce_i64)(void *comm, long long *buf, size_t count, hipStream_t s);
 };
 // weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well.
-// level0_done: launch_curvature_level0 has written level 0 of the pyramids for this frame already
+// level0_done: launch_curvature_level0 has written level 0 of the pyramids for this frame already (1), and the packed
+// ICP operands of level 0 in the global frame as well (2)
 void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const OdoConfig &cfg, DevPose *dp,
-                     const OdoComm *oc /* nullable */, float weight_multiplier, bool level0_done = false);
+                     const OdoComm *oc /* nullable */, float weight_multiplier, int level0_done = 0);
 // the curvature pass with level 0 of the registration pyramids written from its tail (odo_level0_pixel): the live values
 // are in registers there and the kernel is ALU-bound, so the 100 MB of level-0 traffic hide behind it.  Needs a valid
 // should_fill_in flag in *dp (set at the end of the previous frame).
-struct Level0Args { OdoLevel L; OdoSources src; const DevPose *dp; int f2f; float curv_thr; };
+struct Level0Args { OdoLevel L; OdoSources src; const DevPose *dp; int f2f; float curv_thr; int pack; };
 void launch_curvature_level0(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
                              float *gradmag, float4 *normal_out, int win, const Level0Args &l0);
 // pose bookkeeping
