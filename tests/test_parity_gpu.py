@@ -510,6 +510,22 @@ def test_stage_seams_in_isolation(pair):
     assert g.fuse_stats()[2] == 0 and len(g.download_map()) <= len(before)
 
 
+def test_frame_path_with_and_without_the_fused_per_pixel_passes(pair):
+    """process_frame runs level 0 of the registration pyramids from the curvature kernel's tail and the fill-in from the
+    ray cast's — unless the shouldFillIn flag on the device may be stale, e.g. after hrbf_set_image, when it falls back to
+    the separate kernels.  Alternating between the two must not show anywhere."""
+    W, H = 320, 240
+    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 19)
+    o, g = pair(p)
+    for k in range(10):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        if k in (3, 4, 7):   # same content written back: marks the prediction as touched
+            for x in (o, g):
+                x.set_image("PRED_TIME", x.get_image("PRED_TIME"))
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "frame %d" % k)
+
+
 def test_fuse_ring_stride(gpu_available):
     """hrbf_set_fuse_ring_stride: only frames whose time stamp is a multiple of the stride are bracketed by events"""
     from hrbffusion3d_amd.api import HRBFFusion
