@@ -627,18 +627,10 @@ __device__ __forceinline__ void pack_icp_texels(const OdoLevel &L, int i)
 // last pass over the pyramids, all levels in one launch (blockIdx.y = level): model maps into the global frame
 // (in place), Sobel + back-projected cloud of the live frame; workgroup (0,0) also resets the registration state
 struct OdoLevels { OdoLevel lv[HRBF_NUM_PYRS]; };
-__global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg, int do_rgb,
-                              int gn_level, long long *__restrict__ so3_sets, int level0_packed /* by odo_level0_pixel */)
+// one pixel of one level: nothing here depends on another pixel's result
+__device__ __forceinline__ void prepare_pixel(const OdoLevel &L, int level, int i, const DevPose *__restrict__ dp,
+                                              const OdoConfig &cfg, int do_rgb, int level0_packed)
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) odo_begin_state(st, dp, cfg, gn_level);
-    if (blockIdx.y == 0) {   // the per-iteration SO3 slot sets start from zero every frame
-        const int t = blockIdx.x * blockDim.x + threadIdx.x;
-        if (t < SO3_ITERS * ODO_SLOTS * 33) so3_sets[t] = 0;
-    }
-    const int level = blockIdx.y;
-    const OdoLevel &L = all.lv[level];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.rows * L.cols) return;
     if (!(level == 0 && level0_packed)) {
         transform_pixel(L, i, dp->pose);
         pack_icp_texels(L, i);
@@ -651,6 +643,24 @@ __global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__rest
         const float minScale = (float)(((double)minGrad * (double)minGrad) / (0.125 * 0.125));
         L.rgb_mask[i] = rgb_residual_static_test(L, minScale, i) ? 1 : 0;
     }
+}
+// state_only: the pixel work of all levels rides along in the SO3 kernel (k_so3_persistent, filler workgroups); only the
+// state reset and the slot sets remain here
+__global__ void k_odo_prepare(OdoLevels all, OdoState *st, const DevPose *__restrict__ dp, OdoConfig cfg, int do_rgb,
+                              int gn_level, long long *__restrict__ so3_sets, int level0_packed /* by odo_level0_pixel */,
+                              int state_only)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) odo_begin_state(st, dp, cfg, gn_level);
+    if (blockIdx.y == 0) {   // the per-iteration SO3 slot sets start from zero every frame
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < SO3_ITERS * ODO_SLOTS * 33) so3_sets[t] = 0;
+    }
+    if (state_only) return;
+    const int level = blockIdx.y;
+    const OdoLevel &L = all.lv[level];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.rows * L.cols) return;
+    prepare_pixel(L, level, i, dp, cfg, do_rgb, level0_packed);
 }
 
 // one SO3 step on folded totals (RGBDOdometry.cpp:551-640); S is OdoState or the LDS copy of the persistent kernel
@@ -798,9 +808,26 @@ struct So3Local {
 // arrival of iteration it, so the usual (co-resident) case pays no extra round trip.  The loop ends at convergence
 // (typically 4 iterations).  The LAST workgroup to leave publishes the final state: by then every other workgroup
 // has read the initial one.
+// Filler: the SO3 iterations are 75 workgroups chasing each other through memory round trips for 36 us while the rest of
+// the chip idles, and k_odo_prepare's per-pixel work (all levels; needed only by the Gauss-Newton loop that follows) is
+// independent of them.  Workgroups n_so3 .. gridDim.x - 1 do that work and leave; they take no ticket, count in no
+// election and are dispatched after the SO3 workgroups (dispatch follows blockIdx).
+struct So3Filler { OdoLevels all; const DevPose *dp; int do_rgb, level0_packed; unsigned int first[HRBF_NUM_PYRS + 1]; };
 __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st, long long *__restrict__ part,
-                                                       OdoConfig cfg, int gn_level, unsigned int nchunk)
+                                                       OdoConfig cfg, int gn_level, unsigned int nchunk, unsigned int n_so3,
+                                                       So3Filler fill)
 {
+    if (blockIdx.x >= n_so3) {
+        const unsigned int f = blockIdx.x - n_so3;
+#pragma unroll
+        for (int lv = 0; lv < HRBF_NUM_PYRS; ++lv)
+            if (f >= fill.first[lv] && f < fill.first[lv + 1]) {
+                const OdoLevel &FL = fill.all.lv[lv];
+                const int i = (int)((f - fill.first[lv]) * RB + threadIdx.x);
+                if (i < FL.rows * FL.cols) prepare_pixel(FL, lv, i, fill.dp, cfg, fill.do_rgb, fill.level0_packed);
+            }
+        return;
+    }
     __shared__ So3Local S;
     __shared__ long long s_tot[33];
     __shared__ unsigned int s_chunk, s_next;
@@ -874,7 +901,7 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
         __syncthreads();
     }
     if (threadIdx.x == 0 &&
-        __hip_atomic_fetch_add(&st->so3_exit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+        __hip_atomic_fetch_add(&st->so3_exit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_so3 - 1u) {
         for (int k = 0; k < 9; ++k) {
             st->resultR[k] = S.resultR[k]; st->lastResultR[k] = S.lastResultR[k]; st->R_lr[k] = S.R_lr[k];
             st->basis[k] = S.basis[k]; st->kinv[k] = S.kinv[k]; st->krlr[k] = S.krlr[k];
@@ -1581,8 +1608,14 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
     {
         OdoLevels all;
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) all.lv[i] = ob.lv[i];
-        hipLaunchKernelGGL(k_odo_prepare, dim3((P + 255) / 256, HRBF_NUM_PYRS), dim3(256), 0, s, all, ob.state, dp, cfg, rgb,
-                           cfg.so3 ? -1 : gn_level, ob.so3_part, level0_done == 2 ? 1 : 0);
+        // single-GPU path with the SO3 stage: the pixel work goes into the SO3 kernel as filler (see there)
+        const bool filler = cfg.so3 && !sharded;
+        if (filler)
+            hipLaunchKernelGGL(k_odo_prepare, dim3((SO3_ITERS * ODO_SLOTS * 33 + 255) / 256, 1), dim3(256), 0, s, all, ob.state, dp,
+                               cfg, rgb, -1, ob.so3_part, 0, 1);
+        else
+            hipLaunchKernelGGL(k_odo_prepare, dim3((P + 255) / 256, HRBF_NUM_PYRS), dim3(256), 0, s, all, ob.state, dp, cfg, rgb,
+                               cfg.so3 ? -1 : gn_level, ob.so3_part, level0_done == 2 ? 1 : 0, 0);
     }
     // O2: SO3 pre-alignment on level 2: one persistent launch for all iterations (75 chunks at VGA).  A plain launch on
     // purpose: hipLaunchCooperativeKernel serialises against the whole device and cost 30 frames/s in the benchmark,
@@ -1615,8 +1648,18 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
             }
         } else {   // any grid size is safe (ticketed chunks); one workgroup per chunk while the device can hold them all
             const long long grid = capacity > 0 && nb > capacity ? capacity : nb;
-            hipLaunchKernelGGL(k_so3_persistent, dim3((unsigned)grid), dim3(RB), 0, s, L, ob.state, ob.so3_part, cfg, gn_level,
-                               (unsigned int)nb);
+            So3Filler fill;
+            unsigned int nfill = 0;
+            for (int i = 0; i < HRBF_NUM_PYRS; ++i) fill.all.lv[i] = ob.lv[i];
+            // filler ranges in workgroup units, level by level
+            for (int lv = 0; lv < HRBF_NUM_PYRS; ++lv) {
+                fill.first[lv] = nfill;
+                nfill += (unsigned int)((ob.lv[lv].rows * ob.lv[lv].cols + RB - 1) / RB);
+            }
+            fill.first[HRBF_NUM_PYRS] = nfill;
+            fill.dp = dp; fill.do_rgb = rgb; fill.level0_packed = level0_done == 2 ? 1 : 0;
+            hipLaunchKernelGGL(k_so3_persistent, dim3((unsigned)grid + nfill), dim3(RB), 0, s, L, ob.state, ob.so3_part, cfg,
+                               gn_level, (unsigned int)nb, (unsigned int)grid, fill);
         }
     }
     // O3-O6: coarse-to-fine Gauss-Newton, three launches per iteration.  On the single-GPU path the whole loop (57
