@@ -357,6 +357,41 @@ __global__ void k_pyrdown_u8(const uint8_t *__restrict__ src, int srows, int sco
 // diagonal-pivoted LDL^T, same arithmetic as the oracle's ldlt (oracle/orc_odo.c).  Everything is indexed
 // by compile-time constants (pivot row/column swaps are select chains), so A, perm and y live in registers —
 // the one-lane solve kernels are pure latency and runtime-indexed arrays would sit in scratch memory.
+// Symmetric swap k <-> piv of the pivoted factorisation: rows, then columns, then the permutation record.  The solve runs
+// in ONE lane, so the pivot index is wave-uniform: it goes to a scalar register and the swap is a scalar branch around
+// 4 N register moves.  Selecting over every candidate row instead (no branch; N - k - 1 candidates x 4 N selects of 64
+// bits) was 700 of the 6x6 solve's 2 200 instructions.  The empty asm keeps the compiler from turning the branch back
+// into those selects.
+__host__ __device__ __forceinline__ int ldlt_uniform(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+template <typename T, int N, int IDX>
+__host__ __device__ __forceinline__ void ldlt_swap(T (&A)[N * N], int (&perm)[N], int k, int piv)
+{
+    if constexpr (IDX < N * N) {
+        constexpr int K = IDX / N, I = IDX % N;
+        if constexpr (I > K) {
+            if (k == K && piv == I) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                for (int j = 0; j < N; ++j) { const T t = A[K * N + j]; A[K * N + j] = A[I * N + j]; A[I * N + j] = t; }
+#pragma unroll
+                for (int j = 0; j < N; ++j) { const T t = A[j * N + K]; A[j * N + K] = A[j * N + I]; A[j * N + I] = t; }
+                const int t = perm[K]; perm[K] = perm[I]; perm[I] = t;
+                return;
+            }
+        }
+        ldlt_swap<T, N, IDX + 1>(A, perm, k, piv);
+    }
+}
+
 template <typename T, int N>
 __host__ __device__ __forceinline__ void ldlt_solve(T (&A)[N * N], const T (&b)[N], T (&x)[N])
 {
@@ -373,20 +408,7 @@ __host__ __device__ __forceinline__ void ldlt_solve(T (&A)[N * N], const T (&b)[
             T v = A[i * N + i] < 0 ? -A[i * N + i] : A[i * N + i];
             if (v > best) { best = v; piv = i; }
         }
-#pragma unroll
-        for (int i = k + 1; i < N; ++i) {       // swap rows k <-> piv
-            const bool sel = (i == piv);
-#pragma unroll
-            for (int j = 0; j < N; ++j) { const T a = A[k * N + j], c = A[i * N + j]; A[k * N + j] = sel ? c : a; A[i * N + j] = sel ? a : c; }
-        }
-#pragma unroll
-        for (int i = k + 1; i < N; ++i) {       // swap columns k <-> piv
-            const bool sel = (i == piv);
-#pragma unroll
-            for (int j = 0; j < N; ++j) { const T a = A[j * N + k], c = A[j * N + i]; A[j * N + k] = sel ? c : a; A[j * N + i] = sel ? a : c; }
-            const int pa = perm[k], pc = perm[i];
-            perm[k] = sel ? pc : pa; perm[i] = sel ? pa : pc;
-        }
+        ldlt_swap<T, N, 0>(A, perm, k, ldlt_uniform(piv));   // rows and columns k <-> piv, perm[k] <-> perm[piv]
         const T d = A[k * N + k];
         if (d != 0) {
 #pragma unroll
