@@ -361,7 +361,7 @@ __global__ void k_pyrdown_u8(const uint8_t *__restrict__ src, int srows, int sco
 // in ONE lane, so the pivot index is wave-uniform: it goes to a scalar register and the swap is a scalar branch around
 // 4 N register moves.  Selecting over every candidate row instead (no branch; N - k - 1 candidates x 4 N selects of 64
 // bits) was 700 of the 6x6 solve's 2 200 instructions.  The empty asm keeps the compiler from turning the branch back
-// into those selects.
+// into those selects.  REQUIRES wave-uniform data: every caller runs the solve in a single active lane.
 __host__ __device__ __forceinline__ int ldlt_uniform(int v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
