@@ -105,6 +105,76 @@ __device__ __forceinline__ void wave_transpose_sum(int32_t (&a)[VM], const int l
     }
 }
 
+// ---- the same wave totals through doubles, for waves whose values are all below 2^6 in magnitude ----
+// q = rint(p * 2^40) is then an integer below 2^46 that a double holds exactly, and so is every partial sum of 64 of them
+// (< 2^52): the butterfly adds doubles — the same exact integers as the limb form, 3 instructions to prepare a value
+// instead of 7 — and the lane that ends up with a total cuts it into the 25-bit limbs the workgroup stage expects.
+__device__ __forceinline__ double f64_from_halves(uint32_t lo, uint32_t hi)
+{
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <int VM, int V, int S>
+__device__ __forceinline__ void wave_transpose_sum_f64(double (&a)[VM], const int lane)
+{
+    if constexpr (S < 6) {
+        constexpr int h = (V + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const double x = a[i], y = (i + h < V) ? a[i + h] : 0.0;
+            const uint32_t xl = (uint32_t)__double2loint(x), xh = (uint32_t)__double2hiint(x);
+            const uint32_t yl = (uint32_t)__double2loint(y), yh = (uint32_t)__double2hiint(y);
+            if constexpr (S == 0) {
+                const auto rl = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+                const auto rh = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+                a[i] = f64_from_halves(rl[0], rh[0]) + f64_from_halves(rl[1], rh[1]);
+            } else if constexpr (S == 1) {
+                const auto rl = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+                const auto rh = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+                a[i] = f64_from_halves(rl[0], rh[0]) + f64_from_halves(rl[1], rh[1]);
+            } else {
+                const bool sel = ((lane >> (5 - S)) & 1) != 0;
+                const double keep = sel ? y : x, send = sel ? x : y;
+                constexpr int ctrl = S == 2 ? 0x128 : S == 3 ? 0x141 : S == 4 ? 0x4e : 0xb1;
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_update_dpp(0, __double2loint(send), ctrl, 0xf, 0xf, false);
+                const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp(0, __double2hiint(send), ctrl, 0xf, 0xf, false);
+                a[i] = keep + f64_from_halves(sl, sh);
+            }
+        }
+        wave_transpose_sum_f64<VM, h, S + 1>(a, lane);
+    }
+}
+template <int N>
+__device__ __forceinline__ void wave_reduce_f64(const float *vals, bool valid, int lane, int32_t *__restrict__ sums)
+{
+    int vs[7];
+    vs[0] = N;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vs[k + 1] = (vs[k] + 1) / 2;
+    double a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = hd_rint((double)(valid ? vals[i] : 0.0f) * 0x1p40);
+    wave_transpose_sum_f64<N, N, 0>(a, lane);
+    static_assert(N <= 64, "one total per lane");
+    {
+        int idx = 0;
+        bool ok = 0 < vs[6];
+#pragma unroll
+        for (int S = 5; S >= 0; --S) {
+            idx += ((lane >> (5 - S)) & 1) * vs[S + 1];
+            ok = ok && idx < vs[S];
+        }
+        if (ok) {   // Q = d0 + d1 2^24 + d2 2^49 with limbs of the sign of Q; d3 = d4 = 0
+            const double q = a[0];
+            const double d2 = __builtin_trunc(q * 0x1p-49);
+            const double r = hd_fma(-d2, 0x1p49, q);
+            const double d1 = __builtin_trunc(r * 0x1p-24);
+            const double d0 = hd_fma(-d1, 0x1p24, r);
+            sums[5 * idx] = (int32_t)d0; sums[5 * idx + 1] = (int32_t)d1; sums[5 * idx + 2] = (int32_t)d2;
+            sums[5 * idx + 3] = 0; sums[5 * idx + 4] = 0;
+        }
+    }
+}
+
 // one wave: NL low limbs of N values per lane -> wave totals parked in sums[5 * value + limb]
 template <int N, int NL>
 __device__ __forceinline__ void wave_reduce_limbs(const float *vals, bool valid, int lane, int32_t *__restrict__ sums)
@@ -159,7 +229,8 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
         for (int i = 0; i < N; ++i) { const uint32_t b = hd_f2u(vals[i]) & 0x7fffffffu; m = b > m ? b : m; }
         if (!ZEROED && !valid) m = 0u;
         const bool use = ZEROED ? true : valid;
-        if (__ballot(m >= ((127u + 9u) << 23)) == 0ull) wave_reduce_limbs<N, 2>(vals, use, lane, s_sum[wid]);
+        if (N <= 64 && __ballot(m >= ((127u + 6u) << 23)) == 0ull) wave_reduce_f64<N>(vals, use, lane, s_sum[wid]);
+        else if (__ballot(m >= ((127u + 9u) << 23)) == 0ull) wave_reduce_limbs<N, 2>(vals, use, lane, s_sum[wid]);
         else if (__ballot(m >= ((127u + 34u) << 23)) == 0ull) wave_reduce_limbs<N, 3>(vals, use, lane, s_sum[wid]);
         else wave_reduce_limbs<N, 5>(vals, use, lane, s_sum[wid]);
     } else {
