@@ -930,6 +930,47 @@ def test_icp_step_seam(oracle_lib_built, gpu_available, K):
     g.close()
 
 
+@pytest.mark.parametrize("wscale", [1.0, 40.0, 3.0e3, 1.0e9, 1.0e15, 1.0e30])
+def test_icp_step_exact_sums_across_reduction_paths(oracle_lib_built, gpu_available, wscale):
+    """The wave stage of the exact reduction picks its form by the largest magnitude in the wave: doubles below 2^6, two
+    / three / five 25-bit limbs above.  The same ICP system with the weight map scaled into each range: every sum bit-equal
+    to the oracle's 128-bit accumulation."""
+    import torch
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 160, 120
+    K = synth.intrinsics(W, H)
+    z = scenes.corner_depth(W, H, *K)
+    P = scenes.pixel_rays(W, H, *K) * z[..., None]
+    dx = np.zeros_like(P); dy = np.zeros_like(P)
+    dx[:, 1:-1] = P[:, 2:] - P[:, :-2]; dy[1:-1] = P[2:] - P[:-2]
+    n = np.cross(dx, dy); ln = np.linalg.norm(n, axis=-1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-12), 0); n = np.where(n[..., 2:3] < 0, -n, n)
+    v = np.stack([P[..., 0], P[..., 1], P[..., 2], np.ones_like(z)]).astype(np.float32)
+    nn = np.stack([n[..., 0], n[..., 1], n[..., 2], np.ones_like(z)]).astype(np.float32)
+    v[0][z <= 0] = np.nan; nn[0][ln[..., 0] <= 0] = np.nan
+    kk = np.zeros_like(v); kk[3] = 0.5
+    rng = np.random.default_rng(6)
+    w = (rng.uniform(0.1, 3.0, (H, W)) * wscale).astype(np.float32)
+    w[:, : W // 2] *= np.float32(1e-3)          # half of the image three decades lower: waves of different ranges in one launch
+    Rc = np.eye(3, dtype=np.float32); Rc[0, 1] = -0.004; Rc[1, 0] = 0.004
+    tc = np.array([0.003, -0.002, 0.004], np.float32)
+    I3 = np.eye(3, dtype=np.float32); t0 = np.zeros(3, np.float32)
+    lib = oracle_lib_built.load()
+    A0 = np.zeros(36); b0 = np.zeros(6); r0 = np.zeros(2)
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.orc_icp_step(pp(Rc), pp(tc), pp(v), pp(nn), pp(kk), pp(kk), pp(I3), pp(t0), *K, pp(v), pp(nn), pp(kk), pp(kk),
+                     pp(w), H, W, 0.1, 0.342, 1, pp(A0), pp(b0), pp(r0))
+    g = HRBFFusion(default_params(W, H, *K, max_surfels=1024))
+    dv, dn, dk, dw = (torch.from_numpy(a).cuda() for a in (v, nn, kk, w))
+    A1 = np.zeros(36); b1 = np.zeros(6); r1 = np.zeros(2)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    rc = g.lib.hrbf_icp_step(g.h, pp(Rc), pp(tc), dp(dv), dp(dn), dp(dk), dp(dk), pp(I3), pp(t0), *K, dp(dv), dp(dn),
+                             dp(dk), dp(dk), dp(dw), H, W, 0.1, 0.342, 1, pp(A1), pp(b1), pp(r1))
+    g.close()
+    assert rc == 0 and r1[1] > 0.5 * W * H
+    assert np.array_equal(A0, A1) and np.array_equal(b0, b1) and np.array_equal(r0, r1)
+
+
 def test_icp_step_sparse_seam(oracle_lib_built, gpu_available):
     """hrbf_icp_step_sparse / hrbf_update_lambda_map (icpStep with useSparse, updateLambdaMap) on caller-owned device
     images against the oracle: sums, z_thrinkMap, corresICP and the updated lambdaMap bit for bit, over three
