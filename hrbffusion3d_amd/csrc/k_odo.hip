@@ -175,6 +175,54 @@ __device__ __forceinline__ void wave_reduce_f64(const float *vals, bool valid, i
     }
 }
 
+// Values up to 2^34: q = rint(p * 2^40) (< 2^74, exact in a double: p has 24 significant bits) is cut into
+// q = lo + hi * 2^30 with |lo| < 2^30 and |hi| < 2^44, two doubles whose 64-lane sums (< 2^36, < 2^50) are exact again —
+// 6 instructions to prepare a value instead of 10 for three limbs, and 58 registers through the butterfly instead of 87.
+// The lane holding a total cuts it into limbs: lo -> limbs 0, 1; hi * 2^30 = h0 * 2^6 * 2^24 + hp * 2^49 -> limbs 1 (added), 2, 3.
+template <int N>
+__device__ __forceinline__ void wave_reduce_f64x2(const float *vals, bool valid, int lane, int32_t *__restrict__ sums)
+{
+    constexpr int V = 2 * N;
+    static_assert(V <= 64, "one total per lane");
+    int vs[7];
+    vs[0] = V;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vs[k + 1] = (vs[k] + 1) / 2;
+    double a[V];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double q = hd_rint((double)(valid ? vals[i] : 0.0f) * 0x1p40);
+        const double hi = __builtin_trunc(q * 0x1p-30);
+        a[2 * i] = hd_fma(-hi, 0x1p30, q);
+        a[2 * i + 1] = hi;
+    }
+    wave_transpose_sum_f64<V, V, 0>(a, lane);
+    int idx = 0;
+    bool ok = 0 < vs[6];
+#pragma unroll
+    for (int S = 5; S >= 0; --S) {
+        idx += ((lane >> (5 - S)) & 1) * vs[S + 1];
+        ok = ok && idx < vs[S];
+    }
+    const int v = idx >> 1;
+    const double t = a[0];
+    if (ok && (idx & 1) == 0) {   // the lo total
+        const double d1 = __builtin_trunc(t * 0x1p-24);
+        sums[5 * v] = (int32_t)hd_fma(-d1, 0x1p24, t);
+        sums[5 * v + 1] = (int32_t)d1;
+    }
+    // LDS operations of one wave execute in program order: the add below lands on the value just stored
+    if (ok && (idx & 1) == 1) {   // the hi total
+        const double hp = __builtin_trunc(t * 0x1p-19);
+        const double h0 = hd_fma(-hp, 0x1p19, t);
+        const double d3 = __builtin_trunc(hp * 0x1p-25);
+        atomicAdd(&sums[5 * v + 1], (int32_t)(h0 * 64.0));
+        sums[5 * v + 2] = (int32_t)hd_fma(-d3, 0x1p25, hp);
+        sums[5 * v + 3] = (int32_t)d3;
+        sums[5 * v + 4] = 0;
+    }
+}
+
 // one wave: NL low limbs of N values per lane -> wave totals parked in sums[5 * value + limb]
 template <int N, int NL>
 __device__ __forceinline__ void wave_reduce_limbs(const float *vals, bool valid, int lane, int32_t *__restrict__ sums)
@@ -231,6 +279,7 @@ __device__ __forceinline__ void block_reduce_exact(const float *vals, bool valid
         const bool use = ZEROED ? true : valid;
         if (N <= 64 && __ballot(m >= ((127u + 6u) << 23)) == 0ull) wave_reduce_f64<N>(vals, use, lane, s_sum[wid]);
         else if (__ballot(m >= ((127u + 9u) << 23)) == 0ull) wave_reduce_limbs<N, 2>(vals, use, lane, s_sum[wid]);
+        else if (2 * N <= 64 && __ballot(m >= ((127u + 34u) << 23)) == 0ull) wave_reduce_f64x2<N>(vals, use, lane, s_sum[wid]);
         else if (__ballot(m >= ((127u + 34u) << 23)) == 0ull) wave_reduce_limbs<N, 3>(vals, use, lane, s_sum[wid]);
         else wave_reduce_limbs<N, 5>(vals, use, lane, s_sum[wid]);
     } else {
