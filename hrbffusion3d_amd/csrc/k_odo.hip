@@ -1520,10 +1520,12 @@ __device__ __forceinline__ void fold_residual(const long long *__restrict__ res_
         long long c = 0, s = 0;
         for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
         float sigmaVal = hd_sqrtf((((float)s / (float)c) == 0.0f) ? 1.0f : (float)c);
-        float rgbError = (float)(hd_sqrt((double)s) / (double)(c == 0 ? 1 : c));
         int brk = gn_break;
-        if (rgb_only && rgbError > lastRGBError) brk = 1;
-        if (rgb_only) sigmaVal = -1.0f;
+        if (rgb_only) {   // only this mode consults the error here (an fp64 sqrt + division on every workgroup's critical path)
+            const float rgbError = (float)(hd_sqrt((double)s) / (double)(c == 0 ? 1 : c));
+            if (rgbError > lastRGBError) brk = 1;
+            sigmaVal = -1.0f;
+        }
         *s_sigma = sigmaVal; *s_break = brk;
         s_res[0] = c; s_res[1] = s;
     }
