@@ -98,6 +98,7 @@ struct hrbf_context {
     uint32_t *d_counts;         // [2][HRBF_MAX_SHARDS]: live surfel counts of all G shards, ping-pong with the clean pass
     uint32_t *h_count_pinned;   // [HRBF_MAX_SHARDS] async read-back (1-frame lag)
     uint8_t *h_stage[3]; hipEvent_t ev_stage[3]; bool stage_used[3]; uint32_t stage_head;   // pinned input staging ring
+    const uint8_t *ride_rgb_src;   // device view of a staged RGB image that the next st_filter uploads (hrbf_process_frame)
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
     uint32_t *d_init_flags, *d_init_offs;
@@ -428,8 +429,11 @@ static OdoConfig make_cfg(hrbf_context *c)
 
 static void st_filter(hrbf_context *c)
 {
+    // a pending RGB upload of the host-pointer entry rides in this launch (nothing reads the RGB image before the next kernel but one)
     launch_filter_metric(c->stream, c->cam, c->d_depth, c->d_depth_filtered, c->d_depth_metric, c->d_depth_metric_f,
-                         c->prm.depth_scale, c->prm.depth_cutoff, c->prm.use_bilateral);
+                         c->prm.depth_scale, c->prm.depth_cutoff, c->prm.use_bilateral, c->ride_rgb_src, c->d_rgb,
+                         (size_t)c->P * 3);
+    c->ride_rgb_src = nullptr;
 }
 static void st_vnr(hrbf_context *c)
 {
@@ -763,11 +767,14 @@ extern "C" int hrbf_process_frame(hrbf_handle c, const uint8_t *rgb, const uint1
     uint8_t *dev_view = nullptr;
     HIP_CHECK(hipHostGetDevicePointer((void **)&dev_view, c->h_stage[slot], 0));
     const size_t dep_off = (nrgb + 15) & ~(size_t)15;   // keeps the depth half 16-byte aligned
-    launch_copy_inputs(c->stream, dev_view, nrgb, dev_view + dep_off, ndep, c->d_rgb, (uint8_t *)c->d_depth);
-    HIP_CHECK(hipEventRecord(c->ev_stage[slot], c->stream));
+    // only the depth image heads the frame; the RGB image is copied by filler workgroups of the first kernel (st_filter)
+    launch_copy_inputs(c->stream, dev_view, 0, dev_view + dep_off, ndep, c->d_rgb, (uint8_t *)c->d_depth);
+    c->ride_rgb_src = dev_view;
+    const int r = process_frame_resident(c, wmul);
+    HIP_CHECK(hipEventRecord(c->ev_stage[slot], c->stream));   // the slot is free once its readers are through
     c->stage_used[slot] = true;
     c->stage_head++;
-    return process_frame_resident(c, wmul);
+    return r;
 }
 
 extern "C" int hrbf_process_frame_device(hrbf_handle c, const void *d_rgb, const void *d_depth, int64_t ts, float wmul)

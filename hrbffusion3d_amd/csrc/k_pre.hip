@@ -87,11 +87,24 @@ int pre_probe_exp_scaling(hipStream_t s, unsigned long long *d_out2)
 // ---------------------------------------------------------------------------------------------
 // P1 + P2: bilateral (13x13) or gated Gaussian (9x9) on raw depth, plus both metric images.
 // LDS: (16+12)^2 raw depths as float-mm (value / adj precomputed once per texel).
+// ride: workgroup rows beyond the tile grid copy `ride.bytes` bytes from `ride.src` to `ride.dst` and leave — the RGB half of
+// the host-pointer entry's upload (0.9 MB read over PCIe, 23 us), which nothing needs before the curvature kernel, hidden
+// behind this kernel's arithmetic instead of heading the frame (the depth half must be there first and stays in front)
+struct RideCopy { const uint8_t *src; uint8_t *dst; size_t bytes; };
 template <bool BILATERAL>
 __global__ __launch_bounds__(256) void k_filter_metric(Cam cam, const uint16_t *__restrict__ raw,
                                                        float *__restrict__ filtered, float *__restrict__ metric,
-                                                       float *__restrict__ metric_f, float depthFactor, float maxD)
+                                                       float *__restrict__ metric_f, float depthFactor, float maxD,
+                                                       RideCopy ride)
 {
+    const int tiles_y = (cam.H + TB - 1) / TB;
+    if ((int)blockIdx.y >= tiles_y) {
+        const size_t t = ((size_t)(blockIdx.y - tiles_y) * gridDim.x + blockIdx.x) * (TB * TB) + threadIdx.y * TB + threadIdx.x;
+        const size_t nt = (size_t)(gridDim.y - tiles_y) * gridDim.x * (TB * TB), nv = ride.bytes / 16;
+        for (size_t i = t; i < nv; i += nt) reinterpret_cast<uint4 *>(ride.dst)[i] = reinterpret_cast<const uint4 *>(ride.src)[i];
+        for (size_t i = nv * 16 + t; i < ride.bytes; i += nt) ride.dst[i] = ride.src[i];
+        return;
+    }
     constexpr int R = BILATERAL ? 6 : 4;
     constexpr int TW = TB + 2 * R;
     __shared__ float tile[TW * TW];
@@ -669,13 +682,16 @@ __global__ void k_confidence(Cam cam, const float *__restrict__ gradmag, float *
 static inline dim3 grid2d(const Cam &c) { return dim3((c.W + TB - 1) / TB, (c.H + TB - 1) / TB); }
 
 void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, float *filtered, float *metric,
-                          float *metric_f, float depthFactor, float maxD, int bilateral)
+                          float *metric_f, float depthFactor, float maxD, int bilateral, const uint8_t *ride_src,
+                          uint8_t *ride_dst, size_t ride_bytes)
 {
-    dim3 b(TB, TB);
+    dim3 b(TB, TB), g = grid2d(cam);
+    RideCopy ride = {ride_src, ride_dst, ride_src ? ride_bytes : 0};
+    if (ride.bytes) g.y += (unsigned)((ride.bytes / 16 + (size_t)g.x * TB * TB - 1) / ((size_t)g.x * TB * TB));   // one 16-byte word per lane
     if (bilateral)
-        hipLaunchKernelGGL(k_filter_metric<true>, grid2d(cam), b, 0, s, cam, raw, filtered, metric, metric_f, depthFactor, maxD);
+        hipLaunchKernelGGL(k_filter_metric<true>, g, b, 0, s, cam, raw, filtered, metric, metric_f, depthFactor, maxD, ride);
     else
-        hipLaunchKernelGGL(k_filter_metric<false>, grid2d(cam), b, 0, s, cam, raw, filtered, metric, metric_f, depthFactor, maxD);
+        hipLaunchKernelGGL(k_filter_metric<false>, g, b, 0, s, cam, raw, filtered, metric, metric_f, depthFactor, maxD, ride);
 }
 void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm, const float *dmf, float4 *vr,
                                  float4 *vf, float4 *n, float4 *npca, float *radius, float radius_mult, int use_pca)

@@ -33,7 +33,8 @@ struct PoseLog {
 
 // ---- k_pre.hip
 void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, float *filtered, float *metric,
-                          float *metric_f, float depthFactor, float maxD, int bilateral);
+                          float *metric_f, float depthFactor, float maxD, int bilateral, const uint8_t *ride_src = nullptr,
+                          uint8_t *ride_dst = nullptr, size_t ride_bytes = 0);   // ride: a copy hidden behind the kernel (see k_filter_metric)
 void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm, const float *dmf, float4 *vr,
                                  float4 *vf, float4 *n, float4 *npca, float *radius, float radius_mult, int use_pca);
 void launch_curvature(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
