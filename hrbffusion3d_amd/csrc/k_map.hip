@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
             if (h.z > maxDepth || h.z < 0.0f) continue;
             float u = ((cam.fx * h.x) / h.z) + cam.cx;
             float v = ((cam.fy * h.y) / h.z) + cam.cy;
-            if (!(u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H)) continue;
+            // viewport transform + snap to the 1/256-pixel grid, as the GL rasteriser places the point (hrbf_detmath.h)
+            int clip_u, clip_v;
+            u = hd_gl_point_window_coord(u, (float)cam.W, &clip_u);
+            v = hd_gl_point_window_coord(v, (float)cam.H, &clip_v);
+            if (clip_u || clip_v || !(u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H)) continue;
             int ix = (int)hd_floorf(u), iy = (int)hd_floorf(v);
             unsigned long long key = ((unsigned long long)hd_f2u(h.z) << 32) | (unsigned long long)(off + s);
             unsigned long long *cell = &zbuf[iy * cam.W + ix];
@@ -194,8 +198,10 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
 {
     const int P = cam.W * cam.H;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;   // P is a multiple of 64: whole waves leave
-    unsigned long long key = zbuf[i];
+    // P is a multiple of 64 (W, H multiples of 8) but not always of 256: a wave past the end is dead as a whole.  It must not
+    // return — the record packing below has workgroup barriers and sums one count per wave
+    const bool live = i < P;
+    unsigned long long key = live ? zbuf[i] : ZB_EMPTY;
     const Rigid tinv = dp->tinv;
     const float4 z4 = make_float4(0, 0, 0, 0);
     uint32_t sg = 0u, s = 0u;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
         s = sg - shard_offset(sh);
         owned = s < sh.counts[sh.k];   // else the winner lives on another shard: contribute zeros to the sum-reduction
     }
-    if (dense) idx[i] = sg;
+    if (dense && live) idx[i] = sg;
     float4 o_vc = z4, o_nr = z4, o_ct = z4, o_c1 = z4, o_c2 = z4, o_clean = z4;
     bool updated = false;
     if (owned) {
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
             }
         }
     }
-    if (dense) {
+    if (dense && live) {
         if (what & RESOLVE_GEOM) { vertconf[i] = o_vc; normrad[i] = o_nr; }
         if (what & RESOLVE_ATTR) { colortime[i] = o_ct; curvmax[i] = o_c1; curvmin[i] = o_c2; }
         if (what & RESOLVE_CLEAN) {

@@ -47,6 +47,25 @@ HD_FN float hd_sqrtf(float a) { return __builtin_sqrtf(a); }
 HD_FN double hd_sqrt(double a) { return __builtin_sqrt(a); }
 HD_FN float hd_fabsf(float a) { return __builtin_fabsf(a); }
 HD_FN float hd_floorf(float a) { return __builtin_floorf(a); }
+
+/* Where the GL rasteriser places a 1-pixel point (IndexMap::predictIndices, index_map.vert:57-60): the shader emits the
+ * normalised device coordinate (u - extent/2) / (extent/2); the fixed-function viewport transform maps it back to a
+ * window coordinate, which is snapped to the sub-pixel grid (GL_SUBPIXEL_BITS = 8 on NVIDIA hardware and on Mesa,
+ * round half up) before the point is rasterised; the fragment is the pixel that contains the snapped centre.  Executing
+ * the reference's shaders on Mesa llvmpipe (oracle/ref_glsl) reproduces exactly this rule: 0 index-map mismatches on
+ * 124 116 drawn surfels, against 991 for floor(u).  It matters most when the camera has not moved: the reference's
+ * vertices sit on integer pixel coordinates (depth_vertex_normal_radius.frag:25-29), i.e. exactly on pixel corners,
+ * and only the snap puts each back on its own pixel.
+ * Returns the snapped window coordinate; *clipped != 0 when the point's centre is outside the view volume in this
+ * axis (-1 <= ndc <= 1, points are clipped by their centre). */
+HD_FN float hd_gl_point_window_coord(float u, float extent, int *clipped)
+{
+    const float half = extent * 0.5f;
+    const float ndc = (u - half) / half;
+    *clipped = !(ndc >= -1.0f && ndc <= 1.0f);
+    const float w = ndc * half + half;
+    return hd_floorf(w * 256.0f + 0.5f) * (1.0f / 256.0f);
+}
 HD_FN int hd_isnanf(float a) { return a != a; }
 HD_FN float hd_nanf(void) { return hd_u2f(0x7fffffffu); }
 

@@ -4,8 +4,9 @@
  * IndexMap::predictIndices (Core/src/IndexMap.cpp:193-267) and their shaders.
  *
  * GL rasterisation semantics fixed by this restatement:
- *  - a 1-px GL point at window coordinate (u,v) lands on pixel (floor(u), floor(v)) and is clipped
- *    unless 0 <= u < W, 0 <= v < H;
+ *  - a 1-px GL point lands on the pixel that contains its window coordinate after the viewport transform and the snap to
+ *    the 1/256-pixel grid (hd_gl_point_window_coord, include/hrbf_detmath.h — the rule llvmpipe executes and NVIDIA's
+ *    GL_SUBPIXEL_BITS = 8 implies); it is clipped when its centre leaves the view volume;
  *  - GL_LESS z-test: smallest camera-space z wins, ties go to the lower surfel index (draw order);
  *    the reference's 24-bit depth quantisation is not modelled;
  *  - the 4596^2 scatter target of fuse stage 1 is "first primitive in draw order wins"
@@ -79,7 +80,10 @@ void orc_predict_indices(orc_ctx *c)
         if (h.z > maxDepth || h.z < 0.0f) continue;
         float u = ((fx * h.x) / h.z) + cx;
         float v = ((fy * h.y) / h.z) + cy;
-        if (!(u >= 0.0f && u < (float)W && v >= 0.0f && v < (float)H)) continue;
+        int clip_u, clip_v;
+        u = hd_gl_point_window_coord(u, (float)W, &clip_u);
+        v = hd_gl_point_window_coord(v, (float)H, &clip_v);
+        if (clip_u || clip_v || !(u >= 0.0f && u < (float)W && v >= 0.0f && v < (float)H)) continue;
         int ix = (int)floorf(u), iy = (int)floorf(v);
         int pi = iy * W + ix;
         if (win[pi] < 0 || h.z < zbuf[pi]) { zbuf[pi] = h.z; win[pi] = s; }

@@ -1,0 +1,217 @@
+"""Generates tests/golden/ref_glsl/*.npz: outputs of the REFERENCE'S OWN GLSL SHADERS, executed.
+
+Runs only in the build container (needs /root/reference and Mesa's llvmpipe): oracle/ref_glsl/refgl.py loads the shader
+text from /root/reference/Core/src/Shaders at run time, compiles it with Mesa's GLSL compiler and drives it with the GL
+calls the reference's host code makes.  The fixtures are data: per pass, the inputs that were bound and the images /
+surfel buffers the shaders wrote.  tests/test_ref_glsl.py feeds the same inputs to the C oracle (CPU suite) and to the
+HIP library (GPU suite) and compares.
+
+    python tests/golden/make_ref_glsl.py            # writes the fixtures
+    python tests/golden/make_ref_glsl.py --check    # also prints an oracle-vs-reference report per pass
+
+Scenes are power-of-two sized (256 x 128 and 128 x 128).  There every texture coordinate, loop bound and half-pixel step of the
+shaders is exact in fp32, so the passes have no implementation-defined sampling (DESIGN.md §8 lists what is
+implementation-defined at 640 x 480 and how the two executions differ there).
+  pair    : a 256 x 128 window of the reference's GPUTest pair (frame 1 seeds the map, frame 2 is fused), the camera
+            pose of frame 2 from the oracle's own registration of the two crops (an input here: registration is CUDA)
+  sphere  : an analytic scene (sphere on a slanted plane) under fx != fy and an off-centre principal point, second view
+            from a different pose
+"""
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from hrbffusion3d_amd.params import default_params  # noqa: E402
+
+OUT = os.path.join(HERE, "ref_glsl")
+X0, Y0 = 256, 224          # window of the 640 x 480 GPUTest frames
+# scene -> (W, H, fx, fy, cx, cy)
+GEOM = {"pair": (256, 128, 528.0, 528.0, 320.0 - X0, 240.0 - Y0),
+        "sphere": (128, 128, 150.0, 170.0, 60.3, 66.9)}    # fx != fy, off-centre principal point
+
+
+def params(scene, **kw):
+    W, H, fx, fy, cx, cy = GEOM[scene]
+    return default_params(width=W, height=H, fx=fx, fy=fy, cx=cx, cy=cy, max_surfels=1 << 17, **kw)
+
+
+def crop(name):
+    W, H = GEOM["pair"][:2]
+    return np.ascontiguousarray(np.array(Image.open(os.path.join(HERE, name + ".png")))[Y0:Y0 + H, X0:X0 + W])
+
+
+def scene_pair():
+    from oracle_lib import Oracle
+    f1, f2 = (crop("1c"), crop("1d")), (crop("2c"), crop("2d"))
+    o = Oracle(params("pair"), omp=True)
+    o.process_frame(*f1); o.process_frame(*f2)
+    T2, w2 = o.get_pose(), o.get_weighting()
+    o.close()
+    return f1, f2, T2.astype(np.float32), float(w2)
+
+
+def scene_sphere():
+    import scenes
+    W, H, FX, FY, CX, CY = GEOM["sphere"]
+
+    def view(T):
+        # depth of a sphere in front of a slanted plane, rendered for camera pose T (camera-to-world)
+        Tinv = np.linalg.inv(T)
+        c = (Tinv @ np.array([0.05, 0.02, 1.3, 1.0]))[:3]
+        n = Tinv[:3, :3] @ np.array([0.25, -0.15, 1.0]); n /= np.linalg.norm(n)
+        d0 = 1.9 * n[2] + n @ (Tinv[:3, 3] * 0)   # plane through (0,0,1.9)-ish in this view
+        zs = scenes.sphere_depth(W, H, FX, FY, CX, CY, c, 0.35)
+        zp = scenes.plane_depth(W, H, FX, FY, CX, CY, n, d0)
+        z = np.where(zs > 0, zs, zp)
+        # sensor-like noise: without it the reprojected grid of frame 1 lines up with frame 2's rays along whole columns
+        # and the association's `dist < bestDist` is decided between exactly equidistant candidates
+        z = z + rng.normal(0.0, 0.0006, z.shape) * (z > 0)
+        return scenes.gray_rgb(W, H, seed=3), scenes.to_u16(z)
+    rng = np.random.default_rng(5)
+    T1 = np.eye(4)
+    T2 = np.eye(4); T2[:3, 3] = [0.006, -0.004, 0.005]
+    a = 0.004; T2[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    return view(T1), view(T2), T2.astype(np.float32), 0.8
+
+
+def run_reference(scene, f1, f2, T2, w2, prm_over=None):
+    """the reference's GL passes in processFrame order (HRBFFusion.cpp:991-1260) for two frames; returns {name: array}"""
+    from ref_glsl import refgl
+    W, H, FX, FY, CX, CY = GEOM[scene]
+    p = refgl.RefPipeline(W, H, FX, FY, CX, CY, 1.0 / 5000.0, prm=prm_over, tex_dim=512, max_surfels=1 << 17)
+    out = {}
+    I4 = np.eye(4, dtype=np.float32)
+
+    def pre(tag, rgb, depth):
+        p.upload_frame(rgb, depth)
+        out[tag + "rgb"], out[tag + "depth"] = rgb, depth
+        p.filter_depth(); out[tag + "DEPTH_FILTERED"] = p.get("DEPTH_FILTERED")
+        p.metricise_depth()
+        out[tag + "DEPTH_METRIC"], out[tag + "DEPTH_METRIC_FILTERED"] = p.get("DEPTH_METRIC"), p.get("DEPTH_METRIC_FILTERED")
+        p.compute_vertex_normal_radius()
+        for n in ("VERTEX_RAW", "VERTEX_FILTERED", "RADIUS"):
+            out[tag + n] = p.get(n)
+        out[tag + "NORMAL_P3"] = p.get("NORMAL")                       # NORMAL after computeVertexNormalRadius
+        p.compute_curvature_gradient()
+        out[tag + "CURV1"], out[tag + "CURV2"] = p.get("PRINCIPAL_CURV1"), p.get("PRINCIPAL_CURV2")
+        out[tag + "GRADIENT_MAG"] = p.get("GRADIENT_MAG")
+        p.update_normal_rad(); out[tag + "NORMAL"] = p.get("NORMAL")   # NORMAL after updateNormalRad
+
+    def predict(tag, pose, tick, weighting):
+        p.predict_indices(pose, tick)
+        for k, v in p.index_images().items():
+            out[tag + "p_" + k] = v
+        p.predict_hrbf()
+        for k, v in p.prediction_images().items():
+            out[tag + k] = v
+        p.fill_in(tick, weighting)
+        for k, v in p.fill_images().items():
+            out[tag + k] = v
+
+    # frame 1 (tick 1): pre-processing, initialise.  Only the frame and the map it seeds are kept (the passes are compared
+    # on frame 2); its prediction at the identity pose is the degenerate raster case (every surfel exactly on a pixel
+    # corner) and is not recorded.
+    pre("f1_", *f1)
+    for k in [k for k in out if k.startswith("f1_") and k not in ("f1_rgb", "f1_depth")]:
+        del out[k]
+    p.initialise(I4); out["f1_map"] = p.download_map()
+    # frame 2 (tick 2) at pose T2
+    pre("f2_", *f2)
+    p.vertex_confidence(w2); out["f2_CONFIDENCE"] = p.get("CONFIDENCE")
+    out["f2_pose"], out["f2_weighting"] = T2, np.float32(w2)
+    def map_flow(tag, map_in):
+        """predictIndices, fuse, predictIndices, clean on `map_in` with frame 2 bound (HRBFFusion.cpp:1186-1228)"""
+        p.upload_map(map_in)
+        p.predict_indices(T2, 2)
+        for k, v in p.index_images().items():
+            if k in ("INDEX", "INDEX_VERTCONF", "INDEX_NORMRAD"):          # what data.vert reads of the index map
+                out[tag + "a_" + k] = v
+        p.fuse(T2, 2, w2)
+        rec = out[tag + "records"] = p.fuse_records()                      # stage 1: merge marks and new surfels
+        fused = p.download_map()                                           # stage 2: only merged surfels change
+        ch = np.nonzero((fused.view(np.uint32) != map_in.view(np.uint32)).any(1))[0]
+        out[tag + "fused_rows"], out[tag + "fused_vals"] = ch.astype(np.uint32), fused[ch]
+        p.predict_indices(T2, 2)
+        out[tag + "c_INDEX"] = p.index_images()["INDEX"]                   # index map the clean pass reads (ids only)
+        p.clean(T2, 2)
+        final = p.download_map()
+        # the clean pass copies: survivors of the fused map in order, then the new surfels among the records in order, their
+        # time stamp set.  Stored as that structure (keep mask, record picks) and checked to reproduce the buffer bit for bit.
+        fb, ob = fused.view(np.uint32), final.view(np.uint32)
+        keep = np.zeros(fused.shape[0], bool)
+        j = 0
+        for i in range(fused.shape[0]):
+            if j < final.shape[0] and np.array_equal(fb[i], ob[j]):
+                keep[i] = True; j += 1
+        picks = []
+        rec_new = rec.copy(); rec_new[rec_new[:, 7] == -2.0, 7] = 2.0      # vColor.w = time (copy_unstable.vert:152-155)
+        rn = rec_new.view(np.uint32)
+        for i in range(rec_new.shape[0]):
+            if j < final.shape[0] and rec[i, 7] == -2.0 and np.array_equal(rn[i], ob[j]):
+                picks.append(i); j += 1
+        assert j == final.shape[0], (j, final.shape)
+        out[tag + "keep"] = np.packbits(keep); out[tag + "new_picks"] = np.array(picks, np.uint32)
+        out[tag + "map_count"] = np.array([final.shape[0]], np.uint32)
+        return final
+
+    # (1) the plain second frame: young map (confidence ~1), nothing is removed, new surfels are appended
+    map_flow("f2_", out["f1_map"])
+    # (2) a map that has been observed for a while (confidence + 6: stable), plus surfels the clean pass must remove:
+    #     floating outliers 4 cm in front of the surface (free-space violation, copy_unstable.vert:124-134), newer duplicates
+    #     2 mm in front of stable older surfels (:112-122) and long-unseen unstable surfels (:158-161)
+    m = out["f1_map"].copy()
+    m[:, 3] += 6.0
+    rng = np.random.default_rng(11)
+    Tinv = np.linalg.inv(T2.astype(np.float64))
+    cam = Tinv[:3, :3] @ m[:, 0:3].T.astype(np.float64) + Tinv[:3, 3:4]
+    rays = (cam / np.linalg.norm(cam, axis=0)).T                           # unit view rays in the camera frame
+    R = T2[:3, :3].astype(np.float64)
+
+    def shifted(sel, dist, init_time):
+        x = m[sel].copy()
+        x[:, 0:3] -= (dist * (R @ rays[sel].T).T).astype(np.float32)       # towards the camera
+        x[:, 8:11] = (-(R @ rays[sel].T).T).astype(np.float32)             # facing it (|n_z| > 0.85 in the camera frame)
+        x[:, 6] = init_time
+        return x
+    n0 = m.shape[0]
+    sel = rng.permutation(n0)
+    extra = np.concatenate([shifted(sel[:400], 0.04, 1.0), shifted(sel[400:800], 0.002, 2.0)])
+    old = sel[800:1000]
+    m[old, 3] = 1.0; m[old, 7] = -250.0                                   # unstable and not seen for > 200 frames
+    out["x_extra"], out["x_old"] = extra, old.astype(np.uint32)           # x_map = stable_map(f1_map, x_old) ++ x_extra
+    x_map = np.concatenate([m, extra])
+    final = map_flow("x_", x_map)
+    p.upload_map(final)
+    predict("x_", T2, 2, w2)
+    # updateModel on the final map: one correction per submap id (only submap 0 exists)
+    D = np.eye(4, dtype=np.float32)
+    a = 0.01
+    D[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    D[:3, 3] = [0.01, -0.02, 0.005]
+    p.update_model([D]); out["x_delta"] = D; out["x_map_updated_head"] = p.download_map()[:4096]
+    # initialise from frame 2's images at pose T2 (GlobalModel::initialise takes any init_pose)
+    p.initialise(T2)
+    im = p.download_map()
+    out["f2_init_count"], out["f2_init_head"] = np.array([im.shape[0]], np.uint32), im[:4096]
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, scene in (("pair", scene_pair), ("sphere", scene_sphere)):
+        f1, f2, T2, w2 = scene()
+        out = run_reference(name, f1, f2, T2, w2)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "surfels:", out["f1_map"].shape[0], "->",
+              int(out["f2_map_count"][0]), "records:", out["f2_records"].shape[0], "| stable map + outliers:", out["f1_map"].shape[0] + out["x_extra"].shape[0], "->",
+              int(out["x_map_count"][0]), "predicted pixels:", int((out["x_PRED_VERTEX"][..., 2] != 0).sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,307 @@
+"""Shared by tests/test_ref_glsl.py (CPU: the C oracle; GPU: the HIP library): runs one implementation through the passes
+recorded in tests/golden/ref_glsl/<scene>.npz — outputs of the reference's own GLSL shaders executed on llvmpipe
+(tests/golden/make_ref_glsl.py) — on the inputs the shaders had bound, and compares.
+
+`impl` is an object with the stage API both implementations share (tests/oracle_lib.Oracle, hrbffusion3d_amd.api.HRBFFusion):
+upload_frame, set_image / get_image, run_stage, upload_map / download_map, set_pose, set_tick, set_weighting, update_model.
+
+Tolerances are in units in the last place of the fp32 result ("ulp"), per output, and stated where they are used.  Why
+they are not zero: the shaders' exp / sqrt / inversesqrt / acos / division are llvmpipe's (polynomial exp2, rsqrt-based
+normalize, a * rcp(b)), the oracle's and the kernels' are hrbf_detmath.h's; everything else is IEEE and agrees bit for bit.
+Discrete results — which pixels are valid, which surfel wins a pixel, which surfels merge / are created / are removed, the
+order of the map — are compared exactly, except at the few stated tie pixels.
+"""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glsl")
+
+
+def load(scene):
+    return dict(np.load(os.path.join(GOLD, scene + ".npz")))
+
+
+def ulp_diff(a, b):
+    """distance in representable fp32 values between a and b (elementwise); NaN vs NaN = 0, NaN vs number = 2^31"""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    ai = a.view(np.int32).astype(np.int64); bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai); bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    d = np.abs(ai - bi)
+    na, nb = np.isnan(a), np.isnan(b)
+    d[na & nb] = 0
+    d[na ^ nb] = 1 << 31
+    return d
+
+
+class Report:
+    """collects (pass, output, statistic) rows; `strict` raises on the first violated bound"""
+
+    def __init__(self, strict=True, verbose=False):
+        self.rows, self.strict, self.verbose = [], strict, verbose
+
+    def add(self, what, ok, detail):
+        self.rows.append((what, bool(ok), detail))
+        if self.verbose:
+            print("%-44s %s  %s" % (what, "ok  " if ok else "FAIL", detail))
+        if self.strict and not ok:
+            raise AssertionError("%s: %s" % (what, detail))
+
+    def close_ulp(self, what, got, ref, max_ulp, frac_within=1.0, abs_floor=0.0, mask=None):
+        """every element within max_ulp of the reference (or |difference| <= abs_floor, for results of cancelling sums
+        whose magnitude is far below their terms'); frac_within < 1 allows that share of outliers (stated by the caller)"""
+        got = np.asarray(got, np.float32); ref = np.asarray(ref, np.float32)
+        d = ulp_diff(got, ref)
+        with np.errstate(invalid="ignore"):
+            small = np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= abs_floor
+        good = (d <= max_ulp) | small
+        if mask is not None:
+            good = good | ~mask
+        share = float(good.mean()) if good.size else 1.0
+        self.add(what, share >= frac_within, "within %d ulp: %.5f%% (need %.3f%%), worst %d ulp" % (
+            max_ulp, 100 * share, 100 * frac_within, int(d[mask].max() if mask is not None and mask.any() else d.max() if d.size else 0)))
+
+    def exact(self, what, got, ref):
+        got = np.ascontiguousarray(got); ref = np.ascontiguousarray(ref)
+        if got.dtype == np.float32:
+            n = int((ulp_diff(got, ref) != 0).sum())
+        else:
+            n = int((got != ref).sum())
+        self.add(what, n == 0, "%d of %d differ" % (n, got.size))
+
+
+def run(impl, fx, rep, has_records=False):
+    g, P = impl, "f2_"
+    rgb, depth = fx[P + "rgb"], fx[P + "depth"]
+    T2, w2 = fx[P + "pose"], float(fx[P + "weighting"])
+
+    # ---- P1 filterDepth (depth_bilateral.frag): 169 exp per pixel, normalised sum --------------------------------
+    g.upload_frame(rgb, depth)
+    g.run_stage("FILTER_DEPTH")
+    ref = fx[P + "DEPTH_FILTERED"]
+    got = g.get_image("DEPTH_FILTERED")
+    rep.exact("P1 which pixels are filtered", got == 0, ref == 0)
+    rep.close_ulp("P1 DEPTH_FILTERED", got, ref, 16)
+    # ---- P2 metriciseDepth -----------------------------------------------------------------------------------------
+    g.set_image("DEPTH_FILTERED", ref)
+    g.run_stage("METRICISE")
+    rep.exact("P2 DEPTH_METRIC", g.get_image("DEPTH_METRIC"), fx[P + "DEPTH_METRIC"])
+    rep.exact("P2 DEPTH_METRIC_FILTERED", g.get_image("DEPTH_METRIC_FILTERED"), fx[P + "DEPTH_METRIC_FILTERED"])
+    # ---- P3 computeVertexNormalRadius ---------------------------------------------------------------------------------
+    g.run_stage("VERTEX_NORMAL_RADIUS")
+    vr, vf = g.get_image("VERTEX_RAW"), g.get_image("VERTEX_FILTERED")
+    rep.exact("P3 VERTEX_RAW xyz", vr[..., :3], fx[P + "VERTEX_RAW"][..., :3])
+    rep.close_ulp("P3 VERTEX_RAW w (radial confidence, exp)", vr[..., 3], fx[P + "VERTEX_RAW"][..., 3], 16)
+    rep.exact("P3 VERTEX_FILTERED", vf, fx[P + "VERTEX_FILTERED"])
+    n3 = g.get_image("NORMAL")
+    rep.exact("P3 which pixels have a normal", (n3[..., :3] == 0).all(-1), (fx[P + "NORMAL_P3"][..., :3] == 0).all(-1))
+    # PCA normal: eigen-solve of a covariance formed by cancellation (geometry.glsl:176-193), atan2/cos/sin inside
+    rep.close_ulp("P3 NORMAL (PCA) xyz", n3[..., :3], fx[P + "NORMAL_P3"][..., :3], 64, abs_floor=2e-6)
+    rep.close_ulp("P3 NORMAL w = RADIUS", n3[..., 3], fx[P + "NORMAL_P3"][..., 3], 64)
+    rep.close_ulp("P3 RADIUS", g.get_image("RADIUS"), fx[P + "RADIUS"], 64)
+    # ---- P4 + P5 computeCurvatureGradient, updateNormalRad -----------------------------------------------------------
+    g.set_image("NORMAL", fx[P + "NORMAL_P3"])
+    g.run_stage("CURVATURE")
+    gm, gmr = g.get_image("GRADIENT_MAG"), fx[P + "GRADIENT_MAG"]
+    rep.exact("P4 which pixels have > 15 neighbours", gm == 0, gmr == 0)
+    # sums of <= 49 Hessian terms with mixed signs: a few hundred ulp of the result where terms cancel
+    rep.close_ulp("P4 GRADIENT_MAG", gm, gmr, 1024, abs_floor=1e-3)
+    no, nor = g.get_image("NORMAL"), fx[P + "NORMAL"]
+    rep.close_ulp("P5 NORMAL (HRBF gradient direction)", no[..., :3], nor[..., :3], 64, abs_floor=4e-6)
+    rep.exact("P5 NORMAL w (radius carried over)", no[..., 3], nor[..., 3])
+    for name in ("CURV1", "CURV2"):
+        c, cr = g.get_image(name), fx[P + name]
+        rep.exact("P4 %s which pixels are the 1000-sentinel" % name, c[..., 3] == 1000.0, cr[..., 3] == 1000.0)
+        curvature_checks(rep, name, c, cr)
+    # ---- P5 VertexConfidence -------------------------------------------------------------------------------------------
+    for name in ("CURV1", "CURV2", "GRADIENT_MAG", "NORMAL"):
+        g.set_image(name, fx[P + name])
+    g.set_weighting(w2)
+    g.run_stage("CONFIDENCE")
+    rep.close_ulp("P5 CONFIDENCE", g.get_image("CONFIDENCE"), fx[P + "CONFIDENCE"], 16)
+    g.set_image("CONFIDENCE", fx[P + "CONFIDENCE"])
+    g.set_image("NORMAL_PCA", fx[P + "NORMAL_P3"])
+
+    # ---- F4 initialise (init_unstableTex.*) from frame 2's images at pose T2 -----------------------------------------------
+    g.set_image("VERTEX_RAW", fx[P + "VERTEX_RAW"])
+    g.set_pose(T2)
+    g.run_stage("INITIALISE")
+    im = g.download_map()
+    rep.add("F4 surfel count", im.shape[0] == int(fx[P + "init_count"][0]), "%d vs reference %d" % (im.shape[0], int(fx[P + "init_count"][0])))
+    ih = fx[P + "init_head"]
+    rep.close_ulp("F4 position", im[:4096, 0:3], ih[:, 0:3], 4, abs_floor=1e-7)
+    rep.close_ulp("F4 confidence (exp)", im[:4096, 3], ih[:, 3], 16)
+    rep.exact("F4 colour / submap / init time / time", im[:4096, 4:8], ih[:, 4:8])
+    rep.close_ulp("F4 normal + radius", im[:4096, 8:12], ih[:, 8:12], 4, abs_floor=1e-7)
+    rep.exact("F4 curvature records", im[:4096, 12:20], ih[:, 12:20])
+
+    # ---- (1) the plain second frame on the young map of frame 1 --------------------------------------------------------------
+    m1 = fx["f1_map"]
+    map_flow(rep, g, fx, "f2_", "young map: ", m1, T2)
+    # ---- (2) a stable map + surfels that must be removed -------------------------------------------------------------------------
+    m = m1.copy(); m[:, 3] += 6.0
+    old = fx["x_old"]; m[old, 3] = 1.0; m[old, 7] = -250.0
+    xm = np.concatenate([m, fx["x_extra"]])
+    ref_final = map_flow(rep, g, fx, "x_", "stable map + outliers: ", xm, T2)
+    # ---- M1 + H2 predictHRBF, H3 fill-in on the reference's map ----------------------------------------------------------
+    g.upload_map(ref_final)
+    g.set_pose(T2); g.set_tick(2)
+    g.run_stage("PREDICT_INDICES")
+    index_checks(rep, "M1 (prediction)", g, fx, "x_p_", full=True)
+    for k in ("INDEX", "INDEX_VERTCONF", "INDEX_COLORTIME", "INDEX_NORMRAD", "INDEX_CURVMAX", "INDEX_CURVMIN"):
+        g.set_image(k, fx["x_p_" + k])
+    g.run_stage("PREDICT_HRBF")
+    prediction_checks(rep, g, fx, "x_")
+    for k in ("PRED_IMAGE", "PRED_VERTEX", "PRED_NORMAL", "PRED_CURV1", "PRED_CURV2", "PRED_ICPWEIGHT"):
+        g.set_image(k, fx["x_" + k])
+    g.set_image("VERTEX_FILTERED", fx[P + "VERTEX_FILTERED"])
+    g.run_stage("FILLIN")
+    fill_checks(rep, g, fx, "x_")
+    # ---- f-3 updateModel ----------------------------------------------------------------------------------------------------
+    g.upload_map(ref_final)
+    g.update_model([fx["x_delta"]])
+    um, umr = g.download_map()[:4096], fx["x_map_updated_head"]
+    rep.close_ulp("f-3 updateModel positions", um[:, 0:3], umr[:, 0:3], 4)
+    rep.close_ulp("f-3 updateModel normals", um[:, 8:11], umr[:, 8:11], 4, abs_floor=1e-7)
+    rep.exact("f-3 updateModel everything else", np.delete(um, [0, 1, 2, 8, 9, 10], 1), np.delete(umr, [0, 1, 2, 8, 9, 10], 1))
+    return rep
+
+
+def map_flow(rep, g, fx, pre, tag, map_in, T2):
+    """predictIndices -> fuse -> predictIndices -> clean on `map_in` with frame 2's images set; returns the reference's final map"""
+    g.upload_map(map_in)
+    g.set_pose(T2); g.set_tick(2)
+    g.run_stage("PREDICT_INDICES")
+    index_checks(rep, tag + "M1", g, fx, pre + "a_", full=False)
+    for k in ("INDEX", "INDEX_VERTCONF", "INDEX_NORMRAD"):
+        g.set_image(k, fx[pre + "a_" + k])
+    g.run_stage("FUSE")
+    rec = fx[pre + "records"]
+    st = g.fuse_stats()
+    rep.add(tag + "F1 records", True, "stats %s; reference: %d merge marks, %d new" % (
+        st.tolist(), int((rec[:, 7] == -1).sum()), int((rec[:, 7] == -2).sum())))
+    fused = g.download_map()
+    rows, vals = fx[pre + "fused_rows"], fx[pre + "fused_vals"]
+    ch = np.nonzero((ulp_diff(fused, map_in) != 0).any(1))[0]
+    # Association ties: a candidate whose normal is parallel to the new point's to within ~2e-4 rad has cos = 1 to within an ulp;
+    # acos of 1 + ulp is NaN and rejects it (data.vert:150-152 through utils.glsl angleBetween) — which of 1 and 1 + ulp comes out
+    # depends on the last bit of the division, so two executions can associate such a pixel with different neighbours (or none).
+    ties = max(2, rows.size // 400)
+    odd = np.setxor1d(ch, rows)
+    rep.add(tag + "F1/F2 which surfels were merged into (%d)" % rows.size, odd.size <= 2 * ties,
+            "%d surfels merged in one execution only (acos-domain ties; allowed %d)" % (odd.size, 2 * ties))
+    common = np.isin(rows, ch)
+    gv, rv = fused[rows[common]], vals[common]
+    same_rec = (ulp_diff(gv[:, 4:8], rv[:, 4:8]) == 0).all(1) & (ulp_diff(gv[:, 3], rv[:, 3]) <= 8)   # merged with the same record
+    rep.add(tag + "F2 surfels merged with another record", int((~same_rec).sum()) <= 2 * ties, "%d" % int((~same_rec).sum()))
+    gv, rv = gv[same_rec], rv[same_rec]
+    rep.close_ulp(tag + "F2 merged position + confidence", gv[:, 0:4], rv[:, 0:4], 8)
+    rep.close_ulp(tag + "F2 merged normal + radius", gv[:, 8:12], rv[:, 8:12], 16, abs_floor=1e-6)
+    rep.close_ulp(tag + "F2 merged curvature records", gv[:, 12:20], rv[:, 12:20], 16, abs_floor=1e-5)
+    g.run_stage("PREDICT_INDICES")
+    ic = g.get_image("INDEX")
+    bad = int((ic != fx[pre + "c_INDEX"]).sum())
+    rep.add(tag + "M1 (after fuse) INDEX", bad <= max(2, ic.size // 5000) + 2 * odd.size, "%d of %d pixels differ (sub-pixel snap ties)" % (bad, ic.size))
+    g.run_stage("CLEAN")
+    ref_fused = map_in.copy(); ref_fused[rows] = vals
+    keep = np.unpackbits(fx[pre + "keep"])[:map_in.shape[0]].astype(bool)
+    new = rec[fx[pre + "new_picks"]].copy(); new[:, 7] = 2.0
+    ref_final = np.concatenate([ref_fused[keep], new])
+    assert ref_final.shape[0] == int(fx[pre + "map_count"][0])
+    final = g.download_map()
+    # align the two maps row by row: key = position to 10 um + init time; rows present in both must come in the same order
+    def keys(m):
+        q = np.rint(m[:, 0:3].astype(np.float64) * 1e5).astype(np.int64)
+        return [(int(a), int(b), int(c), float(t)) for (a, b, c), t in zip(q, m[:, 6])]
+    kr = {k: i for i, k in enumerate(keys(ref_final))}
+    pos = np.array([kr.get(k, -1) for k in keys(final)])
+    found = pos >= 0
+    unmatched = int((~found).sum()) + (ref_final.shape[0] - int(found.sum()))
+    # a tie can turn a merge into a new surfel (+1 row) and moves a merge from one surfel to a neighbour (2 rows whose position differs)
+    rep.add(tag + "F3 map after clean: rows", unmatched <= 4 * ties + 2 * odd.size, "%d rows vs reference %d (removed %d, appended %d); %d rows without partner" % (
+        final.shape[0], ref_final.shape[0], int((~keep).sum()), new.shape[0], unmatched))
+    rep.add(tag + "F3 map order", bool((np.diff(pos[found]) > 0).all()), "common rows in the same order")
+    a, b = final[found], ref_final[pos[found]]
+    rep.exact(tag + "F3 colour / submap / init time / time of every common row", a[:, 4:8], b[:, 4:8])
+    rep.close_ulp(tag + "F3 map positions + confidence", a[:, 0:4], b[:, 0:4], 16, frac_within=1.0 - (4.0 * ties + 1) / max(1, a.shape[0]))
+    rep.close_ulp(tag + "F3 map normals + radii", a[:, 8:12], b[:, 8:12], 64, abs_floor=2e-6, frac_within=1.0 - (4.0 * ties + 1) / max(1, a.shape[0]))
+    rep.close_ulp(tag + "F3 map curvature records", a[:, 12:20], b[:, 12:20], 64, abs_floor=1e-5, frac_within=1.0 - (8.0 * ties + 1) / max(1, a.shape[0]))
+    removed_ref = int((~keep).sum())
+    rep.add(tag + "F3 removals", abs((map_in.shape[0] + new.shape[0] - removed_ref) - final.shape[0]) <= 2 * ties,
+            "reference removed %d of %d, appended %d" % (removed_ref, map_in.shape[0], new.shape[0]))
+    return ref_final
+
+
+def curvature_checks(rep, name, c, cr):
+    """principal curvature k (w) and direction (xyz).  Second derivatives of the HRBF implicit: sums of third-derivative
+    terms of both signs divided by g_z^3 — conditioned far worse than the gradient.  Bounds: 99 % of the valid pixels within
+    1e-3 relative (+1e-3 absolute) on k; directions compared up to sign flips of near-degenerate (umbilic) pixels."""
+    valid = (cr[..., 3] != 1000.0) & (c[..., 3] != 1000.0) & np.isfinite(cr[..., 3]) & np.isfinite(c[..., 3])
+    k, kr = c[..., 3][valid].astype(np.float64), cr[..., 3][valid].astype(np.float64)
+    err = np.abs(k - kr) / (np.abs(kr) + 1.0)
+    share = float((err <= 1e-3).mean()) if err.size else 1.0
+    rep.add("P4 %s k" % name, share >= 0.99, "|dk| <= 1e-3 (|k| + 1): %.3f%% of %d valid pixels, median %.2e, p99 %.2e" % (
+        100 * share, err.size, np.median(err) if err.size else 0, np.percentile(err, 99) if err.size else 0))
+    d, dr = c[..., :3][valid].astype(np.float64), cr[..., :3][valid].astype(np.float64)
+    ok = np.isfinite(d).all(1) & np.isfinite(dr).all(1)
+    dev = np.linalg.norm(d[ok] - dr[ok], axis=1)
+    share = float((dev <= 1e-3).mean()) if dev.size else 1.0
+    rep.add("P4 %s direction" % name, share >= 0.97, "|d - d_ref| <= 1e-3: %.3f%% of %d, median %.2e" % (
+        100 * share, dev.size, np.median(dev) if dev.size else 0))
+    rep.add("P4 %s non-finite values" % name, True, "NaN/inf pattern differs in %d values" % int((np.isfinite(c) != np.isfinite(cr)).sum()))
+
+
+def index_checks(rep, tag, g, fx, pre, full):
+    idx, ref = g.get_image("INDEX"), fx[pre + "INDEX"]
+    bad = int((idx != ref).sum())
+    # a point whose window coordinate falls within an ulp of the middle of a 1/256-pixel snap interval can round either way
+    rep.add(tag + " INDEX (winning surfel per pixel)", bad <= max(2, idx.size // 5000), "%d of %d pixels differ (sub-pixel snap ties)" % (bad, idx.size))
+    same = idx == ref
+    if full:
+        for k in ("INDEX_COLORTIME", "INDEX_CURVMAX", "INDEX_CURVMIN"):
+            rep.exact(tag + " " + k, g.get_image(k)[same], fx[pre + k][same])
+    for k, tol in (("INDEX_VERTCONF", 8), ("INDEX_NORMRAD", 16)):
+        a, b = g.get_image(k), fx[pre + k]
+        rep.close_ulp(tag + " " + k, a[same], b[same], tol, abs_floor=1e-6)
+
+
+def prediction_checks(rep, g, fx, P):
+    """predict_hrbf.frag: ray march to a sign change of the implicit, then <= 10 bisection steps that stop when the bracket is
+    shorter than 1e-5 m or |f| < 1e-5 (predict_hrbf.frag:229-262).  An implicit value within rounding of 0 or of 1e-5 can fall
+    either side in two executions: the march may stop one sample apart or the bisection one iteration apart, which moves the
+    result by at most one bracket.  Hence absolute bounds set by the algorithm's own thresholds: every point within 4e-5 m
+    (typical: identical, 99 % within 1e-6 m), normals within 1e-2 (99 % within 2e-4)."""
+    v, vr = g.get_image("PRED_VERTEX"), fx[P + "PRED_VERTEX"]
+    hit, hitr = v[..., 2] != 0, vr[..., 2] != 0
+    d = int((hit != hitr).sum())
+    rep.add("H2 which pixels have a prediction", d <= max(2, hit.size // 2000), "%d of %d pixels differ (%d predicted)" % (d, hit.size, int(hitr.sum())))
+    both = hit & hitr
+    dp = np.linalg.norm((v[..., :3] - vr[..., :3]).astype(np.float64), axis=-1)[both]
+    rep.add("H2 PRED_VERTEX xyz", dp.max() <= 4e-5 and np.percentile(dp, 99) <= 1e-6, "|dp| max %.2e m, p99 %.2e, identical %.1f%%" % (
+        dp.max(), np.percentile(dp, 99), 100 * (dp == 0).mean()))
+    n, nr = g.get_image("PRED_NORMAL"), fx[P + "PRED_NORMAL"]
+    dn = np.linalg.norm((n[..., :3] - nr[..., :3]).astype(np.float64), axis=-1)[both]
+    rep.add("H2 PRED_NORMAL xyz", dn.max() <= 1e-2 and np.percentile(dn, 99) <= 2e-4, "|dn| max %.2e, p99 %.2e, median %.2e" % (
+        dn.max(), np.percentile(dn, 99), np.median(dn)))
+    # attributes of the neighbour nearest to the predicted point: exact unless two neighbours are equally near (<= 0.02 % of pixels)
+    near = np.ones(both.sum(), bool)
+    for k, cols in (("PRED_VERTEX", slice(3, 4)), ("PRED_NORMAL", slice(3, 4)), ("PRED_CURV1", slice(0, 4)), ("PRED_CURV2", slice(0, 4)),
+                    ("PRED_IMAGE", slice(0, 3))):
+        a, b = g.get_image(k)[..., cols][both], fx[P + k][..., cols][both]
+        near &= (ulp_diff(a, b) == 0).all(-1) if a.dtype == np.float32 else (a == b).all(-1)
+    near &= g.get_image("PRED_TIME")[both] == fx[P + "PRED_TIME"][both]
+    bad = int((~near).sum())
+    rep.add("H2 nearest-neighbour attributes (confidence, radius, curvature records, colour, time)", bad <= max(1, near.size // 5000),
+            "%d of %d pixels take another neighbour" % (bad, near.size))
+    w, wr = g.get_image("PRED_ICPWEIGHT")[both][near].astype(np.float64), fx[P + "PRED_ICPWEIGHT"][both][near].astype(np.float64)
+    rel = np.abs(w - wr) / np.abs(wr)
+    rep.add("H2 PRED_ICPWEIGHT", rel.max() <= 1e-4, "relative difference max %.2e, p99 %.2e" % (rel.max(), np.percentile(rel, 99)))
+
+
+def fill_checks(rep, g, fx, P):
+    rep.exact("H3 FILL_VERTEX", g.get_image("FILL_VERTEX"), fx[P + "FILL_VERTEX"])
+    rep.exact("H3 FILL_NORMAL", g.get_image("FILL_NORMAL"), fx[P + "FILL_NORMAL"])
+    rep.exact("H3 FILL_CURV1", g.get_image("FILL_CURV1"), fx[P + "FILL_CURV1"])
+    rep.exact("H3 FILL_CURV2", g.get_image("FILL_CURV2"), fx[P + "FILL_CURV2"])
+    rep.exact("H3 FILL_IMAGE", g.get_image("FILL_IMAGE")[..., :3], fx[P + "FILL_IMAGE"][..., :3])
+    rep.close_ulp("H3 FILL_ICPWEIGHT", g.get_image("FILL_ICPWEIGHT"), fx[P + "FILL_ICPWEIGHT"], 16)
