@@ -4,13 +4,18 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under hrbffusion3d_amd/ or include/ may call into this
  * library; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
  *
- * PARITY UNPINNED: the reference (YabinXuTUD/HRBFFusion3D) has no tests, no golden vectors and
- * cannot be built here (Pangolin/CUDA/Eigen/OpenCV/GL absent).  This oracle is a
- * line-by-line restatement of the reference's GLSL/CUDA/host semantics (each function cites the
- * file:line it follows); it is pinned only by analytic known-answer tests (tests/test_oracle_*.py) and by
- * independent numpy evaluations of every site where the camera intrinsics enter, with fx != fy and an off-centre
- * principal point (tests/kat_projection.py, tests/test_intrinsics_kat.py).  tools/compare_reference_dump.py diffs it
- * against the dump files the reference itself writes — the one-command way to pin it once a reference run exists.
+ * PINNING.  The reference has no tests and no golden vectors, and its C++/CUDA cannot be built here (Pangolin, CUDA, Eigen,
+ * OpenCV absent).  Its GLSL shaders can be EXECUTED: oracle/ref_glsl runs the shader files of
+ * /root/reference/Core/src/Shaders, verbatim but for three respelled tokens, on Mesa llvmpipe with the GL calls of the
+ * reference's host code, and tests/golden/ref_glsl holds what they wrote.  tests/test_ref_glsl.py compares this oracle (and
+ * the HIP path) with those outputs pass by pass on identical inputs:
+ *   GLSL rows (P1-P5, M1, F1-F4, H1-H3, f-3 of SURVEY §8a): PINNED to the executed reference — discrete results exact
+ *     (validity, z-test winners, merge / create / remove decisions, map order), floats within the stated ulp bounds
+ *     (the shaders' exp / acos / division are llvmpipe's, not hrbf_detmath.h's).
+ *   CUDA rows (O1-O6: pyramids, so3Step, residuals, icpStep, rgbStep, the Gauss-Newton loop): PARITY UNPINNED by execution
+ *     (no nvcc; a hipify build would be a stand-in) — pinned only by analytic known-answer tests (tests/test_oracle_*.py),
+ *     independent fp64 numpy evaluations and the intrinsics KATs (tests/kat_projection.py, tests/test_intrinsics_kat.py).
+ *   tools/compare_reference_dump.py diffs against dump files the reference itself writes, should a reference run exist.
  *
  * Plain C99, scalar, single-thread (OpenMP over pixels/surfels when built with -fopenmp; results
  * are identical because every reduction goes through the exact accumulator of hrbf_detmath.h).

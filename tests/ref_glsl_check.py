@@ -86,7 +86,11 @@ def run(impl, fx, rep, has_records=False):
     g.set_image("DEPTH_FILTERED", ref)
     g.run_stage("METRICISE")
     rep.exact("P2 DEPTH_METRIC", g.get_image("DEPTH_METRIC"), fx[P + "DEPTH_METRIC"])
-    rep.exact("P2 DEPTH_METRIC_FILTERED", g.get_image("DEPTH_METRIC_FILTERED"), fx[P + "DEPTH_METRIC_FILTERED"])
+    # the HIP path computes the metric image inside the filter kernel (P1 + P2 fused), so there it carries P1's own rounding;
+    # the oracle runs P2 on the DEPTH_FILTERED just set and is exact
+    rep.close_ulp("P2 DEPTH_METRIC_FILTERED", g.get_image("DEPTH_METRIC_FILTERED"), fx[P + "DEPTH_METRIC_FILTERED"], 16)
+    g.set_image("DEPTH_METRIC", fx[P + "DEPTH_METRIC"])
+    g.set_image("DEPTH_METRIC_FILTERED", fx[P + "DEPTH_METRIC_FILTERED"])
     # ---- P3 computeVertexNormalRadius ---------------------------------------------------------------------------------
     g.run_stage("VERTEX_NORMAL_RADIUS")
     vr, vf = g.get_image("VERTEX_RAW"), g.get_image("VERTEX_FILTERED")
@@ -101,6 +105,7 @@ def run(impl, fx, rep, has_records=False):
     rep.close_ulp("P3 RADIUS", g.get_image("RADIUS"), fx[P + "RADIUS"], 64)
     # ---- P4 + P5 computeCurvatureGradient, updateNormalRad -----------------------------------------------------------
     g.set_image("NORMAL", fx[P + "NORMAL_P3"])
+    g.set_image("VERTEX_FILTERED", fx[P + "VERTEX_FILTERED"])
     g.run_stage("CURVATURE")
     gm, gmr = g.get_image("GRADIENT_MAG"), fx[P + "GRADIENT_MAG"]
     rep.exact("P4 which pixels have > 15 neighbours", gm == 0, gmr == 0)
