@@ -454,11 +454,11 @@ static void st_curv(hrbf_context *c, bool with_level0 = false)
         l0.L = c->odo.lv[0]; l0.src = make_sources(c); l0.dp = c->d_pose; l0.f2f = cfg.frame_to_frame_rgb; l0.curv_thr = cfg.curv_thr;
         l0.pack = (!cfg.use_search && !cfg.use_sparse) ? 1 : 0;   // the packed-operand registration reads nothing else of level 0's model maps
         launch_curvature_level0(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
-                                c->d_normal_opt, (int)c->prm.curv_estimation_window, l0);
+                                c->d_normal_opt, c->prm.curv_estimation_window, l0);
         c->level0_done = 1 + l0.pack;
     } else
     launch_curvature(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->d_curv1, c->d_curv2, c->d_gradmag,
-                     c->d_normal_opt, (int)c->prm.curv_estimation_window);
+                     c->d_normal_opt, c->prm.curv_estimation_window);
     // updateNormalRad: NORMAL <- NORMAL_OPT (HRBFFusion.cpp:1301-1310); the kernel rewrites every pixel, so the
     // two buffers just trade places
     float4 *t = c->d_normal; c->d_normal = c->d_normal_opt; c->d_normal_opt = t;

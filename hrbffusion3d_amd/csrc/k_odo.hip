@@ -491,7 +491,7 @@ __host__ __device__ __forceinline__ int ldlt_uniform(int v)
 #endif
 }
 template <typename T, int N, int IDX>
-__host__ __device__ __forceinline__ void ldlt_swap(T (&A)[N * N], int (&perm)[N], int k, int piv)
+__host__ __device__ __forceinline__ void ldlt_swap(T (&A)[N * N], uint32_t &perm, int k, int piv)
 {
     if constexpr (IDX < N * N) {
         constexpr int K = IDX / N, I = IDX % N;
@@ -504,7 +504,10 @@ __host__ __device__ __forceinline__ void ldlt_swap(T (&A)[N * N], int (&perm)[N]
                 for (int j = 0; j < N; ++j) { const T t = A[K * N + j]; A[K * N + j] = A[I * N + j]; A[I * N + j] = t; }
 #pragma unroll
                 for (int j = 0; j < N; ++j) { const T t = A[j * N + K]; A[j * N + K] = A[j * N + I]; A[j * N + I] = t; }
-                const int t = perm[K]; perm[K] = perm[I]; perm[I] = t;
+                // the permutation record is one word, 4 bits per entry: an int[N] sat in scratch memory (the asm's memory clobber
+                // pins arrays there) — 32 B / lane of round trips on the solve's serial chain
+                const uint32_t x = ((perm >> (4 * K)) ^ (perm >> (4 * I))) & 15u;
+                perm ^= (x << (4 * K)) | (x << (4 * I));
                 return;
             }
         }
@@ -515,10 +518,9 @@ __host__ __device__ __forceinline__ void ldlt_swap(T (&A)[N * N], int (&perm)[N]
 template <typename T, int N>
 __host__ __device__ __forceinline__ void ldlt_solve(T (&A)[N * N], const T (&b)[N], T (&x)[N])
 {
-    int perm[N];
+    static_assert(N <= 8, "4 bits per entry");
+    uint32_t perm = 0x76543210u;   // perm[i] = (perm >> 4 i) & 15
     T y[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) perm[i] = i;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         int piv = k;
@@ -546,7 +548,7 @@ __host__ __device__ __forceinline__ void ldlt_solve(T (&A)[N * N], const T (&b)[
     for (int i = 0; i < N; ++i) {               // y = P b
         T v = b[0];
 #pragma unroll
-        for (int j = 1; j < N; ++j) v = (perm[i] == j) ? b[j] : v;
+        for (int j = 1; j < N; ++j) v = ((int)((perm >> (4 * i)) & 15u) == j) ? b[j] : v;
         y[i] = v;
     }
 #pragma unroll
@@ -563,7 +565,7 @@ __host__ __device__ __forceinline__ void ldlt_solve(T (&A)[N * N], const T (&b)[
     for (int i = 0; i < N; ++i) {               // x = P^T y
         T v = 0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) v = (perm[j] == i) ? y[j] : v;
+        for (int j = 0; j < N; ++j) v = ((int)((perm >> (4 * j)) & 15u) == i) ? y[j] : v;
         x[i] = v;
     }
 }
@@ -1490,7 +1492,10 @@ __device__ __forceinline__ void gn_solve_block(OdoState *st, long long *__restri
     __shared__ long long s_tot[176];
     const int tid = threadIdx.x;
     if (do_reduce) {
-        fold_slots<false, 4>(icp_part, rgb_part, 87, s_tot, totals);   // launched with 1024 threads
+        // 256 threads: one column of the 174 per thread, its 32 slot rows loaded before the first add.  (1024 threads split the
+        // rows four ways but capped the kernel at 128 VGPRs: the single-lane fp64 solve then spilled 80 B / lane to scratch, on
+        // the serial chain that dominates this kernel.)
+        fold_slots<false, 1>(icp_part, rgb_part, 87, s_tot, totals);
         for (int t = tid; t < RES_SLOTS * 2; t += blockDim.x) res_part[t] = 0;
     } else {
         for (int t = tid; t < 174; t += blockDim.x) s_tot[t] = totals[t];
@@ -1591,7 +1596,7 @@ __global__ void k_residual_to_slot0(const long long *__restrict__ totals2, long 
 }
 
 // stand-alone solve on totals that were summed elsewhere (row-sharded multi-GPU: all-reduce of the limb sums)
-__global__ __launch_bounds__(1024) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
+__global__ __launch_bounds__(256) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
                                                    long long *__restrict__ rgb_part, long long *__restrict__ res_part,
                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
                                                    int next_level, int level_changes, DevPose *dp, float weight_multiplier)
@@ -1864,7 +1869,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(256), 0, s, ob.icp_part, 87, ob.totals, ob.res_part, RES_SLOTS * 2);
                 hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(256), 0, s, ob.rgb_part, 87, ob.totals + 87, (long long *)nullptr, 0);
                 allreduce(ob.totals, 174);
-                hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
+                hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
                                    ob.totals, 0, cfg, next_level, last_of_level ? 1 : 0,
                                    last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
                 continue;
@@ -1876,7 +1881,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
             hipLaunchKernelGGL(k_gn_rgb_step, dim3(nb), dim3(RB), 0, s, L, ob.state, nb, cfg.fx / div, cfg.fy / div,
                                cfg.rgb_only, cfg.rgb_use_grad, ob.res_part, ob.corres, ob.corres_diff, ob.rgb_part,
                                ob.totals, 0, L.rows * L.cols);
-            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
+            hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
                                ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0,
                                last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
         }

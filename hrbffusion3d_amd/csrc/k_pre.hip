@@ -258,25 +258,27 @@ __global__ __launch_bounds__(256) void k_vertex_normal_radius(Cam cam, const flo
     f3 vf = mk3(((float)px - cx) * zf * camz, ((float)py - cy) * zf * camw, zf);
     f3 n = mk3(0.0f, 0.0f, 0.0f);
     if (use_pca) {
-        int x0 = px - 3, x1 = px + 3, y0 = py - 3, y1 = py + 3;
-        float xoff = 0.5f, yoff = 0.5f;
-        if (x0 < 0) { x0 = 0; xoff = 0.0f; }
-        if (y0 < 0) { y0 = 0; yoff = 0.0f; }
-        if (x1 > W - 1) x1 = W - 1;
-        if (y1 > H - 1) y1 = H - 1;
+        // geometry.glsl:198-213: the float-stepped walk, literally (hd_window_axis): the last sample of an axis is not taken
+        // where the accumulated coordinate overshoots the bound by an ulp; a sample's vertex sits at the float position i * cols
+        const hd_window wx = hd_window_axis(px, W, 3.0f), wy = hd_window_axis(py, H, 3.0f);
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
         int cnt = 0;
-        for (int ix = x0; ix <= x1; ++ix)
-            for (int iy = y0; iy <= y1; ++iy) {
-                float z = tile[(iy - by + R) * TW + (ix - bx + R)];
+        for (float fi = wx.lo; fi <= wx.hi; fi += wx.step) {
+            const int lx = hd_window_texel(fi, W) - bx + R;
+            const float xf = fi * (float)W;
+            for (float fj = wy.lo; fj <= wy.hi; fj += wy.step) {
+                const int ly = hd_window_texel(fj, H) - by + R;
+                const float yf = fj * (float)H;
+                float z = tile[ly * TW + lx];
                 if (z > 0.3f && hd_fabsf(z - vf.z) < 0.05f) {
-                    float X = (((float)ix + xoff) - cx) * z * camz;
-                    float Y = (((float)iy + yoff) - cy) * z * camw;
+                    float X = (xf - cx) * z * camz;
+                    float Y = (yf - cy) * z * camw;
                     a0 += X * X; a1 += X * Y; a2 += X * z; a3 += Y * Y; a4 += Y * z; a5 += z * z;
                     a6 += X; a7 += Y; a8 += z;
                     cnt++;
                 }
             }
+        }
         if (cnt >= 8) {
             float fn = (float)cnt;
             a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
@@ -544,14 +546,22 @@ int pre_probe_division(hipStream_t s, unsigned long long *d_out2)
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// The window is the shader's float-stepped walk, literally (hd_window_axis): x outer, y inner; the tile rows of the y walk are
+// the same for every x and are packed once (8 bits each, <= 8 of them)
 template <bool TAME>
-__device__ __forceinline__ int curv_window(const NbTexel *__restrict__ tile, const NbTexel &me, int lx0, int lx1, int ly0,
-                                           int ly1, CurvSums &a)
+__device__ __forceinline__ int curv_window(const NbTexel *__restrict__ tile, const NbTexel &me, const hd_window wx, const hd_window wy,
+                                           int W, int H, int bx, int by, CurvSums &a)
 {
     constexpr int RMAX = 3, TW = TB + 2 * RMAX;
     int n = 0;
-    for (int lx = lx0; lx <= lx1; ++lx)
-        for (int ly = ly0; ly <= ly1; ++ly) {
+    unsigned long long rows = 0ull;
+    int ny = 0;
+    for (float fj = wy.lo; fj <= wy.hi && ny < 8; fj += wy.step, ++ny)
+        rows |= (unsigned long long)(uint32_t)(hd_window_texel(fj, H) - by + RMAX) << (8 * ny);
+    for (float fi = wx.lo; fi <= wx.hi; fi += wx.step) {
+        const int lx = hd_window_texel(fi, W) - bx + RMAX;
+        for (int k = 0; k < ny; ++k) {
+            const int ly = (int)((rows >> (8 * k)) & 255ull);
             const NbTexel nb = tile[ly * TW + lx];
             const float vz = me.pz - nb.pz;
             if (!(hd_fabsf(nb.pz - me.pz) < 0.10f && nb.valid > 0.0f)) continue;
@@ -573,6 +583,7 @@ __device__ __forceinline__ int curv_window(const NbTexel *__restrict__ tile, con
             if (__builtin_amdgcn_ballot_w64(qd < 0x1p-40f) != 0ull) curv_neighbour_literal(me, nb, a);   // r < 2^-20: not tame
             else curv_neighbour_fast(V, vz, SQ, vz2, qd, nb, a);
         }
+    }
     return n;
 }
 
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
                                                    const float4 *__restrict__ normal_in,
                                                    float4 *__restrict__ curv1, float4 *__restrict__ curv2,
                                                    float *__restrict__ gradmag, float4 *__restrict__ normal_out,
-                                                   int win, Level0Args l0)
+                                                   float win, Level0Args l0)
 {
     constexpr int RMAX = 3, TW = TB + 2 * RMAX;
     __shared__ NbTexel tile[TW * TW];
@@ -617,12 +628,10 @@ __global__ __launch_bounds__(256) void k_curvature(Cam cam, const float4 *__rest
     if (me.pz > 0.3f && len3(mk3(me_n.x, me_n.y, me_n.z)) > 0.5f) {
         float k1 = 1000.0f, k2 = 1000.0f;
         f3 pmax = mk3(0, 0, 0), pmin = mk3(0, 0, 0);
-        int x0 = px - win < 0 ? 0 : px - win, x1 = px + win > W - 1 ? W - 1 : px + win;
-        int y0 = py - win < 0 ? 0 : py - win, y1 = py + win > H - 1 ? H - 1 : py + win;
+        const hd_window wx = hd_window_axis(px, W, win), wy = hd_window_axis(py, H, win);
         CurvSums a;
         a.grxy = (v2f)(0.0f); a.grz = 0.0f; a.g04 = (v2f)(0.0f); a.g1 = 0.0f; a.g25 = (v2f)(0.0f); a.g8 = 0.0f;
-        const int n = s_untame ? curv_window<false>(tile, me, x0 - bx + RMAX, x1 - bx + RMAX, y0 - by + RMAX, y1 - by + RMAX, a)
-                               : curv_window<true>(tile, me, x0 - bx + RMAX, x1 - bx + RMAX, y0 - by + RMAX, y1 - by + RMAX, a);
+        const int n = s_untame ? curv_window<false>(tile, me, wx, wy, W, H, bx, by, a) : curv_window<true>(tile, me, wx, wy, W, H, bx, by, a);
         const float grx = a.grxy.x, gry = a.grxy.y, grz = a.grz;
         const float g0 = a.g04.x, g1 = a.g1, g2 = a.g25.x, g4 = a.g04.y, g5 = a.g25.y, g8 = a.g8;
         if (n > 15) {
@@ -700,13 +709,13 @@ void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm,
                        radius_mult, use_pca);
 }
 void launch_curvature(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
-                      float *gradmag, float4 *normal_out, int win)
+                      float *gradmag, float4 *normal_out, float win)
 {
     hipLaunchKernelGGL(k_curvature<false>, grid2d(cam), dim3(TB, TB), 0, s, cam, vf, normal_in, c1, c2, gradmag, normal_out, win,
                        Level0Args{});
 }
 void launch_curvature_level0(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
-                             float *gradmag, float4 *normal_out, int win, const Level0Args &l0)
+                             float *gradmag, float4 *normal_out, float win, const Level0Args &l0)
 {
     hipLaunchKernelGGL(k_curvature<true>, grid2d(cam), dim3(TB, TB), 0, s, cam, vf, normal_in, c1, c2, gradmag, normal_out, win, l0);
 }

@@ -338,7 +338,10 @@ __device__ __forceinline__ void fill_pixel(int i, float thr, float lambda, int f
         }
         f.fi_vertex[i] = outv; f.fi_icpw[i] = outw;
     } else { f.fi_vertex[i] = s; f.fi_icpw[i] = icpw; }
-    f.fi_normal[i] = (len3(xyz(n)) < 0.8f) ? f.normal[i] : n;
+    // not `cond ? f.normal[i] : n`: the ?: on HIP_vector_type objects left a (never read) 16-byte copy in scratch memory, and
+    // with it a scratch segment for every wave of k_predict_hrbf<true> and k_fillin (ScratchSize 32 -> 0)
+    if (len3(xyz(n)) < 0.8f) f.fi_normal[i] = f.normal[i];
+    else f.fi_normal[i] = n;
     if (k1.w > 300.0f || k2.w > 300.0f) { f.fi_curv1[i] = f.curv1[i]; f.fi_curv2[i] = f.curv2[i]; }
     else { f.fi_curv1[i] = k1; f.fi_curv2[i] = k2; }
     if ((int)e.x + (int)e.y + (int)e.z == 0 || frame_to_frame_rgb)

@@ -38,7 +38,7 @@ void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, fl
 void launch_vertex_normal_radius(hipStream_t s, const Cam &cam, const float *dm, const float *dmf, float4 *vr,
                                  float4 *vf, float4 *n, float4 *npca, float *radius, float radius_mult, int use_pca);
 void launch_curvature(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
-                      float *gradmag, float4 *normal_out, int win);
+                      float *gradmag, float4 *normal_out, float win);
 void launch_confidence(hipStream_t s, const Cam &cam, const float *gradmag, float *conf, const float *weighting,
                        int use_conf_eval, float eps);
 
@@ -278,7 +278,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
 // should_fill_in flag in *dp (set at the end of the previous frame).
 struct Level0Args { OdoLevel L; OdoSources src; const DevPose *dp; int f2f; float curv_thr; int pack; };
 void launch_curvature_level0(hipStream_t s, const Cam &cam, const float4 *vf, const float4 *normal_in, float4 *c1, float4 *c2,
-                             float *gradmag, float4 *normal_out, int win, const Level0Args &l0);
+                             float *gradmag, float4 *normal_out, float win, const Level0Args &l0);
 // pose bookkeeping
 void launch_pose_set(hipStream_t s, DevPose *dp, const float pose16_colmajor[16], int also_prev);
 void launch_frame_epilogue(hipStream_t s, DevPose *dp, float weight_multiplier, int tracked);

@@ -48,6 +48,38 @@ HD_FN double hd_sqrt(double a) { return __builtin_sqrt(a); }
 HD_FN float hd_fabsf(float a) { return __builtin_fabsf(a); }
 HD_FN float hd_floorf(float a) { return __builtin_floorf(a); }
 
+/* One axis of the shaders' float-stepped window loops, literally (geometry.glsl:198-207 getNormalPCA,
+ * depth_curvature_gradient.frag:54-63):
+ *     float step = 1.0f / n;                    // indexXStep
+ *     float lo = max(0.0f, t - step * win), hi = min(1.0f, t + step * win);
+ *     for (float i = lo; i <= hi; i += step) sample(texel floor(i * n), position i * n)
+ * with t = (p + 0.5) / n, the texture coordinate the rasteriser interpolates for pixel p (taken correctly rounded).  In exact
+ * arithmetic that is 2 win + 1 samples; in fp32 the accumulated i overshoots hi by an ulp for about 40 % of the columns of a
+ * 640-wide and 53 % of the rows of a 480-high image, and the LAST sample is then not taken — on any IEEE implementation.
+ * The reference's shaders executed on Mesa llvmpipe (oracle/ref_glsl, profiles/r03_ref_glsl_vga_report.txt) show exactly this
+ * pattern (this rule reproduces its window at all but 4 of 640 columns and 4 of 480 rows, where llvmpipe's interpolated t is an
+ * ulp off the correctly rounded one), and the curvature it yields differs from the nominal 7 x 7 window's by 5 % in the median.
+ * At power-of-two sizes every quantity above is exact and the loop takes the nominal samples.
+ * Callers iterate `for (float i = w.lo; i <= w.hi; i += w.step)` and take texel hd_window_texel(i, n). */
+typedef struct hd_window { float lo, hi, step; } hd_window;
+HD_FN hd_window hd_window_axis(int p, int n, float win)
+{
+    hd_window w;
+    const float fn = (float)n;
+    const float t = ((float)p + 0.5f) / fn;
+    w.step = 1.0f / fn;
+    const float reach = w.step * win;
+    const float lo = t - reach, hi = t + reach;
+    w.lo = lo > 0.0f ? lo : 0.0f;
+    w.hi = hi < 1.0f ? hi : 1.0f;
+    return w;
+}
+HD_FN int hd_window_texel(float i, int n)   /* NEAREST filtering, CLAMP_TO_EDGE */
+{
+    int t = (int)hd_floorf(i * (float)n);
+    return t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
+}
+
 /* Where the GL rasteriser places a 1-pixel point (IndexMap::predictIndices, index_map.vert:57-60): the shader emits the
  * normalised device coordinate (u - extent/2) / (extent/2); the fixed-function viewport transform maps it back to a
  * window coordinate, which is snapped to the sub-pixel grid (GL_SUBPIXEL_BITS = 8 on NVIDIA hardware and on Mesa,

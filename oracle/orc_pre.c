@@ -147,25 +147,27 @@ static f3 normal_pca(const float *depth, int W, int H, int px, int py, float zc,
 {
     /* sample set: interior offsets -3..3; left/top clamp starts on texel 0 with integer
        coordinates (tx_min = max(0, ..) lands on texel boundaries, geometry.glsl:196-200) */
-    int x0 = px - 3, x1 = px + 3, y0 = py - 3, y1 = py + 3;
-    float xoff = 0.5f, yoff = 0.5f;
-    if (x0 < 0) { x0 = 0; xoff = 0.0f; }
-    if (y0 < 0) { y0 = 0; yoff = 0.0f; }
-    if (x1 > W - 1) x1 = W - 1;
-    if (y1 > H - 1) y1 = H - 1;
+    /* geometry.glsl:198-213: the float-stepped 7 x 7 walk, literally (hd_window_axis); a sample's vertex is formed at the
+       float position i * cols, j * rows — the float overload of getVertex (:21-25), unlike the pixel's own vertex */
+    const hd_window wx = hd_window_axis(px, W, 3.0f), wy = hd_window_axis(py, H, 3.0f);
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
     int n = 0;
-    for (int ix = x0; ix <= x1; ++ix)
-        for (int iy = y0; iy <= y1; ++iy) {
+    for (float i = wx.lo; i <= wx.hi; i += wx.step) {
+        const int ix = hd_window_texel(i, W);
+        const float xf = i * (float)W;
+        for (float j = wy.lo; j <= wy.hi; j += wy.step) {
+            const int iy = hd_window_texel(j, H);
+            const float yf = j * (float)H;
             float z = depth[iy * W + ix];
             if (z > 0.3f && fabsf(z - zc) < 0.05f) {
-                float X = (((float)ix + xoff) - cx) * z * camz;
-                float Y = (((float)iy + yoff) - cy) * z * camw;
+                float X = (xf - cx) * z * camz;
+                float Y = (yf - cy) * z * camw;
                 a0 += X * X; a1 += X * Y; a2 += X * z; a3 += Y * Y; a4 += Y * z; a5 += z * z;
                 a6 += X; a7 += Y; a8 += z;
                 n++;
             }
         }
+    }
     if (n < 8) return v3(0.0f, 0.0f, 0.0f);
     float fn = (float)n;
     a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
@@ -256,7 +258,6 @@ void orc_vertex_normal_radius(orc_ctx *c)
 void orc_curvature(orc_ctx *c)
 {
     const int W = c->W, H = c->H;
-    const int win = (int)c->prm.curv_estimation_window;
     const float camz = (float)(1.0 / (double)c->prm.fx), camw = (float)(1.0 / (double)c->prm.fy);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < H; ++py)
@@ -270,10 +271,13 @@ void orc_curvature(orc_ctx *c)
                 f3 pmax = v3(0, 0, 0), pmin = v3(0, 0, 0);
                 f4 vc[100], nr[100];
                 int n = 0;
-                int x0 = px - win < 0 ? 0 : px - win, x1 = px + win > W - 1 ? W - 1 : px + win;
-                int y0 = py - win < 0 ? 0 : py - win, y1 = py + win > H - 1 ? H - 1 : py + win;
-                for (int ix = x0; ix <= x1; ++ix)
-                    for (int iy = y0; iy <= y1; ++iy) {
+                /* depth_curvature_gradient.frag:48-73: the float-stepped window, literally (hd_window_axis) */
+                const hd_window wx = hd_window_axis(px, W, c->prm.curv_estimation_window);
+                const hd_window wy = hd_window_axis(py, H, c->prm.curv_estimation_window);
+                for (float fi = wx.lo; fi <= wx.hi; fi += wx.step) {
+                    const int ix = hd_window_texel(fi, W);
+                    for (float fj = wy.lo; fj <= wy.hi; fj += wy.step) {
+                        const int iy = hd_window_texel(fj, H);
                         f4 v = c->vertex_filtered[iy * W + ix], nn = c->normal[iy * W + ix];
                         if (fabsf(v.z - vfil.z) < 0.10f && v.z > 0.3f && len3(xyz(nn)) > 0.8f) {
                             vc[n] = v4(v.x, v.y, v.z, 1.0f);
@@ -281,6 +285,7 @@ void orc_curvature(orc_ctx *c)
                             n++;
                         }
                     }
+                }
                 if (n > 15) {
                     float p[3] = {vfil.x, vfil.y, vfil.z};
                     float gr[3], g[9];

@@ -20,7 +20,12 @@ from oracle_lib import Oracle  # noqa: E402
 
 
 def digest(a):
-    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:   # NaN payload/sign is the one platform difference (x86 0xFFC00000, gfx950 0x7FC00000)
+        u = a.view(np.uint32).copy(); u[np.isnan(a)] = 0x7FC00000; a = u
+    else:
+        a = a.view(np.uint8)
+    return np.frombuffer(hashlib.sha256(a.tobytes()).digest(), np.uint8)
 
 
 def run(make):

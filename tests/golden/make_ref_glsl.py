@@ -7,7 +7,8 @@ surfel buffers the shaders wrote.  tests/test_ref_glsl.py feeds the same inputs 
 HIP library (GPU suite) and compares.
 
     python tests/golden/make_ref_glsl.py            # writes the fixtures
-    python tests/golden/make_ref_glsl.py --check    # also prints an oracle-vs-reference report per pass
+    python tests/golden/make_ref_glsl.py --vga-report   # what differs between the two executions at 640 x 480, and why
+    python tests/ref_glsl_report.py oracle|hip           # per-pass comparison of an implementation with the fixtures
 
 Scenes are power-of-two sized (256 x 128 and 128 x 128).  There every texture coordinate, loop bound and half-pixel step of the
 shaders is exact in fp32, so the passes have no implementation-defined sampling (DESIGN.md §8 lists what is
@@ -213,5 +214,75 @@ def main():
               int(out["x_map_count"][0]), "predicted pixels:", int((out["x_PRED_VERTEX"][..., 2] != 0).sum()))
 
 
+def vga_report():
+    """What is implementation-defined at 640 x 480: frame 1 of the GPUTest pair through P1-P4 on llvmpipe and
+    on the oracle, each pass on the reference's own input images."""
+    from ref_glsl import refgl
+    from oracle_lib import Oracle
+    import ref_glsl_check as R
+    W, H = 640, 480
+    rgb = np.array(Image.open(os.path.join(HERE, "1c.png"))); d = np.array(Image.open(os.path.join(HERE, "1d.png")))
+    prm = default_params(max_surfels=1 << 20)
+    p = refgl.RefPipeline(W, H, prm.fx, prm.fy, prm.cx, prm.cy, prm.depth_scale, tex_dim=64, max_surfels=1024)
+    o = Oracle(prm, omp=True)
+    p.upload_frame(rgb, d); o.upload_frame(rgb, d)
+    f = np.float32
+    print("== texel-boundary taps: texture(s, vec2(float(c) / n, ..)) with NEAREST filtering samples floor(fl(fl(c / n) * n))")
+    for n in (640, 480):
+        c = np.arange(n, dtype=f)
+        print("   n = %d: columns/rows whose tap lands one texel low under fp32 floor: %s" % (n, np.nonzero(np.floor((c / f(n)) * f(n)) != c)[0].tolist()))
+    p.filter_depth(); o.run_stage("FILTER_DEPTH")
+    a, b = p.get("DEPTH_FILTERED").astype(np.float64), o.get_image("DEPTH_FILTERED").astype(np.float64)
+    rel = np.abs(a - b) / np.maximum(b, 1.0)
+    rows = np.nonzero(rel.max(1) > 1e-5)[0]
+    print("P1 bilateral: rows with a relative difference > 1e-5: %s" % rows.tolist())
+    print("   everywhere else: max relative difference %.2e" % np.delete(rel, rows, 0).max())
+    print("== float-stepped window loops: for (i = t - 3 s; i <= t + 3 s; i += s), s = 1 / n, t = (p + 0.5) / n, all fp32")
+    counts = {}
+    for n in (640, 480, 256, 128):
+        s_ = f(1) / f(n); cnt = []
+        for px in range(n):
+            t = f(f(px) + f(0.5)) / f(n)
+            lo, hi = max(f(0), f(t - f(s_ * f(3)))), min(f(1), f(t + f(s_ * f(3))))
+            i, k = lo, 0
+            while i <= hi:
+                k += 1; i = f(i + s_)
+            cnt.append(k)
+        cnt = counts[n] = np.array(cnt)
+        print("   n = %d: iterations per pixel 7 (nominal): %d, 6: %d, 5 / 4 (image border): %d" % (n, (cnt == 7).sum(), (cnt == 6).sum(), (cnt < 6).sum()))
+    o.set_image("DEPTH_FILTERED", p.get("DEPTH_FILTERED"))
+    p.metricise_depth(); o.run_stage("METRICISE")
+    p.compute_vertex_normal_radius(); o.run_stage("VERTEX_NORMAL_RADIUS")
+    for nme in ("VERTEX_RAW", "VERTEX_FILTERED"):
+        print("P3 %s xyz identical: %s" % (nme, bool((R.ulp_diff(p.get(nme)[..., :3], o.get_image(nme)[..., :3]) == 0).all())))
+    a, b = p.get("NORMAL"), o.get_image("NORMAL")
+    v = (np.linalg.norm(a[..., :3], axis=-1) > 0.5) & (np.linalg.norm(b[..., :3], axis=-1) > 0.5)
+    ang = np.degrees(np.arccos(np.clip((a[..., :3] * b[..., :3]).sum(-1)[v], -1, 1)))
+    print("P3 PCA normal, 7 x 7 nominal window (oracle) vs fp32-stepped window (llvmpipe): validity differs at %d pixels; angle median %.2f deg, p90 %.2f, p99 %.2f" % (
+        int(((np.linalg.norm(a[..., :3], axis=-1) > 0.5) != (np.linalg.norm(b[..., :3], axis=-1) > 0.5)).sum()), np.median(ang), np.percentile(ang, 90), np.percentile(ang, 99)))
+    full = ((counts[640] == 7)[None, :] & (counts[480] == 7)[:, None])   # pixels whose fp32 window is the nominal 7 x 7
+    angf = np.degrees(np.arccos(np.clip((a[..., :3] * b[..., :3]).sum(-1), -1, 1)))
+    print("   pixels with the nominal window under fp32 (%.1f%% of the image): angle median %.3f deg, p99 %.2f; the others: median %.2f, p99 %.2f" % (
+        100 * full.mean(), np.median(angf[v & full]), np.percentile(angf[v & full], 99), np.median(angf[v & ~full]), np.percentile(angf[v & ~full], 99)))
+    print("   (the sample positions of getNormalPCA are fl(i * cols) with i the accumulated loop variable, geometry.glsl:209: ~1e-5 pixel of\n"
+          "    noise at 640 x 480 that the covariance's cancellation amplifies; exact at power-of-two sizes, where the normals agree to 3 ulp)")
+    o.set_image("VERTEX_FILTERED", p.get("VERTEX_FILTERED")); o.set_image("NORMAL", p.get("NORMAL"))
+    p.compute_curvature_gradient(); o.run_stage("CURVATURE")
+    gm, gmo = p.get("GRADIENT_MAG"), o.get_image("GRADIENT_MAG")
+    ok = (gm != 0) & (gmo != 0)
+    print("P4 gradient magnitude: within 1024 ulp at %.1f%% of the pixels; at %.2f%% of those with the nominal window under fp32 (%.1f%% of the image)" % (
+        100 * (R.ulp_diff(gm, gmo)[ok] <= 1024).mean(), 100 * (R.ulp_diff(gm, gmo)[ok & full] <= 1024).mean(), 100 * full.mean()))
+    k, ko = p.get("PRINCIPAL_CURV1")[..., 3], o.get_image("CURV1")[..., 3]
+    ok = (k != 1000) & (ko != 1000) & np.isfinite(k) & np.isfinite(ko)
+    err = np.abs(k[ok] - ko[ok]) / (np.abs(ko[ok]) + 1)
+    print("P4 k1: |dk| / (|k| + 1): median %.2e, p90 %.2e, p99 %.2e" % (np.median(err), np.percentile(err, 90), np.percentile(err, 99)))
+    okf = ok & full
+    errf = np.abs(k[okf] - ko[okf]) / (np.abs(ko[okf]) + 1)
+    print("   restricted to pixels with the nominal window: median %.2e, p90 %.2e, p99 %.2e" % (np.median(errf), np.percentile(errf, 90), np.percentile(errf, 99)))
+
+
 if __name__ == "__main__":
-    main()
+    if "--vga-report" in sys.argv:
+        vga_report()
+    else:
+        main()

@@ -77,10 +77,10 @@ def test_png_pair_matches_oracle_and_golden(pair, png_pair):
             tag = "f%d_" % (k + 1)
             assert np.array_equal(bits(g.get_pose()), bits(exp[tag + "pose"]))
             assert g.surfel_count() == int(exp[tag + "count"][0])
-            sha = np.frombuffer(hashlib.sha256(g.download_map().tobytes()).digest(), np.uint8)
+            sha = np.frombuffer(hashlib.sha256(bits(g.download_map()).tobytes()).digest(), np.uint8)
             assert np.array_equal(sha, exp[tag + "map_sha"])
             for name in IMAGES:
-                sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(g.get_image(name)).tobytes()).digest(), np.uint8)
+                sha = np.frombuffer(hashlib.sha256(bits(g.get_image(name)).tobytes()).digest(), np.uint8)
                 assert np.array_equal(sha, exp[tag + "sha_" + name]), name
 
 
@@ -94,7 +94,7 @@ def test_png_pair_variants_match_golden_digests(gpu_available, png_pair):
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
     mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
     exp = np.load(os.path.join(gdir, "gputest_pair_variants.npz"))
-    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    sha = lambda a: np.frombuffer(hashlib.sha256(bits(a).tobytes()).digest(), np.uint8)   # NaN payloads canonicalised
     for name, kw in mg.VARIANTS.items():
         g = HRBFFusion(default_params(max_surfels=1 << 20, **kw))
         for rgb, d in png_pair:
