@@ -71,6 +71,30 @@ def load_trajectory_tum(path):
     return np.array(stamps), poses
 
 
+def load_trajectory_file(path, fmt="TUM"):
+    """the pose files TrajectoryManager::LoadFromFile replays (Core/src/Utils/TrajectoryManager.cpp:61-282): TUM / CoRBS,
+    zhou (re-based on the first pose), ICL_NUIM_RT (x mirrored on the left, y on the right); returns a list of 4x4 T_wc"""
+    if fmt in ("TUM", "CoRBS"):
+        return [np.asarray(T, np.float32) for T in load_trajectory_tum(path)[1]]
+    vals = open(path).read().split()
+    out = []
+    if fmt == "zhou":
+        for k in range(0, len(vals) - 18, 19):
+            out.append(np.array([float(x) for x in vals[k + 3:k + 19]], np.float64).reshape(4, 4))
+        if out:
+            inv0 = np.linalg.inv(out[0])
+            out = [np.eye(4)] + [inv0 @ T for T in out[1:]]
+    elif fmt == "ICL_NUIM_RT":
+        for k in range(0, len(vals) - 11, 12):
+            T = np.eye(4); T[:3, :4] = np.array([float(x) for x in vals[k:k + 12]]).reshape(3, 4)
+            out.append(np.diag([-1.0, 1, 1, 1]) @ T @ np.diag([1.0, -1, 1, 1]))
+    else:
+        raise ValueError("trajectory format %r is not supported (TUM, CoRBS, zhou, ICL_NUIM_RT)" % (fmt,))
+    if not out:
+        raise ValueError(path + ": no poses read")
+    return [np.asarray(T, np.float32) for T in out]
+
+
 def save_ply(path, surfels, conf_threshold=0.0):
     """surfels: (N,20) float32 in the GlobalModel layout (hrbf_download_map)."""
     s = np.asarray(surfels, np.float32)

@@ -77,8 +77,14 @@ def apply_reference_config(args):
             raise SystemExit("sensorType %r (live camera) has no counterpart here" % (st,))
         if g.get("globalInputICLNUIMDataset"):
             args.icl_nuim = True
-        if not args.max_frames and g.get("globalEndFrame", -1) > 0:
-            args.max_frames = int(g["globalEndFrame"])
+        # MainController::run (GUI/src/HRBF_fusion.cpp:190-239): start fast-forwards source and tick, the skip is applied once
+        # (tick jump + fusion weight), the end frame bounds the tick; globalInputLoadTrajectory replays a pose file
+        args.start_frame = int(g.get("globalStartFrame", 0) or 0)
+        args.frames_to_skip = int(g.get("globalFrameToSkip", 0) or 0)
+        if g.get("globalEndFrame", -1) > 0:
+            args.end_tick = int(g["globalEndFrame"])
+        if g.get("globalInputLoadTrajectory"):
+            args.replay = (hcfg.resolve(g, "globalInputTrajectoryFile", base), g.get("globalInputTrajectoryFormat", "TUM"))
         if g.get("optimizationUseLocalBA") or g.get("optimizationUseGlobalBA"):
             sys.stderr.write("note: optimizationUseLocalBA / GlobalBA are set in %s; the sparse ORB back-end is out of "
                              "scope here (front-end only, as BASELINE configs 2 / 3 specify)\n" % args.config)
@@ -148,12 +154,38 @@ def main(argv=None):
     p = default_params(args.width, args.height, args.fx, args.fy, args.cx, args.cy, **kw)
     fus = HRBFFusion(p, device=args.device)
     poses, stamps, gts = [], [], []
+    replay = None
+    if getattr(args, "replay", None):
+        replay = hio.load_trajectory_file(*args.replay)          # HRBFFusion.cpp:55-59: LoadFromFile, currPose = poses[0]
+        fus.set_load_trajectory(1)
+        fus.set_pose(replay[0])
+    start, skip, end_tick = getattr(args, "start_frame", 0), getattr(args, "frames_to_skip", 0), getattr(args, "end_tick", 65535)
     t0 = time.perf_counter()
     n = 0
-    for ts, rgb, depth, T in frame_source(args):
-        if n == 0 and T is not None:
+    src = enumerate(frame_source(args))
+    skip_to = 0        # source index below which frames are passed over (fastForward)
+    for i, (ts, rgb, depth, T) in src:
+        if i < skip_to:
+            continue
+        if fus.tick >= end_tick:
+            break
+        if fus.tick < start:
+            fus.set_tick(start)
+            skip_to = start
+            if i < start:
+                continue
+        wm = float(skip + 1)
+        if skip > 0:
+            fus.set_tick(fus.tick + skip)
+            skip_to = i + 1 + skip
+            skip = 0
+        if n == 0 and T is not None and replay is None:
             fus.set_pose(T)          # the synthetic stream starts at its analytic pose
-        fus.process_frame(rgb, depth, ts)
+        if replay is not None and fus.tick > 1:
+            if fus.tick - 1 >= len(replay):
+                raise SystemExit("globalInputLoadTrajectory: the trajectory file has fewer poses than frames")
+            fus.set_pose(replay[fus.tick - 1])                   # HRBFFusion.cpp:1105-1108
+        fus.process_frame(rgb, depth, ts, wm)
         poses.append(fus.get_pose()); stamps.append(ts); gts.append(T)
         n += 1
         if args.max_frames and n >= args.max_frames:

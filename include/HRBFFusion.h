@@ -13,8 +13,8 @@
  *   TrajectoryManager::SaveTrajectoryToFile (TUM / zhou / lefloch)   Core/src/Utils/TrajectoryManager.cpp:284-373
  *
  * Differences a maintainer must know:
- *   - the reference reads resolution / intrinsics from the Resolution / Intrinsics singletons and
- *     1/DepthMapFactor from a camera YAML; here they are constructor arguments;
+ *   - both construction styles exist: the reference's 8-argument constructor over the Resolution / Intrinsics /
+ *     GlobalStateParam singletons (and the camera YAML for 1/DepthMapFactor), and one that takes them as arguments;
  *   - poses are exposed as 16 floats, column-major (bit-compatible with Eigen::Matrix4f::data());
  *     with Eigen available (#include <Eigen/Core> first) getCurrPose() returns an Eigen::Map;
  *   - GL handles (model(), textures) do not exist: use downloadMap() / getImage();
@@ -41,10 +41,86 @@
 #include <vector>
 
 #include "hrbf_mi355.h"
+#include "hrbf_io.h"   // ParameterFile, GlobalState, CameraFile, trajectory files (header-only; zlib only if the PNG / klg readers are used)
 
 namespace hrbf_mi355 {
 
 struct Pose { float m[16]; };   // column-major 4x4, T_wc
+
+/* ---- the three singletons the reference's HRBFFusion constructor reads instead of taking arguments -------------------------
+ * Resolution / Intrinsics (Core/src/Utils/Resolution.h:26-68, Intrinsics.h:26-66): initialised by the first getInstance() call
+ * that carries values (GUI/src/HRBF_fusion.cpp:51-52), read-only afterwards.  GlobalStateParam (Utils/GlobalStateParams.h:
+ * 66-128): public members named like the keys of GlobalStateParam.txt, filled by readMembers(ParameterFile).  With these a
+ * caller written against the reference — `GlobalStateParam::getInstance().readMembers(pf); Resolution::getInstance(w, h);
+ * Intrinsics::getInstance(fx, fy, cx, cy); new HRBFFusion(icpCountThresh, icpErrThresh, confidence, depth, icp, fastOdom,
+ * so3, frameToFrameRGB)` — compiles against this header unchanged (tests/cpp/reference_caller_test.cpp). */
+class Resolution {
+public:
+    static const Resolution &getInstance(int width = 0, int height = 0)
+    {
+        static const Resolution instance(width, height);
+        return instance;
+    }
+    const int &width() const { return w_; }
+    const int &height() const { return h_; }
+    const int &cols() const { return w_; }
+    const int &rows() const { return h_; }
+    const int &numPixels() const { return n_; }
+private:
+    Resolution(int w, int h) : w_(w), h_(h), n_(w * h)
+    {
+        if (!(w > 0 && h > 0)) throw std::runtime_error("You haven't initialised the Resolution class!");
+    }
+    const int w_, h_, n_;
+};
+class Intrinsics {
+public:
+    static const Intrinsics &getInstance(float fx = 0, float fy = 0, float cx = 0, float cy = 0)
+    {
+        static const Intrinsics instance(fx, fy, cx, cy);
+        return instance;
+    }
+    const float &fx() const { return fx_; }
+    const float &fy() const { return fy_; }
+    const float &cx() const { return cx_; }
+    const float &cy() const { return cy_; }
+private:
+    Intrinsics(float fx, float fy, float cx, float cy) : fx_(fx), fy_(fy), cx_(cx), cy_(cy)
+    {
+        if (!(fx != 0 && fy != 0)) throw std::runtime_error("You haven't initialised the Intrinsics class!");
+    }
+    const float fx_, fy_, cx_, cy_;
+};
+class GlobalStateParam : public GlobalState {
+public:
+    static GlobalStateParam &getInstance() { static GlobalStateParam s; return s; }
+    static GlobalStateParam &get() { return getInstance(); }
+    void readMembers(const ParameterFile &parameterFile) { static_cast<GlobalState &>(*this) = GlobalState::fromParameterFile(parameterFile); }
+};
+/* hrbf_params from the singletons + the reference constructor's arguments: exactly what HRBFFusion::HRBFFusion and the
+   members it constructs read (HRBFFusion.cpp:26-75, the Uniform pushes of :1262-1345, GlobalModel.cpp, IndexMap.cpp, FillIn.cpp,
+   RGBDOdometry.cpp); the camera YAML named by parameterFileCvFormat supplies 1 / DepthMapFactor (HRBFFusion.cpp:772-780) */
+inline hrbf_params paramsFromGlobalState(const GlobalState &g, int width, int height, float fx, float fy, float cx, float cy,
+                                         float depthScale, float confidence, float depthCut, float icpThresh, bool fastOdom,
+                                         bool so3, bool frameToFrameRGB)
+{
+    hrbf_params p;
+    hrbf_default_params(&p, width, height, fx, fy, cx, cy, depthScale);
+    p.confidence_threshold = confidence; p.depth_cutoff = depthCut; p.icp_weight = icpThresh;
+    p.fast_odom = fastOdom; p.so3 = so3; p.frame_to_frame_rgb = frameToFrameRGB;
+    p.use_bilateral = g.preprocessingUsebilateralFilter; p.init_radius_multiplier = g.preprocessingInitRadiusMultiplier;
+    p.curv_estimation_window = g.preprocessingCurvEstimationWindow; p.curv_valid_threshold = g.preprocessingCurvValidThreshold;
+    p.normal_estimation_pca = g.preprocessingNormalEstimationPCA; p.use_conf_eval = g.preprocessingUseConfEval;
+    p.conf_eval_epsilon = g.preprocessingConfEvalEpsilon;
+    p.icp_use_corr_search = g.registrationICPUseCoorespondenceSearch; p.icp_search_radius = g.registrationICPNeighborSearchRadius;
+    p.icp_use_weighted = g.registrationICPUseWeightedICP; p.icp_curv_weight_lambda = g.registrationICPCurvWeightImpactControl;
+    p.rgb_use_grad_weight = g.registrationColorUseRGBGrad; p.use_sparse_icp = g.registrationICPUseSparseICP;
+    p.predict_window_multiplier = g.preictionWindowMultiplier; p.predict_min_neighbors = g.preictionMinNeighbors;
+    p.predict_max_neighbors = g.preictionMaxNeighbors; p.predict_conf_threshold = g.preictionConfThreshold;
+    p.clean_window_multiplier = g.fusionCleanWindowMultiplier; p.dense_enough_thresh = g.globalDenseEnoughThresh;
+    p.load_trajectory = g.globalInputLoadTrajectory;
+    return p;
+}
 
 class GlobalModel {
 public:
@@ -203,6 +279,43 @@ public:
         trajectory_manager = new TrajectoryManager();
         trajectory_manager->sync = [this]() { this->syncTrajectory(); };
     }
+    /* THE REFERENCE'S SIGNATURE (Core/src/HRBFFusion.h:87-94): resolution and intrinsics from the singletons, every tunable
+       from GlobalStateParam::get(), 1 / DepthMapFactor from the camera YAML it names (HRBFFusion.cpp:682-781); with
+       globalInputLoadTrajectory the poses of globalInputTrajectoryFile are replayed (HRBFFusion.cpp:55-59,1105-1108).
+       The sparse back-end options (optimizationUseLocalBA / GlobalBA) are outside this library: refused, not ignored. */
+    HRBFFusion(const int countThresh = 35000, const float errThresh = 5e-05f, const float confidence = 10.0f,
+               const float depthCut = 3.0f, const float icpThresh = 10.0f, const bool fastOdom = false, const bool so3 = true,
+               const bool frameToFrameRGB = false)
+        : h_(nullptr), model_(nullptr), load_trajectory_(false), synced_(0)
+    {
+        (void)countThresh; (void)errThresh;
+        const GlobalStateParam &g = GlobalStateParam::get();
+        if (g.optimizationUseLocalBA || g.optimizationUseGlobalBA)
+            throw std::runtime_error("optimizationUseLocalBA / optimizationUseGlobalBA: the ORB-SLAM2 back-end is not part of libhrbf_mi355");
+        const Resolution &res = Resolution::getInstance();
+        const Intrinsics &K = Intrinsics::getInstance();
+        float depthScale = 1.0f / 5000.0f;
+        if (!g.parameterFileCvFormat.empty()) depthScale = CameraFile::fromFile(g.parameterFileCvFormat).depthScale;
+        const hrbf_params p = paramsFromGlobalState(g, res.width(), res.height(), K.fx(), K.fy(), K.cx(), K.cy(), depthScale, confidence,
+                                                    depthCut, icpThresh, fastOdom, so3, frameToFrameRGB);
+        load_trajectory_ = p.load_trajectory != 0;
+        if (hrbf_create(&p, 0, &h_) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+        model_ = new GlobalModel(h_);
+        index_ = new IndexMap(h_);
+        trajectory_manager = new TrajectoryManager();
+        trajectory_manager->sync = [this]() { this->syncTrajectory(); };
+        if (load_trajectory_) loadTrajectory(g.globalInputTrajectoryFile, g.globalInputTrajectoryFormat);
+    }
+    /* globalInputLoadTrajectory: TrajectoryManager::LoadFromFile + `currPose = poses[0]` (HRBFFusion.cpp:55-59); from then on
+       processFrame sets currPose = poses[tick - 1] instead of registering (HRBFFusion.cpp:1105-1108) */
+    void loadTrajectory(const std::string &file, const std::string &format)
+    {
+        const std::vector<PoseCM> t = loadTrajectoryFile(file, format, &trajectory_manager->timstamp);
+        replay_.clear(); trajectory_manager->poses.clear();
+        for (const PoseCM &q : t) { Pose p; memcpy(p.m, q.m, sizeof(p.m)); replay_.push_back(p); trajectory_manager->poses.push_back(p); }
+        setLoadTrajectory(true);
+        setPose(replay_[0].m);
+    }
     /* every tunable at once: `p` as filled from GlobalStateParam (hrbf_default_params + the fields of
        GUI/GlobalStateParam.txt:20-81; tools/hrbf_run.cpp shows the mapping) */
     explicit HRBFFusion(const hrbf_params &p, int device = 0) : h_(nullptr), model_(nullptr), load_trajectory_(p.load_trajectory != 0), synced_(0)
@@ -221,6 +334,7 @@ public:
                       const float weightMultiplier = 1.f)
     {
         const int tick_before = hrbf_get_tick(h_);
+        replayPose(tick_before);
         if (hrbf_process_frame(h_, rgb, depth, timestamp, weightMultiplier) != HRBF_OK)
             throw std::runtime_error(hrbf_last_error());
         /* HRBFFusion.cpp:1058,1129-1133: the first frame pushes the initial pose, every later frame currPose and its
@@ -234,6 +348,7 @@ public:
     void processFrameDevice(const void *d_rgb, const void *d_depth, const int64_t &timestamp, const float weightMultiplier = 1.f)
     {
         const int tick_before = hrbf_get_tick(h_);
+        replayPose(tick_before);
         if (hrbf_process_frame_device(h_, d_rgb, d_depth, timestamp, weightMultiplier) != HRBF_OK)
             throw std::runtime_error(hrbf_last_error());
         const bool pushes = tick_before == 1 || !load_trajectory_;
@@ -243,6 +358,7 @@ public:
     /* bring trajectory_manager->poses up to date (blocks until every enqueued frame is done) */
     void syncTrajectory()
     {
+        if (!replay_.empty()) return;   // replayed trajectory: `poses` is the loaded file, nothing is pushed
         const uint32_t n = hrbf_frames_enqueued(h_);
         if (synced_ >= n) return;
         std::vector<float> buf((size_t)(n - synced_) * 16);
@@ -329,6 +445,14 @@ public:
     TrajectoryManager *trajectory_manager;   /* public like HRBFFusion.h:383-384 */
 
 private:
+    void replayPose(int tick)
+    {
+        if (!load_trajectory_ || replay_.empty() || tick <= 1) return;
+        if ((size_t)(tick - 1) >= replay_.size())
+            throw std::runtime_error("globalInputLoadTrajectory: the trajectory file has fewer poses than frames");
+        setPose(replay_[(size_t)(tick - 1)].m);
+    }
+    std::vector<Pose> replay_;   // poses of globalInputTrajectoryFile when the trajectory is replayed
     hrbf_handle h_;
     GlobalModel *model_;
     IndexMap *index_;
@@ -339,4 +463,14 @@ private:
 };
 
 }  // namespace hrbf_mi355
+
+/* The reference's names at global scope, so that its caller compiles with only the #include changed.  Define
+   HRBF_MI355_NO_GLOBAL_NAMES to keep them inside the namespace (e.g. when linking next to the reference itself). */
+#ifndef HRBF_MI355_NO_GLOBAL_NAMES
+using hrbf_mi355::HRBFFusion;
+using hrbf_mi355::GlobalStateParam;
+using hrbf_mi355::Intrinsics;
+using hrbf_mi355::ParameterFile;
+using hrbf_mi355::Resolution;
+#endif
 #endif

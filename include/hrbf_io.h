@@ -139,12 +139,17 @@ struct GlobalState {
     float fusionCleanWindowMultiplier = 2.0f;
     float globalConfidenceThreshold = 5.0f, globalDenseEnoughThresh = 0.75f, globalDepthCutoff = 3.5f;
     bool globalInputICLNUIMDataset = false, globalInputLoadTrajectory = false;
+    std::string globalInputTrajectoryFormat = "TUM", globalInputTrajectoryFile;
     float globalOutputSavePointCloudConfThreshold = 0.0f;
     int globalStartFrame = 0, globalEndFrame = -1, globalFrameToSkip = 0;
+    /* read by the reference's caller only (GUI/src/HRBF_fusion.cpp:87-93), carried so that such a caller compiles */
+    float registrationICPErrorThreshold = 5e-05f, registrationICPCovarianceThreshold = 1e-05f, registrationColorPhotoThreshold = 115.0f;
+    bool globalOutputSaveTrjectoryFile = false;
+    std::string globalOutputSaveTrjectoryFileType = "TUM";
 
-    static GlobalState fromFile(const std::string &filename)
+    static GlobalState fromFile(const std::string &filename) { return fromParameterFile(ParameterFile(filename)); }
+    static GlobalState fromParameterFile(const ParameterFile &pf)
     {
-        ParameterFile pf(filename);
         GlobalState g;
 #define HRBF_S(n) g.n = pf.getString(#n, g.n)
 #define HRBF_B(n) g.n = pf.getBool(#n, g.n)
@@ -164,6 +169,9 @@ struct GlobalState {
         HRBF_B(globalInputICLNUIMDataset); HRBF_B(globalInputLoadTrajectory);
         HRBF_F(globalOutputSavePointCloudConfThreshold); HRBF_I(globalStartFrame); HRBF_I(globalEndFrame);
         HRBF_I(globalFrameToSkip);
+        HRBF_S(globalInputTrajectoryFormat); HRBF_S(globalInputTrajectoryFile);
+        HRBF_F(registrationICPErrorThreshold); HRBF_F(registrationICPCovarianceThreshold); HRBF_F(registrationColorPhotoThreshold);
+        HRBF_B(globalOutputSaveTrjectoryFile); HRBF_S(globalOutputSaveTrjectoryFileType);
 #undef HRBF_S
 #undef HRBF_B
 #undef HRBF_I
@@ -211,6 +219,79 @@ struct CameraFile {
         return cam;
     }
 };
+
+// ------------------------------------------------------------------------------------------------ trajectory files
+/* The pose files TrajectoryManager::LoadFromFile reads for globalInputLoadTrajectory (Core/src/Utils/TrajectoryManager.cpp:
+ * 61-282): "TUM" / "CoRBS" (stamp tx ty tz qx qy qz qw per line, '#' comments), "zhou" (three ints, then a 4x4 matrix in four
+ * rows; every pose re-based on the first one, which becomes the identity), "ICL_NUIM_RT" (3x4 matrices, x mirrored on the left
+ * and y on the right).  Poses are returned as column-major 4x4 (the layout of hrbf_set_pose / Eigen::Matrix4f::data()). */
+struct PoseCM { float m[16]; };
+inline void mul44cm(const float *a, const float *b, float *o)
+{
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) {
+        float v = 0.0f;
+        for (int k = 0; k < 4; ++k) v += a[k * 4 + r] * b[c * 4 + k];
+        o[c * 4 + r] = v;
+    }
+}
+inline void rigidInverseCm(const float *a, float *o)
+{
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) o[c * 4 + r] = a[r * 4 + c];
+    for (int r = 0; r < 3; ++r) o[12 + r] = -(o[r] * a[12] + o[4 + r] * a[13] + o[8 + r] * a[14]);
+    o[3] = o[7] = o[11] = 0.0f; o[15] = 1.0f;
+}
+inline std::vector<PoseCM> loadTrajectoryFile(const std::string &filename, const std::string &format, std::vector<int64_t> *stamps = nullptr)
+{
+    std::ifstream f(filename.c_str());
+    if (!f.is_open()) throw std::runtime_error("cannot open trajectory file " + filename);
+    std::vector<PoseCM> out;
+    auto fromRows = [](const float r[16]) { PoseCM p; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) p.m[j * 4 + i] = r[i * 4 + j]; return p; };
+    if (format == "TUM" || format == "CoRBS") {
+        std::string line;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream is(line);
+            double ts; float x, y, z, qx, qy, qz, qw;
+            if (!(is >> ts >> x >> y >> z >> qx >> qy >> qz >> qw)) continue;
+            const float n = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+            qx /= n; qy /= n; qz /= n; qw /= n;
+            const float R[16] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw), x,
+                                 2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw), y,
+                                 2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy), z, 0, 0, 0, 1};
+            out.push_back(fromRows(R));
+            if (stamps) stamps->push_back((int64_t)(ts * 1e6));
+        }
+    } else if (format == "zhou") {
+        int a, b, c;
+        while (f >> a >> b >> c) {
+            float r[16];
+            for (float &v : r) if (!(f >> v)) throw std::runtime_error(filename + ": truncated zhou record");
+            out.push_back(fromRows(r));
+        }
+        if (!out.empty()) {
+            float inv0[16]; rigidInverseCm(out[0].m, inv0);
+            for (size_t i = 1; i < out.size(); ++i) { PoseCM t; mul44cm(inv0, out[i].m, t.m); out[i] = t; }
+            const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+            memcpy(out[0].m, I, sizeof(I));
+        }
+    } else if (format == "ICL_NUIM_RT") {
+        float r[16];
+        for (;;) {
+            bool ok = true;
+            for (int i = 0; i < 12 && ok; ++i) ok = (bool)(f >> r[i]);
+            if (!ok) break;
+            r[12] = r[13] = r[14] = 0.0f; r[15] = 1.0f;
+            // trans1 * pose * trans with trans1 = diag(-1, 1, 1, 1), trans = diag(1, -1, 1, 1): row 0 and column 1 change sign
+            for (int j = 0; j < 4; ++j) r[j] = -r[j];
+            for (int i = 0; i < 4; ++i) r[i * 4 + 1] = -r[i * 4 + 1];
+            out.push_back(fromRows(r));
+        }
+    } else {
+        throw std::runtime_error("trajectory format '" + format + "' is not supported (TUM, CoRBS, zhou, ICL_NUIM_RT)");
+    }
+    if (out.empty()) throw std::runtime_error(filename + ": no poses read");
+    return out;
+}
 
 // ------------------------------------------------------------------------------------------------ PNG
 struct Image {

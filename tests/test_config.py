@@ -102,7 +102,7 @@ def test_run_cli_reads_the_reference_configuration(tmp_path):
     assert args.tum == str(tmp_path) and args.assoc_name == "associations.txt" and args.klg is None
     assert (args.width, args.height) == (640, 480) and args.depth_factor == pytest.approx(5000.0)
     assert args.fx == pytest.approx(517.306408) and args.fy == pytest.approx(516.469215)
-    assert args.param_overrides["icp_weight"] == 12.5 and args.max_frames == 120
+    assert args.param_overrides["icp_weight"] == 12.5 and args.end_tick == 120 and args.start_frame == 0   # globalEndFrame bounds the TICK (HRBF_fusion.cpp:98-100)
     args = run.parse(["--config", str(tmp_path / "GlobalStateParam.txt"), "--fx", "500", "--data-dir", str(tmp_path)])
     assert args.fx == 500.0 and args.fy == pytest.approx(516.469215)       # explicit flags win
     args = run.parse(["--synthetic", "3"])

@@ -135,3 +135,60 @@ def test_cpp_caller_loop_matches_the_python_runner(tmp_path, gpu_available, sens
     assert rep["surfels"] == j["surfels"]
     head = open(tmp_path / "cpp.ply", "rb").read(400).split(b"end_header")[0]
     assert b"element vertex" in head
+
+
+def test_trajectory_file_readers_agree(tmp_path):
+    """the C++ (hrbf_io.h loadTrajectoryFile, through the reference-caller test binary's twin in Python) and Python readers of
+    the pose files globalInputLoadTrajectory replays: TUM round trip, zhou re-basing, ICL_NUIM_RT mirroring"""
+    from hrbffusion3d_amd import io as hio
+    T = [synth.camera_pose(k) for k in range(4)]
+    hio.save_trajectory(str(tmp_path / "t.freiburg"), T, stamps_us=[k * 33333 for k in range(4)], fmt="TUM")
+    back = hio.load_trajectory_file(str(tmp_path / "t.freiburg"), "TUM")
+    assert len(back) == 4 and all(np.allclose(a, b, atol=2e-6) for a, b in zip(back, T))
+    hio.save_trajectory(str(tmp_path / "t.log"), T, fmt="zhou")
+    z = hio.load_trajectory_file(str(tmp_path / "t.log"), "zhou")
+    assert np.array_equal(z[0], np.eye(4, dtype=np.float32))
+    assert np.allclose(z[2], np.linalg.inv(T[0]) @ T[2], atol=2e-5)
+    with open(tmp_path / "icl.txt", "w") as f:
+        for M in T:
+            f.write("\n".join(" ".join("%.8f" % v for v in row) for row in M[:3]) + "\n\n")
+    r = hio.load_trajectory_file(str(tmp_path / "icl.txt"), "ICL_NUIM_RT")
+    assert np.allclose(r[1], np.diag([-1.0, 1, 1, 1]) @ T[1] @ np.diag([1.0, -1, 1, 1]), atol=1e-6)
+    with pytest.raises(ValueError):
+        hio.load_trajectory_file(str(tmp_path / "t.log"), "lefloch")
+
+
+@pytest.mark.gpu
+def test_runners_agree_on_start_skip_end_and_trajectory_replay(tmp_path, gpu_available):
+    """the frame selection of MainController::run (globalStartFrame / globalFrameToSkip / globalEndFrame) and
+    globalInputLoadTrajectory (poses replayed from globalInputTrajectoryFile instead of registration, HRBFFusion.cpp:1105-1108):
+    C++ runner == Python runner, and the replayed run is fused at the file's poses"""
+    from hrbffusion3d_amd import run
+    from hrbffusion3d_amd import io as hio
+    exe = _build(str(tmp_path))
+    W, H = 320, 240
+    K = tuple(v / 2 for v in synth.TUM_FR1)
+    frames = _write_sequence(str(tmp_path), W, H, K, 12, 3)
+    cfg = str(tmp_path / "GlobalStateParam.txt")
+    base = open(cfg).read()
+    # (a) frame selection: the skip jumps the tick and the source once, the end frame bounds the tick
+    open(cfg, "w").write(base + "globalFrameToSkip = 2;\nglobalEndFrame = 9;\n")
+    out = subprocess.run([exe, "--config", cfg, "--out", str(tmp_path / "cpp.freiburg"), "--max-surfels", str(1 << 20)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    rep = run.main(["--config", cfg, "--out", str(tmp_path / "py.freiburg"), "--max-surfels", str(1 << 20)])
+    # ticks: frame 0 at tick 1 -> 3 (skip 2) -> processed, tick 4; source jumps to frame 3; ... until tick reaches 9
+    assert j["frames"] == rep["frames"] == 6 and j["surfels"] == rep["surfels"]
+    sa, pa = hio.load_trajectory_tum(str(tmp_path / "cpp.freiburg")); sb, pb = hio.load_trajectory_tum(str(tmp_path / "py.freiburg"))
+    assert len(pa) == len(pb) and all(np.allclose(a, b, atol=2e-6) for a, b in zip(pa, pb)) and np.allclose(sa, sb)
+    # (b) replay: fuse at the analytic poses of the synthetic stream
+    hio.save_trajectory(str(tmp_path / "gt.freiburg"), [f[2] for f in frames], stamps_us=[k * 33333 for k in range(12)], fmt="TUM")
+    open(cfg, "w").write(base + 'globalInputLoadTrajectory = true;\nglobalInputTrajectoryFormat = "TUM";\nglobalInputTrajectoryFile = "gt.freiburg";\n')
+    out = subprocess.run([exe, "--config", cfg, "--ply", str(tmp_path / "cpp.ply"), "--max-surfels", str(1 << 20)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    rep = run.main(["--config", cfg, "--out", str(tmp_path / "py2.freiburg"), "--max-surfels", str(1 << 20)])
+    assert j["frames"] == rep["frames"] == 12 and j["surfels"] == rep["surfels"]
+    _, pr = hio.load_trajectory_tum(str(tmp_path / "py2.freiburg"))
+    for a, f in zip(pr, frames):
+        assert np.allclose(a, f[2], atol=2e-5)        # every frame was processed AT the replayed pose (not at the initial one)

@@ -52,3 +52,44 @@ def test_shim_process_frame_and_ply_on_gpu(tmp_path, gpu_available):
     assert rec[8] < 0                                             # normals negated on export
     traj = open(tmp_path / "run.freiburg").read().strip().split("\n")
     assert len(traj) == 2
+
+
+def _build_reference_caller(tmp):
+    from hrbffusion3d_amd import build
+    so = build.build()
+    exe = os.path.join(tmp, "reference_caller_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "reference_caller_test.cpp"), "-o", exe, so,
+                           "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _reference_caller_files(tmp_path):
+    (tmp_path / "cam.yaml").write_text("%YAML:1.0\nCamera.fx: 132.0\nCamera.fy: 132.0\nCamera.cx: 80.0\nCamera.cy: 60.0\n"
+                                       "Camera.width: 160\nCamera.height: 120\nCamera.RGB: 1\nDepthMapFactor: 5000.0\n")
+    (tmp_path / "GlobalStateParam.txt").write_text('parameterFileCvFormat = "%s";\nsensorType = 3;\nglobalConfidenceThreshold = 5.0;\n'
+                                                   'globalDepthCutoff = 3.5;\nregistrationJointICPWeight = 10;\nregistrationPreAlignSO3 = true;\n'
+                                                   'globalStartFrame = 0;\nglobalEndFrame = -1;\n' % (tmp_path / "cam.yaml"))
+    return str(tmp_path / "GlobalStateParam.txt")
+
+
+def test_reference_caller_compiles_with_only_the_include_changed(tmp_path):
+    """MainController's constructor + run() statements (GUI/src/HRBF_fusion.cpp:35-54,87-100,174-181,190-239): ParameterFile ->
+    GlobalStateParam singleton, Resolution / Intrinsics singletons, `new HRBFFusion(<the reference's eight arguments>)`, the
+    start / skip / processFrame loop — against include/HRBFFusion.h, names at global scope; without a GPU the constructor throws"""
+    exe = _build_reference_caller(str(tmp_path))
+    out = subprocess.run([exe, _reference_caller_files(tmp_path), str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "NOGPU-OK" in out.stdout or "GPU-OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_caller_runs_on_gpu(tmp_path, gpu_available):
+    exe = _build_reference_caller(str(tmp_path))
+    out = subprocess.run([exe, _reference_caller_files(tmp_path), str(tmp_path), "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "GPU-OK" in out.stdout, out.stdout + out.stderr
+    assert "constructed: 160 x 120, tick 1" in out.stdout
+    traj = open(tmp_path / "ref_caller.freiburg").read().strip().split("\n")
+    assert len(traj) == 4
+    head = open(tmp_path / "ref_caller.ply", "rb").read(300)
+    assert b"element vertex" in head

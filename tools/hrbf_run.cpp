@@ -36,21 +36,8 @@ static uint64_t fnv(const void *p, size_t n)
    HRBFFusion.cpp:1263-1345, RGBDOdometry.cpp, IndexMap.cpp:413-518, GlobalModel.cpp:551-688 */
 static hrbf_params paramsFrom(const GlobalState &g, const CameraFile &cam, int maxSurfels)
 {
-    hrbf_params p;
-    hrbf_default_params(&p, cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.depthScale);
-    p.confidence_threshold = g.globalConfidenceThreshold; p.depth_cutoff = g.globalDepthCutoff;
-    p.icp_weight = g.registrationJointICPWeight; p.so3 = g.registrationPreAlignSO3;
-    p.use_bilateral = g.preprocessingUsebilateralFilter; p.init_radius_multiplier = g.preprocessingInitRadiusMultiplier;
-    p.curv_estimation_window = g.preprocessingCurvEstimationWindow; p.curv_valid_threshold = g.preprocessingCurvValidThreshold;
-    p.normal_estimation_pca = g.preprocessingNormalEstimationPCA; p.use_conf_eval = g.preprocessingUseConfEval;
-    p.conf_eval_epsilon = g.preprocessingConfEvalEpsilon;
-    p.icp_use_corr_search = g.registrationICPUseCoorespondenceSearch; p.icp_search_radius = g.registrationICPNeighborSearchRadius;
-    p.icp_use_weighted = g.registrationICPUseWeightedICP; p.icp_curv_weight_lambda = g.registrationICPCurvWeightImpactControl;
-    p.rgb_use_grad_weight = g.registrationColorUseRGBGrad; p.use_sparse_icp = g.registrationICPUseSparseICP;
-    p.predict_window_multiplier = g.preictionWindowMultiplier; p.predict_min_neighbors = g.preictionMinNeighbors;
-    p.predict_max_neighbors = g.preictionMaxNeighbors; p.predict_conf_threshold = g.preictionConfThreshold;
-    p.clean_window_multiplier = g.fusionCleanWindowMultiplier; p.dense_enough_thresh = g.globalDenseEnoughThresh;
-    p.load_trajectory = g.globalInputLoadTrajectory;
+    hrbf_params p = paramsFromGlobalState(g, cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.depthScale, g.globalConfidenceThreshold,
+                                          g.globalDepthCutoff, g.registrationJointICPWeight, false, g.registrationPreAlignSO3, false);
     p.max_surfels = maxSurfels;
     return p;
 }
@@ -76,18 +63,17 @@ int main(int argc, char **argv)
         const CameraFile cam = CameraFile::fromFile(cameraFile);
         if (g.optimizationUseLocalBA || g.optimizationUseGlobalBA)
             fprintf(stderr, "note: optimizationUseLocalBA / GlobalBA are set; the sparse ORB back-end is out of scope (front-end only)\n");
-        if (g.globalEndFrame > 0 && !maxFrames) maxFrames = g.globalEndFrame;
         const bool flip = cam.rgb == 0;
         AssociationReader *assoc = nullptr; KlgReader *klg = nullptr;
-        size_t total = 0;
+        size_t total = 0, klgPos = 0;
         if (g.sensorType == 3) { assoc = new AssociationReader(resolve(g, g.AssociationFile, base), cam.width, cam.height); total = assoc->size(); }
         else if (g.sensorType == 2) { klg = new KlgReader(resolve(g, g.klgFileName, base), cam.width, cam.height, flip); total = klg->size(); }
         else throw std::runtime_error("sensorType 1 (live camera) has no counterpart here");
         if (maxFrames && (size_t)maxFrames < total) total = (size_t)maxFrames;
         Frame fr;
-        auto fetch = [&](size_t i) {
+        auto fetch = [&](size_t i) {   // frame i of the source (the .klg log is sequential: read forward to it)
             if (assoc) { assoc->read(i, fr); if (flip) for (size_t k = 0; k < fr.depth.size(); ++k) std::swap(fr.rgb[3 * k], fr.rgb[3 * k + 2]); }
-            else klg->next(fr);
+            else { while (klgPos <= i) { klg->next(fr); ++klgPos; } }
         };
         if (selftest) {
             if (total) fetch(0);
@@ -103,12 +89,32 @@ int main(int argc, char **argv)
             return 0;
         }
         HRBFFusion fusion(paramsFrom(g, cam, maxSurfels));
+        /* globalInputLoadTrajectory: replay the poses of globalInputTrajectoryFile instead of registering
+           (HRBFFusion.cpp:55-59,1105-1108) */
+        if (g.globalInputLoadTrajectory) fusion.loadTrajectory(resolve(g, g.globalInputTrajectoryFile, base), g.globalInputTrajectoryFormat);
         const auto t0 = std::chrono::steady_clock::now();
         size_t n = 0;
-        for (size_t i = 0; i < total; ++i) {
-            fetch(i);
-            if ((int)i < g.globalStartFrame) continue;
-            fusion.processFrame(fr.rgb.data(), fr.depth.data(), fr.timestamp);   // enqueues; the readers overlap with the GPU
+        /* MainController::run (GUI/src/HRBF_fusion.cpp:190-239): globalStartFrame fast-forwards source and tick, globalFrameToSkip
+           is applied once (tick jump + fusion weight), globalEndFrame bounds the tick */
+        int framesToSkip = g.globalFrameToSkip;
+        const int start = g.globalStartFrame;
+        const int end = g.globalEndFrame > 0 ? g.globalEndFrame : 65535;
+        size_t cur = 0;   // logReader->currentFrame
+        while (cur < total && fusion.getTick() < end) {
+            fetch(cur); ++cur;                                   // logReader->getNext()
+            if (fusion.getTick() < start) {
+                fusion.setTick(start);
+                cur = (size_t)start;                             // fastForward(start); getNext()
+                if (cur >= total) break;
+                fetch(cur); ++cur;
+            }
+            const float weightMultiplier = (float)(framesToSkip + 1);
+            if (framesToSkip > 0) {
+                fusion.setTick(fusion.getTick() + framesToSkip);
+                cur += (size_t)framesToSkip;                     // fastForward(currentFrame + framesToSkip)
+                framesToSkip = 0;
+            }
+            fusion.processFrame(fr.rgb.data(), fr.depth.data(), fr.timestamp, weightMultiplier);   // enqueues; the readers overlap with the GPU
             ++n;
         }
         const size_t poses = fusion.getTrajectory().size();
