@@ -32,13 +32,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=200, help="timed frames (SURVEY §8d: 200 measured frames after 20 warm-up)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--surfels", type=int, default=1_050_000)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--noise", action="store_true", help="Kinect-style depth noise + 3%% drop-outs")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle sample, ~10 s of host time (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle sample (OpenMP), ~10 s of host time (0 = skip)")
+    ap.add_argument("--cpu-frames-1t", type=int, default=2, help="frames of the single-thread CPU-oracle sample (~10 s; 0 = skip)")
+    ap.add_argument("--big-surfels", type=int, default=8_800_000,
+                    help="third leg (rank 0, N=1): BASELINE config 5's largest single-GPU shape, a 1280x960 stream against a map of this "
+                         "many surfels (0 = skip)")
+    ap.add_argument("--big-frames", type=int, default=10)
     ap.add_argument("--shard-odometry", action="store_true",
                     help="N > 1: all ranks track ONE sequence, registration reductions row-sharded + RCCL all-reduce "
                          "(SURVEY §8e sharding 1; strong scaling, a latency cost at VGA). Default: independent replicas")
@@ -63,29 +68,98 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, seed, frames, poses):
-    """Oracle (OpenMP build) on the same workload, bounded sample: bootstrap + n frames."""
+REGIONS = ("Initialization", "Registration", "Integration", "Prediction")   # HRBFFusion.cpp:1016,1063,1196,1248
+
+
+def _cpu_run(args, seed, frames, poses, n, omp):
     from oracle_lib import Oracle
     from hrbffusion3d_amd import synth
     from hrbffusion3d_amd.params import default_params
-    n = args.cpu_frames
-    cores = len(os.sched_getaffinity(0))
-    threads = max(1, min(cores, 32))
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     fx, fy, cx, cy = synth.intrinsics(args.width, args.height)
     p = default_params(args.width, args.height, fx, fy, cx, cy, max_surfels=int(seed.shape[0] + 200_000 + 80_000 * (n + 1)))
-    o = Oracle(p, omp=True)
+    o = Oracle(p, omp=omp)
     o.upload_map(seed)
     o.set_pose(poses[0])
     o.bootstrap(frames[0][0], frames[0][1])
+    reg = np.zeros(4)
     t0 = time.perf_counter()
     for k in range(1, n + 1):
         o.process_frame(frames[k][0], frames[k][1])
+        reg += o.timings()[:4]
     dt = time.perf_counter() - t0
     o.close()
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d frames of the same %dx%d stream against the same %d-surfel map (oracle, OpenMP)" %
-                      (n, args.width, args.height, seed.shape[0])}
+    return n / dt, {r: float(v / n) for r, v in zip(REGIONS, reg)}
+
+
+def cpu_baseline(args, seed, frames, poses):
+    """the CPU oracle on the same workload, (a) single thread, (b) OpenMP over pixels / surfels on the host cores of
+    this box, ms per frame in the reference's four Stopwatch regions.  Bounded samples: bootstrap + n frames each."""
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, min(cores, 32))
+    os.environ["OMP_NUM_THREADS"] = str(threads)     # read by libgomp when the OpenMP build is first loaded
+    n = args.cpu_frames
+    fps, reg = _cpu_run(args, seed, frames, poses, n, True)
+    out = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port", "host_cores": cores,
+           "sample": "%d frames of the same %dx%d stream against the same %d-surfel map (oracle, OpenMP, %d threads)" %
+                     (n, args.width, args.height, seed.shape[0], threads),
+           "region_ms": reg}
+    if args.cpu_frames_1t > 0:
+        fps1, reg1 = _cpu_run(args, seed, frames, poses, args.cpu_frames_1t, False)
+        out["single_thread"] = {"value": fps1, "unit": "frames/s", "cores": 1, "region_ms": reg1,
+                                "sample": "%d frames, same workload, scalar build of the oracle" % args.cpu_frames_1t}
+    return out
+
+
+def big_leg(args, local_rank):
+    """BASELINE config 5's largest single-GPU shape: 1280x960 frames against an 8.8 M-surfel map on ONE GPU (the 8-GPU split of
+    that config is the driver's to run): ms per full processFrame, inputs resident in HBM."""
+    import torch
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion
+    from hrbffusion3d_amd.params import default_params
+    W, H = 1280, 960
+    K = synth.intrinsics(W, H)
+    seed = synth.seed_map(args.big_surfels, t_now=1, width=W)
+    warm, n = 3, args.big_frames
+    fr = _frames(range(1 + warm + n), W, H, False)
+    p = default_params(W, H, *K, max_surfels=int(seed.shape[0] + (W // 2) * (H // 2) * (warm + n + 8)))
+    fus = HRBFFusion(p, device=local_rank)
+    fus.upload_map(seed); fus.set_pose(fr[0][2]); fus.bootstrap(fr[0][0], fr[0][1])
+    d = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1].view(np.int16)).cuda()) for f in fr]
+    for k in range(1, 1 + warm):
+        fus.process_frame_device(d[k][0].data_ptr(), d[k][1].data_ptr(), k)
+    fus.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + warm, 1 + warm + n):
+        fus.process_frame_device(d[k][0].data_ptr(), d[k][1].data_ptr(), k)
+    fus.synchronize()
+    dt = time.perf_counter() - t0
+    fus.enable_timing(1)
+    fus.process_frame_device(d[warm + n][0].data_ptr(), d[warm + n][1].data_ptr(), warm + n)
+    tm = fus.timings()
+    T = fus.get_pose()
+    out = {"workload": "synthetic %dx%d stream, map pre-seeded to %d surfels, one GPU" % (W, H, seed.shape[0]), "frames": n,
+           "ms_per_frame": 1000.0 * dt / n, "frames_per_s": n / dt, "surfels_end": fus.surfel_count(), "status": fus.status(),
+           "final_translation_error_mm": float(1000.0 * np.linalg.norm(T[:3, 3] - fr[warm + n][2][:3, 3])),
+           "last_frame_region_ms": {r: float(v) for r, v in zip(REGIONS + ("fuse_stream_pass",), tm[:5])}}
+    fus.close()
+    return out
+
+
+def _one_frame(a):
+    from hrbffusion3d_amd import synth
+    return synth.frame(a[0], a[1], a[2], noise=a[3])
+
+
+def _frames(ks, W, H, noise):
+    """synthetic frames (rgb, depth, pose); generated by a pool of forked workers — numpy only, 0.26 s per VGA frame"""
+    ks = list(ks)
+    nproc = max(1, min(len(os.sched_getaffinity(0)), 16, len(ks)))
+    if nproc == 1:
+        return [_one_frame((k, W, H, noise)) for k in ks]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(nproc) as pool:
+        return pool.map(_one_frame, [(k, W, H, noise) for k in ks], chunksize=max(1, len(ks) // (4 * nproc)))
 
 
 def cpp_shim_leg(args, seed, frames, poses):
@@ -210,6 +284,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    t_gen = time.perf_counter()
+    gen = _frames(range(1 + args.warmup + args.steps), args.width, args.height, args.noise)   # forked workers: before the HIP runtime starts
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -227,11 +303,9 @@ def main():
     W, H = args.width, args.height
     K, Wm = args.steps, args.warmup
     nframes = 1 + Wm + K
-    t_gen = time.perf_counter()
-    frames, poses = [], []
-    for k in range(nframes):
-        rgb, depth, T = synth.frame(k, W, H, noise=args.noise)
-        frames.append((rgb, depth)); poses.append(T)
+    frames = [(g[0], g[1]) for g in gen]
+    poses = [g[2] for g in gen]
+    del gen
     seed = synth.seed_map(args.surfels, t_now=1, width=W)
     t_gen = time.perf_counter() - t_gen
 
@@ -378,6 +452,14 @@ def main():
         except Exception as e:   # the second leg must never take the bench line down
             worst = {"error": repr(e)}
 
+    big = None
+    if rank == 0 and world == 1 and args.big_surfels > 0 and args.virtual_shards <= 1 and not one_sequence:
+        fus.synchronize()
+        try:
+            big = big_leg(args, local_rank)
+        except Exception as e:   # the extra leg must never take the bench line down
+            big = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "frames/sec at 640x480, 1M-surfel map, 1 MI355X",
@@ -412,6 +494,7 @@ def main():
                                  "currency; roofline_worst_case is the HBM-bound measurement",
                          "moved_per_frame": float(st[ok][:, 6].mean()) if ok.any() else 0.0, "status": status},
             "roofline_worst_case": worst,
+            "config5_single_gpu": big,
         }
         if args.cpu_frames > 0 and world == 1:
             try:

@@ -1039,11 +1039,11 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     uint32_t blocks = tiles < 256u * FUSE_WG_PER_CU ? tiles : 256u * FUSE_WG_PER_CU;
     if (blocks == 0) blocks = 1;
     const size_t lds = sizeof(uint32_t) * (size_t)(tiles ? tiles : 1);
-    static size_t lds_allowed = 48 * 1024;
-    if (lds > lds_allowed) {   // maps beyond ~25 M surfels per shard
+    // maps beyond ~25 M surfels per shard need more than the default 48 KB of dynamic LDS.  The attribute belongs to the current
+    // DEVICE's copy of the function, so it is set whenever it is needed (a process-wide "already raised" flag skipped it for a
+    // second context on another device, whose launch then failed): a host-side call per frame, only for such maps
+    if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_allowed = lds;
-    }
     hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), lds, s, time, m, rec, Q, keep_flags, tile_count,
                        count_in, count_out, stats, cap, tile_done, epoch, tiles, tile_count_next, tile_dirty[1],
                        (zero_records && Q > 0) ? rec_flag : nullptr);

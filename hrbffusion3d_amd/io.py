@@ -75,7 +75,23 @@ def load_trajectory_file(path, fmt="TUM"):
     """the pose files TrajectoryManager::LoadFromFile replays (Core/src/Utils/TrajectoryManager.cpp:61-282): TUM / CoRBS,
     zhou (re-based on the first pose), ICL_NUIM_RT (x mirrored on the left, y on the right); returns a list of 4x4 T_wc"""
     if fmt in ("TUM", "CoRBS"):
-        return [np.asarray(T, np.float32) for T in load_trajectory_tum(path)[1]]
+        # Eigen::Quaternionf(qw, qx, qy, qz) -> Isometry3f::rotate (TrajectoryManager.cpp:225-231): fp32, the quaternion as read
+        # (not normalised), Eigen's toRotationMatrix operation order — the same floats as include/hrbf_io.h loadTrajectoryFile
+        out = []
+        f = np.float32
+        for line in open(path):
+            v = line.split()
+            if len(v) != 8 or line.startswith("#"):
+                continue
+            x, y, z, qx, qy, qz, qw = (f(float(a)) for a in v[1:8])
+            tx, ty, tz = f(2) * qx, f(2) * qy, f(2) * qz
+            twx, twy, twz, txx, txy, txz = tx * qw, ty * qw, tz * qw, tx * qx, ty * qx, tz * qx
+            tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+            out.append(np.array([[f(1) - (tyy + tzz), txy - twz, txz + twy, x], [txy + twz, f(1) - (txx + tzz), tyz - twx, y],
+                                 [txz - twy, tyz + twx, f(1) - (txx + tyy), z], [0, 0, 0, 1]], np.float32))
+        if not out:
+            raise ValueError(path + ": no poses read")
+        return out
     vals = open(path).read().split()
     out = []
     if fmt == "zhou":

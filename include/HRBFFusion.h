@@ -343,6 +343,7 @@ public:
         const bool pushes = tick_before == 1 || !load_trajectory_;
         pushes_.push_back(pushes);
         if (tick_before > 1 && pushes) trajectory_manager->timstamp.push_back(timestamp);
+        if (hrbf_frames_enqueued(h_) - synced_ > 16384u) pullPoses(false);
     }
     /* same, inputs already in device memory (HBM): nothing is copied and nothing blocks */
     void processFrameDevice(const void *d_rgb, const void *d_depth, const int64_t &timestamp, const float weightMultiplier = 1.f)
@@ -354,15 +355,19 @@ public:
         const bool pushes = tick_before == 1 || !load_trajectory_;
         pushes_.push_back(pushes);
         if (tick_before > 1 && pushes) trajectory_manager->timstamp.push_back(timestamp);
+        if (hrbf_frames_enqueued(h_) - synced_ > 16384u) pullPoses(false);
     }
     /* bring trajectory_manager->poses up to date (blocks until every enqueued frame is done) */
-    void syncTrajectory()
+    void syncTrajectory() { pullPoses(true); }
+    /* wait = false: only the frames whose pose has already landed (never blocks).  processFrame calls this once a quarter of
+       the device's 65536-entry ring is pending, so that a caller who never looks at the trajectory cannot overrun it */
+    void pullPoses(bool wait)
     {
         if (!replay_.empty()) return;   // replayed trajectory: `poses` is the loaded file, nothing is pushed
-        const uint32_t n = hrbf_frames_enqueued(h_);
+        const uint32_t n = wait ? hrbf_frames_enqueued(h_) : hrbf_frames_completed(h_);
         if (synced_ >= n) return;
         std::vector<float> buf((size_t)(n - synced_) * 16);
-        const int got = hrbf_get_pose_log(h_, synced_, n - synced_, buf.data(), 1);
+        const int got = hrbf_get_pose_log(h_, synced_, n - synced_, buf.data(), wait ? 1 : 0);
         if (got < 0) throw std::runtime_error(hrbf_last_error());
         for (int k = 0; k < got; ++k) {
             if (synced_ + (uint32_t)k < pushes_.size() && !pushes_[synced_ + (uint32_t)k]) continue;

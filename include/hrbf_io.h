@@ -253,11 +253,14 @@ inline std::vector<PoseCM> loadTrajectoryFile(const std::string &filename, const
             std::istringstream is(line);
             double ts; float x, y, z, qx, qy, qz, qw;
             if (!(is >> ts >> x >> y >> z >> qx >> qy >> qz >> qw)) continue;
-            const float n = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
-            qx /= n; qy /= n; qz /= n; qw /= n;
-            const float R[16] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw), x,
-                                 2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw), y,
-                                 2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy), z, 0, 0, 0, 1};
+            // Eigen::Quaternionf(qw, qx, qy, qz) -> Isometry3f::rotate (TrajectoryManager.cpp:225-231): fp32, the quaternion is
+            // used as read (not normalised), Eigen's toRotationMatrix operation order
+            const float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+            const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx;
+            const float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+            const float R[16] = {1.0f - (tyy + tzz), txy - twz, txz + twy, x,
+                                 txy + twz, 1.0f - (txx + tzz), tyz - twx, y,
+                                 txz - twy, tyz + twx, 1.0f - (txx + tyy), z, 0, 0, 0, 1};
             out.push_back(fromRows(R));
             if (stamps) stamps->push_back((int64_t)(ts * 1e6));
         }
