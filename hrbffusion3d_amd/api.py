@@ -26,7 +26,7 @@ EXPORTS = [
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
-    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_map_shard_init", "hrbf_map_rebalance",
+    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_map_shard_init", "hrbf_map_rebalance",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
@@ -92,6 +92,7 @@ def load_library():
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
     lib.hrbf_update_lambda_map.argtypes = [vp] + [vp] * 9 + [i32, i32]
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.hrbf_peer_unique_id.argtypes = [vp]; lib.hrbf_comm_init_peer.argtypes = [vp, i32, i32, vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
     lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
@@ -203,6 +204,20 @@ class HRBFFusion:
     def comm_init(self, rank, world, unique_id=None):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
         self._check(self.lib.hrbf_comm_init(self.h, int(rank), int(world), buf))
+
+    # the sharded map without RCCL: rendezvous through a POSIX shared-memory segment, images peer-mapped with hipIpcMemHandle;
+    # also works with several ranks on ONE GPU (which RCCL refuses), which is how the path is tested on a single device
+    @staticmethod
+    def peer_unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        if lib.hrbf_peer_unique_id(buf) != 0:
+            raise HrbfError(lib.hrbf_last_error().decode())
+        return bytes(buf)
+
+    def comm_init_peer(self, rank, world, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.hrbf_comm_init_peer(self.h, int(rank), int(world), buf))
 
     # submap bookkeeping + rigid map correction (GlobalModel::updateModel), SURVEY §8f-3
     # GlobalModel / IndexMap operators under the reference's names (explicit pose / time / cut-offs)

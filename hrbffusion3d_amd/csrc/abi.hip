@@ -66,8 +66,33 @@ struct ShardScratch {
     uint32_t *h_counts;         // pinned: the all-gathered counts (sizes of the variable-length exchange)
 };
 
+// Peer link of a sharded map: the ranks of one node map each other's index-map images and z-buffers through
+// hipIpcMemHandle, the owner of a pixel's winner writes its attributes into every rank's images (k_resolve_scatter).  Two
+// transports meet the ranks: (a) RCCL, when hrbf_comm_init joined a communicator — key min-reduce = ncclAllReduce(min), the
+// "everybody has written" point = a one-word ncclAllReduce, all on the context's stream, handles exchanged by ncclAllGather;
+// (b) a POSIX shared-memory rendezvous (hrbf_peer_unique_id / hrbf_comm_init_peer) — handles, counts and barriers go through
+// the segment, the key min-reduce reads the peers' z-buffers.  (b) needs no RCCL and also runs with several ranks on ONE GPU
+// (RCCL refuses that: "Duplicate GPU detected"), which is how the path is tested on a single device.
+#define PEER_BUFS 7   // z-buffer + six image planes
+struct PeerShm {
+    volatile uint32_t arrived;                  // monotone barrier counter
+    volatile uint32_t counts[2][HRBF_PEER_MAX]; // live surfel counts, double buffered by barrier generation
+    hipIpcMemHandle_t handles[HRBF_PEER_MAX][PEER_BUFS];
+};
+struct PeerLink {
+    int enabled;            // images are peer-mapped (either transport)
+    int shm_mode;           // transport (b)
+    int rank, world;
+    PeerShm *shm; char shm_name[64]; int shm_owner;
+    uint32_t gen;           // barriers passed
+    PeerImages img;
+    void *opened[HRBF_PEER_MAX][PEER_BUFS];   // what hipIpcOpenMemHandle returned (to close)
+    uint32_t *d_token;      // one word all-reduced as the on-stream meeting point (transport a)
+};
+
 struct hrbf_context {
     hrbf_params prm;
+    PeerLink peer;
     int device;
     hipStream_t stream;
     Cam cam;
@@ -122,6 +147,9 @@ struct hrbf_context {
     PoseLog *h_pose_log, *d_pose_log_view;   // pinned host ring + its device-side address
     uint32_t frames_enqueued;   // process_frame calls so far = index of the next frame in the pose log
 };
+
+static void peer_close(hrbf_context *c);
+static void peer_shm_release(hrbf_context *c);
 
 template <typename T>
 static int dalloc(T **p, size_t n)
@@ -395,6 +423,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
         free(r);
     }
     if (c->d_stats_ring) hipFree(c->d_stats_ring);
+    peer_close(c); peer_shm_release(c);
     if (c->comm.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm.comm);
     if (c->d_submap_active) hipFree(c->d_submap_active);
     if (c->d_delta) hipFree(c->d_delta);
@@ -468,6 +497,101 @@ static void st_conf(hrbf_context *c)
     launch_confidence(c->stream, c->cam, c->d_gradmag, c->d_confidence, &c->d_pose->weighting, c->prm.use_conf_eval,
                       c->prm.conf_eval_epsilon);
 }
+// ---- peer link -----------------------------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+static int peer_barrier_host(hrbf_context *c)
+{
+    PeerLink &pl = c->peer;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { hrbf_set_error("peer barrier: stream error"); return HRBF_ERR_DEVICE; }
+    const uint32_t target = ++pl.gen * (uint32_t)pl.world;
+    __sync_fetch_and_add(&pl.shm->arrived, 1u);
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t spins = 0;; ++spins) {
+        if ((int32_t)(__atomic_load_n(&pl.shm->arrived, __ATOMIC_ACQUIRE) - target) >= 0) return HRBF_OK;
+        if ((spins & 63u) == 63u) {
+            struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 60) { hrbf_set_error("peer barrier: a rank did not arrive within 60 s"); c->status |= HRBF_STATUS_INTERNAL_BOUND; return HRBF_ERR_COMM; }
+            usleep(20);
+        }
+    }
+}
+// the point after which every rank's writes into this rank's images are complete
+static int peer_meet(hrbf_context *c)
+{
+    if (c->peer.shm_mode) return peer_barrier_host(c);
+    return rccl_allreduce_sum_u32(c->comm.comm, c->peer.d_token, 1, c->stream) == 0 ? HRBF_OK : HRBF_ERR_COMM;
+}
+static void peer_close(hrbf_context *c)
+{
+    PeerLink &pl = c->peer;
+    for (int g = 0; g < HRBF_PEER_MAX; ++g)
+        for (int b = 0; b < PEER_BUFS; ++b)
+            if (pl.opened[g][b]) { hipIpcCloseMemHandle(pl.opened[g][b]); pl.opened[g][b] = nullptr; }
+    if (pl.d_token) { hipFree(pl.d_token); pl.d_token = nullptr; }
+    pl.enabled = 0;
+}
+static void peer_shm_release(hrbf_context *c)
+{
+    PeerLink &pl = c->peer;
+    if (pl.shm) { munmap((void *)pl.shm, sizeof(PeerShm)); pl.shm = nullptr; }
+    if (pl.shm_owner && pl.shm_name[0]) shm_unlink(pl.shm_name);
+    pl.shm_mode = 0; pl.shm_owner = 0; pl.shm_name[0] = 0;
+}
+// exchange the IPC handles of this rank's z-buffer and six index-map planes and map everybody else's
+static int peer_map_images(hrbf_context *c)
+{
+    PeerLink &pl = c->peer;
+    const int G = pl.world, me = pl.rank;
+    void *mine[PEER_BUFS] = {c->d_zbuf, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax, c->d_im_curvmin, c->d_clean_tex};
+    hipIpcMemHandle_t all[HRBF_PEER_MAX][PEER_BUFS];
+    memset(all, 0, sizeof(all));
+    for (int b = 0; b < PEER_BUFS; ++b) {
+        const hipError_t e = hipIpcGetMemHandle(&all[me][b], mine[b]);
+        if (e != hipSuccess) { hrbf_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    }
+    if (pl.shm_mode) {
+        memcpy((void *)pl.shm->handles[me], all[me], sizeof(all[me]));
+        __sync_synchronize();
+        int r = peer_barrier_host(c);
+        if (r) return r;
+        memcpy(all, (const void *)pl.shm->handles, sizeof(all));
+    } else {
+        // all-gather of the handle bytes through the communicator (device staging, 448 B per rank)
+        uint32_t *d = nullptr;
+        const size_t words = sizeof(all[0]) / 4;
+        if (hipMalloc((void **)&d, sizeof(all)) != hipSuccess) return HRBF_ERR_DEVICE;
+        hipMemcpyAsync(d + (size_t)me * words, all[me], sizeof(all[me]), hipMemcpyHostToDevice, c->stream);
+        const int e = rccl_allgather_u32(c->comm.comm, d + (size_t)me * words, d, words, c->stream);
+        hipMemcpyAsync(all, d, sizeof(all[0]) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t se = hipStreamSynchronize(c->stream);
+        hipFree(d);
+        if (e != 0 || se != hipSuccess) { hrbf_set_error("peer link: handle all-gather failed"); return HRBF_ERR_COMM; }
+    }
+    PeerImages &pi = pl.img;
+    memset(&pi, 0, sizeof(pi));
+    pi.world = G; pi.me = me;
+    for (int g = 0; g < G; ++g) {
+        void *q[PEER_BUFS];
+        for (int b = 0; b < PEER_BUFS; ++b) {
+            if (g == me) { q[b] = mine[b]; continue; }
+            const hipError_t e = hipIpcOpenMemHandle(&q[b], all[g][b], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { hrbf_set_error("hipIpcOpenMemHandle(rank %d, buffer %d): %s", g, b, hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+            pl.opened[g][b] = q[b];
+        }
+        pi.zbuf[g] = (unsigned long long *)q[0]; pi.vertconf[g] = (float4 *)q[1]; pi.normrad[g] = (float4 *)q[2];
+        pi.colortime[g] = (float4 *)q[3]; pi.curvmax[g] = (float4 *)q[4]; pi.curvmin[g] = (float4 *)q[5]; pi.clean[g] = (float4 *)q[6];
+    }
+    if (!pl.shm_mode) {
+        if (hipMalloc((void **)&pl.d_token, sizeof(uint32_t)) != hipSuccess) return HRBF_ERR_DEVICE;
+        hipMemsetAsync(pl.d_token, 0, sizeof(uint32_t), c->stream);
+    }
+    pl.enabled = 1;
+    return pl.shm_mode ? peer_barrier_host(c) : HRBF_OK;   // nobody touches a peer's memory before everybody has mapped it
+}
+
 static void refresh_count_ub(hrbf_context *c)
 {
     // 1-frame-lag read-back of the surfel counts; never blocks in steady state
@@ -493,7 +617,23 @@ static void request_count(hrbf_context *c)
 // single-process test mode reduces the private outputs of the virtual shards with local kernels instead (st_indices).
 static void shard_allgather_counts(hrbf_context *c, uint32_t *row)
 {
-    if (c->shard_real && c->comm.comm) rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
+    if (!c->shard_real) return;
+    if (c->peer.shm_mode) {   // through the rendezvous segment (double buffered by barrier generation)
+        PeerLink &pl = c->peer;
+        uint32_t mine = 0;
+        hipMemcpyAsync(&mine, row + pl.rank, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+        const int slot = (int)((pl.gen + 1u) & 1u);
+        pl.shm->counts[slot][pl.rank] = mine;
+        __sync_synchronize();
+        if (peer_barrier_host(c)) return;
+        uint32_t all[HRBF_PEER_MAX];
+        for (int g = 0; g < pl.world; ++g) all[g] = pl.shm->counts[slot][g];
+        hipMemcpyAsync(row, all, sizeof(uint32_t) * (size_t)pl.world, hipMemcpyHostToDevice, c->stream);
+        hipStreamSynchronize(c->stream);   // `all` is a stack buffer
+        return;
+    }
+    if (c->comm.comm) rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
 }
 static void st_init(hrbf_context *c)
 {
@@ -551,6 +691,22 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
                 launch_winner_unpack(c->stream, c->P, cnt, 0, cap, c->x.send_idx, c->x.send_f, cap, what, c->d_im_vertconf,
                                      c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
         }
+        return;
+    }
+    if (c->peer.enabled) {
+        // one shard per rank, images peer-mapped: the ranks meet once the keys are reduced and once the owners have written
+        PeerLink &pl = c->peer;
+        const unsigned long long *zred = c->d_zbuf;
+        if (pl.shm_mode) {
+            if (peer_barrier_host(c)) return;                              // everybody has projected
+            launch_zbuf_min_peers(c->stream, pl.img, c->x.zbuf, c->P);       // min over the ranks' private z-buffers
+            zred = c->x.zbuf;
+        }   // RCCL transport: the all-reduce above left the reduced keys in d_zbuf
+        launch_resolve_scatter(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), zred, c->d_idx, pl.img, what, for_clean,
+                               c->clean_thr, c->clean_time);
+        if (peer_meet(c)) return;                                           // every owner has written into every rank's images
+        launch_zbuf_reset(c->stream, c->d_zbuf, c->P);                       // re-arm the private z-buffer: nobody reads it any more
+        if (for_clean && (what & 4)) launch_clean_bits_decode(c->stream, c->d_clean_tex, c->P);
         return;
     }
     // one shard per rank
@@ -1441,6 +1597,7 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     hipSetDevice(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
+    peer_close(c); peer_shm_release(c);
     c->comm.rank = 0; c->comm.world = 1; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
     if (rank < 0) { c->comm.virtual_world = world > 1 ? world : 0; return HRBF_OK; }
     if (rank >= world || !id128) return HRBF_ERR_INVALID;
@@ -1453,6 +1610,41 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     if (e != 0 || !comm) { hrbf_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
     c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world; c->comm.allreduce_i64 = rccl_allreduce_i64;
     return HRBF_OK;
+}
+
+// Rendezvous of the peer link without RCCL: a POSIX shared-memory segment whose name is the id.  Works for ranks on different
+// GPUs of one node and for several ranks on ONE GPU (which RCCL refuses) — the single-device test of the sharded map.
+extern "C" int hrbf_peer_unique_id(uint8_t out128[128])
+{
+    if (!out128) return HRBF_ERR_INVALID;
+    memset(out128, 0, 128);
+    struct timespec t; clock_gettime(CLOCK_REALTIME, &t);
+    snprintf((char *)out128, 64, "/hrbf_peer_%d_%lx", (int)getpid(), (unsigned long)t.tv_nsec);
+    const int fd = shm_open((const char *)out128, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) { hrbf_set_error("shm_open(%s) failed", (const char *)out128); return HRBF_ERR_COMM; }
+    const int r = ftruncate(fd, sizeof(PeerShm));
+    close(fd);
+    if (r != 0) { shm_unlink((const char *)out128); hrbf_set_error("ftruncate of the rendezvous segment failed"); return HRBF_ERR_COMM; }
+    return HRBF_OK;   // zero-filled by the kernel; rank 0 of hrbf_comm_init_peer unlinks it when its context goes away
+}
+extern "C" int hrbf_comm_init_peer(hrbf_handle c, int rank, int world, const uint8_t id128[128])
+{
+    if (!c || !id128 || world < 2 || world > HRBF_PEER_MAX || rank < 0 || rank >= world || id128[0] != '/') return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
+    peer_close(c); peer_shm_release(c);
+    c->comm.rank = rank; c->comm.world = world; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
+    PeerLink &pl = c->peer;
+    memcpy(pl.shm_name, id128, 63); pl.shm_name[63] = 0;
+    const int fd = shm_open(pl.shm_name, O_RDWR, 0600);
+    if (fd < 0) { hrbf_set_error("shm_open(%s) failed", pl.shm_name); return HRBF_ERR_COMM; }
+    void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { hrbf_set_error("mmap of the rendezvous segment failed"); return HRBF_ERR_COMM; }
+    pl.shm = (PeerShm *)m; pl.shm_mode = 1; pl.shm_owner = rank == 0; pl.rank = rank; pl.world = world; pl.gen = 0;
+    c->rows_replicated = 1;   // no communicator for the registration sums: every rank reduces the whole image
+    return peer_barrier_host(c);
 }
 
 // ------------------------------------------------------------------------------------------ sharded surfel map
@@ -1469,7 +1661,7 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
     if (hrbf_surfel_count(c) != 0) { hrbf_set_error("map_shard_init: the map must be empty (upload it afterwards)"); return HRBF_ERR_INVALID; }
     int G = 1, nsh = 1, first = 0, real = 0;
     if (enable) {
-        if (c->comm.comm) { G = c->comm.world; nsh = 1; first = c->comm.rank; real = 1; }
+        if (c->comm.comm || c->peer.shm_mode) { G = c->comm.world; nsh = 1; first = c->comm.rank; real = 1; }
         else if (c->comm.virtual_world > 1) { G = c->comm.virtual_world; nsh = G; }
         else { hrbf_set_error("map_shard_init: call hrbf_comm_init first"); return HRBF_ERR_INVALID; }
         if (G > HRBF_MAX_SHARDS) { hrbf_set_error("map_shard_init: at most %d shards", HRBF_MAX_SHARDS); return HRBF_ERR_INVALID; }
@@ -1488,7 +1680,7 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
         int r = dalloc(&c->x.rec_count, HRBF_MAX_SHARDS);
         if (!r) r = dalloc(&c->x.send_idx, P);
         if (!r) r = dalloc(&c->x.send_f, 6 * P);
-        if (!r && nsh > 1) r = dalloc(&c->x.zbuf, P);
+        if (!r && (nsh > 1 || c->peer.shm_mode)) r = dalloc(&c->x.zbuf, P);   // virtual shards' scratch / the reduced keys of the shm transport
         if (!r && real) r = dalloc(&c->x.recv_idx, P);
         if (!r && real) r = dalloc(&c->x.recv_f, 6 * P);
         if (r) return r;
@@ -1497,6 +1689,17 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
         if (c->x.zbuf) launch_zbuf_reset(c->stream, c->x.zbuf, c->P);
     }
     c->G = G; c->nsh = nsh; c->shard_first = first; c->shard_real = real;
+    peer_close(c);
+    if (real) {
+        // the index-map images of all ranks are mapped into every rank (the owner of a winner writes them, st_indices).
+        // HRBF_SHARD_EXCHANGE=records keeps the packed-record exchange over ncclSend / ncclRecv instead (RCCL transport only).
+        const char *ex = getenv("HRBF_SHARD_EXCHANGE");
+        if (c->peer.shm_mode || !(ex && !strcmp(ex, "records"))) {
+            if (!c->peer.shm_mode) { c->peer.rank = c->comm.rank; c->peer.world = c->comm.world; }
+            const int r = peer_map_images(c);
+            if (r) return r;
+        }
+    }
     for (int k = 0; k < nsh; ++k) c->sh[k].count_ub = 0;
     HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1548,6 +1751,7 @@ extern "C" int hrbf_map_rebalance(hrbf_handle c)
 {
     if (!c) return HRBF_ERR_INVALID;
     if (c->G == 1) return HRBF_OK;
+    if (c->peer.shm_mode) { hrbf_set_error("map_rebalance: the re-cut moves surfels with ncclSend / ncclRecv; not available on the shared-memory transport"); return HRBF_ERR_INVALID; }
     hipSetDevice(c->device);
     uint32_t cnt[HRBF_MAX_SHARDS], ncnt[HRBF_MAX_SHARDS] = {0}, moves[5 * 2 * HRBF_MAX_SHARDS];
     if (read_counts(c, cnt)) { hrbf_set_error("map_rebalance: count read-back failed"); return HRBF_ERR_DEVICE; }

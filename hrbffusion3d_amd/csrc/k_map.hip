@@ -188,6 +188,33 @@ __device__ __forceinline__ const uint32_t *clean_bits(const float4 *clean_tex, i
 // rec.f holds six planes of `cap` float4: 0 vertconf, 1 normrad, 2 colortime, 3 curvmax, 4 curvmin, 5 clean texel.
 struct WinnerRecords { uint32_t *count; uint32_t *idx; float4 *f; uint32_t cap; };
 
+// what the index map holds for a pixel whose z-test winner is surfel `s` of this shard (global id `sg`)
+struct WinnerTexels {
+    float4 vc = {0, 0, 0, 0}, nr = {0, 0, 0, 0}, ct = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, clean = {0, 0, 0, 0};
+};
+__device__ __forceinline__ bool resolve_winner(const MapPlanes &m, uint32_t s, uint32_t sg, const Rigid &tinv, int what,
+                                               float clean_conf_thr, int clean_time, WinnerTexels &o)
+{
+    bool updated = false;
+    const float4 p = m.p0[s];
+    const f3 h = xform(tinv, xyz(p));
+    if (what & RESOLVE_GEOM) {
+        const float4 nr = m.p2[s];
+        const f3 n = normalize3(rot_mul(tinv, xyz(nr)));
+        o.vc = make_float4(h.x, h.y, h.z, p.w);
+        o.nr = make_float4(n.x, n.y, n.z, nr.w);
+    }
+    if (what & (RESOLVE_ATTR | RESOLVE_CLEAN)) {
+        const float4 ct = m.p1[s];
+        if (what & RESOLVE_ATTR) { o.ct = ct; o.c1 = m.p3[s]; o.c2 = m.p4[s]; }
+        if ((what & RESOLVE_CLEAN) && sg > 0u && p.w > clean_conf_thr) {
+            o.clean = make_float4(h.x, h.y, h.z, ct.z);
+            updated = ct.w == (float)clean_time;
+        }
+    }
+    return updated;
+}
+
 __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restrict__ dp, MapPlanes m, ShardRef sh, int rearm,
                                                  unsigned long long *__restrict__ zbuf,
                                                  uint32_t *__restrict__ idx, float4 *__restrict__ vertconf,
@@ -213,26 +240,10 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
         owned = s < sh.counts[sh.k];   // else the winner lives on another shard: contribute zeros to the sum-reduction
     }
     if (dense && live) idx[i] = sg;
-    float4 o_vc = z4, o_nr = z4, o_ct = z4, o_c1 = z4, o_c2 = z4, o_clean = z4;
+    WinnerTexels o;
     bool updated = false;
-    if (owned) {
-        const float4 p = m.p0[s];
-        const f3 h = xform(tinv, xyz(p));
-        if (what & RESOLVE_GEOM) {
-            const float4 nr = m.p2[s];
-            const f3 n = normalize3(rot_mul(tinv, xyz(nr)));
-            o_vc = make_float4(h.x, h.y, h.z, p.w);
-            o_nr = make_float4(n.x, n.y, n.z, nr.w);
-        }
-        if (what & (RESOLVE_ATTR | RESOLVE_CLEAN)) {
-            const float4 ct = m.p1[s];
-            if (what & RESOLVE_ATTR) { o_ct = ct; o_c1 = m.p3[s]; o_c2 = m.p4[s]; }
-            if ((what & RESOLVE_CLEAN) && sg > 0u && p.w > clean_conf_thr) {
-                o_clean = make_float4(h.x, h.y, h.z, ct.z);
-                updated = ct.w == (float)clean_time;
-            }
-        }
-    }
+    if (owned) updated = resolve_winner(m, s, sg, tinv, what, clean_conf_thr, clean_time, o);
+    const float4 o_vc = o.vc, o_nr = o.nr, o_ct = o.ct, o_c1 = o.c1, o_c2 = o.c2, o_clean = o.clean;
     if (dense && live) {
         if (what & RESOLVE_GEOM) { vertconf[i] = o_vc; normrad[i] = o_nr; }
         if (what & RESOLVE_ATTR) { colortime[i] = o_ct; curvmax[i] = o_c1; curvmin[i] = o_c2; }
@@ -946,6 +957,78 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
     hipLaunchKernelGGL(k_init_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, vertex_raw, normal, rgb, curv1,
                        curv2, gradmag, use_conf_eval, eps, flags, offs, out, cap);
     hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap, status);
+}
+
+// ---- sharded map over peer-mapped images (SURVEY §8e sharding 2): the OWNER of a pixel's winner writes the
+// winner's attributes straight into every rank's index-map images (hipIpcMemHandle-mapped; xGMI peers on one node) — no
+// packing, no count exchange, no host read-back.  A pixel has exactly one owner, so the writes never collide; a pixel nobody
+// hit is zeroed by every rank locally.  The clean pass's "winner updated this frame" bit travels in the sign of the clean
+// texel's w (the winner's init time, >= 0): w < 0 encodes updated with init time -w - 1; k_clean_bits_decode restores the texel
+// and builds the local 1-bit-per-pixel mask after the ranks have met.
+__global__ __launch_bounds__(256) void k_zbuf_min_peers(PeerImages pi, unsigned long long *__restrict__ zred, int P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    unsigned long long k = ZB_EMPTY;
+    for (int g = 0; g < pi.world; ++g) { const unsigned long long v = pi.zbuf[g][i]; k = v < k ? v : k; }
+    zred[i] = k;
+}
+__global__ __launch_bounds__(256) void k_resolve_scatter(Cam cam, const DevPose *__restrict__ dp, MapPlanes m, ShardRef sh,
+                                                         const unsigned long long *__restrict__ zred, uint32_t *__restrict__ idx,
+                                                         PeerImages pi, int what, float clean_conf_thr, int clean_time)
+{
+    const int P = cam.W * cam.H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const unsigned long long key = zred[i];
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    if (key == ZB_EMPTY) {   // nobody's surfel: every rank clears its own texels
+        idx[i] = 0u;
+        const int g = pi.me;
+        if (what & RESOLVE_GEOM) { pi.vertconf[g][i] = z4; pi.normrad[g][i] = z4; }
+        if (what & RESOLVE_ATTR) { pi.colortime[g][i] = z4; pi.curvmax[g][i] = z4; pi.curvmin[g][i] = z4; }
+        if (what & RESOLVE_CLEAN) pi.clean[g][i] = z4;
+        return;
+    }
+    const uint32_t sg = (uint32_t)(key & 0xFFFFFFFFull);
+    idx[i] = sg;
+    const uint32_t s = sg - shard_offset(sh);
+    if (!(s < sh.counts[sh.k])) return;   // another rank owns the winner and writes this pixel
+    WinnerTexels o;
+    const bool updated = resolve_winner(m, s, sg, dp->tinv, what, clean_conf_thr, clean_time, o);
+    if (updated) o.clean.w = -(o.clean.w + 1.0f);
+    for (int g = 0; g < pi.world; ++g) {
+        if (what & RESOLVE_GEOM) { pi.vertconf[g][i] = o.vc; pi.normrad[g][i] = o.nr; }
+        if (what & RESOLVE_ATTR) { pi.colortime[g][i] = o.ct; pi.curvmax[g][i] = o.c1; pi.curvmin[g][i] = o.c2; }
+        if (what & RESOLVE_CLEAN) pi.clean[g][i] = o.clean;
+    }
+}
+__global__ __launch_bounds__(256) void k_clean_bits_decode(float4 *__restrict__ clean_tex, int P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // P is a multiple of 64: whole waves
+    bool updated = false;
+    if (i < P) {
+        float4 t = clean_tex[i];
+        updated = t.w < 0.0f;
+        if (updated) { t.w = -t.w - 1.0f; clean_tex[i] = t; }
+    }
+    const unsigned long long bal = __ballot(updated);
+    if (i < P && (threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(clean_tex + P)[i >> 6] = bal;
+}
+void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long long *zred, int P)
+{
+    hipLaunchKernelGGL(k_zbuf_min_peers, dim3((P + 255) / 256), dim3(256), 0, s, pi, zred, P);
+}
+void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, const unsigned long long *zred,
+                            uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time)
+{
+    const int P = cam.W * cam.H;
+    if (!for_clean) what &= ~RESOLVE_CLEAN;
+    hipLaunchKernelGGL(k_resolve_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, zred, idx, pi, what, clean_conf_thr, clean_time);
+}
+void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P)
+{
+    hipLaunchKernelGGL(k_clean_bits_decode, dim3((P + 255) / 256), dim3(256), 0, s, clean_tex, P);
 }
 
 void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,

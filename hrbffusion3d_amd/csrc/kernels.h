@@ -68,6 +68,19 @@ void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t 
                           float4 *curvmax, float4 *curvmin, float4 *clean_tex);
 size_t clean_tex_elems(int P);   // float4 elements of the clean-texel buffer (texels + one bit per pixel)
 void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P);   // local stand-in for allReduce(min)
+// sharded map over peer-mapped images: the index-map images (and the private z-buffer) of every rank of the node, as mapped
+// into this process (hipIpcOpenMemHandle; entry `me` = the local buffers)
+#define HRBF_PEER_MAX 8
+struct PeerImages {
+    int world, me;
+    unsigned long long *zbuf[HRBF_PEER_MAX];
+    float4 *vertconf[HRBF_PEER_MAX], *normrad[HRBF_PEER_MAX], *colortime[HRBF_PEER_MAX], *curvmax[HRBF_PEER_MAX], *curvmin[HRBF_PEER_MAX],
+        *clean[HRBF_PEER_MAX];
+};
+void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long long *zred, int P);
+void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, const unsigned long long *zred,
+                            uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time);
+void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P);
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,

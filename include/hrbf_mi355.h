@@ -338,7 +338,20 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  *   hrbf_upload_map            always takes the WHOLE map; a rank keeps its slice.
  *   hrbf_surfel_count          global count; hrbf_local_surfel_count / hrbf_download_map: the local range(s).
  *   hrbf_rebalance_plan        the host-side arithmetic of the re-cut (pure function, no device needed):
- *                              moves5[i] = {src shard, dst shard, offset in src, offset in dst, length}, <= 2*G - 1. */
+ *                              moves5[i] = {src shard, dst shard, offset in src, offset in dst, length}, <= 2*G - 1.
+ *
+ * How the ranks exchange the index map: every rank maps the other ranks' index-map images (hipIpcMemHandle; the
+ * ranks of one node) and the OWNER of a pixel's z-test winner writes the winner's attributes straight into every rank's
+ * images — no packing, no count exchange, no host read-back; per projection the ranks meet twice on the stream (key
+ * min-reduce, "everybody has written").  HRBF_SHARD_EXCHANGE=records selects the older packed-record ncclSend / ncclRecv.
+ *
+ * hrbf_peer_unique_id / hrbf_comm_init_peer: the same sharded map WITHOUT RCCL — rendezvous, surfel counts and the meeting
+ * points go through a POSIX shared-memory segment (the id is its name), the key min-reduce reads the peers' z-buffers.  It
+ * exists because RCCL refuses two ranks on one GPU ("Duplicate GPU detected"): with it the whole sharded-map path runs as
+ * two PROCESSES on ONE device, bit-identical to the single map (tests/test_peer_shards_gpu.py).  Registration is then not
+ * row-sharded (every rank reduces the whole image) and hrbf_map_rebalance is unavailable. */
+int hrbf_peer_unique_id(uint8_t out128[128]);
+int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
 int hrbf_map_shard_init(hrbf_handle h, int enable);
 int hrbf_set_row_sharding(hrbf_handle h, int enable);   /* 0: keep the communicator (sharded map) but let every rank reduce the whole image: no registration collectives */
 int hrbf_map_rebalance(hrbf_handle h);

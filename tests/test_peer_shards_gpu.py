@@ -1,0 +1,111 @@
+"""The sharded surfel map across PROCESSES (SURVEY §8e sharding 2) on the one GPU a test box has.
+
+Two processes, each with its own context on device 0, join through hrbf_peer_unique_id / hrbf_comm_init_peer (a POSIX
+shared-memory rendezvous: RCCL refuses two ranks on one GPU), cut one map into two contiguous ranges and track the same
+sequence.  Everything a multi-GPU run of the sharded map does is executed for real: hipIpcMemHandle exchange and mapping of
+the peers' index-map images and z-buffers, projection under global ids, key min-reduce over the peers' z-buffers, the
+OWNER-side scatter of winner attributes into every rank's images (k_resolve_scatter), the clean mask carried in the texel,
+replicated association, merges by the owner, per-rank clean + compaction, appends on the last rank, the count exchange.
+The result must be bit-identical to one process holding the whole map: every image on every rank, the concatenation of the
+ranks' slices, the pose."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+IMAGES_CHECKED = ("INDEX", "INDEX_VERTCONF", "INDEX_COLORTIME", "INDEX_NORMRAD", "INDEX_CURVMAX", "INDEX_CURVMIN", "PRED_VERTEX",
+                  "PRED_NORMAL", "PRED_ICPWEIGHT", "FILL_VERTEX", "CONFIDENCE")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        u = a.view(np.uint32).copy(); u[np.isnan(a)] = 0x7FC00000
+        return u
+    return a.view(np.uint8)
+
+
+def _run(rank, world, uid, cfg, out):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion
+    from hrbffusion3d_amd.params import default_params
+    try:
+        W, H, nseed, frames, sparse = cfg
+        K = synth.intrinsics(W, H)
+        seed = synth.seed_map(nseed, width=W) if nseed else None
+        p = default_params(W, H, *K, max_surfels=(nseed or 0) + 300_000, use_sparse_icp=sparse)
+        g = HRBFFusion(p)
+        if world > 1:
+            g.comm_init_peer(rank, world, uid)
+            g.map_shard_init(True)
+        rgb, d, T = synth.frame(0, W, H, noise=True)
+        if seed is not None:
+            g.upload_map(seed); g.set_pose(T); g.bootstrap(rgb, d)
+            first = 1
+        else:
+            first = 0
+        res = {}
+        for k in range(first, frames):
+            rgb, d, T = synth.frame(k, W, H, noise=True)
+            g.process_frame(rgb, d)
+            res["pose%d" % k] = _bits(g.get_pose())
+            res["stats%d" % k] = g.fuse_stats()
+            res["count%d" % k] = g.surfel_count()
+            if k in (first, frames - 1):
+                for name in IMAGES_CHECKED:
+                    res["%s%d" % (name, k)] = _bits(g.get_image(name))
+        res["local_count"] = g.local_surfel_count()
+        res["map"] = _bits(g.download_map())
+        res["status"] = g.status()
+        g.close()
+        out.put((rank, res))
+    except Exception as e:   # surface the failure in the parent instead of a hang
+        import traceback
+        out.put((rank, {"error": "%r\n%s" % (e, traceback.format_exc())}))
+
+
+def _launch(world, cfg):
+    from hrbffusion3d_amd.api import HRBFFusion
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = HRBFFusion.peer_unique_id() if world > 1 else None
+    procs = [ctx.Process(target=_run, args=(r, world, uid, cfg, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(world):
+        r, res = q.get(timeout=600)
+        got[r] = res
+    for pr in procs:
+        pr.join(timeout=60)
+    for r in got:
+        assert "error" not in got[r], got[r]["error"]
+    return got
+
+
+@pytest.mark.parametrize("cfg", [(160, 120, 0, 6, 0), (320, 240, 150_000, 6, 1)], ids=["from_empty_map", "uploaded_150k_sparse_icp"])
+def test_two_processes_share_one_sharded_map_bit_identical_to_a_single_map(gpu_available, cfg):
+    single = _launch(1, cfg)[0]
+    two = _launch(2, cfg)
+    assert two[0]["status"] == 0 and two[1]["status"] == 0
+    for k, v in single.items():
+        if k in ("map", "local_count", "status"):
+            continue
+        if k.startswith("stats"):   # {in, merged, appended, out} are per rank: they add up to the single map's
+            assert np.array_equal(two[0][k].astype(np.int64) + two[1][k], v), k
+            continue
+        for r in (0, 1):
+            assert np.array_equal(two[r][k], v), "rank %d differs in %s" % (r, k)
+    # the ranks hold contiguous ranges of the single map's order
+    n = single["local_count"]
+    assert two[0]["local_count"] + two[1]["local_count"] == n
+    joined = np.concatenate([two[0]["map"].reshape(-1, 20), two[1]["map"].reshape(-1, 20)])
+    assert np.array_equal(joined, single["map"].reshape(-1, 20))
+    if cfg[2]:
+        assert min(two[0]["local_count"], two[1]["local_count"]) > 10_000   # both ranks really own part of the view
