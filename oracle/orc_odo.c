@@ -258,11 +258,14 @@ void orc_odo_init_first_rgb(orc_ctx *c)
         pyrdown_gauss_u8(c->last_next_image[i], c->H >> i, c->W >> i, c->last_next_image[i + 1]);
 }
 
-/* ------------------------------------------------------------------ small dense linear algebra */
+/* ------------------------------------------------------------------ small dense linear algebra
+ * Diagonal-pivoted LDL^T (the reference calls Eigen's ldlt().solve, RGBDOdometry.cpp:1173-1185: own factorisation, DESIGN §8
+ * deviations).  One reciprocal per pivot: the device runs this on ONE lane, where each of the 21 divisions of the textbook
+ * form (15 column scalings + 6 diagonal solves) is a ~30-instruction dependent chain in fp64. */
 #define DEF_LDLT(NAME, T)                                                                        \
     static void NAME(int n, const T *Ain, const T *b, T *x)                                      \
     {                                                                                            \
-        T A[36]; int perm[6]; T y[6];                                                            \
+        T A[36]; int perm[6]; T y[6]; T rdiag[6];                                                \
         for (int i = 0; i < n * n; ++i) A[i] = Ain[i];                                           \
         for (int i = 0; i < n; ++i) perm[i] = i;                                                 \
         for (int k = 0; k < n; ++k) {                                                            \
@@ -277,8 +280,11 @@ void orc_odo_init_first_rgb(orc_ctx *c)
                 int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;                           \
             }                                                                                    \
             T d = A[k * n + k];                                                                  \
+            rdiag[k] = 0;                                                                        \
             if (d == 0) continue;                                                                \
-            for (int i = k + 1; i < n; ++i) A[i * n + k] = A[i * n + k] / d;                     \
+            const T rd = 1 / d;   /* ONE division per pivot; columns and the diagonal solve multiply by it */ \
+            rdiag[k] = rd;                                                                       \
+            for (int i = k + 1; i < n; ++i) A[i * n + k] = A[i * n + k] * rd;                    \
             for (int i = k + 1; i < n; ++i)                                                      \
                 for (int j = k + 1; j <= i; ++j) {                                               \
                     A[i * n + j] = A[i * n + j] - A[i * n + k] * d * A[j * n + k];               \
@@ -287,7 +293,7 @@ void orc_odo_init_first_rgb(orc_ctx *c)
         }                                                                                        \
         for (int i = 0; i < n; ++i) y[i] = b[perm[i]];                                           \
         for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] = y[i] - A[i * n + j] * y[j]; \
-        for (int i = 0; i < n; ++i) y[i] = (A[i * n + i] == 0) ? 0 : y[i] / A[i * n + i];        \
+        for (int i = 0; i < n; ++i) y[i] = (A[i * n + i] == 0) ? 0 : y[i] * rdiag[i];           \
         for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] = y[i] - A[j * n + i] * y[j]; \
         for (int i = 0; i < n; ++i) x[perm[i]] = y[i];                                           \
     }

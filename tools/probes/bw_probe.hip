@@ -1,0 +1,88 @@
+// Measurement probe (not part of the path): what a plain streaming kernel reaches on this GPU at the sizes of the fuse pass.
+//   read  : one float4 plane of N surfels (16 B / surfel), summed            -> the floor of k_project / pass A's position stream
+//   copy5 : five float4 planes read and written out of place (160 B / surfel) -> the ceiling of pass B (in-place compaction)
+// hipcc --offload-arch=gfx950 -O3 tools/probes/bw_probe.hip -o /tmp/bw_probe && /tmp/bw_probe 4343735
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+__global__ __launch_bounds__(256) void k_read(const float4 *__restrict__ p, size_t n, float *out)
+{
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { float4 v = p[i]; acc += v.x + v.w; }
+    if (acc == 12345.678f) *out = acc;
+}
+template <int IPT>
+__global__ __launch_bounds__(512) void k_copy5(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n, size_t plane)
+{
+    for (size_t base = (size_t)blockIdx.x * blockDim.x * IPT; base < n; base += (size_t)gridDim.x * blockDim.x * IPT) {
+        float4 v[IPT][5];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { size_t i = base + k * blockDim.x + threadIdx.x; if (i < n) for (int q = 0; q < 5; ++q) v[k][q] = a[q * plane + i]; }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { size_t i = base + k * blockDim.x + threadIdx.x; if (i < n) for (int q = 0; q < 5; ++q) b[q * plane + i] = v[k][q]; }
+    }
+}
+// V1/V2: one contiguous stream of 5 n float4 (what hipMemcpy sees), U float4 per thread per trip
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy_flat(const float4 *__restrict__ a4, float4 *__restrict__ b4, size_t n)
+{
+    const f4v *a = reinterpret_cast<const f4v *>(a4); f4v *b = reinterpret_cast<f4v *>(b4);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride * U) {
+        f4v v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) if (i + k * stride < n) v[k] = NT ? __builtin_nontemporal_load(&a[i + k * stride]) : a[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; ++k) if (i + k * stride < n) { if (NT) __builtin_nontemporal_store(v[k], &b[i + k * stride]); else b[i + k * stride] = v[k]; }
+    }
+}
+// V3: a workgroup takes a tile of T surfels and moves it plane by plane (one stream in, one out at a time)
+template <int T>
+__global__ __launch_bounds__(512) void k_copy_tile_planes(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n, size_t plane)
+{
+    const size_t tiles = (n + T - 1) / T;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        for (int q = 0; q < 5; ++q) {
+            float4 v[T / 512];
+#pragma unroll
+            for (int k = 0; k < T / 512; ++k) { size_t i = t * T + k * 512 + threadIdx.x; if (i < n) v[k] = a[q * plane + i]; }
+#pragma unroll
+            for (int k = 0; k < T / 512; ++k) { size_t i = t * T + k * 512 + threadIdx.x; if (i < n) b[q * plane + i] = v[k]; }
+        }
+    }
+}
+int main(int argc, char **argv)
+{
+    size_t n = argc > 1 ? atoll(argv[1]) : 4343735;
+    float4 *a, *b; float *o;
+    hipMalloc(&a, n * 80); hipMalloc(&b, n * 80); hipMalloc(&o, 4);
+    hipMemset(a, 1, n * 80); hipMemset(b, 0, n * 80);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](const char *name, double bytes, auto launch) {
+        for (int w = 0; w < 3; ++w) launch();
+        float best = 1e9, sum = 0; const int R = 20;
+        for (int r = 0; r < R; ++r) { hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; sum += ms; }
+        printf("%-28s avg %7.1f us  best %7.1f us  -> %.2f TB/s (best %.2f)\n", name, 1e3 * sum / R, 1e3 * best, bytes / (sum / R * 1e-3) / 1e12, bytes / (best * 1e-3) / 1e12);
+    };
+    for (int blocks : {256, 512, 1024, 2048, 4096, 16384})
+        timeit(("read16 blocks=" + std::to_string(blocks)).c_str(), n * 16.0, [&] { hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, 0, a, n, o); });
+    for (int blocks : {256, 512, 1024, 2048})
+        timeit(("copy5 ipt1 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy5<1>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
+    for (int blocks : {256, 512, 1024})
+        timeit(("copy5 ipt2 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy5<2>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
+    for (int blocks : {256, 512})
+        timeit(("copy5 ipt4 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy5<4>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
+    for (int blocks : {512, 1024, 2048, 4096, 8192}) {
+        timeit(("flat U1 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<1, false>), dim3(blocks), dim3(256), 0, 0, a, b, n * 5); });
+        timeit(("flat U4 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<4, false>), dim3(blocks), dim3(256), 0, 0, a, b, n * 5); });
+    }
+    timeit("flat U4 NT blocks=2048", n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<4, true>), dim3(2048), dim3(256), 0, 0, a, b, n * 5); });
+    timeit("flat U8 blocks=1024", n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<8, false>), dim3(1024), dim3(256), 0, 0, a, b, n * 5); });
+    for (int blocks : {256, 512, 1024})
+        timeit(("tile2048 planes blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy_tile_planes<2048>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
+    timeit("hipMemcpyDtoD 5 planes", n * 160.0, [&] { hipMemcpyAsync(b, a, n * 80, hipMemcpyDeviceToDevice, 0); });
+    return 0;
+}
