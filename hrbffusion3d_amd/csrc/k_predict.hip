@@ -391,17 +391,27 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
         tile[i] = ta; tile[PTW * PTH + 1 + i] = tb;
     }
     __syncthreads();
-    const int px = bx + threadIdx.x, py = by + threadIdx.y;
+    // a wave marches an 8 x 8 block of the tile, not a 16 x 4 strip: the number of samples a ray takes and the length of its
+    // neighbour list vary smoothly over the image, and the wave pays for its slowest lane (PREDICT_WAVE_8X8=0: the strip)
+#ifndef PREDICT_WAVE_8X8
+#define PREDICT_WAVE_8X8 1
+#endif
+#if PREDICT_WAVE_8X8 && PREDICT_TBX == 16 && PREDICT_TBY == 16
+    const int lxx = (tid & 7) + ((tid >> 6) & 1) * 8, lyy = ((tid >> 3) & 7) + (tid >> 7) * 8;
+#else
+    const int lxx = (int)threadIdx.x, lyy = (int)threadIdx.y;
+#endif
+    const int px = bx + lxx, py = by + lyy;
     if (px >= W || py >= H) return;
     const int pi = py * W + px;
-    const uint32_t lbase_bytes = (uint32_t)(((threadIdx.y + PR) * PTW + threadIdx.x + PR) * PTEXEL_BYTES);
+    const uint32_t lbase_bytes = (uint32_t)(((lyy + PR) * PTW + lxx + PR) * PTEXEL_BYTES);
     uint16_t *list = s_list + 2 * tid;
 
     int n = 0;
     {
         uint32_t wrow[7];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) wrow[r] = s_rowbits[threadIdx.y + r] >> threadIdx.x;
+        for (int r = 0; r < 7; ++r) wrow[r] = s_rowbits[lyy + r] >> lxx;
         bool skip = false;
         gather_ring<0>(wrow, (2 * win + 1) * (2 * win + 1), maxn, lbase_bytes, list, n, skip);
 #pragma unroll

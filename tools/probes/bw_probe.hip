@@ -24,6 +24,18 @@ __global__ __launch_bounds__(512) void k_copy5(const float4 *__restrict__ a, flo
         for (int k = 0; k < IPT; ++k) { size_t i = base + k * blockDim.x + threadIdx.x; if (i < n) for (int q = 0; q < 5; ++q) b[q * plane + i] = v[k][q]; }
     }
 }
+// copy5 with the workgroup shape as a parameter: all loads of a trip first (IPT x 5 float4 per thread), then the stores
+template <int THREADS, int IPT>
+__global__ __launch_bounds__(THREADS) void k_copy5s(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n, size_t plane)
+{
+    for (size_t base = (size_t)blockIdx.x * THREADS * IPT; base < n; base += (size_t)gridDim.x * THREADS * IPT) {
+        float4 v[IPT][5];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { size_t i = base + k * THREADS + threadIdx.x; if (i < n) for (int q = 0; q < 5; ++q) v[k][q] = a[q * plane + i]; }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { size_t i = base + k * THREADS + threadIdx.x; if (i < n) for (int q = 0; q < 5; ++q) b[q * plane + i] = v[k][q]; }
+    }
+}
 // V1/V2: one contiguous stream of 5 n float4 (what hipMemcpy sees), U float4 per thread per trip
 typedef float f4v __attribute__((ext_vector_type(4)));
 template <int U, bool NT>
@@ -75,6 +87,20 @@ int main(int argc, char **argv)
         timeit(("copy5 ipt2 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy5<2>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
     for (int blocks : {256, 512})
         timeit(("copy5 ipt4 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy5<4>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
+    for (int blocks : {256, 512, 1024, 2048, 4096}) {
+        timeit(("copy5 T256 ipt1 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy5s<256, 1>), dim3(blocks), dim3(256), 0, 0, a, b, n, n); });
+        timeit(("copy5 T256 ipt2 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy5s<256, 2>), dim3(blocks), dim3(256), 0, 0, a, b, n, n); });
+        timeit(("copy5 T128 ipt1 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy5s<128, 1>), dim3(blocks), dim3(128), 0, 0, a, b, n, n); });
+        timeit(("copy5 T1024 ipt1 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy5s<1024, 1>), dim3(blocks), dim3(1024), 0, 0, a, b, n, n); });
+    }
+    // does the distance between the planes matter (channel / bank interleave)?  plane stride = n + pad elements of 16 B
+    {
+        float4 *a2, *b2; const size_t big = n + (1u << 20);
+        hipMalloc(&a2, big * 80); hipMalloc(&b2, big * 80); hipMemset(a2, 1, big * 80);
+        for (size_t pad : {(size_t)0, (size_t)1, (size_t)4, (size_t)16, (size_t)64, (size_t)100, (size_t)256, (size_t)1000, (size_t)4096, (size_t)65536 + 4, (size_t)(1u << 20)})
+            timeit(("copy5 T256 ipt1 b=512 pad=" + std::to_string(pad)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy5s<256, 1>), dim3(512), dim3(256), 0, 0, a2, b2, n, n + pad); });
+        hipFree(a2); hipFree(b2);
+    }
     for (int blocks : {512, 1024, 2048, 4096, 8192}) {
         timeit(("flat U1 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<1, false>), dim3(blocks), dim3(256), 0, 0, a, b, n * 5); });
         timeit(("flat U4 blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<4, false>), dim3(blocks), dim3(256), 0, 0, a, b, n * 5); });
