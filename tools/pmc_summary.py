@@ -9,7 +9,7 @@ counters, not with the kernel-trace times).  Derived columns (only when their in
   valu_active_frac   SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   share of the resident waves' cycles spent issuing VALU (quad-cycles)
   wait_frac          SQ_WAIT_ANY / SQ_WAVE_CYCLES           waves parked (s_waitcnt / barrier)
   issue_stall_frac   SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
-  lds_conflict_frac  SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
+  lds_conflict_cycles_per_lds_cycle  SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS   conflict cycles per cycle an LDS instruction is active (a ratio, can exceed 1)
   fp32_gflop         (2 FMA + ADD + MUL + TRANS) x 64 lanes per wave instruction
   fp32_tflops        fp32_gflop / duration                  to be read against the 157 TFLOP/s fp32 vector peak
 """
@@ -36,7 +36,7 @@ def main():
                     seen[(k, c)].add(key)
                     dur[k][c].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     counters = sorted({c for v in acc.values() for c in v})
-    derived = ["valu_active_frac", "wait_frac", "issue_stall_frac", "lds_conflict_frac", "fp32_gflop", "fp32_tflops", "valu_insts_per_wave"]
+    derived = ["valu_active_frac", "wait_frac", "issue_stall_frac", "lds_conflict_cycles_per_lds_cycle", "fp32_gflop", "fp32_tflops", "valu_insts_per_wave"]
     with open(out, "w") as fo:
         fo.write(",".join(["kernel", "grid", "dispatches", "avg_us_profiled"] + counters + derived) + "\n")
         rows = []
@@ -54,7 +54,7 @@ def main():
                     if g(src) is not None:
                         dv[name] = g(src) / wc
             if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_ACTIVE_INST_LDS"):
-                dv["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS")
+                dv["lds_conflict_cycles_per_lds_cycle"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS")
             if g("SQ_INSTS_VALU_FMA_F32") is not None:
                 fl = 64.0 * (2 * g("SQ_INSTS_VALU_FMA_F32") + (g("SQ_INSTS_VALU_ADD_F32") or 0) + (g("SQ_INSTS_VALU_MUL_F32") or 0) +
                              (g("SQ_INSTS_VALU_TRANS_F32") or 0))
