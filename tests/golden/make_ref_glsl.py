@@ -202,8 +202,84 @@ def run_reference(scene, f1, f2, T2, w2, prm_over=None):
     return out
 
 
+def fp32_window_counts(n, tc, win=3.0):
+    """iterations of `for (i = max(0, t - s win); i <= min(1, t + s win); i += s)` in fp32 for every pixel, given the texture
+    coordinates tc[p] (hd_window_axis in include/hrbf_detmath.h is this loop with tc = the correctly rounded (p + 0.5) / n)"""
+    f = np.float32
+    s_ = f(1) / f(n)
+    out = []
+    for p in range(n):
+        t = f(tc[p])
+        lo, hi = max(f(0), f(t - f(s_ * f(win)))), min(f(1), f(t + f(s_ * f(win))))
+        i, k = lo, 0
+        while i <= hi:
+            k += 1; i = f(i + s_)
+        out.append(k)
+    return np.array(out)
+
+
+def run_reference_nonpow2():
+    """P1-P5 at 160 x 120 — NOT a power of two: here the float-stepped window loops of getNormalPCA and the curvature pass take 6
+    instead of 7 samples at 88 of the 160 columns and 17 of the 120 rows, and 4 rows of the bilateral filter's taps land a texel
+    low.  The fixture records, next to the passes' inputs and outputs, the texture coordinates llvmpipe interpolated, so that the
+    check can tell the columns / rows where ITS window differs from the one the correctly rounded coordinate gives."""
+    import ctypes as C
+    from ref_glsl import refgl, glbind as G
+    W, H = 160, 120
+    X1, Y1 = 240, 180
+    fx = fy = 264.0
+    cx, cy = 320.0 / 2 - 40.0, 240.0 / 2 - 30.0     # the GPUTest frames decimated by 2, window at (40, 30) of the 320 x 240 image
+    rgb = np.ascontiguousarray(np.array(Image.open(os.path.join(HERE, "2c.png")))[::2, ::2][30:30 + H, 40:40 + W])
+    depth = np.ascontiguousarray(np.array(Image.open(os.path.join(HERE, "2d.png")))[::2, ::2][30:30 + H, 40:40 + W])
+    p = refgl.RefPipeline(W, H, fx, fy, cx, cy, 1.0 / 5000.0, tex_dim=64, max_surfels=1024)
+    out = {"geom": np.array([W, H, fx, fy, cx, cy], np.float64), "rgb": rgb, "depth": depth}
+    p.upload_frame(rgb, depth)
+    p.filter_depth(); out["DEPTH_FILTERED"] = p.get("DEPTH_FILTERED")
+    p.metricise_depth(); out["DEPTH_METRIC"], out["DEPTH_METRIC_FILTERED"] = p.get("DEPTH_METRIC"), p.get("DEPTH_METRIC_FILTERED")
+    p.compute_vertex_normal_radius()
+    for n in ("VERTEX_RAW", "VERTEX_FILTERED", "RADIUS"):
+        out[n] = p.get(n)
+    out["NORMAL_P3"] = p.get("NORMAL")
+    p.compute_curvature_gradient()
+    out["CURV1"], out["CURV2"], out["GRADIENT_MAG"] = p.get("PRINCIPAL_CURV1"), p.get("PRINCIPAL_CURV2"), p.get("GRADIENT_MAG")
+    p.update_normal_rad(); out["NORMAL"] = p.get("NORMAL")
+    # the interpolated texture coordinate of every pixel (a fragment shader that writes it, behind the reference's quad.geom)
+    gl = p.gl
+    src = b"#version 330 core\nin vec2 texcoord; out vec4 o; void main(){ o = vec4(texcoord, 0.0, 1.0); }\n"
+    pid = gl.glCreateProgram()
+    for kind, text in ((G.GL_VERTEX_SHADER, refgl.shader_source("empty.vert").encode()), (G.GL_GEOMETRY_SHADER, refgl.shader_source("quad.geom").encode()),
+                       (G.GL_FRAGMENT_SHADER, src)):
+        sid = gl.glCreateShader(kind); b = C.c_char_p(text); gl.glShaderSource(sid, 1, C.byref(b), None); gl.glCompileShader(sid); gl.glAttachShader(pid, sid)
+    gl.glLinkProgram(pid)
+
+    class P:
+        def bind(self): gl.glUseProgram(pid)
+        def unbind(self): gl.glUseProgram(0)
+        def set(self, k, v): pass
+    t = refgl.tex_rgba32f(gl, W, H)
+    p._quad_pass(P(), refgl.Fbo(gl, W, H, [t]), [], [])
+    tc = refgl.get_f4(t)
+    out["tc_x"], out["tc_y"] = tc[0, :, 0].copy(), tc[:, 0, 1].copy()
+    f = np.float32
+    ideal_x = ((np.arange(W, dtype=f) + f(0.5)) / f(W)).astype(f); ideal_y = ((np.arange(H, dtype=f) + f(0.5)) / f(H)).astype(f)
+    cxi, cxl = fp32_window_counts(W, ideal_x), fp32_window_counts(W, out["tc_x"])
+    cyi, cyl = fp32_window_counts(H, ideal_y), fp32_window_counts(H, out["tc_y"])
+    out["win_x"], out["win_y"] = cxi.astype(np.uint8), cyi.astype(np.uint8)                 # iterations under the correctly rounded coordinate
+    out["tie_cols"], out["tie_rows"] = np.nonzero(cxi != cxl)[0].astype(np.int32), np.nonzero(cyi != cyl)[0].astype(np.int32)
+    c = np.arange(H, dtype=f)
+    out["tap_rows_low"] = np.nonzero(np.floor((c / f(H)) * f(H)) != c)[0].astype(np.int32)  # bilateral taps one texel low under fp32 floor
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    q = run_reference_nonpow2()
+    path = os.path.join(OUT, "qqvga_pre.npz")
+    np.savez_compressed(path, **q)
+    print("qqvga_pre ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "6-sample columns / rows:", int((q["win_x"] == 6).sum()), int((q["win_y"] == 6).sum()),
+          "tie columns / rows:", q["tie_cols"].tolist(), q["tie_rows"].tolist(), "low tap rows:", q["tap_rows_low"].tolist())
+    if "--only-nonpow2" in sys.argv:
+        return
     for name, scene in (("pair", scene_pair), ("sphere", scene_sphere)):
         f1, f2, T2, w2 = scene()
         out = run_reference(name, f1, f2, T2, w2)

@@ -310,3 +310,60 @@ def fill_checks(rep, g, fx, P):
     rep.exact("H3 FILL_CURV2", g.get_image("FILL_CURV2"), fx[P + "FILL_CURV2"])
     rep.exact("H3 FILL_IMAGE", g.get_image("FILL_IMAGE")[..., :3], fx[P + "FILL_IMAGE"][..., :3])
     rep.close_ulp("H3 FILL_ICPWEIGHT", g.get_image("FILL_ICPWEIGHT"), fx[P + "FILL_ICPWEIGHT"], 16)
+
+
+def run_nonpow2_pre(impl, fx, rep):
+    """P1-P5 at 160 x 120 against the executed shaders (tests/golden/ref_glsl/qqvga_pre.npz).  Not a power of two: the
+    float-stepped window loops take 6 instead of 7 samples at 88 of 160 columns and 17 of 120 rows (hd_window_axis), the bilateral
+    filter's taps of row 63 land a texel low in llvmpipe (implementation-defined), and llvmpipe's interpolated
+    texture coordinate is an ulp off the correctly rounded one at a few columns / rows, where ITS window differs (`tie_cols`,
+    `tie_rows`).  Pixels within 3 of a tie column / row (6 of a low-tap row for P1) are excluded; everywhere else the bounds of the
+    power-of-two scenes apply, loosened where the sample positions fl(i * cols) carry the coordinate's ulp (PCA normal)."""
+    g = impl
+    W, H = int(fx["geom"][0]), int(fx["geom"][1])
+    g.upload_frame(fx["rgb"], fx["depth"])
+    g.run_stage("FILTER_DEPTH")
+    rows_ok = np.ones(H, bool)
+    for r in fx["tap_rows_low"]:
+        rows_ok[max(0, r - 6):r + 7] = False
+    got, ref = g.get_image("DEPTH_FILTERED"), fx["DEPTH_FILTERED"]
+    rep.exact("P1 which pixels are filtered", got == 0, ref == 0)
+    rep.close_ulp("P1 DEPTH_FILTERED (rows away from the low-tap rows)", got[rows_ok], ref[rows_ok], 16)
+    d = np.abs(got[~rows_ok].astype(np.float64) - ref[~rows_ok]) / np.maximum(ref[~rows_ok], 1.0)
+    rep.add("P1 DEPTH_FILTERED near the low-tap rows (implementation-defined taps)", d.max() < 5e-3, "max relative difference %.2e" % d.max())
+    g.set_image("DEPTH_FILTERED", ref)
+    g.run_stage("METRICISE")
+    g.set_image("DEPTH_METRIC", fx["DEPTH_METRIC"]); g.set_image("DEPTH_METRIC_FILTERED", fx["DEPTH_METRIC_FILTERED"])
+    g.run_stage("VERTEX_NORMAL_RADIUS")
+    rep.exact("P3 VERTEX_RAW xyz", g.get_image("VERTEX_RAW")[..., :3], fx["VERTEX_RAW"][..., :3])
+    rep.exact("P3 VERTEX_FILTERED", g.get_image("VERTEX_FILTERED"), fx["VERTEX_FILTERED"])
+    ok = np.ones((H, W), bool)
+    for c in fx["tie_cols"]:
+        ok[:, max(0, c - 3):c + 4] = False
+    for r in fx["tie_rows"]:
+        ok[max(0, r - 3):r + 4, :] = False
+    n3, n3r = g.get_image("NORMAL"), fx["NORMAL_P3"]
+    rep.exact("P3 which pixels have a normal (away from tie columns / rows)", (n3[..., :3] == 0).all(-1)[ok], (n3r[..., :3] == 0).all(-1)[ok])
+    both = ok & (np.linalg.norm(n3[..., :3], axis=-1) > 0.5) & (np.linalg.norm(n3r[..., :3], axis=-1) > 0.5)
+    ang = np.degrees(np.arccos(np.clip((n3[..., :3] * n3r[..., :3]).sum(-1)[both], -1, 1)))
+    # the samples' positions are fl(i * cols) with i accumulated from the interpolated coordinate: its ulp moves a position by
+    # ~1e-5 pixel and the covariance's cancellation turns that into ~0.05 deg; a 6- instead of 7-wide window is 0.5-1 deg
+    rep.add("P3 PCA normal", np.median(ang) < 0.1 and np.percentile(ang, 99) < 1.0, "angle median %.3f deg, p99 %.3f, max %.2f over %d pixels" % (
+        np.median(ang), np.percentile(ang, 99), ang.max(), ang.size))
+    g.set_image("NORMAL", n3r); g.set_image("VERTEX_FILTERED", fx["VERTEX_FILTERED"])
+    g.run_stage("CURVATURE")
+    gm, gmr = g.get_image("GRADIENT_MAG"), fx["GRADIENT_MAG"]
+    rep.exact("P4 which pixels have > 15 neighbours (away from tie columns / rows)", (gm == 0)[ok], (gmr == 0)[ok])
+    rep.close_ulp("P4 GRADIENT_MAG: the 6 / 7-sample windows of the fp32 loop", gm[ok], gmr[ok], 1024, abs_floor=1e-3)
+    nz = ok & (gm != 0) & (gmr != 0)
+    six = ((fx["win_x"] == 6)[None, :] | (fx["win_y"] == 6)[:, None]) & nz
+    rep.add("P4 pixels whose window is 6 wide in x or y", six.sum() > 0.4 * nz.sum(), "%d of %d compared pixels" % (int(six.sum()), int(nz.sum())))
+    for name in ("CURV1", "CURV2"):
+        c, cr = g.get_image(name), fx[name]
+        rep.exact("P4 %s which pixels are the 1000-sentinel (away from tie columns / rows)" % name, (c[..., 3] == 1000.0)[ok], (cr[..., 3] == 1000.0)[ok])
+        cm, crm = c.copy(), cr.copy()
+        cm[~ok] = 1000.0; crm[~ok] = 1000.0
+        curvature_checks(rep, name, cm, crm)
+    no, nor = g.get_image("NORMAL"), fx["NORMAL"]
+    rep.close_ulp("P5 NORMAL (HRBF gradient direction)", no[..., :3][ok], nor[..., :3][ok], 64, abs_floor=4e-6)
+    return rep

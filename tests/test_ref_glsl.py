@@ -64,6 +64,36 @@ def test_hip_path_matches_the_executed_reference_shaders(scene, gpu_available):
     assert len(rep.rows) > 60 and all(ok for _, ok, _ in rep.rows)
 
 
+def _nonpow2_params(fx):
+    from hrbffusion3d_amd.params import default_params
+    W, H, fx_, fy_, cx, cy = fx["geom"]
+    return default_params(width=int(W), height=int(H), fx=float(fx_), fy=float(fy_), cx=float(cx), cy=float(cy), max_surfels=1 << 16)
+
+
+def test_oracle_matches_the_executed_shaders_at_a_size_that_is_not_a_power_of_two(oracle_lib_built):
+    """160 x 120: the float-stepped window loops drop their last sample at 88 columns / 17 rows — the rule of hd_window_axis"""
+    fx = R.load("qqvga_pre")
+    assert int((fx["win_x"] == 6).sum()) == 88 and int((fx["win_y"] == 6).sum()) == 17
+    o = oracle_lib_built.Oracle(_nonpow2_params(fx), omp=True)
+    try:
+        rep = R.run_nonpow2_pre(o, fx, R.Report(strict=True))
+    finally:
+        o.close()
+    assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_executed_shaders_at_a_size_that_is_not_a_power_of_two(gpu_available):
+    from hrbffusion3d_amd.api import HRBFFusion
+    fx = R.load("qqvga_pre")
+    g = HRBFFusion(_nonpow2_params(fx))
+    try:
+        rep = R.run_nonpow2_pre(g, fx, R.Report(strict=True))
+    finally:
+        g.close()
+    assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
+
+
 def test_glsl_harness_source_fixes_are_token_level():
     """the harness may only respell what Mesa's compiler rejects: three spellings, no arithmetic"""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
