@@ -211,10 +211,11 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
     """150 noisy QVGA frames from an empty map (frame 0 seeds it): the trajectory stays near the ground truth (ATE, the
     north star's other metric, against the stream's analytic poses) and a second run reproduces pose and map bit for
     bit (the property that lets the short oracle comparisons stand for long sequences).
-    The bound is loose on purpose: the reference back-projects the live frame at INTEGER pixel coordinates
-    (depth_vertex_normal_radius.frag:25-29, "not the half-pixel coordinates") but ray-casts the model through pixel
-    CENTRES (predict_hrbf.frag:42-47); registration absorbs that half pixel as ~0.1 deg per frame while the map is
-    young, which saturates at about 6 cm at QVGA (2 cm at VGA).  Kept, like every other quirk."""
+    The bound is loose on purpose: while the map is young the model is the filled-in previous frame and the joint
+    registration is dominated by the photometric rows, whose nearest-texel residual (reduce.cu:1027-1046) resolves the
+    pixel-or-two of inter-frame motion only to about half a pixel (~5 mm / 0.1 deg per frame at QVGA); the offset stops
+    growing once the model is predicted from stable surfels, at about 6 cm at QVGA (2 cm at VGA).  Located by
+    tests/test_tracking_accuracy.py and tools/probes/rgb_term_emulation.py."""
     from hrbffusion3d_amd.api import HRBFFusion
     W, H = 320, 240
     fx, fy, cx, cy = synth.intrinsics(W, H)
