@@ -59,6 +59,9 @@ def _build_to(OUT, defines, verbose, suffix):
         raise RuntimeError("hipcc failed")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     subprocess.check_call(cmd)
+    if suffix:      # an experiment variant: its objects are not a cache for anything, do not leave them in csrc/
+        for obj in objs:
+            os.remove(obj)
     return OUT
 
 
