@@ -202,6 +202,115 @@ def run_reference(scene, f1, f2, T2, w2, prm_over=None):
     return out
 
 
+def clean_structure(fused, rec, final):
+    """the clean pass copies survivors of the fused map in order, then the new surfels among the records in order"""
+    fb, ob = fused.view(np.uint32), final.view(np.uint32)
+    keep = np.zeros(fused.shape[0], bool)
+    j = 0
+    for i in range(fused.shape[0]):
+        if j < final.shape[0] and np.array_equal(fb[i], ob[j]):
+            keep[i] = True; j += 1
+    picks = []
+    rec_new = rec.copy(); rec_new[rec_new[:, 7] == -2.0, 7] = 2.0
+    rn = rec_new.view(np.uint32)
+    for i in range(rec_new.shape[0]):
+        if j < final.shape[0] and rec[i, 7] == -2.0 and np.array_equal(rn[i], ob[j]):
+            picks.append(i); j += 1
+    assert j == final.shape[0], (j, final.shape)
+    return np.packbits(keep), np.array(picks, np.uint32), np.array([final.shape[0]], np.uint32)
+
+
+def run_reference_variants(f1, f2, T2, w2, base):
+    """The reference's parameter variants of the GLSL rows (ref_glsl_check.VARIANTS) on the sphere scene: each variant re-runs
+    ONE part of the pipeline with its uniforms changed, on the state the default run (= the committed sphere fixture, asserted)
+    leaves in front of that part.  Only that part's outputs are stored."""
+    import ref_glsl_check as R
+    from ref_glsl import refgl
+    W, H, FX, FY, CX, CY = GEOM["sphere"]
+    p = refgl.RefPipeline(W, H, FX, FY, CX, CY, 1.0 / 5000.0, tex_dim=512, max_surfels=1 << 17)
+    default = dict(p.p)
+    out = {}
+
+    def same(a, b, what):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), what
+
+    def pre(upto):
+        """frame 2 through the default passes in front of `upto`"""
+        p.p.clear(); p.p.update(default)
+        p.upload_frame(*f2)
+        if upto == "filter":
+            return
+        p.filter_depth(); p.metricise_depth()
+        same(p.get("DEPTH_METRIC_FILTERED"), base["f2_DEPTH_METRIC_FILTERED"], "default run differs from the committed fixture")
+        if upto == "vnr":
+            return
+        p.compute_vertex_normal_radius()
+        if upto == "curv":
+            return
+        p.compute_curvature_gradient(); p.update_normal_rad()
+        same(p.get("NORMAL"), base["f2_NORMAL"], "default run differs from the committed fixture")
+        if upto == "conf":
+            return
+        p.vertex_confidence(w2)
+        same(p.get("CONFIDENCE"), base["f2_CONFIDENCE"], "default run differs from the committed fixture")
+
+    xm = R.stable_map_with_outliers(base)
+    fused_ref = xm.copy(); fused_ref[base["x_fused_rows"]] = base["x_fused_vals"]
+    final_ref = R.reference_final(base, "x_", xm)
+    for name, (kw, part) in R.VARIANTS.items():
+        tag = name + "__"
+        pre(part if part in ("filter", "vnr", "curv", "conf") else "all")
+        p.p.update(kw)
+        if part == "filter":
+            p.filter_depth(); out[tag + "f2_DEPTH_FILTERED"] = p.get("DEPTH_FILTERED")
+            p.metricise_depth()
+            out[tag + "f2_DEPTH_METRIC"], out[tag + "f2_DEPTH_METRIC_FILTERED"] = p.get("DEPTH_METRIC"), p.get("DEPTH_METRIC_FILTERED")
+        elif part == "vnr":
+            p.compute_vertex_normal_radius()
+            for n in ("VERTEX_RAW", "VERTEX_FILTERED", "RADIUS"):
+                out[tag + "f2_" + n] = p.get(n)
+            out[tag + "f2_NORMAL_P3"] = p.get("NORMAL")
+        elif part == "curv":
+            p.compute_curvature_gradient()
+            out[tag + "f2_CURV1"], out[tag + "f2_CURV2"] = p.get("PRINCIPAL_CURV1"), p.get("PRINCIPAL_CURV2")
+            out[tag + "f2_GRADIENT_MAG"] = p.get("GRADIENT_MAG")
+            p.update_normal_rad(); out[tag + "f2_NORMAL"] = p.get("NORMAL")
+        elif part == "conf":
+            p.vertex_confidence(w2); out[tag + "f2_CONFIDENCE"] = p.get("CONFIDENCE")
+        elif part == "clean":
+            # the default association and merge (asserted to reproduce the fixture), then the variant's clean pass
+            p.p.clear(); p.p.update(default)
+            p.upload_map(xm); p.predict_indices(T2, 2); p.fuse(T2, 2, w2)
+            rec = p.fuse_records()
+            same(rec, base["x_records"], "records differ from the committed fixture")
+            same(p.download_map(), fused_ref, "fused map differs from the committed fixture")
+            p.predict_indices(T2, 2)
+            p.p.update(kw)
+            p.clean(T2, 2)
+            out[tag + "x_keep"], out[tag + "x_new_picks"], out[tag + "x_map_count"] = clean_structure(fused_ref, rec, p.download_map())
+        elif part == "predict":
+            p.upload_map(final_ref); p.predict_indices(T2, 2)
+            same(p.index_images()["INDEX"], base["x_p_INDEX"], "index map differs from the committed fixture")
+            p.predict_hrbf()
+            for k, v in p.prediction_images().items():
+                out[tag + "x_" + k] = v
+            p.fill_in(2, w2)
+            for k, v in p.fill_images().items():
+                out[tag + "x_" + k] = v
+        print("  variant %-22s %s" % (name, kw))
+    # the variants must differ from the default where they are meant to
+    for name, (kw, part) in R.VARIANTS.items():
+        ks = [k for k in out if k.startswith(name + "__")]
+        diff = sum(int(not np.array_equal(np.ascontiguousarray(out[k]).view(np.uint8), np.ascontiguousarray(base[k.split("__", 1)[1]]).view(np.uint8))) for k in ks)
+        print("  %-22s %d of %d stored outputs differ from the default run" % (name, diff, len(ks)))
+        assert diff > 0, name
+    # outputs a variant leaves as the default run wrote them are not stored twice (variant_fixture falls back to the default)
+    for k in list(out):
+        if np.array_equal(np.ascontiguousarray(out[k]).view(np.uint8), np.ascontiguousarray(base[k.split("__", 1)[1]]).view(np.uint8)):
+            del out[k]
+    return out
+
+
 def fp32_window_counts(n, tc, win=3.0):
     """iterations of `for (i = max(0, t - s win); i <= min(1, t + s win); i += s)` in fp32 for every pixel, given the texture
     coordinates tc[p] (hd_window_axis in include/hrbf_detmath.h is this loop with tc = the correctly rounded (p + 0.5) / n)"""
@@ -279,6 +388,14 @@ def main():
     print("qqvga_pre ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "6-sample columns / rows:", int((q["win_x"] == 6).sum()), int((q["win_y"] == 6).sum()),
           "tie columns / rows:", q["tie_cols"].tolist(), q["tie_rows"].tolist(), "low tap rows:", q["tap_rows_low"].tolist())
     if "--only-nonpow2" in sys.argv:
+        return
+    if "--only-variants" in sys.argv:
+        import ref_glsl_check as R
+        f1, f2, T2, w2 = scene_sphere()
+        out = run_reference_variants(f1, f2, T2, w2, R.load("sphere"))
+        path = os.path.join(OUT, "sphere_variants.npz")
+        np.savez_compressed(path, **out)
+        print("sphere_variants ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), len(out), "arrays")
         return
     for name, scene in (("pair", scene_pair), ("sphere", scene_sphere)):
         f1, f2, T2, w2 = scene()

@@ -70,28 +70,26 @@ class Report:
         self.add(what, n == 0, "%d of %d differ" % (n, got.size))
 
 
-def run(impl, fx, rep, has_records=False):
-    g, P = impl, "f2_"
-    rgb, depth = fx[P + "rgb"], fx[P + "depth"]
-    T2, w2 = fx[P + "pose"], float(fx[P + "weighting"])
-
-    # ---- P1 filterDepth (depth_bilateral.frag): 169 exp per pixel, normalised sum --------------------------------
-    g.upload_frame(rgb, depth)
+def part_filter(rep, g, fx, P="f2_"):
+    """P1 filterDepth (depth_bilateral.frag / depth_guass.frag): up to 169 exp per pixel, normalised sum; P2 metriciseDepth"""
+    g.upload_frame(fx[P + "rgb"], fx[P + "depth"])
     g.run_stage("FILTER_DEPTH")
     ref = fx[P + "DEPTH_FILTERED"]
     got = g.get_image("DEPTH_FILTERED")
     rep.exact("P1 which pixels are filtered", got == 0, ref == 0)
     rep.close_ulp("P1 DEPTH_FILTERED", got, ref, 16)
-    # ---- P2 metriciseDepth -----------------------------------------------------------------------------------------
     g.set_image("DEPTH_FILTERED", ref)
     g.run_stage("METRICISE")
     rep.exact("P2 DEPTH_METRIC", g.get_image("DEPTH_METRIC"), fx[P + "DEPTH_METRIC"])
     # the HIP path computes the metric image inside the filter kernel (P1 + P2 fused), so there it carries P1's own rounding;
     # the oracle runs P2 on the DEPTH_FILTERED just set and is exact
     rep.close_ulp("P2 DEPTH_METRIC_FILTERED", g.get_image("DEPTH_METRIC_FILTERED"), fx[P + "DEPTH_METRIC_FILTERED"], 16)
+
+
+def part_vertex_normal_radius(rep, g, fx, P="f2_", pca=True):
+    """P3 computeVertexNormalRadius on the reference's metric images"""
     g.set_image("DEPTH_METRIC", fx[P + "DEPTH_METRIC"])
     g.set_image("DEPTH_METRIC_FILTERED", fx[P + "DEPTH_METRIC_FILTERED"])
-    # ---- P3 computeVertexNormalRadius ---------------------------------------------------------------------------------
     g.run_stage("VERTEX_NORMAL_RADIUS")
     vr, vf = g.get_image("VERTEX_RAW"), g.get_image("VERTEX_FILTERED")
     rep.exact("P3 VERTEX_RAW xyz", vr[..., :3], fx[P + "VERTEX_RAW"][..., :3])
@@ -99,11 +97,18 @@ def run(impl, fx, rep, has_records=False):
     rep.exact("P3 VERTEX_FILTERED", vf, fx[P + "VERTEX_FILTERED"])
     n3 = g.get_image("NORMAL")
     rep.exact("P3 which pixels have a normal", (n3[..., :3] == 0).all(-1), (fx[P + "NORMAL_P3"][..., :3] == 0).all(-1))
-    # PCA normal: eigen-solve of a covariance formed by cancellation (geometry.glsl:176-193), atan2/cos/sin inside
-    rep.close_ulp("P3 NORMAL (PCA) xyz", n3[..., :3], fx[P + "NORMAL_P3"][..., :3], 64, abs_floor=2e-6)
+    # PCA normal: eigen-solve of a covariance formed by cancellation (geometry.glsl:176-193), atan2/cos/sin inside;
+    # central differences (geometry.glsl:152-174): a cross product of differences, normalised
+    # (vertex differences of ~5 mm, their cross product cancels to ~1e-5 of products of ~2.5e-5: the components of the normal
+    # carry ~1e-5 absolute of rounding, and llvmpipe contracts the cross product's a*b - c*d where the oracle may not)
+    rep.close_ulp("P3 NORMAL (%s) xyz" % ("PCA" if pca else "central differences"), n3[..., :3], fx[P + "NORMAL_P3"][..., :3], 64,
+                  abs_floor=2e-6 if pca else 2e-5)
     rep.close_ulp("P3 NORMAL w = RADIUS", n3[..., 3], fx[P + "NORMAL_P3"][..., 3], 64)
     rep.close_ulp("P3 RADIUS", g.get_image("RADIUS"), fx[P + "RADIUS"], 64)
-    # ---- P4 + P5 computeCurvatureGradient, updateNormalRad -----------------------------------------------------------
+
+
+def part_curvature(rep, g, fx, P="f2_"):
+    """P4 + P5 computeCurvatureGradient, updateNormalRad on the reference's vertex / normal images"""
     g.set_image("NORMAL", fx[P + "NORMAL_P3"])
     g.set_image("VERTEX_FILTERED", fx[P + "VERTEX_FILTERED"])
     g.run_stage("CURVATURE")
@@ -118,12 +123,71 @@ def run(impl, fx, rep, has_records=False):
         c, cr = g.get_image(name), fx[P + name]
         rep.exact("P4 %s which pixels are the 1000-sentinel" % name, c[..., 3] == 1000.0, cr[..., 3] == 1000.0)
         curvature_checks(rep, name, c, cr)
-    # ---- P5 VertexConfidence -------------------------------------------------------------------------------------------
+
+
+def part_confidence(rep, g, fx, P="f2_"):
+    """P5 VertexConfidence on the reference's curvature images"""
     for name in ("CURV1", "CURV2", "GRADIENT_MAG", "NORMAL"):
         g.set_image(name, fx[P + name])
-    g.set_weighting(w2)
+    g.set_image("DEPTH_METRIC", fx[P + "DEPTH_METRIC"])
+    g.set_weighting(float(fx[P + "weighting"]))
     g.run_stage("CONFIDENCE")
     rep.close_ulp("P5 CONFIDENCE", g.get_image("CONFIDENCE"), fx[P + "CONFIDENCE"], 16)
+
+
+def bind_frame(g, fx, P="f2_"):
+    """frame 2's images as the reference's shaders left them: what the map passes read"""
+    g.upload_frame(fx[P + "rgb"], fx[P + "depth"])
+    for name, key in (("DEPTH_FILTERED", "DEPTH_FILTERED"), ("DEPTH_METRIC", "DEPTH_METRIC"), ("DEPTH_METRIC_FILTERED", "DEPTH_METRIC_FILTERED"),
+                      ("VERTEX_RAW", "VERTEX_RAW"), ("VERTEX_FILTERED", "VERTEX_FILTERED"), ("RADIUS", "RADIUS"), ("CURV1", "CURV1"),
+                      ("CURV2", "CURV2"), ("GRADIENT_MAG", "GRADIENT_MAG"), ("NORMAL", "NORMAL"), ("CONFIDENCE", "CONFIDENCE"),
+                      ("NORMAL_PCA", "NORMAL_P3")):
+        g.set_image(name, fx[P + key])
+    g.set_weighting(float(fx[P + "weighting"]))
+
+
+def stable_map_with_outliers(fx):
+    m = fx["f1_map"].copy(); m[:, 3] += 6.0
+    old = fx["x_old"]; m[old, 3] = 1.0; m[old, 7] = -250.0
+    return np.concatenate([m, fx["x_extra"]])
+
+
+def reference_final(fx, pre, map_in):
+    """the map the reference's clean pass left: survivors of its fused map in order, then its new surfels"""
+    ref_fused = map_in.copy(); ref_fused[fx[pre + "fused_rows"]] = fx[pre + "fused_vals"]
+    keep = np.unpackbits(fx[pre + "keep"])[:map_in.shape[0]].astype(bool)
+    rec = fx[pre + "records"]
+    new = rec[fx[pre + "new_picks"]].copy(); new[:, 7] = 2.0
+    out = np.concatenate([ref_fused[keep], new])
+    assert out.shape[0] == int(fx[pre + "map_count"][0])
+    return out
+
+
+def part_prediction(rep, g, fx, ref_final, P="f2_"):
+    """M1 + H2 predictHRBF, H3 fill-in on the reference's map"""
+    T2 = fx[P + "pose"]
+    g.upload_map(ref_final)
+    g.set_pose(T2); g.set_tick(2)
+    g.run_stage("PREDICT_INDICES")
+    index_checks(rep, "M1 (prediction)", g, fx, "x_p_", full=True)
+    for k in ("INDEX", "INDEX_VERTCONF", "INDEX_COLORTIME", "INDEX_NORMRAD", "INDEX_CURVMAX", "INDEX_CURVMIN"):
+        g.set_image(k, fx["x_p_" + k])
+    g.run_stage("PREDICT_HRBF")
+    prediction_checks(rep, g, fx, "x_")
+    for k in ("PRED_IMAGE", "PRED_VERTEX", "PRED_NORMAL", "PRED_CURV1", "PRED_CURV2", "PRED_ICPWEIGHT"):
+        g.set_image(k, fx["x_" + k])
+    g.set_image("VERTEX_FILTERED", fx[P + "VERTEX_FILTERED"])
+    g.run_stage("FILLIN")
+    fill_checks(rep, g, fx, "x_")
+
+
+def run(impl, fx, rep, has_records=False):
+    g, P = impl, "f2_"
+    T2, w2 = fx[P + "pose"], float(fx[P + "weighting"])
+    part_filter(rep, g, fx, P)
+    part_vertex_normal_radius(rep, g, fx, P)
+    part_curvature(rep, g, fx, P)
+    part_confidence(rep, g, fx, P)
     g.set_image("CONFIDENCE", fx[P + "CONFIDENCE"])
     g.set_image("NORMAL_PCA", fx[P + "NORMAL_P3"])
 
@@ -141,27 +205,10 @@ def run(impl, fx, rep, has_records=False):
     rep.exact("F4 curvature records", im[:4096, 12:20], ih[:, 12:20])
 
     # ---- (1) the plain second frame on the young map of frame 1 --------------------------------------------------------------
-    m1 = fx["f1_map"]
-    map_flow(rep, g, fx, "f2_", "young map: ", m1, T2)
+    map_flow(rep, g, fx, "f2_", "young map: ", fx["f1_map"], T2)
     # ---- (2) a stable map + surfels that must be removed -------------------------------------------------------------------------
-    m = m1.copy(); m[:, 3] += 6.0
-    old = fx["x_old"]; m[old, 3] = 1.0; m[old, 7] = -250.0
-    xm = np.concatenate([m, fx["x_extra"]])
-    ref_final = map_flow(rep, g, fx, "x_", "stable map + outliers: ", xm, T2)
-    # ---- M1 + H2 predictHRBF, H3 fill-in on the reference's map ----------------------------------------------------------
-    g.upload_map(ref_final)
-    g.set_pose(T2); g.set_tick(2)
-    g.run_stage("PREDICT_INDICES")
-    index_checks(rep, "M1 (prediction)", g, fx, "x_p_", full=True)
-    for k in ("INDEX", "INDEX_VERTCONF", "INDEX_COLORTIME", "INDEX_NORMRAD", "INDEX_CURVMAX", "INDEX_CURVMIN"):
-        g.set_image(k, fx["x_p_" + k])
-    g.run_stage("PREDICT_HRBF")
-    prediction_checks(rep, g, fx, "x_")
-    for k in ("PRED_IMAGE", "PRED_VERTEX", "PRED_NORMAL", "PRED_CURV1", "PRED_CURV2", "PRED_ICPWEIGHT"):
-        g.set_image(k, fx["x_" + k])
-    g.set_image("VERTEX_FILTERED", fx[P + "VERTEX_FILTERED"])
-    g.run_stage("FILLIN")
-    fill_checks(rep, g, fx, "x_")
+    ref_final = map_flow(rep, g, fx, "x_", "stable map + outliers: ", stable_map_with_outliers(fx), T2)
+    part_prediction(rep, g, fx, ref_final, P)
     # ---- f-3 updateModel ----------------------------------------------------------------------------------------------------
     g.upload_map(ref_final)
     g.update_model([fx["x_delta"]])
@@ -169,6 +216,55 @@ def run(impl, fx, rep, has_records=False):
     rep.close_ulp("f-3 updateModel positions", um[:, 0:3], umr[:, 0:3], 4)
     rep.close_ulp("f-3 updateModel normals", um[:, 8:11], umr[:, 8:11], 4, abs_floor=1e-7)
     rep.exact("f-3 updateModel everything else", np.delete(um, [0, 1, 2, 8, 9, 10], 1), np.delete(umr, [0, 1, 2, 8, 9, 10], 1))
+    return rep
+
+
+# ---- the reference's parameter variants of the GLSL rows, executed (tests/golden/ref_glsl/sphere_variants.npz) -------------
+# name -> (parameter overrides, the part of the pipeline they reach).  Every variant runs ONE part on the inputs the default
+# sphere fixture holds for it; only that part's outputs are stored, as "<name>__<key of the default fixture>".
+VARIANTS = {
+    "gauss_filter": (dict(use_bilateral=0), "filter"),                               # depth_guass.frag instead of depth_bilateral.frag
+    "depth_cutoff": (dict(depth_cutoff=1.5), "filter"),                               # maxD cuts the plane behind the sphere (P1, P2)
+    "central_diff_normals": (dict(normal_estimation_pca=0.0), "vnr"),                # geometry.glsl getNormal instead of getNormalPCA
+    "radius_multiplier_3": (dict(init_radius_multiplier=3.0), "vnr"),
+    "curv_window_2": (dict(curv_estimation_window=2.0), "curv"),                     # 5 x 5 HRBF window
+    "conf_eval": (dict(use_conf_eval=1), "conf"),                                    # exp(-epsilon / sqrt(gradient_mag)) factor
+    "clean_window_1": (dict(clean_window_multiplier=1.0), "clean"),
+    "clean_window_2_25": (dict(clean_window_multiplier=2.25), "clean"),              # ceil(4.5) = 5 samples per axis
+    "clean_window_4": (dict(clean_window_multiplier=4.0), "clean"),
+    "clean_thresholds": (dict(confidence_threshold=9.0, curv_valid_threshold=40.0), "clean"),
+    "predict_small": (dict(predict_window_multiplier=2.0, predict_min_neighbors=4, predict_max_neighbors=6), "predict"),
+    "predict_conf_6_6": (dict(predict_conf_threshold=6.6), "predict"),            # about half of the stable map qualifies
+}
+
+
+def variant_fixture(base, var, name):
+    """the default fixture with the variant's outputs in place of the default ones"""
+    fx = dict(base)
+    pre = name + "__"
+    for k, v in var.items():
+        if k.startswith(pre):
+            fx[k[len(pre):]] = v
+    return fx
+
+
+def run_variant(impl, base, var, name, rep):
+    kw, part = VARIANTS[name]
+    fx, g = variant_fixture(base, var, name), impl
+    if part == "filter":
+        part_filter(rep, g, fx)
+    elif part == "vnr":
+        part_vertex_normal_radius(rep, g, fx, pca=kw.get("normal_estimation_pca", 1.0) != 0.0)
+    elif part == "curv":
+        part_curvature(rep, g, fx)
+    elif part == "conf":
+        part_confidence(rep, g, fx)
+    elif part == "clean":
+        bind_frame(g, base)
+        map_flow(rep, g, fx, "x_", name + ": ", stable_map_with_outliers(base), base["f2_pose"])
+    elif part == "predict":
+        bind_frame(g, base)
+        part_prediction(rep, g, fx, reference_final(base, "x_", stable_map_with_outliers(base)))
     return rep
 
 
@@ -208,11 +304,9 @@ def map_flow(rep, g, fx, pre, tag, map_in, T2):
     bad = int((ic != fx[pre + "c_INDEX"]).sum())
     rep.add(tag + "M1 (after fuse) INDEX", bad <= max(2, ic.size // 5000) + 2 * odd.size, "%d of %d pixels differ (sub-pixel snap ties)" % (bad, ic.size))
     g.run_stage("CLEAN")
-    ref_fused = map_in.copy(); ref_fused[rows] = vals
     keep = np.unpackbits(fx[pre + "keep"])[:map_in.shape[0]].astype(bool)
-    new = rec[fx[pre + "new_picks"]].copy(); new[:, 7] = 2.0
-    ref_final = np.concatenate([ref_fused[keep], new])
-    assert ref_final.shape[0] == int(fx[pre + "map_count"][0])
+    new = rec[fx[pre + "new_picks"]]
+    ref_final = reference_final(fx, pre, map_in)
     final = g.download_map()
     # align the two maps row by row: key = position to 10 um + init time; rows present in both must come in the same order
     def keys(m):
@@ -281,6 +375,9 @@ def prediction_checks(rep, g, fx, P):
     d = int((hit != hitr).sum())
     rep.add("H2 which pixels have a prediction", d <= max(2, hit.size // 2000), "%d of %d pixels differ (%d predicted)" % (d, hit.size, int(hitr.sum())))
     both = hit & hitr
+    if not both.any():
+        rep.add("H2 PRED_VERTEX xyz", not hit.any() and not hitr.any(), "no pixel predicted in either")
+        return
     dp = np.linalg.norm((v[..., :3] - vr[..., :3]).astype(np.float64), axis=-1)[both]
     rep.add("H2 PRED_VERTEX xyz", dp.max() <= 4e-5 and np.percentile(dp, 99) <= 1e-6, "|dp| max %.2e m, p99 %.2e, identical %.1f%%" % (
         dp.max(), np.percentile(dp, 99), 100 * (dp == 0).mean()))

@@ -94,6 +94,47 @@ def test_hip_path_matches_the_executed_shaders_at_a_size_that_is_not_a_power_of_
     assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
 
 
+VARIANT_NAMES = sorted(R.VARIANTS)
+
+
+def test_variant_fixture_covers_every_variant_and_differs_from_the_default():
+    var, base = R.load("sphere_variants"), R.load("sphere")
+    for name in VARIANT_NAMES:
+        ks = [k for k in var if k.startswith(name + "__")]
+        assert ks, name
+        for k in ks:   # only outputs that the variant changes are stored
+            assert not np.array_equal(var[k], base[k.split("__", 1)[1]]), k
+    # the removal rules react to the window and the thresholds as the shader's loops say they must
+    n = {name: int(var[name + "__x_map_count"][0]) for name in VARIANT_NAMES if name.startswith("clean_")}
+    assert n["clean_window_1"] > int(base["x_map_count"][0]) > n["clean_window_4"], n
+
+
+@pytest.mark.parametrize("name", VARIANT_NAMES)
+def test_oracle_matches_the_executed_shaders_under_the_references_parameter_variants(name, oracle_lib_built):
+    """the reference's switches of the GLSL rows (Gauss filter, central-difference normals, 5 x 5 curvature window, confidence
+    evaluation, clean windows 1 / 2.25 / 4, thresholds, prediction window and neighbour bounds), each executed on llvmpipe"""
+    base, var = R.load("sphere"), R.load("sphere_variants")
+    o = oracle_lib_built.Oracle(scene_params("sphere", **R.VARIANTS[name][0]), omp=True)
+    try:
+        rep = R.run_variant(o, base, var, name, R.Report(strict=True))
+    finally:
+        o.close()
+    assert rep.rows and all(ok for _, ok, _ in rep.rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", VARIANT_NAMES)
+def test_hip_path_matches_the_executed_shaders_under_the_references_parameter_variants(name, gpu_available):
+    from hrbffusion3d_amd.api import HRBFFusion
+    base, var = R.load("sphere"), R.load("sphere_variants")
+    g = HRBFFusion(scene_params("sphere", **R.VARIANTS[name][0]))
+    try:
+        rep = R.run_variant(g, base, var, name, R.Report(strict=True))
+    finally:
+        g.close()
+    assert rep.rows and all(ok for _, ok, _ in rep.rows)
+
+
 def test_glsl_harness_source_fixes_are_token_level():
     """the harness may only respell what Mesa's compiler rejects: three spellings, no arithmetic"""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
