@@ -260,7 +260,7 @@ def run_reference_variants(f1, f2, T2, w2, base):
     for name, (kw, part) in R.VARIANTS.items():
         tag = name + "__"
         pre(part if part in ("filter", "vnr", "curv", "conf") else "all")
-        p.p.update(kw)
+        p.p.update({k: v for k, v in kw.items() if k in default})   # frame_to_frame_rgb is an argument of fill_in, not a uniform set
         if part == "filter":
             p.filter_depth(); out[tag + "f2_DEPTH_FILTERED"] = p.get("DEPTH_FILTERED")
             p.metricise_depth()
@@ -294,7 +294,7 @@ def run_reference_variants(f1, f2, T2, w2, base):
             p.predict_hrbf()
             for k, v in p.prediction_images().items():
                 out[tag + "x_" + k] = v
-            p.fill_in(2, w2)
+            p.fill_in(2, w2, frame_to_frame_rgb=bool(kw.get("frame_to_frame_rgb", 0)))
             for k, v in p.fill_images().items():
                 out[tag + "x_" + k] = v
         print("  variant %-22s %s" % (name, kw))

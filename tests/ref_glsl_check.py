@@ -234,6 +234,7 @@ VARIANTS = {
     "clean_window_4": (dict(clean_window_multiplier=4.0), "clean"),
     "clean_thresholds": (dict(confidence_threshold=9.0, curv_valid_threshold=40.0), "clean"),
     "predict_small": (dict(predict_window_multiplier=2.0, predict_min_neighbors=4, predict_max_neighbors=6), "predict"),
+    "fill_frame_to_frame_rgb": (dict(frame_to_frame_rgb=1), "predict"),             # fill_rgb.frag with passthrough: the live image everywhere
     "predict_conf_6_6": (dict(predict_conf_threshold=6.6), "predict"),            # about half of the stable map qualifies
 }
 
