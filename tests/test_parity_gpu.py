@@ -243,6 +243,28 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
     assert np.array_equal(bits(m), bits(m2))
 
 
+def test_icp_dominated_registration_tracks_the_same_stream_to_a_centimetre(gpu_available):
+    """the stream of test_long_sequence_trajectory_and_determinism with icp_weight 100 instead of 10: the geometric term
+    outweighs the nearest-texel photometric term and the offset goes from ~6 cm to ~1 cm — the accuracy of the rest of the
+    pipeline (pre-processing, fusion, prediction, ICP) on this stream, and the evidence that the loose bound of the default
+    configuration is the photometric term's"""
+    from hrbffusion3d_amd.api import HRBFFusion
+    W, H = 320, 240
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    frames = [synth.frame(k, W, H, noise=True) for k in range(150)]
+    ate = {}
+    for w in (10.0, 100.0):
+        g = HRBFFusion(default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 21, icp_weight=w))
+        g.set_pose(frames[0][2])
+        est = []
+        for rgb, d, _ in frames:
+            g.process_frame(rgb, d)
+            est.append(g.get_pose())
+        g.close()
+        ate[w] = synth.ate_rmse(est, [f[2] for f in frames])
+    assert ate[100.0] < 0.02 and ate[100.0] < ate[10.0] / 3.0, ate
+
+
 @pytest.mark.parametrize("variant", ["gauss_filter", "central_diff_normals", "no_so3_no_pyramid", "conf_eval", "rgb_only",
                                      "icp_only", "corr_search", "sparse_icp_corr_search", "clean_window_1", "clean_window_4", "clean_window_2_25",
                                      "frame_to_frame_rgb", "rgb_grad_weight", "icp_unweighted", "predict_small",
