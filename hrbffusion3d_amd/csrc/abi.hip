@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "common.h"
 #include "kernels.h"
 
@@ -55,6 +56,7 @@ struct MapShard {
     int tile_par;               // buffer the next pass accumulates into
     uint32_t *d_tile_done; uint32_t epoch;   // tile_done holds the epoch (pass counter) of the pass that raised it
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
+    uint32_t *d_merged_part;    // the merged count of the last fuse, one word per workgroup of k_apply_merges
 };
 // sharded map: the private z-buffer of the virtual shards k >= 1 and the winner records ("winners' attributes
 // gathered only for hit pixels"): `send` = the records this shard packed, `recv` = those of the other ranks (real mode)
@@ -188,15 +190,17 @@ static int alloc_shard(hrbf_context *c, MapShard &sh)
     sh.tile_dirty[0] = sh.tile_dirty[1] = 0; sh.tile_par = 0; sh.epoch = 0;
     if (!r) r = dalloc(&sh.d_tile_done, c->max_tiles);
     if (!r) r = dalloc(&sh.d_keep_flags, (size_t)c->cap + (size_t)c->Q + 64);
+    if (!r) r = dalloc(&sh.d_merged_part, (size_t)merge_workgroups(c->Q));
     sh.count_ub = 0;
     return r;
 }
 static void free_shard(MapShard &sh)
 {
     free_planes(sh.map);
-    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count[0], sh.d_tile_count[1], sh.d_tile_done, sh.d_keep_flags};
+    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count[0], sh.d_tile_count[1], sh.d_tile_done, sh.d_keep_flags, sh.d_merged_part};
     for (void *p : q) if (p) hipFree(p);
     sh.d_slot = sh.d_stats = sh.d_tile_count[0] = sh.d_tile_count[1] = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr;
+    sh.d_merged_part = nullptr;
 }
 static void free_scratch(ShardScratch &x)
 {
@@ -762,7 +766,7 @@ static void st_fuse(hrbf_context *c)
                     c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf,
                     c->d_im_normrad, c->rec, c->d_rec_flag, c->d_rec_best, c->sh[k].d_slot, c->sh[k].map, shard_ref(c, k),
                     c->sh[k].d_stats, c->prm.curv_valid_threshold, ring ? c->ring_m0[c->ring_head % HRBF_RING] : nullptr,
-                    ring ? c->ring_m1[c->ring_head % HRBF_RING] : nullptr);
+                    ring ? c->ring_m1[c->ring_head % HRBF_RING] : nullptr, c->sh[k].d_merged_part);
     c->fuse_tick = c->tick; c->ring_merge_head = c->ring_head;
 }
 static void st_clean(hrbf_context *c)
@@ -785,7 +789,7 @@ static void st_clean(hrbf_context *c)
                      c->max_tiles, ring ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
                      ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
                      last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0,
-                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr);
+                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr, sh.d_merged_part);
         sh.tile_dirty[cur] = dirty[0]; sh.tile_dirty[1 - cur] = dirty[1]; sh.tile_par = 1 - cur;
         if (last) {
             const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
@@ -1471,8 +1475,13 @@ extern "C" int hrbf_get_fuse_stats(hrbf_handle c, uint32_t out[4])
     out[0] = out[1] = out[2] = out[3] = 0;
     for (int k = 0; k < c->nsh; ++k) {
         uint32_t v[4];
+        const uint32_t nparts = merge_workgroups(c->Q);
+        std::vector<uint32_t> parts(nparts);   // merged = the per-workgroup words of k_apply_merges, added up here
         HIP_CHECK(hipMemcpyAsync(v, c->sh[k].d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(parts.data(), c->sh[k].d_merged_part, sizeof(uint32_t) * nparts, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
+        v[1] = 0;
+        for (uint32_t t : parts) v[1] += t;
         for (int t = 0; t < 4; ++t) out[t] += v[t];
     }
     return HRBF_OK;

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
 __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick, RecPlanes rec,
                                                       const int32_t *__restrict__ rec_flag,
                                                       const uint32_t *__restrict__ rec_best, uint32_t *__restrict__ slot,
-                                                      MapPlanes m, ShardRef sh, uint32_t *__restrict__ merged, float curvThr)
+                                                      MapPlanes m, ShardRef sh, uint32_t *__restrict__ merged, float curvThr,
+                                                      uint32_t *__restrict__ merged_part)
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     bool act = q < Q && rec_flag[q] == 1;
@@ -429,8 +430,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick,
     const float4 r0 = rec.p0[qs], r1 = rec.p1[qs], r2 = rec.p2[qs], r3 = rec.p3[qs], r4 = rec.p4[qs];
     const float4 vp = m.p0[s], vc = m.p1[s], vn = m.p2[s], c1 = m.p3[s], c2 = m.p4[s];
     act = act && winner == (uint32_t)q;
-    {   // merged count: ONE atomic per workgroup — same-address atomics from 1200 waves serialise at the memory side
-#ifndef MERGE_NO_COUNT
+    {   // merged count: one plain store per workgroup into its own word; whoever wants the number adds the words up
+        // (k_copy_stats for the timing ring, hrbf_get_fuse_stats on the host).  One atomic per workgroup on one address —
+        // 300, then 150 of them — had cost the kernel 1.5 us each way: same-address atomics serialise at the memory side
         __shared__ uint32_t s_m[MERGE_THREADS / 64];
         const unsigned long long bal = __ballot(act);
         if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
@@ -439,9 +441,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick,
             uint32_t t = 0;
 #pragma unroll
             for (int w = 0; w < MERGE_THREADS / 64; ++w) t += s_m[w];
-            if (t) atomicAdd(merged, t);
+            merged_part[blockIdx.x] = t;
         }
-#endif
     }
     if (!act) return;
     slot[s] = 0xFFFFFFFFu;   // re-arm for the next frame (only touched entries are reset)
@@ -932,9 +933,14 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
 }
 
 // instrumentation only (timing ring on): park the pass's item statistics {in, merged, appended, out, -, -, moved, status}
-__global__ void k_copy_stats(const uint32_t *__restrict__ stats, uint32_t *__restrict__ slot)
+__global__ void k_copy_stats(const uint32_t *__restrict__ stats, uint32_t *__restrict__ slot,
+                             const uint32_t *__restrict__ merged_part, int nparts)
 {
-    if (threadIdx.x < 8) slot[threadIdx.x] = stats[threadIdx.x];
+    if (threadIdx.x < 8 && threadIdx.x != 1) slot[threadIdx.x] = stats[threadIdx.x];
+    uint32_t t = 0;   // merged = sum of k_apply_merges' per-workgroup words (one wave)
+    for (int i = threadIdx.x; i < nparts; i += 64) t += merged_part[i];
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (threadIdx.x == 0) slot[1] = t;
 }
 __global__ void k_zero_i32(int32_t *p, int n)
 {
@@ -1084,15 +1090,15 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr, hipEvent_t m0, hipEvent_t m1)
+                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr, hipEvent_t m0, hipEvent_t m1, uint32_t *merged_part)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     hipLaunchKernelGGL(k_associate, dim3(quarter_tile_blocks(cam.W, cam.H)), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
                        rec_best, slot, sh, stats);
     if (m0) hipEventRecord(m0, s);   // F2 (update.vert) is part of the roofline-timed fuse: SURVEY §8d "F2+F3"
-    hipLaunchKernelGGL(k_apply_merges, dim3((Q + MERGE_THREADS - 1) / MERGE_THREADS), dim3(MERGE_THREADS), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
-                       sh, stats + 1, curvThr);
+    hipLaunchKernelGGL(k_apply_merges, dim3(merge_workgroups(Q)), dim3(MERGE_THREADS), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
+                       sh, stats + 1, curvThr, merged_part);
     if (m1) hipEventRecord(m1, s);
 }
 
@@ -1102,7 +1108,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_count_next,
                   uint32_t *tile_dirty /* [2]: entries this / the other buffer may hold */, uint32_t *tile_done, uint32_t epoch,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
-                  int n_records, int zero_records, uint32_t *stats_ring_slot)
+                  int n_records, int zero_records, uint32_t *stats_ring_slot, const uint32_t *merged_part)
 {
     const int Qfull = (cam.W / 2) * (cam.H / 2);
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
@@ -1136,7 +1142,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     tile_dirty[0] = tiles; tile_dirty[1] = 0;   // this buffer now holds `tiles` counts, the other one is clean
     if (zero_records && Q == 0)   // a rank of a sharded map that takes no appends still re-arms its (replicated) record flags
         hipLaunchKernelGGL(k_zero_i32, dim3((Qfull + 255) / 256), dim3(256), 0, s, rec_flag, Qfull);
-    if (stats_ring_slot) hipLaunchKernelGGL(k_copy_stats, dim3(1), dim3(64), 0, s, stats, stats_ring_slot);
+    if (stats_ring_slot)
+        hipLaunchKernelGGL(k_copy_stats, dim3(1), dim3(64), 0, s, stats, stats_ring_slot, merged_part, (int)merge_workgroups(Qfull));
 }
 
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P)
@@ -1149,6 +1156,7 @@ void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v)
 }
 
 uint32_t fuse_tile_items() { return FUSE_TILE; }
+uint32_t merge_workgroups(int Q) { return (uint32_t)((Q + MERGE_THREADS - 1) / MERGE_THREADS); }
 size_t clean_tex_elems(int P) { return clean_tex_float4s(P); }
 uint32_t fuse_tile_count_stride() { return TC_STRIDE; }
 

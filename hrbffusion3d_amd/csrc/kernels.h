@@ -86,7 +86,8 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
                  MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr,
-                 hipEvent_t m0, hipEvent_t m1 /* nullable: bracket the merge kernel (F2) */);
+                 hipEvent_t m0, hipEvent_t m1 /* nullable: bracket the merge kernel (F2) */,
+                 uint32_t *merged_part /* merge_workgroups(Q) words: the merged count, one word per workgroup of k_apply_merges */);
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,
@@ -98,13 +99,15 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
                   int n_records /* Q on the shard that takes the appends (the last one), else 0 */,
                   int zero_records /* re-arm the record flags at the end */,
-                  uint32_t *stats_ring_slot /* nullable (timing ring): the pass's 8 statistics words are copied here afterwards */);
+                  uint32_t *stats_ring_slot /* nullable (timing ring): the pass's 8 statistics words are copied here afterwards */,
+                  const uint32_t *merged_part /* as launch_fuse: summed into word 1 of the ring slot */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
 void launch_copy_inputs(hipStream_t s, const uint8_t *src_rgb, size_t nrgb, const uint8_t *src_dep, size_t ndep,
                         uint8_t *d_rgb, uint8_t *d_dep);   // src: device-visible pinned host memory
 uint32_t fuse_tile_items();
+uint32_t merge_workgroups(int Q);
 uint32_t fuse_tile_count_stride();
 
 // ---- k_predict.hip
