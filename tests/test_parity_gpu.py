@@ -243,9 +243,9 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
     assert np.array_equal(bits(m), bits(m2))
 
 
-def test_icp_dominated_registration_tracks_the_same_stream_to_a_centimetre(gpu_available):
-    """the stream of test_long_sequence_trajectory_and_determinism with icp_weight 100 instead of 10: the geometric term
-    outweighs the nearest-texel photometric term and the offset goes from ~6 cm to ~1 cm — the accuracy of the rest of the
+def test_icp_only_registration_tracks_the_same_stream_to_a_centimetre(gpu_available):
+    """the stream of test_long_sequence_trajectory_and_determinism with icp_weight 100 instead of 10, which switches the
+    photometric term off (`rgb = rgbOnly || icpWeight < 100`, RGBDOdometry.cpp:807): the offset goes from ~6 cm to ~1 cm — the accuracy of the rest of the
     pipeline (pre-processing, fusion, prediction, ICP) on this stream, and the evidence that the loose bound of the default
     configuration is the photometric term's"""
     from hrbffusion3d_amd.api import HRBFFusion

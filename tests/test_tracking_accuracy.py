@@ -3,7 +3,8 @@
 CPU tests on the oracle (bit-identical to the HIP path, tests/test_parity_gpu.py), QVGA, noise-free, frame 0 -> frame 1
 from an empty map, i.e. frame-to-frame against the filled-in previous frame.  They pin three facts that together locate
 the ~5 mm / 0.1 deg per frame the default joint registration loses while the map is young:
-  a static camera is tracked exactly; the ICP term alone is accurate to half a millimetre; the photometric term, whose
+  a static camera is tracked exactly; the ICP term alone (icp_weight 100: `rgb = rgbOnly || icpWeight < 100`,
+  RGBDOdometry.cpp:807) is accurate to half a millimetre; the photometric term, whose
   residual looks the model image up at the nearest texel (reduce.cu:1027-1046), is what carries the error.
 tools/probes/rgb_term_emulation.py reproduces the last fact with an independent numpy emulation
 (profiles/r03_rgb_term_emulation.txt).
@@ -55,9 +56,9 @@ def test_the_nearest_texel_rgb_term_carries_the_offset(oracle_lib_built, mode):
     assert 2.0 < mm < 9.0 and 0.05 < deg < 0.25, (mm, deg)
 
 
-def test_icp_dominated_registration_tracks_thirty_noisy_frames_to_a_centimetre(oracle_lib_built):
+def test_icp_only_registration_tracks_thirty_noisy_frames_to_a_centimetre(oracle_lib_built):
     """30 noisy QVGA frames from an empty map: ATE ~ 5.6 cm with the default weights (photometric rows dominate), ~ 0.8 cm
-    with icp_weight 100 — same stream, same pre-processing, fusion and prediction"""
+    with icp_weight 100, which switches the photometric term off (RGBDOdometry.cpp:807) — same stream, same pre-processing, fusion and prediction"""
     fx, fy, cx, cy = synth.intrinsics(W, H)
     frames = [synth.frame(k, W, H, noise=True) for k in range(30)]
     ate = {}

@@ -127,7 +127,7 @@ def main():
         return
     print("\nthe oracle (the restated reference), frame 0 then frame 1 from an empty map:")
     ests = {}
-    for name, kw in (("joint, w_icp = 10 (default)", {}), ("rgb only", dict(rgb_only=1)), ("icp-dominated, w_icp = 100", dict(icp_weight=100.0))):
+    for name, kw in (("joint, w_icp = 10 (default)", {}), ("rgb only", dict(rgb_only=1)), ("icp only, w_icp = 100 (rgb off)", dict(icp_weight=100.0))):
         p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 20)
         for k, val in kw.items():
             setattr(p, k, val)
