@@ -825,13 +825,13 @@ def test_sharded_map_uploaded_and_tracked(pair):
 
 
 @pytest.mark.parametrize("cfg", ["config4_vga_4M_4_shards", "config5_1280x960_8M_8_shards"])
-def test_baseline_config_4_and_5_geometry_sharded_equals_single(gpu_available, cfg):
+def test_baseline_config_4_and_5_geometry_sharded_equals_single_equals_oracle(gpu_available, oracle_lib_built, cfg):
     """BASELINE configs 4 / 5 at their full sizes on the one GPU a test box has: a 640x480 stream against 4.3 M surfels
     cut into 4 shards, and a 1280x960 stream against 8.7 M surfels cut into 8 — every shard played in turn by one
-    process with the winner-record exchange between them (key min-merge, pack, scatter).  The oracle cannot run these
-    sizes in test time, so the property is sharded == unsharded on the same library, bit for bit: pose, fuse statistics
-    and the whole concatenated map (content and order) over tracked noisy frames with a stale-surfel purge in frame 1
-    (so that the shards' in-place compactions really move their ranges), then again after a re-cut of the ranges."""
+    process with the winner-record exchange between them (key min-merge, pack, scatter).  Property: sharded == unsharded
+    == the CPU oracle (about a second per frame and million surfels on its OpenMP build), bit for bit: pose, fuse
+    statistics and the whole concatenated map (content and order) over tracked noisy frames with a stale-surfel purge in
+    frame 1 (so that the shards' in-place compactions really move their ranges), then again after a re-cut of the ranges."""
     from hrbffusion3d_amd.api import HRBFFusion
     W, H, n_seed, G = (640, 480, 4_300_000, 4) if cfg.startswith("config4") else (1280, 960, 8_700_000, 8)
     K = synth.intrinsics(W, H)
@@ -870,6 +870,19 @@ def test_baseline_config_4_and_5_geometry_sharded_equals_single(gpu_available, c
         assert np.array_equal(a[1], b[1]) and a[2] == b[2], "%s frame %d counts" % (cfg, k + 1)
     assert np.array_equal(bits(m_ref), bits(m_got))
     assert np.linalg.norm(got[-1][0][:3, 3] - frames[3][2][:3, 3]) < 0.03
+    del m_got
+    # the oracle on the same map and frames
+    o = oracle_lib_built.Oracle(default_params(W, H, *K, max_surfels=n + 8 * Q), omp=True)
+    try:
+        o.upload_map(seed); o.set_pose(frames[0][2]); o.bootstrap(frames[0][0], frames[0][1])
+        o.set_tick(300)
+        for k in range(1, 4):
+            o.process_frame(frames[k][0], frames[k][1])
+            assert np.array_equal(bits(o.get_pose()), bits(ref[k - 1][0])), "%s frame %d pose vs oracle" % (cfg, k)
+            assert np.array_equal(o.fuse_stats(), ref[k - 1][1]) and o.surfel_count() == ref[k - 1][2], "%s frame %d counts vs oracle" % (cfg, k)
+        assert np.array_equal(bits(o.download_map()), bits(m_ref)), cfg + " map vs oracle"
+    finally:
+        o.close()
 
 
 @pytest.mark.parametrize("sharded", [False, True])
