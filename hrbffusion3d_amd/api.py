@@ -26,7 +26,7 @@ EXPORTS = [
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
-    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_map_shard_init", "hrbf_map_rebalance",
+    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
@@ -94,6 +94,7 @@ def load_library():
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
     lib.hrbf_peer_unique_id.argtypes = [vp]; lib.hrbf_comm_init_peer.argtypes = [vp, i32, i32, vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
+    lib.hrbf_download_gids.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_shard_counts.argtypes = [vp, vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
     lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
     lib.hrbf_predict_indices.argtypes = [vp, vp, i32, f32, i32]; lib.hrbf_fuse.argtypes = [vp, vp, i32, f32, i32]
@@ -240,9 +241,27 @@ class HRBFFusion:
     def predict_hrbf(self):
         self._check(self.lib.hrbf_predict_hrbf(self.h))
 
-    def map_shard_init(self, enable=True):
-        """cut the surfel map over the ranks of comm_init (SURVEY §8e sharding 2); the map must be empty"""
-        self._check(self.lib.hrbf_map_shard_init(self.h, int(bool(enable))))
+    def map_shard_init(self, enable=True, partition="ranges"):
+        """cut the surfel map over the ranks of comm_init (SURVEY §8e sharding 2); the map must be empty.
+        partition: "ranges" = contiguous ranges of the global order, "hash" = ownership by spatial hash of the surfel's cell"""
+        mode = 0 if not enable else (2 if partition == "hash" else 1)
+        self._check(self.lib.hrbf_map_shard_init(self.h, mode))
+
+    def shard_counts(self):
+        """(partition, counts): partition 0 one map | 1 contiguous ranges | 2 spatial hash; live surfel counts of the G shards"""
+        o = np.zeros(8, np.uint32)
+        mode = self.lib.hrbf_shard_counts(self.h, _p(o))
+        if mode < 0:
+            self._check(mode)
+        return mode, o
+
+    def download_gids(self):
+        """hash ownership, one shard per rank: the global-order ids of the rank's surfels (order of download_map)"""
+        n = self.local_surfel_count()
+        o = np.zeros(n, np.uint32)
+        if n:
+            self._check(self.lib.hrbf_download_gids(self.h, _p(o), n))
+        return o
 
     def set_row_sharding(self, enable):
         self._check(self.lib.hrbf_set_row_sharding(self.h, int(bool(enable))))

@@ -57,6 +57,11 @@ struct MapShard {
     uint32_t *d_tile_done; uint32_t epoch;   // tile_done holds the epoch (pass counter) of the pass that raised it
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
     uint32_t *d_merged_part;    // the merged count of the last fuse, one word per workgroup of k_apply_merges
+    // ownership by spatial hash (kernels.h, ShardRef): allocated by hrbf_map_shard_init(c, 2)
+    uint32_t *d_gid;            // cap words: the surfel's place in the global order, moved along with the planes
+    uint32_t *d_own_local;      // P words: local index of the pixel's winner where this shard owns it
+    uint32_t *d_rec_lbest;      // Q words: local index of the record's matched surfel where this shard owns it
+    unsigned long long *d_zpriv;   // P keys {depth, local index}: the shard's private z-buffer
 };
 // sharded map: the private z-buffer of the virtual shards k >= 1 and the winner records ("winners' attributes
 // gathered only for hit pixels"): `send` = the records this shard packed, `recv` = those of the other ranks (real mode)
@@ -127,6 +132,9 @@ struct hrbf_context {
     uint8_t *h_stage[3]; hipEvent_t ev_stage[3]; bool stage_used[3]; uint32_t stage_head;   // pinned input staging ring
     const uint8_t *ride_rgb_src;   // device view of a staged RGB image that the next st_filter uploads (hrbf_process_frame)
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
+    // ownership by spatial hash: the next free global-order id (the same on every rank: seed size, then + Q per clean pass),
+    // 1 / cell size, the device word holding the smallest id alive, scratch of the hashed seeding
+    int hash_mode; uint32_t g_next; float hash_inv_cell; uint32_t *d_gfirst; uint32_t *d_init_flags2, *d_init_offs2, *d_gtotal;
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
     uint32_t *d_init_flags, *d_init_offs;
     uint32_t max_tiles;
@@ -201,6 +209,9 @@ static void free_shard(MapShard &sh)
     for (void *p : q) if (p) hipFree(p);
     sh.d_slot = sh.d_stats = sh.d_tile_count[0] = sh.d_tile_count[1] = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr;
     sh.d_merged_part = nullptr;
+    void *hq[] = {sh.d_gid, sh.d_own_local, sh.d_rec_lbest, sh.d_zpriv};
+    for (void *p : hq) if (p) hipFree(p);
+    sh.d_gid = sh.d_own_local = sh.d_rec_lbest = nullptr; sh.d_zpriv = nullptr;
 }
 static void free_scratch(ShardScratch &x)
 {
@@ -215,7 +226,12 @@ static float4 *map_plane(const MapPlanes &m, int k)
 }
 static uint32_t *counts_live(hrbf_context *c) { return c->d_counts + (size_t)c->target * HRBF_MAX_SHARDS; }
 static uint32_t *counts_next(hrbf_context *c) { return c->d_counts + (size_t)(1 - c->target) * HRBF_MAX_SHARDS; }
-static ShardRef shard_ref(hrbf_context *c, int k) { ShardRef r = {counts_live(c), c->shard_first + k, c->G}; return r; }
+static ShardRef shard_ref(hrbf_context *c, int k)
+{
+    ShardRef r = {counts_live(c), c->shard_first + k, c->G, nullptr, nullptr, nullptr, nullptr};
+    if (c->hash_mode) { r.gid = c->sh[k].d_gid; r.g_first = c->d_gfirst; r.own_local = c->sh[k].d_own_local; r.rec_lbest = c->sh[k].d_rec_lbest; }
+    return r;
+}
 
 extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
 {
@@ -403,7 +419,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
                     c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, c->d_pr_image, c->d_fi_image, c->d_pr_vertex,
                     c->d_pr_normal, c->d_pr_curv1, c->d_pr_curv2, c->d_fi_vertex, c->d_fi_normal, c->d_fi_curv1,
                     c->d_fi_curv2, c->d_pr_time, c->d_pr_icpw, c->d_fi_icpw, c->d_counts, c->d_rec_flag, c->d_rec_best,
-                    c->d_init_flags, c->d_init_offs, c->d_pose, c->d_clean_tex,
+                    c->d_init_flags, c->d_init_offs, c->d_pose, c->d_clean_tex, c->d_gfirst, c->d_init_flags2, c->d_init_offs2, c->d_gtotal,
                     c->odo.state, c->odo.corres, c->odo.corres_diff, c->odo.icp_part, c->odo.totals};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < HRBF_MAX_SHARDS; ++k) free_shard(c->sh[k]);
@@ -603,7 +619,7 @@ static void refresh_count_ub(hrbf_context *c)
         c->ev_pending = false;
         for (int k = 0; k < c->nsh; ++k) {
             const int gk = c->shard_first + k;
-            const uint32_t ub = c->h_count_pinned[gk] + (gk == c->G - 1 ? c->ub_growth_since : 0u);   // only the last shard grows
+            const uint32_t ub = c->h_count_pinned[gk] + ((c->hash_mode || gk == c->G - 1) ? c->ub_growth_since : 0u);   // only the last shard grows (hash ownership: all may)
             if (ub < c->sh[k].count_ub) c->sh[k].count_ub = ub;
         }
     }
@@ -639,8 +655,61 @@ static void shard_allgather_counts(hrbf_context *c, uint32_t *row)
     }
     if (c->comm.comm) rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
 }
+// hash ownership: the smallest global-order id alive, over all shards of all ranks, into c->d_gfirst (device word).  Local
+// shards by a one-thread kernel; between ranks the word travels with the counts (shard_allgather_counts).
+static void hash_refresh_gfirst(hrbf_context *c, const uint32_t *counts_row)
+{
+    if (!c->hash_mode) return;
+    const uint32_t *gids[HRBF_MAX_SHARDS];
+    for (int k = 0; k < c->nsh; ++k) gids[k] = c->sh[k].d_gid;
+    launch_gfirst(c->stream, counts_row, c->shard_first, c->nsh, gids, c->d_gfirst, 0);
+    if (!c->shard_real) return;
+    uint32_t mine = HRBF_NO_SURFEL, all[HRBF_PEER_MAX];
+    if (c->peer.shm_mode) {   // through the rendezvous segment, like the counts
+        PeerLink &pl = c->peer;
+        hipMemcpyAsync(&mine, c->d_gfirst, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+        const int slot = (int)((pl.gen + 1u) & 1u);
+        pl.shm->counts[slot][pl.rank] = mine;
+        __sync_synchronize();
+        if (peer_barrier_host(c)) return;
+        for (int g = 0; g < pl.world; ++g) { all[g] = pl.shm->counts[slot][g]; mine = all[g] < mine ? all[g] : mine; }
+        hipMemcpyAsync(c->d_gfirst, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        hipStreamSynchronize(c->stream);
+    } else if (c->comm.comm) {   // RCCL: all-gather one word per rank into the scratch row, then the minimum of the row
+        uint32_t *row = c->x.rec_count;   // HRBF_MAX_SHARDS words, free outside a projection
+        hipMemcpyAsync(row + c->comm.rank, c->d_gfirst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
+        rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
+        hipMemcpyAsync(all, row, sizeof(uint32_t) * (size_t)c->comm.world, hipMemcpyDeviceToHost, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+        for (int g = 0; g < c->comm.world; ++g) mine = all[g] < mine ? all[g] : mine;
+        hipMemcpyAsync(c->d_gfirst, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        hipStreamSynchronize(c->stream);
+    }
+}
 static void st_init(hrbf_context *c)
 {
+    if (c->hash_mode) {
+        // every shard seeds the surfels whose cell is its own; their place in the seed frame's draw order is their global id
+        hipMemsetAsync(counts_live(c), 0, sizeof(uint32_t) * HRBF_MAX_SHARDS, c->stream);
+        c->ev_pending = false; c->ub_growth_since = 0;
+        for (int k = 0; k < c->nsh; ++k) {
+            launch_initialise_hashed(c->stream, c->cam, c->d_pose, c->d_vertex_raw, c->d_normal, c->d_rgb, c->d_curv1, c->d_curv2,
+                                     c->d_gradmag, c->prm.use_conf_eval, c->prm.conf_eval_epsilon, c->prm.curv_valid_threshold,
+                                     c->d_init_flags, c->d_init_offs, c->d_init_flags2, c->d_init_offs2, c->sh[k].map, c->sh[k].d_gid,
+                                     c->cap, counts_live(c) + c->shard_first + k, c->d_gtotal, c->sh[k].d_stats + 7, c->G,
+                                     c->shard_first + k, c->hash_inv_cell);
+            c->sh[k].count_ub = (uint32_t)c->P < c->cap ? (uint32_t)c->P : c->cap;
+        }
+        uint32_t total = 0;
+        hipMemcpyAsync(&total, c->d_gtotal, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        hipStreamSynchronize(c->stream);
+        c->g_next = total;
+        shard_allgather_counts(c, counts_live(c));
+        hash_refresh_gfirst(c, counts_live(c));
+        launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
+        return;
+    }
     // the seed goes to the end of the global order = the last shard; every other shard starts empty
     const int kl = c->G - 1 - c->shard_first;
     if (c->G > 1) hipMemsetAsync(counts_live(c), 0, sizeof(uint32_t) * HRBF_MAX_SHARDS, c->stream);
@@ -673,6 +742,12 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
     // shard gathers the winners it owns (zeros elsewhere) and packs them as winner records -> the records of the other
     // shards are exchanged (variable length: 4 + 16..80 bytes per HIT pixel instead of dense images) and scattered.
     for (int k = 0; k < c->nsh; ++k) {
+        if (c->hash_mode) {   // two-level z-test: private {depth, local index}, then {depth, gid} into the buffer that is reduced
+            launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[k].map, shard_ref(c, k), c->sh[k].count_ub, c->sh[k].d_zpriv,
+                           c->d_submap_active, c->n_submap_active);
+            launch_keys_global(c->stream, c->sh[k].d_zpriv, c->sh[k].d_gid, c->d_zbuf, c->P, k > 0 ? 1 : 0);
+            continue;
+        }
         unsigned long long *zb = k == 0 ? c->d_zbuf : c->x.zbuf;
         launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[k].map, shard_ref(c, k), c->sh[k].count_ub, zb,
                        c->d_submap_active, c->n_submap_active);
@@ -690,7 +765,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
             launch_resolve(c->stream, c->cam, c->d_pose, c->sh[k].map, shard_ref(c, k), c->d_zbuf, c->d_idx, c->d_im_vertconf,
                            c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean, what,
                            k == c->nsh - 1 ? 1 : 0, c->clean_thr, c->clean_time, k > 0 ? cnt : nullptr,
-                           k > 0 ? c->x.send_idx : nullptr, c->x.send_f, cap, k == 0 ? 1 : 0);
+                           k > 0 ? c->x.send_idx : nullptr, c->x.send_f, cap, k == 0 ? 1 : 0, c->sh[k].d_zpriv);
             if (k > 0)
                 launch_winner_unpack(c->stream, c->P, cnt, 0, cap, c->x.send_idx, c->x.send_f, cap, what, c->d_im_vertconf,
                                      c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
@@ -707,7 +782,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
             zred = c->x.zbuf;
         }   // RCCL transport: the all-reduce above left the reduced keys in d_zbuf
         launch_resolve_scatter(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), zred, c->d_idx, pl.img, what, for_clean,
-                               c->clean_thr, c->clean_time);
+                               c->clean_thr, c->clean_time, c->sh[0].d_zpriv);
         if (peer_meet(c)) return;                                           // every owner has written into every rank's images
         launch_zbuf_reset(c->stream, c->d_zbuf, c->P);                       // re-arm the private z-buffer: nobody reads it any more
         if (for_clean && (what & 4)) launch_clean_bits_decode(c->stream, c->d_clean_tex, c->P);
@@ -719,7 +794,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
     hipMemsetAsync(cnt, 0, sizeof(uint32_t), c->stream);
     launch_resolve(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), c->d_zbuf, c->d_idx, c->d_im_vertconf,
                    c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean, what, 1, c->clean_thr,
-                   c->clean_time, cnt, c->x.send_idx, c->x.send_f, cap, 1);
+                   c->clean_time, cnt, c->x.send_idx, c->x.send_f, cap, 1, c->sh[0].d_zpriv);
     if (!c->comm.comm || G == 1) return;
     // sizes of the variable-length exchange: all-gather of the record counts, read back (the one host round trip of the pass)
     rccl_allgather_u32(c->comm.comm, cnt, c->x.rec_count, 1, c->stream);
@@ -777,7 +852,7 @@ static void st_clean(hrbf_context *c)
     const bool ring = ring_frame(c);
     for (int k = 0; k < c->nsh; ++k) {
         const int gk = c->shard_first + k;
-        const bool last = gk == c->G - 1;   // new surfels are appended at the end of the global order
+        const bool last = c->hash_mode || gk == c->G - 1;   // new surfels are appended at the end of the global order (hash ownership: by every shard, its own)
         MapShard &sh = c->sh[k];
         const int cur = sh.tile_par;
         uint32_t dirty[2] = {sh.tile_dirty[cur], sh.tile_dirty[1 - cur]};
@@ -789,7 +864,8 @@ static void st_clean(hrbf_context *c)
                      c->max_tiles, ring ? c->ring_e0[c->ring_head % HRBF_RING] : nullptr,
                      ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
                      last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0,
-                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr, sh.d_merged_part);
+                     ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr, sh.d_merged_part,
+                     c->hash_mode ? sh.d_gid : nullptr, c->g_next, c->G, gk, c->hash_inv_cell);
         sh.tile_dirty[cur] = dirty[0]; sh.tile_dirty[1 - cur] = dirty[1]; sh.tile_par = 1 - cur;
         if (last) {
             const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
@@ -797,6 +873,7 @@ static void st_clean(hrbf_context *c)
         }
     }
     shard_allgather_counts(c, counts_next(c));
+    if (c->hash_mode) { c->g_next += (uint32_t)c->Q; hash_refresh_gfirst(c, counts_next(c)); }
     if (ring) {   // the statistics are parked in the ring slot behind the pass
         if (c->ring_merge_head != c->ring_head || c->fuse_tick != c->tick) {   // no merge this frame: an empty F2 interval
             hipEventRecord(c->ring_m0[c->ring_head % HRBF_RING], c->stream);
@@ -1136,6 +1213,32 @@ extern "C" int hrbf_download_map(hrbf_handle c, float *out, size_t cap_surfels)
     for (int k = 0; k < c->nsh; ++k) n += cnt[c->shard_first + k];
     if (cap_surfels < n) { hrbf_set_error("download_map: buffer holds %zu surfels, map has %zu", cap_surfels, n); return HRBF_ERR_CAPACITY; }
     if (n == 0) return HRBF_OK;
+    if (c->hash_mode && c->nsh > 1) {
+        // the local shards merged by global-order id: the order of the single map (one process playing all shards: the whole map)
+        std::vector<std::vector<float>> rows(c->nsh); std::vector<std::vector<uint32_t>> ids(c->nsh);
+        for (int k = 0; k < c->nsh; ++k) {
+            const uint32_t nk = cnt[c->shard_first + k];
+            rows[k].resize((size_t)nk * 20); ids[k].resize(nk);
+            if (!nk) continue;
+            float4 *tmp = nullptr;
+            HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * (size_t)nk));
+            hipLaunchKernelGGL(k_map_to_aos, dim3((nk + 255) / 256), dim3(256), 0, c->stream, c->sh[k].map, nk, tmp);
+            hipError_t e = hipMemcpyAsync(rows[k].data(), tmp, sizeof(float4) * 5 * (size_t)nk, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ids[k].data(), c->sh[k].d_gid, sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipFree(tmp);
+            if (e != hipSuccess) { hrbf_set_error("download_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+        }
+        std::vector<size_t> at(c->nsh, 0);
+        for (size_t o = 0; o < n; ++o) {
+            int best = -1;
+            for (int k = 0; k < c->nsh; ++k)
+                if (at[k] < ids[k].size() && (best < 0 || ids[k][at[k]] < ids[best][at[best]])) best = k;
+            memcpy(out + o * 20, &rows[best][at[best] * 20], 80);
+            ++at[best];
+        }
+        return HRBF_OK;
+    }
     float4 *tmp = nullptr;
     HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * n));
     size_t at = 0;
@@ -1150,6 +1253,31 @@ extern "C" int hrbf_download_map(hrbf_handle c, float *out, size_t cap_surfels)
     if (e != hipSuccess) { hrbf_set_error("download_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
     return HRBF_OK;
 }
+// hash ownership: the global-order ids of the local shards' surfels, in the order hrbf_download_map returns them for ONE local
+// shard (a rank of a real sharded map) — the caller merges the ranks' maps by id to obtain the order of the single map
+extern "C" int hrbf_download_gids(hrbf_handle c, uint32_t *out, size_t cap_surfels)
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    if (!c->hash_mode || c->nsh != 1) { hrbf_set_error("download_gids: a rank of a hash-owned map only"); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    uint32_t cnt[HRBF_MAX_SHARDS];
+    if (read_counts(c, cnt)) { hrbf_set_error("download_gids: count read-back failed"); return HRBF_ERR_DEVICE; }
+    const size_t n = cnt[c->shard_first];
+    if (cap_surfels < n) return HRBF_ERR_CAPACITY;
+    if (n) HIP_CHECK(hipMemcpyAsync(out, c->sh[0].d_gid, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return HRBF_OK;
+}
+// the live surfel counts of all G shards (0 for k >= G); returns the partition: 0 one map, 1 contiguous ranges, 2 spatial hash
+extern "C" int hrbf_shard_counts(hrbf_handle c, uint32_t out[8])
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    uint32_t cnt[HRBF_MAX_SHARDS];
+    if (read_counts(c, cnt)) return HRBF_ERR_DEVICE;
+    for (int k = 0; k < 8; ++k) out[k] = k < c->G ? cnt[k] : 0u;
+    return c->G <= 1 ? 0 : (c->hash_mode ? 2 : 1);
+}
 // equal split of n items over G shards: shard g gets [lo, hi)
 static void shard_slice(size_t n, int G, int g, size_t *lo, size_t *hi)
 {
@@ -1163,6 +1291,44 @@ extern "C" int hrbf_upload_map(hrbf_handle c, const float *in, size_t n)
     if (!c || (!in && n)) return HRBF_ERR_INVALID;
     hipSetDevice(c->device);
     uint32_t cnt[HRBF_MAX_SHARDS] = {0};
+    if (c->hash_mode) {
+        // every surfel goes to the shard its cell hashes to, keeping the order of `in`; its row number is its global-order id
+        std::vector<uint8_t> owner(n);
+        for (size_t i = 0; i < n; ++i) {
+            owner[i] = (uint8_t)hash_owner(in[i * 20], in[i * 20 + 1], in[i * 20 + 2], c->hash_inv_cell, c->G);
+            ++cnt[owner[i]];
+        }
+        for (int g = 0; g < c->G; ++g)
+            if (cnt[g] > c->cap) { hrbf_set_error("upload_map: %u surfels of shard %d exceed the shard capacity %u", cnt[g], g, c->cap); return HRBF_ERR_CAPACITY; }
+        for (int k = 0; k < c->nsh; ++k) {
+            const int gk = c->shard_first + k;
+            const uint32_t nk = cnt[gk];
+            if (nk) {
+                std::vector<float> rows((size_t)nk * 20); std::vector<uint32_t> ids(nk);
+                size_t at = 0;
+                for (size_t i = 0; i < n; ++i)
+                    if (owner[i] == gk) { memcpy(&rows[at * 20], in + i * 20, 80); ids[at++] = (uint32_t)i; }
+                float4 *tmp = nullptr;
+                HIP_CHECK(hipMalloc((void **)&tmp, sizeof(float4) * 5 * (size_t)nk));
+                hipError_t e = hipMemcpyAsync(tmp, rows.data(), sizeof(float4) * 5 * (size_t)nk, hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(c->sh[k].d_gid, ids.data(), sizeof(uint32_t) * (size_t)nk, hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(k_map_from_aos, dim3((nk + 255) / 256), dim3(256), 0, c->stream, c->sh[k].map, nk, tmp);
+                    e = hipStreamSynchronize(c->stream);
+                }
+                hipFree(tmp);
+                if (e != hipSuccess) { hrbf_set_error("upload_map: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+            }
+            c->sh[k].count_ub = nk;
+        }
+        HIP_CHECK(hipMemcpyAsync(counts_live(c), cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->g_next = (uint32_t)n;
+        hash_refresh_gfirst(c, counts_live(c));
+        c->map_dirty = 1;
+        c->ev_pending = false; c->ub_growth_since = 0;
+        return HRBF_OK;
+    }
     for (int g = 0; g < c->G; ++g) {
         size_t lo, hi; shard_slice(n, c->G, g, &lo, &hi);
         if (hi - lo > c->cap) { hrbf_set_error("upload_map: %zu surfels exceed the shard capacity %u", hi - lo, c->cap); return HRBF_ERR_CAPACITY; }
@@ -1713,6 +1879,31 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
     HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->ev_pending = false;
+    // enable == 2: ownership by spatial hash of the surfel's cell instead of contiguous ranges of the global order
+    c->hash_mode = 0;
+    if (enable == 2 && G > 1) {
+        const char *cs = getenv("HRBF_HASH_CELL");   // cell edge in metres
+        const float cell = cs ? (float)atof(cs) : 0.25f;
+        c->hash_inv_cell = 1.0f / (cell > 0.0f ? cell : 0.25f);
+        c->g_next = 0;
+        int r = 0;
+        if (!c->d_gfirst) { r = dalloc(&c->d_gfirst, 1); if (!r) r = dalloc(&c->d_gtotal, 1); if (!r) r = dalloc(&c->d_init_flags2, (size_t)c->P); if (!r) r = dalloc(&c->d_init_offs2, (size_t)c->P); }
+        for (int k = 0; k < nsh && !r; ++k) {
+            MapShard &sh = c->sh[k];
+            if (sh.d_gid) continue;
+            r = dalloc(&sh.d_gid, (size_t)c->cap);
+            if (!r) r = dalloc(&sh.d_own_local, (size_t)c->P);
+            if (!r) r = dalloc(&sh.d_rec_lbest, (size_t)c->Q);
+            if (!r) r = dalloc(&sh.d_zpriv, (size_t)c->P);
+        }
+        if (r) return r;
+        HIP_CHECK(hipDeviceSynchronize());
+        for (int k = 0; k < nsh; ++k) launch_zbuf_reset(c->stream, c->sh[k].d_zpriv, c->P);
+        const uint32_t none = HRBF_NO_SURFEL;
+        HIP_CHECK(hipMemcpyAsync(c->d_gfirst, &none, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->hash_mode = 1;
+    }
     return HRBF_OK;
 }
 
@@ -1760,6 +1951,7 @@ extern "C" int hrbf_map_rebalance(hrbf_handle c)
 {
     if (!c) return HRBF_ERR_INVALID;
     if (c->G == 1) return HRBF_OK;
+    if (c->hash_mode) return HRBF_OK;   // ownership by cell: the hash balances the shards, there is no range to re-cut
     if (c->peer.shm_mode) { hrbf_set_error("map_rebalance: the re-cut moves surfels with ncclSend / ncclRecv; not available on the shared-memory transport"); return HRBF_ERR_INVALID; }
     hipSetDevice(c->device);
     uint32_t cnt[HRBF_MAX_SHARDS], ncnt[HRBF_MAX_SHARDS] = {0}, moves[5 * 2 * HRBF_MAX_SHARDS];

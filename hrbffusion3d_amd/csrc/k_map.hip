@@ -72,7 +72,7 @@ __global__ void k_init_scatter(Cam cam, const DevPose *__restrict__ dp, const fl
                                const float4 *__restrict__ curv1, const float4 *__restrict__ curv2,
                                const float *__restrict__ gradmag, int use_conf_eval, float eps,
                                const uint32_t *__restrict__ flags, const uint32_t *__restrict__ offs, MapPlanes out,
-                               uint32_t cap)
+                               uint32_t cap, const uint32_t *__restrict__ gid_src /* nullable */, uint32_t *__restrict__ gid_out)
 {
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     int P = cam.W * cam.H;
@@ -92,6 +92,39 @@ __global__ void k_init_scatter(Cam cam, const DevPose *__restrict__ dp, const fl
     out.p2[n] = make_float4(ng.x, ng.y, ng.z, nl.w);
     out.p3[n] = curv1[i];
     out.p4[n] = curv2[i];
+    if (gid_src) gid_out[n] = gid_src[o];   // hash ownership: place in the seed frame's global (column-major draw) order
+}
+
+// hash ownership: of the seed frame's surfels this shard keeps those whose cell is its own
+__global__ void k_init_owner(Cam cam, const DevPose *__restrict__ dp, const float4 *__restrict__ vertex_raw,
+                             const uint32_t *__restrict__ flags, uint32_t *__restrict__ flags_mine, int G, int me, float inv_cell)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    int P = cam.W * cam.H;
+    if (o >= P) return;
+    int px = o / cam.H, py = o - px * cam.H;
+    const f3 pg = xform(dp->pose, xyz(vertex_raw[py * cam.W + px]));
+    flags_mine[o] = (flags[o] && hash_owner(pg.x, pg.y, pg.z, inv_cell, G) == (uint32_t)me) ? 1u : 0u;
+}
+// smallest global-order id alive over the given shards (HRBF_NO_SURFEL if all are empty); merge: min with what *out holds
+struct GidPtrs { const uint32_t *p[8]; };
+__global__ void k_gfirst(const uint32_t *__restrict__ counts, int first, int nsh, GidPtrs g, uint32_t *__restrict__ out, int merge)
+{
+    uint32_t m = merge ? *out : HRBF_NO_SURFEL;
+    for (int k = 0; k < nsh; ++k)
+        if (counts[first + k] > 0u) { const uint32_t v = g.p[k][0]; m = v < m ? v : m; }
+    *out = m;
+}
+void launch_gfirst(hipStream_t s, const uint32_t *counts, int first, int nsh, const uint32_t *const *gids, uint32_t *out, int merge)
+{
+    GidPtrs g;
+    for (int k = 0; k < 8; ++k) g.p[k] = k < nsh ? gids[k] : nullptr;
+    hipLaunchKernelGGL(k_gfirst, dim3(1), dim3(1), 0, s, counts, first, nsh, g, out, merge);
+}
+__global__ void k_iota_u32(uint32_t *p, uint32_t n, uint32_t base)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = base + i;
 }
 
 __global__ void k_clamp_count(uint32_t *count, uint32_t cap, uint32_t *status)
@@ -122,7 +155,8 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
                                                  const float4 *__restrict__ color_time /* read only with a mask */,
                                                  const uint8_t *__restrict__ submap_active /* nullable */, int n_active)
 {
-    const uint32_t n = sh.counts[sh.k], off = shard_offset(sh);   // ids in the keys are GLOBAL
+    // ids in the keys are GLOBAL for contiguous ranges; LOCAL in the private z-buffer of a hash-owned shard (kernels.h)
+    const uint32_t n = sh.counts[sh.k], off = sh.gid ? 0u : shard_offset(sh);
     const Rigid tinv = dp->tinv;
     // PROJECT_UNROLL position loads in flight per lane.  Measured at 4.3 M surfels (69.5 MB stream): 1 / 2 / 4 / 8 loads in
     // flight = 25.3 / 26.1 / 25.4 / 28.3 us — the kernel is not latency-bound, more loads in flight buy nothing
@@ -162,6 +196,46 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
             if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell, key);
         }
     }
+}
+
+// hash ownership, second level of the z-test: {depth, gid of the private winner} per pixel; merge != 0 takes the minimum with
+// what `out` already holds (one process playing several shards: the reduction RCCL / the peers perform between ranks)
+__global__ __launch_bounds__(256) void k_keys_global(const unsigned long long *__restrict__ zpriv, const uint32_t *__restrict__ gid,
+                                                     unsigned long long *__restrict__ out, int P, int merge)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const unsigned long long kp = zpriv[i];
+    unsigned long long k = ZB_EMPTY;
+    if (kp != ZB_EMPTY) k = (kp & 0xFFFFFFFF00000000ull) | (unsigned long long)gid[(uint32_t)(kp & 0xFFFFFFFFull)];
+    if (merge) { const unsigned long long o = out[i]; k = o < k ? o : k; }
+    out[i] = k;
+}
+void launch_keys_global(hipStream_t s, const unsigned long long *zpriv, const uint32_t *gid, unsigned long long *out, int P, int merge)
+{
+    hipLaunchKernelGGL(k_keys_global, dim3((P + 255) / 256), dim3(256), 0, s, zpriv, gid, out, P, merge);
+}
+// the pixel's winner as this shard sees it: {owned, local index, id the index image shows}
+struct PixelWinner { bool owned; uint32_t s, id; };
+__device__ __forceinline__ PixelWinner pixel_winner(const ShardRef &sh, unsigned long long key, unsigned long long *__restrict__ zpriv, int i)
+{
+    PixelWinner w; w.owned = false; w.s = 0u;
+    const uint32_t sg = (uint32_t)(key & 0xFFFFFFFFull);
+    w.id = sg;
+    if (sh.gid) {
+        const unsigned long long kp = zpriv[i];
+        if (kp != ZB_EMPTY) {
+            zpriv[i] = ZB_EMPTY;   // the private z-buffer is left clean for the next projection
+            const uint32_t sl = (uint32_t)(kp & 0xFFFFFFFFull);
+            if (((kp & 0xFFFFFFFF00000000ull) | (unsigned long long)sh.gid[sl]) == key) { w.owned = true; w.s = sl; }
+        }
+        if (key != ZB_EMPTY && sg == *sh.g_first) w.id = 0u;   // the first surfel of the global order is the reference's id 0
+        if (sh.own_local) sh.own_local[i] = w.owned ? w.s : HRBF_NO_SURFEL;
+    } else if (key != ZB_EMPTY) {
+        w.s = sg - shard_offset(sh);
+        w.owned = w.s < sh.counts[sh.k];
+    }
+    return w;
 }
 
 // `what`: 1 = vertconf + normrad (association), 2 = colortime + curvature images (prediction), 4 = packed clean
@@ -221,7 +295,8 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
                                                  float4 *__restrict__ colortime, float4 *__restrict__ normrad,
                                                  float4 *__restrict__ curvmax, float4 *__restrict__ curvmin,
                                                  float4 *__restrict__ clean_tex, int what, float clean_conf_thr,
-                                                 int clean_time, WinnerRecords rec, int dense)
+                                                 int clean_time, WinnerRecords rec, int dense,
+                                                 unsigned long long *__restrict__ zpriv /* hash ownership: this shard's private z-buffer */)
 {
     const int P = cam.W * cam.H;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,11 +308,10 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
     const float4 z4 = make_float4(0, 0, 0, 0);
     uint32_t sg = 0u, s = 0u;
     bool owned = false;
-    if (key != ZB_EMPTY) {
-        if (rearm) zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
-        sg = (uint32_t)(key & 0xFFFFFFFFull);   // global id of the winner
-        s = sg - shard_offset(sh);
-        owned = s < sh.counts[sh.k];   // else the winner lives on another shard: contribute zeros to the sum-reduction
+    if (key != ZB_EMPTY && rearm) zbuf[i] = ZB_EMPTY;   // leave the depth buffer clean for the next projection (no separate clear pass)
+    if (live && (key != ZB_EMPTY || sh.gid)) {
+        const PixelWinner w = pixel_winner(sh, key, zpriv, i);   // not owned: the winner lives on another shard, contribute zeros
+        owned = w.owned; s = w.s; sg = key != ZB_EMPTY ? w.id : 0u;
     }
     if (dense && live) idx[i] = sg;
     WinnerTexels o;
@@ -337,7 +411,7 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
     const int tpar = tick % 2;
     const int px = qx * 2 + tpar, py = qy * 2 + tpar;
     int flag = 0;
-    uint32_t best = 0;
+    uint32_t best = 0, lbest = HRBF_NO_SURFEL;
     if (px < cam.W && py < cam.H) {
         const int i = py * cam.W + px;
         const float x = (float)px + 0.5f, y = (float)py + 0.5f;
@@ -349,7 +423,7 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
         if (len3(nl) > 0.8f && vl.z > 0.3f && vl.z <= maxDepth && k1.w > -300.0f && k1.w < 300.0f &&
             k2.w > -300.0f && k2.w < 300.0f) {
             float bestDist = 1000.0f;
-            int counter = 0;
+            int counter = 0, best_t = 0;
             float xl = (x - cam.cx) * cam.camz, yl = (y - cam.cy) * cam.camw;
             float lambda = hd_sqrtf((xl * xl + yl * yl) + 1.0f);
             f3 ray = mk3(xl, yl, 1.0f);
@@ -383,7 +457,7 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                             float ang = hd_acosf(dot3(xyz(nr), nl) / (len3(xyz(nr)) * lnl));
                             ok = hd_fabsf(ang) < 0.5f;
                         }
-                        if (dist < bestDist && ok) { counter++; bestDist = dist; best = current; }
+                        if (dist < bestDist && ok) { counter++; bestDist = dist; best = current; best_t = t; }
                     }
                 }
             }
@@ -397,13 +471,20 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
             rec.p4[q] = k2;
             flag = counter > 0 ? 1 : 2;
             if (counter > 0) {   // first primitive in draw order wins; the slot lives with the surfel's owner
-                const uint32_t l = best - shard_offset(sh);
-                if (l < sh.counts[sh.k]) atomicMin(&slot[l], (uint32_t)q);
+                if (sh.gid) {   // hash ownership: the owner knows the local index of the winner of that pixel (k_resolve)
+                    const int sx = clampi(px + best_t / 3 - 1, 0, cam.W - 1), sy = clampi(py + best_t % 3 - 1, 0, cam.H - 1);
+                    lbest = sh.own_local[sy * cam.W + sx];
+                    if (lbest != HRBF_NO_SURFEL) atomicMin(&slot[lbest], (uint32_t)q);
+                } else {
+                    const uint32_t l = best - shard_offset(sh);
+                    if (l < sh.counts[sh.k]) atomicMin(&slot[l], (uint32_t)q);
+                }
             }
         }
     }
     rec_flag[q] = flag;
     rec_best[q] = best;
+    if (sh.rec_lbest) sh.rec_lbest[q] = lbest;
 }
 
 // F2: sparse in-place merge (update.vert:51-115): only the winning record of each surfel applies.
@@ -420,8 +501,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick,
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     bool act = q < Q && rec_flag[q] == 1;
-    const uint32_t l = act ? rec_best[q] - shard_offset(sh) : 0u;
-    act = act && l < sh.counts[sh.k];   // only the owner of the matched surfel applies the merge
+    uint32_t l = 0u;
+    if (sh.gid) { l = act ? sh.rec_lbest[q] : HRBF_NO_SURFEL; act = act && l != HRBF_NO_SURFEL; }
+    else { l = act ? rec_best[q] - shard_offset(sh) : 0u; act = act && l < sh.counts[sh.k]; }   // only the owner of the matched surfel applies the merge
     const uint32_t s = act ? l : 0u;
     // everything the merge may need is requested in one round (record planes, the slot word and the target surfel's
     // planes) instead of slot -> surfel in two dependent rounds; surfel 0 stands in for inactive lanes
@@ -517,6 +599,7 @@ struct CleanParams {
     int full_check;
     const uint8_t *submap_active;   // nullable: KeyFrameIDMap (copy_unstable.vert:98-101)
     int n_active;
+    int hash_G, hash_me; float hash_inv_cell;   // hash ownership (hash_G > 1): a shard appends the new surfels whose cell is its own
 };
 
 // window part of the test; returns false when the surfel must be dropped.
@@ -686,7 +769,9 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
         const uint32_t qx = (tile % tiles_x) * 8u + (lane >> 3), qy = (tile / tiles_x) * 8u + (lane & 7u);
         if (qx < QW && qy < QH) {
             const uint32_t q = qx * QH + qy;
-            const bool keep = rec_flag[q] != 0 && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex, rec.p0[q]);
+            const float4 rp = rec.p0[q];
+            const bool mine = cp.hash_G <= 1 || hash_owner(rp.x, rp.y, rp.z, cp.hash_inv_cell, cp.hash_G) == (uint32_t)cp.hash_me;
+            const bool keep = rec_flag[q] != 0 && mine && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex, rp);
             keep_flags[N + q] = keep ? 1 : 0;
             if (keep) {
                 const uint32_t tl = (N + q) / FUSE_TILE;
@@ -745,10 +830,12 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
 // lanes that move the records: the pass needs no re-arm kernel.
 // Tiles before the first one whose survivors change place (first tile that is not completely kept, or the tile that
 // holds the end of the map) are never touched and never written into: the ticket starts there.
-struct MoveSlot { float4 a, b, c, d, e; uint32_t it, o; bool keep; };
-__device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, const RecPlanes &rec, uint32_t N, float ftime)
+struct MoveSlot { float4 a, b, c, d, e; uint32_t it, o, g; bool keep; };
+__device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, const RecPlanes &rec, uint32_t N, float ftime,
+                                          const uint32_t *__restrict__ gid, uint32_t g_base)
 {
     if (!sl.keep) return;
+    if (gid) sl.g = sl.it < N ? gid[sl.it] : g_base + (sl.it - N);   // hash ownership: the surfel's place in the global order moves along
     // (non-temporal loads / stores measured: 195 vs 187 us for the whole pass at 4.3 M surfels — plain accesses stay)
     if (sl.it < N) { sl.a = m.p0[sl.it]; sl.b = m.p1[sl.it]; sl.c = m.p2[sl.it]; sl.d = m.p3[sl.it]; sl.e = m.p4[sl.it]; }
     else {
@@ -758,10 +845,13 @@ __device__ __forceinline__ void move_load(MoveSlot &sl, const MapPlanes &m, cons
         sl.b = make_float4(ct.x, ct.y, ct.z, ct.w == -2.0f ? ftime : ct.w);     // copy_unstable.vert:155-158
     }
 }
-__device__ __forceinline__ uint32_t move_store(const MoveSlot &sl, const MapPlanes &m, uint32_t N, uint32_t cap)
+__device__ __forceinline__ uint32_t move_store(const MoveSlot &sl, const MapPlanes &m, uint32_t N, uint32_t cap, uint32_t *__restrict__ gid)
 {
     if (!sl.keep || sl.o >= cap) return 0u;
-    if (sl.o != sl.it || sl.it >= N) { m.p0[sl.o] = sl.a; m.p1[sl.o] = sl.b; m.p2[sl.o] = sl.c; m.p3[sl.o] = sl.d; m.p4[sl.o] = sl.e; }
+    if (sl.o != sl.it || sl.it >= N) {
+        m.p0[sl.o] = sl.a; m.p1[sl.o] = sl.b; m.p2[sl.o] = sl.c; m.p3[sl.o] = sl.d; m.p4[sl.o] = sl.e;
+        if (gid) gid[sl.o] = sl.g;
+    }
     return sl.it >= N ? 1u : 0u;
 }
 
@@ -773,7 +863,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
                                                               uint32_t *__restrict__ stats, uint32_t cap,
                                                               uint32_t *__restrict__ tile_done, uint32_t epoch,
                                                               uint32_t lds_tiles, uint32_t *__restrict__ tile_count_next,
-                                                              uint32_t nzero_next, int32_t *__restrict__ rec_flag_rearm)
+                                                              uint32_t nzero_next, int32_t *__restrict__ rec_flag_rearm,
+                                                              uint32_t *__restrict__ gid, uint32_t g_base)
 {
     constexpr int NWAVE = FUSE_THREADS / 64;
     __shared__ uint32_t s_wcnt[FUSE_IPT][NWAVE];
@@ -883,8 +974,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
             s0.o = o0 + (uint32_t)__popcll(b0 & lt); s1.o = o1 + (uint32_t)__popcll(b1 & lt);
             s2.o = o2 + (uint32_t)__popcll(b2 & lt); s3.o = o3 + (uint32_t)__popcll(b3 & lt);
         }
-        move_load(s0, m, rec, N, ftime); move_load(s1, m, rec, N, ftime);
-        move_load(s2, m, rec, N, ftime); move_load(s3, m, rec, N, ftime);
+        move_load(s0, m, rec, N, ftime, gid, g_base); move_load(s1, m, rec, N, ftime, gid, g_base);
+        move_load(s2, m, rec, N, ftime, gid, g_base); move_load(s3, m, rec, N, ftime, gid, g_base);
         // every load this tile will ever issue on the map has returned -> publish tile_done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -906,8 +997,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
             }
         }
         __syncthreads();
-        acc_appended += move_store(s0, m, N, cap) + move_store(s1, m, N, cap) + move_store(s2, m, N, cap) +
-                        move_store(s3, m, N, cap);
+        acc_appended += move_store(s0, m, N, cap, gid) + move_store(s1, m, N, cap, gid) + move_store(s2, m, N, cap, gid) +
+                        move_store(s3, m, N, cap, gid);
         if (base + FUSE_TILE > N && rec_flag_rearm) {   // the lanes that handled records re-arm the record flags
             if (s0.it >= N && s0.it < total) rec_flag_rearm[s0.it - N] = 0;
             if (s1.it >= N && s1.it < total) rec_flag_rearm[s1.it - N] = 0;
@@ -963,8 +1054,29 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
     hipLaunchKernelGGL(k_init_flags, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, normal, curv1, curv2, thr, flags);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, flags, offs, P, count);
     hipLaunchKernelGGL(k_init_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, vertex_raw, normal, rgb, curv1,
-                       curv2, gradmag, use_conf_eval, eps, flags, offs, out, cap);
+                       curv2, gradmag, use_conf_eval, eps, flags, offs, out, cap, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap, status);
+}
+// hash ownership: flags / offs rank the seed frame's surfels in the global order (the same on every shard), flags2 / offs2 the
+// ones this shard keeps; *total receives the number of surfels of the whole seed (the next free global id)
+void launch_initialise_hashed(hipStream_t s, const Cam &cam, const DevPose *dp, const float4 *vertex_raw, const float4 *normal,
+                              const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
+                              int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, uint32_t *flags2,
+                              uint32_t *offs2, MapPlanes out, uint32_t *gid_out, uint32_t cap, uint32_t *count, uint32_t *total,
+                              uint32_t *status, int G, int me, float inv_cell)
+{
+    int P = cam.W * cam.H;
+    hipLaunchKernelGGL(k_init_flags, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, normal, curv1, curv2, thr, flags);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, flags, offs, P, total);
+    hipLaunchKernelGGL(k_init_owner, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, vertex_raw, flags, flags2, G, me, inv_cell);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, flags2, offs2, P, count);
+    hipLaunchKernelGGL(k_init_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, vertex_raw, normal, rgb, curv1,
+                       curv2, gradmag, use_conf_eval, eps, flags2, offs2, out, cap, (const uint32_t *)offs, gid_out);
+    hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap, status);
+}
+void launch_iota_u32(hipStream_t s, uint32_t *p, uint32_t n, uint32_t base)
+{
+    if (n) hipLaunchKernelGGL(k_iota_u32, dim3((n + 255) / 256), dim3(256), 0, s, p, n, base);
 }
 
 // ---- sharded map over peer-mapped images (SURVEY §8e sharding 2): the OWNER of a pixel's winner writes the
@@ -983,7 +1095,8 @@ __global__ __launch_bounds__(256) void k_zbuf_min_peers(PeerImages pi, unsigned 
 }
 __global__ __launch_bounds__(256) void k_resolve_scatter(Cam cam, const DevPose *__restrict__ dp, MapPlanes m, ShardRef sh,
                                                          const unsigned long long *__restrict__ zred, uint32_t *__restrict__ idx,
-                                                         PeerImages pi, int what, float clean_conf_thr, int clean_time)
+                                                         PeerImages pi, int what, float clean_conf_thr, int clean_time,
+                                                         unsigned long long *__restrict__ zpriv)
 {
     const int P = cam.W * cam.H;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -992,16 +1105,17 @@ __global__ __launch_bounds__(256) void k_resolve_scatter(Cam cam, const DevPose 
     const float4 z4 = make_float4(0, 0, 0, 0);
     if (key == ZB_EMPTY) {   // nobody's surfel: every rank clears its own texels
         idx[i] = 0u;
+        if (sh.gid) (void)pixel_winner(sh, key, zpriv, i);   // re-arms the private z-buffer, clears own_local
         const int g = pi.me;
         if (what & RESOLVE_GEOM) { pi.vertconf[g][i] = z4; pi.normrad[g][i] = z4; }
         if (what & RESOLVE_ATTR) { pi.colortime[g][i] = z4; pi.curvmax[g][i] = z4; pi.curvmin[g][i] = z4; }
         if (what & RESOLVE_CLEAN) pi.clean[g][i] = z4;
         return;
     }
-    const uint32_t sg = (uint32_t)(key & 0xFFFFFFFFull);
+    const PixelWinner w = pixel_winner(sh, key, zpriv, i);
+    const uint32_t sg = w.id, s = w.s;
     idx[i] = sg;
-    const uint32_t s = sg - shard_offset(sh);
-    if (!(s < sh.counts[sh.k])) return;   // another rank owns the winner and writes this pixel
+    if (!w.owned) return;   // another rank owns the winner and writes this pixel
     WinnerTexels o;
     const bool updated = resolve_winner(m, s, sg, dp->tinv, what, clean_conf_thr, clean_time, o);
     if (updated) o.clean.w = -(o.clean.w + 1.0f);
@@ -1028,11 +1142,12 @@ void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long lo
     hipLaunchKernelGGL(k_zbuf_min_peers, dim3((P + 255) / 256), dim3(256), 0, s, pi, zred, P);
 }
 void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, const unsigned long long *zred,
-                            uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time)
+                            uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time,
+                            unsigned long long *zpriv)
 {
     const int P = cam.W * cam.H;
     if (!for_clean) what &= ~RESOLVE_CLEAN;
-    hipLaunchKernelGGL(k_resolve_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, zred, idx, pi, what, clean_conf_thr, clean_time);
+    hipLaunchKernelGGL(k_resolve_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, zred, idx, pi, what, clean_conf_thr, clean_time, zpriv);
 }
 void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P)
 {
@@ -1051,13 +1166,13 @@ void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxD
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
                     float4 *clean_tex, int what, int rearm, float clean_conf_thr, int clean_time, uint32_t *rec_count,
-                    uint32_t *rec_idx, float4 *rec_f, uint32_t rec_cap, int dense)
+                    uint32_t *rec_idx, float4 *rec_f, uint32_t rec_cap, int dense, unsigned long long *zpriv)
 {
     const int P = cam.W * cam.H;
     if (!clean_tex) what &= ~RESOLVE_CLEAN;
     WinnerRecords rec = {rec_count, rec_idx, rec_f, rec_cap};
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, rearm, zbuf, idx, vertconf,
-                       colortime, normrad, curvmax, curvmin, clean_tex, what, clean_conf_thr, clean_time, rec, dense);
+                       colortime, normrad, curvmax, curvmin, clean_tex, what, clean_conf_thr, clean_time, rec, dense, zpriv);
 }
 void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
                           const float4 *rf, uint32_t cap, int what, float4 *vertconf, float4 *colortime, float4 *normrad,
@@ -1108,7 +1223,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   const float4 *clean_tex, uint8_t *keep_flags, uint32_t *tile_count, uint32_t *tile_count_next,
                   uint32_t *tile_dirty /* [2]: entries this / the other buffer may hold */, uint32_t *tile_done, uint32_t epoch,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
-                  int n_records, int zero_records, uint32_t *stats_ring_slot, const uint32_t *merged_part)
+                  int n_records, int zero_records, uint32_t *stats_ring_slot, const uint32_t *merged_part,
+                  uint32_t *gid, uint32_t g_base, int hash_G, int hash_me, float hash_inv_cell)
 {
     const int Qfull = (cam.W / 2) * (cam.H / 2);
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
@@ -1116,6 +1232,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
     cp.nw = (int)ceilf(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
     cp.submap_active = submap_active; cp.n_active = n_active;
+    cp.hash_G = gid ? hash_G : 1; cp.hash_me = hash_me; cp.hash_inv_cell = hash_inv_cell;
     const uint32_t items_ub = count_ub + (uint32_t)Q;
     uint32_t tiles = (items_ub + FUSE_TILE - 1) / FUSE_TILE;
     if (tiles > max_tiles) tiles = max_tiles;
@@ -1137,7 +1254,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_fuse_stream, dim3(blocks), dim3(FUSE_THREADS), lds, s, time, m, rec, Q, keep_flags, tile_count,
                        count_in, count_out, stats, cap, tile_done, epoch, tiles, tile_count_next, tile_dirty[1],
-                       (zero_records && Q > 0) ? rec_flag : nullptr);
+                       (zero_records && Q > 0) ? rec_flag : nullptr, gid, g_base);
     if (e1) hipEventRecord(e1, s);
     tile_dirty[0] = tiles; tile_dirty[1] = 0;   // this buffer now holds `tiles` counts, the other one is clean
     if (zero_records && Q == 0)   // a rank of a sharded map that takes no appends still re-arms its (replicated) record flags

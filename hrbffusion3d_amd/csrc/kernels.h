@@ -8,7 +8,31 @@ typedef MapPlanes RecPlanes;
 // Map sharding (SURVEY §8e sharding 2).  The global surfel order is the concatenation of the G shards: shard k holds
 // the global ids [off_k, off_k + n_k) with off_k = n_0 + ... + n_(k-1).  `counts` is the device array of the G live
 // counts (all-gathered after every clean); a single-GPU context is G = 1, k = 0, off = 0.
-struct ShardRef { const uint32_t *counts; int k, G; };
+//
+// Ownership by spatial hash ("sharded by spatial hash of surfel position ... fixed at insertion"): `gid` non-null.
+// The global order is then not a concatenation: every surfel carries its place in it (gid: unique, ascending inside a shard,
+// never renumbered — survivors keep theirs, new surfels take g_next + record index), a shard owns the surfels whose cell
+// hashes to it (hash_owner), and the z-test runs in two levels: a private z-buffer keyed {depth, LOCAL index} per shard,
+// then {depth, gid of the local winner} min-reduced over the shards — the winner of the single map's {depth, index} test,
+// because local index order is gid order.  A shard owns a pixel iff its private winner's global key equals the reduced one.
+struct ShardRef {
+    const uint32_t *counts; int k, G;
+    const uint32_t *gid;       // nullable (contiguous ranges)
+    const uint32_t *g_first;   // device word: smallest gid alive over all shards = "surfel 0" of the reference's `current > 0U` gates
+    uint32_t *own_local;       // P words of this shard: local index of the pixel's winner if this shard owns it, else HRBF_NO_SURFEL
+    uint32_t *rec_lbest;       // Q words of this shard: local index of the record's matched surfel if owned, else HRBF_NO_SURFEL
+};
+#define HRBF_NO_SURFEL 0xFFFFFFFFu
+// cell -> shard.  Host (upload) and device (appends, seeding) must agree: one fp32 multiply and floorf per axis, integer mixing
+__host__ __device__ inline uint32_t hash_owner(float x, float y, float z, float inv_cell, int G)
+{
+    const float fx = floorf(x * inv_cell), fy = floorf(y * inv_cell), fz = floorf(z * inv_cell);
+    const bool ok = fx > -1.0e9f && fx < 1.0e9f && fy > -1.0e9f && fy < 1.0e9f && fz > -1.0e9f && fz < 1.0e9f;   // NaN / far away: cell 0
+    const uint32_t ix = ok ? (uint32_t)(int)fx : 0u, iy = ok ? (uint32_t)(int)fy : 0u, iz = ok ? (uint32_t)(int)fz : 0u;
+    uint32_t h = ix * 73856093u ^ iy * 19349663u ^ iz * 83492791u;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h % (uint32_t)G;
+}
 
 // device-resident pose block: written by the odometry epilogue, read by every map kernel, so a
 // frame needs no host round trip (the reference syncs ~40x per frame)
@@ -47,6 +71,13 @@ void launch_initialise(hipStream_t s, const Cam &cam, const DevPose *dp, const f
                        const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
                        int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, MapPlanes out,
                        uint32_t cap, uint32_t *count, uint32_t *status /* nullable: |= 2 when the seed frame exceeds cap */);
+void launch_initialise_hashed(hipStream_t s, const Cam &cam, const DevPose *dp, const float4 *vertex_raw, const float4 *normal,
+                              const uint8_t *rgb, const float4 *curv1, const float4 *curv2, const float *gradmag,
+                              int use_conf_eval, float eps, float thr, uint32_t *flags, uint32_t *offs, uint32_t *flags2,
+                              uint32_t *offs2, MapPlanes out, uint32_t *gid_out, uint32_t cap, uint32_t *count, uint32_t *total,
+                              uint32_t *status, int G, int me, float inv_cell);
+void launch_gfirst(hipStream_t s, const uint32_t *counts, int first, int nsh, const uint32_t *const *gids, uint32_t *out, int merge);
+void launch_iota_u32(hipStream_t s, uint32_t *p, uint32_t n, uint32_t base);
 // projection = launch_project (z-buffer of packed keys) + launch_resolve (winner gather).  With a sharded map the
 // z-buffers are min-reduced between the two; every shard then resolves the winners it owns (zeros elsewhere), packs
 // them as compact winner records and the records of the other shards are scattered into the images
@@ -61,7 +92,9 @@ void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes 
                     float clean_conf_thr, int clean_time /* baked into the clean texels */,
                     uint32_t *rec_count = nullptr, uint32_t *rec_idx = nullptr /* nullable: pack the owned winners */,
                     float4 *rec_f = nullptr /* 6 planes of rec_cap float4 */, uint32_t rec_cap = 0,
-                    int dense = 1 /* 0: records only (a virtual shard behind the first) */);
+                    int dense = 1 /* 0: records only (a virtual shard behind the first) */,
+                    unsigned long long *zpriv = nullptr /* hash ownership: this shard's private z-buffer {depth, local index}; zbuf then holds the reduced {depth, gid} keys */);
+void launch_keys_global(hipStream_t s, const unsigned long long *zpriv, const uint32_t *gid, unsigned long long *out, int P, int merge);
 // sharded map: scatter `*count` (or, with count == null, n_ub) winner records, starting at record `first`, into the dense images
 void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
                           const float4 *rf, uint32_t cap, int what, float4 *vertconf, float4 *colortime, float4 *normrad,
@@ -79,7 +112,8 @@ struct PeerImages {
 };
 void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long long *zred, int P);
 void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, const unsigned long long *zred,
-                            uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time);
+                            uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time,
+                            unsigned long long *zpriv = nullptr);
 void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P);
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
@@ -100,7 +134,10 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   int n_records /* Q on the shard that takes the appends (the last one), else 0 */,
                   int zero_records /* re-arm the record flags at the end */,
                   uint32_t *stats_ring_slot /* nullable (timing ring): the pass's 8 statistics words are copied here afterwards */,
-                  const uint32_t *merged_part /* as launch_fuse: summed into word 1 of the ring slot */);
+                  const uint32_t *merged_part /* as launch_fuse: summed into word 1 of the ring slot */,
+                  uint32_t *gid /* nullable; hash ownership: the shard's global-order ids, moved along with the planes */,
+                  uint32_t g_base /* id of record 0 if it is appended (record q gets g_base + q) */,
+                  int hash_G, int hash_me, float hash_inv_cell /* only records whose cell hashes to hash_me are appended */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);

@@ -335,6 +335,17 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  *   hrbf_map_shard_init(h, 1)  requires hrbf_comm_init and an empty map; with the virtual communicator
  *                              (rank < 0) this one process plays all shards and local kernels stand in for the
  *                              collectives — the test mode, bit-identical to the single-GPU map.
+ *   hrbf_map_shard_init(h, 2)  the same, but ownership by SPATIAL HASH of the surfel's cell ("sharded by
+ *                              spatial hash of surfel position ... fixed at insertion"; HRBF_HASH_CELL = cell edge in
+ *                              metres, default 0.25): a rank owns the surfels whose cell hashes to it, wherever they stand
+ *                              in the global order, so the surfels in view — the costly ones — spread over the ranks
+ *                              instead of sitting in one range.  Every surfel carries its place in the global order (an
+ *                              id that is never renumbered: the seed's row, then next-free + record index), the z-test
+ *                              runs in two levels ({depth, local index} per rank, then {depth, id} min-reduced), every rank
+ *                              appends the new surfels of its own cells; images (up to the names in the index image),
+ *                              pose, and the map merged by id are the single-GPU ones bit for bit.  No re-cut is ever
+ *                              needed (hrbf_map_rebalance is a no-op).  hrbf_download_map of a rank returns its own
+ *                              surfels, hrbf_download_gids their ids; one process playing all shards returns the merged map.
  *   hrbf_upload_map            always takes the WHOLE map; a rank keeps its slice.
  *   hrbf_surfel_count          global count; hrbf_local_surfel_count / hrbf_download_map: the local range(s).
  *   hrbf_rebalance_plan        the host-side arithmetic of the re-cut (pure function, no device needed):
@@ -352,7 +363,9 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  * row-sharded (every rank reduces the whole image) and hrbf_map_rebalance is unavailable. */
 int hrbf_peer_unique_id(uint8_t out128[128]);
 int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
-int hrbf_map_shard_init(hrbf_handle h, int enable);
+int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ranges | 2 spatial hash */
+int hrbf_shard_counts(hrbf_handle h, uint32_t out[8]);   /* live counts of all shards; returns 0 one map | 1 ranges | 2 hash (negative: error) */
+int hrbf_download_gids(hrbf_handle h, uint32_t *out, size_t cap_surfels);   /* hash ownership, one shard per rank: ids of the rank's surfels */
 int hrbf_set_row_sharding(hrbf_handle h, int enable);   /* 0: keep the communicator (sharded map) but let every rank reduce the whole image: no registration collectives */
 int hrbf_map_rebalance(hrbf_handle h);
 int hrbf_rebalance_plan(const uint32_t *counts, int n_shards, uint32_t *new_counts, uint32_t *moves5, int *n_moves);

@@ -1,0 +1,81 @@
+"""The surfel map owned by spatial hash (SURVEY §8e sharding 2 as written: "sharded by spatial hash of surfel position ...
+fixed at insertion"): hrbf_map_shard_init(h, 2).  One process plays all G shards in turn (local kernels stand in for the
+collectives), so the whole ownership logic runs on the one GPU of a test box:
+
+  private z-buffer {depth, local index} per shard -> {depth, global-order id} min-reduced -> the owner of a pixel's winner
+  resolves it, the others contribute nothing; association replicated; the owner applies the merge; clean + in-place compaction
+  per shard with the id plane moved along; every shard appends the new surfels of its own cells; ids never renumbered.
+
+Property: every image (the index image up to the NAMES of the surfels: it shows ids, the single map shows positions in the
+array; which pixels are empty / show the first surfel is compared), the fuse statistics, the pose and the map merged by id are
+bit-identical to the oracle's single map.
+"""
+import numpy as np
+import pytest
+
+from hrbffusion3d_amd import synth
+from hrbffusion3d_amd.params import IMAGES, default_params
+from test_parity_gpu import assert_same_state, bits, pair  # noqa: F401  (fixture)
+
+NOT_INDEX = [n for n in IMAGES if n != "INDEX"]
+
+
+def same_up_to_names(o, g, tag):
+    assert_same_state(o, g, tag, images=NOT_INDEX)
+    assert np.array_equal(o.get_image("INDEX") == 0, g.get_image("INDEX") == 0), tag + " INDEX zero pattern"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 3, 4])
+def test_hash_owned_map_from_an_empty_map(pair, G):
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    g.comm_init(-1, G); g.map_shard_init(True, partition="hash")
+    for k in range(8):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        same_up_to_names(o, g, "hash G=%d frame %d" % (G, k))
+        if k > 0:
+            assert np.array_equal(o.fuse_stats(), g.fuse_stats()), k
+        mode, cnt = g.shard_counts()
+        assert mode == 2 and cnt[:G].sum() == o.surfel_count()
+        # from the seed frame on every shard owns its share (contiguous ranges put the whole seed on the last shard)
+        assert cnt[:G].min() > 0.4 * cnt[:G].sum() / G and cnt[:G].max() < 1.8 * cnt[:G].sum() / G, cnt[:G]
+    assert g.status() == 0
+    assert g.local_surfel_count() == g.surfel_count() == o.surfel_count()
+    # after removals the index image shows ids where the single map shows array positions: the names differ, nothing else
+    assert not np.array_equal(o.get_image("INDEX"), g.get_image("INDEX"))
+
+
+@pytest.mark.gpu
+def test_hash_owned_map_uploaded_purged_and_tracked(pair):
+    """QVGA against an uploaded 150 k-surfel map over 4 shards; 2 % of the surfels are stale and unstable from index 0 on, so
+    frame 1 purges them (every shard's in-place compaction moves its planes AND its ids), sparse ICP on top"""
+    W, H, G = 320, 240, 4
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    seed = synth.seed_map(150_000, width=W)
+    stale = np.zeros(len(seed), bool)
+    stale[np.random.default_rng(5).choice(len(seed), len(seed) // 50, replace=False)] = True
+    stale[0:64:3] = True
+    seed[stale, 3] = 1.0
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=seed.shape[0] + 300_000, use_sparse_icp=1)
+    o, g = pair(p)
+    g.comm_init(-1, G); g.map_shard_init(True, partition="hash")
+    rgb, d, T = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d); x.set_tick(300)
+    for k in range(1, 6):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        same_up_to_names(o, g, "hash upload frame %d" % k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+        if k == 1:
+            st = o.fuse_stats()
+            assert st[0] + st[2] - st[3] > 0.8 * stale.sum()      # the purge happened
+    mode, cnt = g.shard_counts()
+    assert mode == 2 and cnt[:G].min() > 0.7 * cnt[:G].sum() / G, cnt[:G]
+    g.map_rebalance()                                            # a no-op under hash ownership
+    same_up_to_names(o, g, "after the no-op rebalance")
+    assert g.status() == 0
