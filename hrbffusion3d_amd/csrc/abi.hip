@@ -1268,6 +1268,12 @@ extern "C" int hrbf_download_gids(hrbf_handle c, uint32_t *out, size_t cap_surfe
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return HRBF_OK;
 }
+// the shard a surfel at (x, y, z) is inserted into under hash ownership (host code: no device needed)
+extern "C" int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards)
+{
+    if (!(cell_metres > 0.0f) || n_shards < 1) return HRBF_ERR_INVALID;
+    return (int)hash_owner(x, y, z, 1.0f / cell_metres, n_shards);
+}
 // the live surfel counts of all G shards (0 for k >= G); returns the partition: 0 one map, 1 contiguous ranges, 2 spatial hash
 extern "C" int hrbf_shard_counts(hrbf_handle c, uint32_t out[8])
 {

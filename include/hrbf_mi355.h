@@ -364,6 +364,7 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
 int hrbf_peer_unique_id(uint8_t out128[128]);
 int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
 int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ranges | 2 spatial hash */
+int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards);   /* shard of a surfel inserted at (x, y, z); host code */
 int hrbf_shard_counts(hrbf_handle h, uint32_t out[8]);   /* live counts of all shards; returns 0 one map | 1 ranges | 2 hash (negative: error) */
 int hrbf_download_gids(hrbf_handle h, uint32_t *out, size_t cap_surfels);   /* hash ownership, one shard per rank: ids of the rank's surfels */
 int hrbf_set_row_sharding(hrbf_handle h, int enable);   /* 0: keep the communicator (sharded map) but let every rank reduce the whole image: no registration collectives */

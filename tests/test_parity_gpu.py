@@ -844,10 +844,10 @@ def test_baseline_config_4_and_5_geometry_sharded_equals_single_equals_oracle(gp
     frames = [synth.frame(k, W, H, noise=True) for k in range(4)]
     Q = (W // 2) * (H // 2)
 
-    def run(shards):
-        g = HRBFFusion(default_params(W, H, *K, max_surfels=(n // max(shards, 1)) + 8 * Q + 200_000 if shards else n + 8 * Q))
+    def run(shards, partition="ranges"):
+        g = HRBFFusion(default_params(W, H, *K, max_surfels=int(1.15 * n / max(shards, 1)) + 8 * Q + 200_000 if shards else n + 8 * Q))
         if shards:
-            g.comm_init(-1, shards); g.map_shard_init(True)
+            g.comm_init(-1, shards); g.map_shard_init(True, partition=partition)
         g.upload_map(seed); g.set_pose(frames[0][2]); g.bootstrap(frames[0][0], frames[0][1])
         g.set_tick(300)
         out = []
@@ -870,6 +870,14 @@ def test_baseline_config_4_and_5_geometry_sharded_equals_single_equals_oracle(gp
         assert np.array_equal(a[1], b[1]) and a[2] == b[2], "%s frame %d counts" % (cfg, k + 1)
     assert np.array_equal(bits(m_ref), bits(m_got))
     assert np.linalg.norm(got[-1][0][:3, 3] - frames[3][2][:3, 3]) < 0.03
+    del m_got
+    # the same shards owned by spatial hash instead of contiguous ranges (tests/test_hash_shards_gpu.py): merged by id, the same map
+    got, m_got, st_got = run(G, partition="hash")
+    assert st_got == 0
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(bits(a[0]), bits(b[0])), "%s frame %d pose (hash ownership)" % (cfg, k + 1)
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2], "%s frame %d counts (hash ownership)" % (cfg, k + 1)
+    assert np.array_equal(bits(m_ref), bits(m_got))
     del m_got
     # the oracle on the same map and frames
     o = oracle_lib_built.Oracle(default_params(W, H, *K, max_surfels=n + 8 * Q), omp=True)

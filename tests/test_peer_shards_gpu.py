@@ -36,14 +36,15 @@ def _run(rank, world, uid, cfg, out):
     from hrbffusion3d_amd.api import HRBFFusion
     from hrbffusion3d_amd.params import default_params
     try:
-        W, H, nseed, frames, sparse = cfg
+        W, H, nseed, frames, sparse = cfg[:5]
+        partition = cfg[5] if len(cfg) > 5 else "ranges"
         K = synth.intrinsics(W, H)
         seed = synth.seed_map(nseed, width=W) if nseed else None
         p = default_params(W, H, *K, max_surfels=(nseed or 0) + 300_000, use_sparse_icp=sparse)
         g = HRBFFusion(p)
         if world > 1:
             g.comm_init_peer(rank, world, uid)
-            g.map_shard_init(True)
+            g.map_shard_init(True, partition=partition)
         rgb, d, T = synth.frame(0, W, H, noise=True)
         if seed is not None:
             g.upload_map(seed); g.set_pose(T); g.bootstrap(rgb, d)
@@ -62,6 +63,8 @@ def _run(rank, world, uid, cfg, out):
                     res["%s%d" % (name, k)] = _bits(g.get_image(name))
         res["local_count"] = g.local_surfel_count()
         res["map"] = _bits(g.download_map())
+        if world > 1 and partition == "hash":
+            res["gids"] = g.download_gids()
         res["status"] = g.status()
         g.close()
         out.put((rank, res))
@@ -109,3 +112,32 @@ def test_two_processes_share_one_sharded_map_bit_identical_to_a_single_map(gpu_a
     assert np.array_equal(joined, single["map"].reshape(-1, 20))
     if cfg[2]:
         assert min(two[0]["local_count"], two[1]["local_count"]) > 10_000   # both ranks really own part of the view
+
+
+@pytest.mark.parametrize("cfg", [(160, 120, 0, 7, 0, "hash"), (320, 240, 150_000, 6, 1, "hash")], ids=["from_empty_map", "uploaded_150k_sparse_icp"])
+def test_two_processes_share_one_hash_owned_map_bit_identical_to_a_single_map(gpu_available, cfg):
+    """the same with ownership by spatial hash (hrbf_map_shard_init(h, 2)): two-level z-test over the peers' key buffers, the
+    smallest id alive travelling with the counts, every rank appending the new surfels of its own cells.  The index image shows
+    ids (names) where the single map shows array positions; everything else, and the ranks' maps merged by id, is bit-identical"""
+    single = _launch(1, cfg)[0]
+    two = _launch(2, cfg)
+    assert two[0]["status"] == 0 and two[1]["status"] == 0
+    for k, v in single.items():
+        if k in ("map", "local_count", "status"):
+            continue
+        if k.startswith("stats"):
+            assert np.array_equal(two[0][k].astype(np.int64) + two[1][k], v), k
+            continue
+        for r in (0, 1):
+            if k.startswith("INDEX") and not k.startswith("INDEX_"):
+                assert np.array_equal(two[r][k].view(np.uint32) == 0, v.view(np.uint32) == 0), "rank %d differs in the zero pattern of %s" % (r, k)
+                assert np.array_equal(two[0][k], two[1][k]), k     # both ranks see the same names
+                continue
+            assert np.array_equal(two[r][k], v), "rank %d differs in %s" % (r, k)
+    n = single["local_count"]
+    assert two[0]["local_count"] + two[1]["local_count"] == n
+    assert min(two[0]["local_count"], two[1]["local_count"]) > 0.3 * n        # the hash splits the view, not only the array
+    ids = np.concatenate([two[0]["gids"], two[1]["gids"]])
+    assert len(np.unique(ids)) == n and (np.diff(two[0]["gids"].astype(np.int64)) > 0).all() and (np.diff(two[1]["gids"].astype(np.int64)) > 0).all()
+    joined = np.concatenate([two[0]["map"].reshape(-1, 20), two[1]["map"].reshape(-1, 20)])[np.argsort(ids, kind="stable")]
+    assert np.array_equal(joined, single["map"].reshape(-1, 20))
