@@ -51,6 +51,9 @@ def parse():
                     help="all ranks track ONE sequence against ONE surfel map cut into contiguous ranges over the ranks "
                          "(SURVEY §8e sharding 2; add --shard-odometry for the row-sharded registration too; strong scaling; pays off "
                          "for maps far beyond 1 M surfels). Default: independent replicas")
+    ap.add_argument("--partition", choices=["ranges", "hash"], default="ranges",
+                    help="ownership of a sharded map: contiguous ranges of the global order, or spatial hash of the surfel's cell "
+                         "(SURVEY §8e; the surfels in view then spread over the ranks)")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="single process: play G map shards in turn on one GPU (measures the sharded path's extra "
                          "kernels without any interconnect); not a benchmark configuration")
@@ -322,7 +325,7 @@ def main():
     one_sequence = args.shard_odometry or args.shard_map
     if args.virtual_shards > 1:
         fus.comm_init(-1, args.virtual_shards)
-        fus.map_shard_init(True)
+        fus.map_shard_init(True, partition=args.partition)
     elif one_sequence:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -331,7 +334,7 @@ def main():
             dist.broadcast(uid, src=0)
         fus.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
         if args.shard_map:
-            fus.map_shard_init(True)       # every rank then keeps its slice of the uploaded map
+            fus.map_shard_init(True, partition=args.partition)       # every rank then keeps its slice of the uploaded map
             fus.set_row_sharding(args.shard_odometry)   # the 39 registration all-reduces only when asked for
     fus.upload_map(seed)
     fus.set_pose(poses[0])
@@ -475,9 +478,9 @@ def main():
             "config": {"workload": "synthetic %dx%d RGB-D stream (room+sphere+relief, Lissajous path, seed 12345), "
                                    "map pre-seeded to %d surfels, full processFrame per step" % (W, H, seed.shape[0]),
                        "surfels_start": int(count0), "surfels_end": int(count1),
-                       "parallelism": ("surfel map in %d contiguous shards%s (RCCL)" % (world, " + row-sharded registration" if args.shard_odometry else "")) if args.shard_map
+                       "parallelism": ("surfel map in %d %s shards%s (RCCL)" % (world, "hash-owned" if args.partition == "hash" else "contiguous", " + row-sharded registration" if args.shard_odometry else "")) if args.shard_map
                                       else ("row-sharded registration x%d (RCCL int64 all-reduce)" % world) if args.shard_odometry
-                                      else ("%d virtual map shards on one GPU" % args.virtual_shards) if args.virtual_shards > 1
+                                      else ("%d virtual %s map shards on one GPU" % (args.virtual_shards, "hash-owned" if args.partition == "hash" else "contiguous")) if args.virtual_shards > 1
                                       else ("replicas x%d" % world if world > 1 else "single GPU"),
                        "final_translation_error_mm": err_mm, "pcie_inclusive_fps": pcie_fps,
                        "cpp_shim": shim,
