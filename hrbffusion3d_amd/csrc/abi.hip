@@ -1887,7 +1887,7 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
     c->ev_pending = false;
     // enable == 2: ownership by spatial hash of the surfel's cell instead of contiguous ranges of the global order
     c->hash_mode = 0;
-    if (enable == 2 && G > 1) {
+    if (enable == 2 && (G > 1 || real)) {   // world size 1 with a real communicator: the same code path, every collective issued
         const char *cs = getenv("HRBF_HASH_CELL");   // cell edge in metres
         const float cell = cs ? (float)atof(cs) : 0.25f;
         c->hash_inv_cell = 1.0f / (cell > 0.0f ? cell : 0.25f);

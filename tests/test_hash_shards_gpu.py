@@ -79,3 +79,25 @@ def test_hash_owned_map_uploaded_purged_and_tracked(pair):
     g.map_rebalance()                                            # a no-op under hash ownership
     same_up_to_names(o, g, "after the no-op rebalance")
     assert g.status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["images", "records"])
+def test_hash_owned_map_rccl_world1(pair, exchange, monkeypatch):
+    """the real-mode code path of hash ownership on the one GPU a test box has: an RCCL communicator of world size 1, so the
+    key all-reduce (min over the {depth, id} keys), the one-word all-gather that carries the smallest id alive and the counts
+    all-gather are issued through librccl — with the owner-side scatter into the (self-)mapped images, and with the packed
+    winner records (HRBF_SHARD_EXCHANGE=records)"""
+    from hrbffusion3d_amd.api import HRBFFusion
+    if exchange == "records":
+        monkeypatch.setenv("HRBF_SHARD_EXCHANGE", "records")
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    g.comm_init(0, 1, HRBFFusion.comm_unique_id()); g.map_shard_init(True, partition="hash")
+    for k in range(5):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        same_up_to_names(o, g, "hash rccl1 %s frame %d" % (exchange, k))
+    assert g.status() == 0 and np.array_equal(g.download_gids().astype(np.int64), np.sort(g.download_gids().astype(np.int64)))
