@@ -676,15 +676,11 @@ static void hash_refresh_gfirst(hrbf_context *c, const uint32_t *counts_row)
         for (int g = 0; g < pl.world; ++g) { all[g] = pl.shm->counts[slot][g]; mine = all[g] < mine ? all[g] : mine; }
         hipMemcpyAsync(c->d_gfirst, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
         hipStreamSynchronize(c->stream);
-    } else if (c->comm.comm) {   // RCCL: all-gather one word per rank into the scratch row, then the minimum of the row
+    } else if (c->comm.comm) {   // RCCL: all-gather one word per rank into the scratch row, then its minimum — all on the stream, no host round trip
         uint32_t *row = c->x.rec_count;   // HRBF_MAX_SHARDS words, free outside a projection
         hipMemcpyAsync(row + c->comm.rank, c->d_gfirst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
         rccl_allgather_u32(c->comm.comm, row + c->comm.rank, row, 1, c->stream);
-        hipMemcpyAsync(all, row, sizeof(uint32_t) * (size_t)c->comm.world, hipMemcpyDeviceToHost, c->stream);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) return;
-        for (int g = 0; g < c->comm.world; ++g) mine = all[g] < mine ? all[g] : mine;
-        hipMemcpyAsync(c->d_gfirst, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-        hipStreamSynchronize(c->stream);
+        launch_min_row_u32(c->stream, row, c->comm.world, c->d_gfirst);
     }
 }
 static void st_init(hrbf_context *c)

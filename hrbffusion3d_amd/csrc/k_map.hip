@@ -1074,6 +1074,16 @@ void launch_initialise_hashed(hipStream_t s, const Cam &cam, const DevPose *dp, 
                        curv2, gradmag, use_conf_eval, eps, flags2, offs2, out, cap, (const uint32_t *)offs, gid_out);
     hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap, status);
 }
+__global__ void k_min_row_u32(const uint32_t *__restrict__ row, int n, uint32_t *__restrict__ out)
+{
+    uint32_t m = HRBF_NO_SURFEL;
+    for (int k = 0; k < n; ++k) m = row[k] < m ? row[k] : m;
+    *out = m;
+}
+void launch_min_row_u32(hipStream_t s, const uint32_t *row, int n, uint32_t *out)
+{
+    hipLaunchKernelGGL(k_min_row_u32, dim3(1), dim3(1), 0, s, row, n, out);
+}
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint32_t n, uint32_t base)
 {
     if (n) hipLaunchKernelGGL(k_iota_u32, dim3((n + 255) / 256), dim3(256), 0, s, p, n, base);

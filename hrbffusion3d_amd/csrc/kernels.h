@@ -78,6 +78,7 @@ void launch_initialise_hashed(hipStream_t s, const Cam &cam, const DevPose *dp, 
                               uint32_t *status, int G, int me, float inv_cell);
 void launch_gfirst(hipStream_t s, const uint32_t *counts, int first, int nsh, const uint32_t *const *gids, uint32_t *out, int merge);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint32_t n, uint32_t base);
+void launch_min_row_u32(hipStream_t s, const uint32_t *row, int n, uint32_t *out);
 // projection = launch_project (z-buffer of packed keys) + launch_resolve (winner gather).  With a sharded map the
 // z-buffers are min-reduced between the two; every shard then resolves the winners it owns (zeros elsewhere), packs
 // them as compact winner records and the records of the other shards are scattered into the images
