@@ -181,6 +181,87 @@ def test_sharded_map_exchange_protocol_world2():
     assert np.array_equal(np.concatenate([got[0][2], got[1][2]]), np.arange(N))
 
 
+def _hash_worker(rank, world, port, q):
+    """the exchange of a HASH-OWNED map (hrbf_map_shard_init(h, 2), csrc/abi.hip st_indices) on two real processes: private
+    z-test keyed {depth, local index}, {depth, id of the private winner} MIN-reduced over the ranks, a rank owns a pixel iff its
+    private winner's global key equals the reduced key, the owner's attributes reach every rank (one owner per pixel: exact integer
+    sum), the smallest id alive is all-gathered, every rank appends the new surfels of its own cells with ids g_next + q"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hrbffusion3d_amd import api
+    lib = api.load_library()
+    rng = np.random.default_rng(23)
+    N, P, Q = 6000, 64 * 48, 400
+    pos = rng.uniform(-3, 3, (N, 3)).astype(np.float32)
+    pix = rng.integers(0, P, N); depth = rng.integers(1, 120, N).astype(np.float32) * 0.01      # many exact depth ties
+    attr = rng.standard_normal((N, 4)).astype(np.float32)
+    gid = np.sort(rng.choice(4 * N, N, replace=False)).astype(np.int64)                           # ids with gaps: never renumbered
+    owner = np.array([lib.hrbf_hash_owner(float(x), float(y), float(z), 0.25, world) for x, y, z in pos])
+    mine = np.nonzero(owner == rank)[0]                                                           # local index -> row, ascending in id
+    EMPTY = np.iinfo(np.int64).max
+    zp = np.full(P, EMPTY, np.int64)
+    np.minimum.at(zp, pix[mine], (depth[mine].view(np.uint32).astype(np.int64) << 32) | np.arange(len(mine), dtype=np.int64))
+    hitp = zp != EMPTY
+    keys = np.full(P, EMPTY, np.int64)
+    keys[hitp] = (zp[hitp] & ~np.int64(0xFFFFFFFF)) | gid[mine[zp[hitp] & 0xFFFFFFFF]]         # k_keys_global
+    zt = torch.from_numpy(keys.copy()); dist.all_reduce(zt, op=dist.ReduceOp.MIN)
+    zred = zt.numpy()
+    own = hitp & (keys == zred)                                                                   # pixel_winner
+    img = np.zeros((P, 4), np.float32)
+    img[own] = attr[mine[zp[own] & 0xFFFFFFFF]]
+    it = torch.from_numpy(img.view(np.int32).copy()); dist.all_reduce(it, op=dist.ReduceOp.SUM)   # one owner per pixel: zeros elsewhere
+    nown = torch.tensor([int(own.sum())]); dist.all_reduce(nown)
+    # the smallest id alive travels with the counts
+    g0 = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(g0, torch.tensor([int(gid[mine[0]]) if len(mine) else EMPTY], dtype=torch.int64))
+    gfirst = min(int(t.item()) for t in g0)
+    # appends: every rank takes the records of its own cells, ids g_next + q
+    rpos = rng.uniform(-3, 3, (Q, 3)).astype(np.float32)
+    rown = np.array([lib.hrbf_hash_owner(float(x), float(y), float(z), 0.25, world) for x, y, z in rpos])
+    g_next = 4 * N
+    new_ids = g_next + np.nonzero(rown == rank)[0]
+    q.put((rank, zred.copy(), it.numpy().copy(), int(nown.item()), gfirst, gid[mine], new_ids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hash_owned_map_exchange_protocol_world2():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_hash_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r = q.get(timeout=120); got[r[0]] = r[1:]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: one z-buffer over all surfels keyed {depth, id}
+    rng = np.random.default_rng(23)
+    N, P, Q = 6000, 64 * 48, 400
+    rng.uniform(-3, 3, (N, 3))
+    pix = rng.integers(0, P, N); depth = rng.integers(1, 120, N).astype(np.float32) * 0.01
+    attr = rng.standard_normal((N, 4)).astype(np.float32)
+    gid = np.sort(rng.choice(4 * N, N, replace=False)).astype(np.int64)
+    EMPTY = np.iinfo(np.int64).max
+    z = np.full(P, EMPTY, np.int64)
+    np.minimum.at(z, pix, (depth.view(np.uint32).astype(np.int64) << 32) | gid)
+    hit = z != EMPTY
+    img = np.zeros((P, 4), np.float32); img[hit] = attr[np.searchsorted(gid, z[hit] & 0xFFFFFFFF)]
+    for r in (0, 1):
+        zr, ir, nown, gfirst, ids, new_ids = got[r]
+        assert np.array_equal(zr, z) and np.array_equal(ir, img.view(np.int32))
+        assert nown == int(hit.sum()) and gfirst == int(gid[0])          # every hit pixel has exactly one owner
+        assert (np.diff(ids) > 0).all()
+    assert np.array_equal(np.sort(np.concatenate([got[0][4], got[1][4]])), gid)
+    allnew = np.sort(np.concatenate([got[0][5], got[1][5]]))
+    assert np.array_equal(allnew, 4 * N + np.arange(Q))                   # every record is appended by exactly one rank
+    assert min(len(got[0][4]), len(got[1][4])) > 0.35 * N                 # the hash splits the map
+
+
 def test_bench_json_contract_fields():
     """static check of the bench line's keys (the values need a GPU)"""
     src = open(os.path.join(ROOT, "bench.py")).read()
