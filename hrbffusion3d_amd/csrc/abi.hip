@@ -80,7 +80,7 @@ struct ShardScratch {
 // (b) a POSIX shared-memory rendezvous (hrbf_peer_unique_id / hrbf_comm_init_peer) — handles, counts and barriers go through
 // the segment, the key min-reduce reads the peers' z-buffers.  (b) needs no RCCL and also runs with several ranks on ONE GPU
 // (RCCL refuses that: "Duplicate GPU detected"), which is how the path is tested on a single device.
-#define PEER_BUFS 7   // z-buffer + six image planes
+#define PEER_BUFS 8   // z-buffer + six image planes (+ the id plane of a hash-owned map: only then exchanged)
 struct PeerShm {
     volatile uint32_t arrived;                  // monotone barrier counter
     volatile uint32_t counts[2][HRBF_PEER_MAX]; // live surfel counts, double buffered by barrier generation
@@ -134,7 +134,7 @@ struct hrbf_context {
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
     // ownership by spatial hash: the next free global-order id (the same on every rank: seed size, then + Q per clean pass),
     // 1 / cell size, the device word holding the smallest id alive, scratch of the hashed seeding
-    int hash_mode; uint32_t g_next; float hash_inv_cell; uint32_t *d_gfirst; uint32_t *d_init_flags2, *d_init_offs2, *d_gtotal;
+    int hash_mode; uint32_t g_next, g_renumber_at, hash_renumbered; float hash_inv_cell; uint32_t *d_gfirst; uint32_t *d_init_flags2, *d_init_offs2, *d_gtotal;
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
     uint32_t *d_init_flags, *d_init_offs;
     uint32_t max_tiles;
@@ -565,10 +565,11 @@ static int peer_map_images(hrbf_context *c)
 {
     PeerLink &pl = c->peer;
     const int G = pl.world, me = pl.rank;
-    void *mine[PEER_BUFS] = {c->d_zbuf, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax, c->d_im_curvmin, c->d_clean_tex};
+    void *mine[PEER_BUFS] = {c->d_zbuf, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax, c->d_im_curvmin, c->d_clean_tex, c->sh[0].d_gid};
+    const int NB = c->sh[0].d_gid ? PEER_BUFS : PEER_BUFS - 1;   // the id plane exists under hash ownership only
     hipIpcMemHandle_t all[HRBF_PEER_MAX][PEER_BUFS];
     memset(all, 0, sizeof(all));
-    for (int b = 0; b < PEER_BUFS; ++b) {
+    for (int b = 0; b < NB; ++b) {
         const hipError_t e = hipIpcGetMemHandle(&all[me][b], mine[b]);
         if (e != hipSuccess) { hrbf_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
     }
@@ -594,15 +595,15 @@ static int peer_map_images(hrbf_context *c)
     memset(&pi, 0, sizeof(pi));
     pi.world = G; pi.me = me;
     for (int g = 0; g < G; ++g) {
-        void *q[PEER_BUFS];
-        for (int b = 0; b < PEER_BUFS; ++b) {
+        void *q[PEER_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int b = 0; b < NB; ++b) {
             if (g == me) { q[b] = mine[b]; continue; }
             const hipError_t e = hipIpcOpenMemHandle(&q[b], all[g][b], hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) { hrbf_set_error("hipIpcOpenMemHandle(rank %d, buffer %d): %s", g, b, hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
             pl.opened[g][b] = q[b];
         }
         pi.zbuf[g] = (unsigned long long *)q[0]; pi.vertconf[g] = (float4 *)q[1]; pi.normrad[g] = (float4 *)q[2];
-        pi.colortime[g] = (float4 *)q[3]; pi.curvmax[g] = (float4 *)q[4]; pi.curvmin[g] = (float4 *)q[5]; pi.clean[g] = (float4 *)q[6];
+        pi.colortime[g] = (float4 *)q[3]; pi.curvmax[g] = (float4 *)q[4]; pi.curvmin[g] = (float4 *)q[5]; pi.clean[g] = (float4 *)q[6]; pi.gid[g] = (uint32_t *)q[7];
     }
     if (!pl.shm_mode) {
         if (hipMalloc((void **)&pl.d_token, sizeof(uint32_t)) != hipSuccess) return HRBF_ERR_DEVICE;
@@ -840,11 +841,45 @@ static void st_fuse(hrbf_context *c)
                     ring ? c->ring_m1[c->ring_head % HRBF_RING] : nullptr, c->sh[k].d_merged_part);
     c->fuse_tick = c->tick; c->ring_merge_head = c->ring_head;
 }
+// hash ownership: ids are never renumbered by the frame path and grow by Q per clean pass (55 000 frames of VGA fill 32 bits).
+// When the next pass could run out, every surfel's id becomes its RANK in the global order (the number of ids below it over all
+// shards: a sum of lower bounds over the shards' ascending id planes — the peers' planes are IPC-mapped like their images), and
+// g_next restarts at the surfel count.  Order, hence every result, is unchanged; only the names in the index image change.
+static int read_counts(hrbf_context *c, uint32_t out[HRBF_MAX_SHARDS]);
+static int hash_renumber(hrbf_context *c)
+{
+    uint32_t cnt[HRBF_MAX_SHARDS];
+    if (read_counts(c, cnt)) return HRBF_ERR_DEVICE;
+    uint64_t total = 0;
+    for (int g = 0; g < c->G; ++g) total += cnt[g];
+    const uint32_t *ptrs[HRBF_MAX_SHARDS] = {nullptr};
+    if (!c->shard_real) { for (int k = 0; k < c->nsh; ++k) ptrs[k] = c->sh[k].d_gid; }
+    else if (c->peer.enabled && c->peer.img.gid[c->peer.rank]) { for (int g = 0; g < c->G; ++g) ptrs[g] = c->peer.img.gid[g]; }
+    else { hrbf_set_error("hash ownership: id renumbering needs the peer-mapped id planes (not HRBF_SHARD_EXCHANGE=records)"); return HRBF_ERR_INVALID; }
+    uint32_t *tmp[HRBF_MAX_SHARDS] = {nullptr};
+    for (int k = 0; k < c->nsh; ++k) {
+        const uint32_t nk = cnt[c->shard_first + k];
+        if (hipMalloc((void **)&tmp[k], sizeof(uint32_t) * (size_t)(nk ? nk : 1)) != hipSuccess) return HRBF_ERR_DEVICE;
+        launch_gid_rank(c->stream, ptrs, counts_live(c), c->G, c->sh[k].d_gid, nk, tmp[k]);
+    }
+    if (c->shard_real && peer_meet(c)) return HRBF_ERR_COMM;     // every rank has read every plane
+    for (int k = 0; k < c->nsh; ++k) {
+        const uint32_t nk = cnt[c->shard_first + k];
+        if (nk) hipMemcpyAsync(c->sh[k].d_gid, tmp[k], sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (c->shard_real && peer_meet(c)) return HRBF_ERR_COMM;     // nobody reads a half-written plane in the next pass
+    hipStreamSynchronize(c->stream);
+    for (int k = 0; k < c->nsh; ++k) hipFree(tmp[k]);
+    c->g_next = (uint32_t)total;
+    ++c->hash_renumbered;
+    return HRBF_OK;
+}
 static void st_clean(hrbf_context *c)
 {
     // the clean texels carry the confidence threshold and the time they were resolved with; a caller that changed
     // either since (stage API / named operators) gets a fresh projection instead of a stale test
     if (c->clean_thr != c->prm.confidence_threshold || c->clean_time != c->tick) st_indices(c, true, 7);
+    if (c->hash_mode && c->g_next > c->g_renumber_at) (void)hash_renumber(c);   // the same decision on every rank: g_next is
     const bool ring = ring_frame(c);
     for (int k = 0; k < c->nsh; ++k) {
         const int gk = c->shard_first + k;
@@ -1264,6 +1299,8 @@ extern "C" int hrbf_download_gids(hrbf_handle c, uint32_t *out, size_t cap_surfe
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return HRBF_OK;
 }
+// hash ownership: how often the ids were renumbered (hash_renumber: when the next pass could exhaust 32 bits; HRBF_HASH_RENUMBER_AT)
+extern "C" int hrbf_hash_renumber_count(hrbf_handle c) { return c ? (int)c->hash_renumbered : HRBF_ERR_INVALID; }
 // the shard a surfel at (x, y, z) is inserted into under hash ownership (host code: no device needed)
 extern "C" int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards)
 {
@@ -1866,28 +1903,15 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
         if (c->x.zbuf) launch_zbuf_reset(c->stream, c->x.zbuf, c->P);
     }
     c->G = G; c->nsh = nsh; c->shard_first = first; c->shard_real = real;
-    peer_close(c);
-    if (real) {
-        // the index-map images of all ranks are mapped into every rank (the owner of a winner writes them, st_indices).
-        // HRBF_SHARD_EXCHANGE=records keeps the packed-record exchange over ncclSend / ncclRecv instead (RCCL transport only).
-        const char *ex = getenv("HRBF_SHARD_EXCHANGE");
-        if (c->peer.shm_mode || !(ex && !strcmp(ex, "records"))) {
-            if (!c->peer.shm_mode) { c->peer.rank = c->comm.rank; c->peer.world = c->comm.world; }
-            const int r = peer_map_images(c);
-            if (r) return r;
-        }
-    }
-    for (int k = 0; k < nsh; ++k) c->sh[k].count_ub = 0;
-    HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->ev_pending = false;
     // enable == 2: ownership by spatial hash of the surfel's cell instead of contiguous ranges of the global order
     c->hash_mode = 0;
     if (enable == 2 && (G > 1 || real)) {   // world size 1 with a real communicator: the same code path, every collective issued
         const char *cs = getenv("HRBF_HASH_CELL");   // cell edge in metres
         const float cell = cs ? (float)atof(cs) : 0.25f;
         c->hash_inv_cell = 1.0f / (cell > 0.0f ? cell : 0.25f);
-        c->g_next = 0;
+        c->g_next = 0; c->hash_renumbered = 0;
+        const char *ra = getenv("HRBF_HASH_RENUMBER_AT");   // tests: renumber long before 32 bits run out
+        c->g_renumber_at = ra ? (uint32_t)strtoul(ra, nullptr, 10) : 0xFFFFFFFFu - 4u * (uint32_t)c->Q;
         int r = 0;
         if (!c->d_gfirst) { r = dalloc(&c->d_gfirst, 1); if (!r) r = dalloc(&c->d_gtotal, 1); if (!r) r = dalloc(&c->d_init_flags2, (size_t)c->P); if (!r) r = dalloc(&c->d_init_offs2, (size_t)c->P); }
         for (int k = 0; k < nsh && !r; ++k) {
@@ -1906,6 +1930,21 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
         HIP_CHECK(hipStreamSynchronize(c->stream));
         c->hash_mode = 1;
     }
+    peer_close(c);
+    if (real) {
+        // the index-map images of all ranks are mapped into every rank (the owner of a winner writes them, st_indices).
+        // HRBF_SHARD_EXCHANGE=records keeps the packed-record exchange over ncclSend / ncclRecv instead (RCCL transport only).
+        const char *ex = getenv("HRBF_SHARD_EXCHANGE");
+        if (c->peer.shm_mode || !(ex && !strcmp(ex, "records"))) {
+            if (!c->peer.shm_mode) { c->peer.rank = c->comm.rank; c->peer.world = c->comm.world; }
+            const int r = peer_map_images(c);
+            if (r) return r;
+        }
+    }
+    for (int k = 0; k < nsh; ++k) c->sh[k].count_ub = 0;
+    HIP_CHECK(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 2 * HRBF_MAX_SHARDS, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->ev_pending = false;
     return HRBF_OK;
 }
 

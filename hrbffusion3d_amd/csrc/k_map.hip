@@ -1074,6 +1074,28 @@ void launch_initialise_hashed(hipStream_t s, const Cam &cam, const DevPose *dp, 
                        curv2, gradmag, use_conf_eval, eps, flags2, offs2, out, cap, (const uint32_t *)offs, gid_out);
     hipLaunchKernelGGL(k_clamp_count, dim3(1), dim3(1), 0, s, count, cap, status);
 }
+__global__ __launch_bounds__(256) void k_gid_rank(GidPtrs g, const uint32_t *__restrict__ counts, int G, const uint32_t *__restrict__ mine,
+                                                  uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = mine[i];
+    uint32_t r = 0;
+    for (int k = 0; k < G; ++k) {
+        uint32_t lo = 0, hi = counts[k];
+        const uint32_t *p = g.p[k];
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[mid] < v) lo = mid + 1; else hi = mid; }
+        r += lo;
+    }
+    out[i] = r;
+}
+void launch_gid_rank(hipStream_t s, const uint32_t *const *ptrs, const uint32_t *counts, int G, const uint32_t *mine, uint32_t n, uint32_t *out)
+{
+    if (!n) return;
+    GidPtrs g;
+    for (int k = 0; k < 8; ++k) g.p[k] = k < G ? ptrs[k] : nullptr;
+    hipLaunchKernelGGL(k_gid_rank, dim3((n + 255) / 256), dim3(256), 0, s, g, counts, G, mine, n, out);
+}
 __global__ void k_min_row_u32(const uint32_t *__restrict__ row, int n, uint32_t *__restrict__ out)
 {
     uint32_t m = HRBF_NO_SURFEL;

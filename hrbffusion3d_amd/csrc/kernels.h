@@ -79,6 +79,8 @@ void launch_initialise_hashed(hipStream_t s, const Cam &cam, const DevPose *dp, 
 void launch_gfirst(hipStream_t s, const uint32_t *counts, int first, int nsh, const uint32_t *const *gids, uint32_t *out, int merge);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint32_t n, uint32_t base);
 void launch_min_row_u32(hipStream_t s, const uint32_t *row, int n, uint32_t *out);
+// out[i] = number of ids, over the G ascending planes ptrs[g][0 .. counts[g]), that are smaller than mine[i]
+void launch_gid_rank(hipStream_t s, const uint32_t *const *ptrs, const uint32_t *counts, int G, const uint32_t *mine, uint32_t n, uint32_t *out);
 // projection = launch_project (z-buffer of packed keys) + launch_resolve (winner gather).  With a sharded map the
 // z-buffers are min-reduced between the two; every shard then resolves the winners it owns (zeros elsewhere), packs
 // them as compact winner records and the records of the other shards are scattered into the images
@@ -110,6 +112,7 @@ struct PeerImages {
     unsigned long long *zbuf[HRBF_PEER_MAX];
     float4 *vertconf[HRBF_PEER_MAX], *normrad[HRBF_PEER_MAX], *colortime[HRBF_PEER_MAX], *curvmax[HRBF_PEER_MAX], *curvmin[HRBF_PEER_MAX],
         *clean[HRBF_PEER_MAX];
+    uint32_t *gid[HRBF_PEER_MAX];   // hash ownership: the ranks' id planes (renumbering reads them)
 };
 void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long long *zred, int P);
 void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, const unsigned long long *zred,

@@ -344,7 +344,9 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  *                              runs in two levels ({depth, local index} per rank, then {depth, id} min-reduced), every rank
  *                              appends the new surfels of its own cells; images (up to the names in the index image),
  *                              pose, and the map merged by id are the single-GPU ones bit for bit.  No re-cut is ever
- *                              needed (hrbf_map_rebalance is a no-op).  hrbf_download_map of a rank returns its own
+ *                              needed (hrbf_map_rebalance is a no-op).  Ids grow by W*H/4 per frame; before 32 bits run out
+ *                              every id is replaced by its rank in the global order (peer-mapped id planes; not with
+ *                              HRBF_SHARD_EXCHANGE=records) — the order, hence every result, is unchanged.  hrbf_download_map of a rank returns its own
  *                              surfels, hrbf_download_gids their ids; one process playing all shards returns the merged map.
  *   hrbf_upload_map            always takes the WHOLE map; a rank keeps its slice.
  *   hrbf_surfel_count          global count; hrbf_local_surfel_count / hrbf_download_map: the local range(s).
@@ -364,6 +366,7 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
 int hrbf_peer_unique_id(uint8_t out128[128]);
 int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
 int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ranges | 2 spatial hash */
+int hrbf_hash_renumber_count(hrbf_handle h);   /* hash ownership: times the 32-bit ids were renumbered to ranks (every ~55 000 VGA frames; order unchanged) */
 int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards);   /* shard of a surfel inserted at (x, y, z); host code */
 int hrbf_shard_counts(hrbf_handle h, uint32_t out[8]);   /* live counts of all shards; returns 0 one map | 1 ranges | 2 hash (negative: error) */
 int hrbf_download_gids(hrbf_handle h, uint32_t *out, size_t cap_surfels);   /* hash ownership, one shard per rank: ids of the rank's surfels */

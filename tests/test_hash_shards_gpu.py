@@ -101,3 +101,22 @@ def test_hash_owned_map_rccl_world1(pair, exchange, monkeypatch):
         o.process_frame(rgb, d); g.process_frame(rgb, d)
         same_up_to_names(o, g, "hash rccl1 %s frame %d" % (exchange, k))
     assert g.status() == 0 and np.array_equal(g.download_gids().astype(np.int64), np.sort(g.download_gids().astype(np.int64)))
+
+
+@pytest.mark.gpu
+def test_hash_owned_map_renumbers_its_ids_without_changing_anything(pair, monkeypatch):
+    """ids grow by Q per frame and are 32 bits wide; before they run out every id is replaced by its rank in the global order
+    (hash_renumber).  Forced here every other frame: the run stays bit-identical to the oracle's single map"""
+    monkeypatch.setenv("HRBF_HASH_RENUMBER_AT", "20000")
+    W, H, G = 160, 120, 3
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    g.comm_init(-1, G); g.map_shard_init(True, partition="hash")
+    for k in range(9):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        same_up_to_names(o, g, "renumbered frame %d" % k)
+    assert g.hash_renumber_count() >= 3 and g.status() == 0
+    idx = g.get_image("INDEX")
+    assert idx.max() < g.surfel_count() + 2 * (W // 2) * (H // 2)          # names are ranks again (+ the appends since)

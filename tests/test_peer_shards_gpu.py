@@ -38,6 +38,8 @@ def _run(rank, world, uid, cfg, out):
     try:
         W, H, nseed, frames, sparse = cfg[:5]
         partition = cfg[5] if len(cfg) > 5 else "ranges"
+        if len(cfg) > 6:
+            os.environ["HRBF_HASH_RENUMBER_AT"] = str(cfg[6])
         K = synth.intrinsics(W, H)
         seed = synth.seed_map(nseed, width=W) if nseed else None
         p = default_params(W, H, *K, max_surfels=(nseed or 0) + 300_000, use_sparse_icp=sparse)
@@ -65,6 +67,7 @@ def _run(rank, world, uid, cfg, out):
         res["map"] = _bits(g.download_map())
         if world > 1 and partition == "hash":
             res["gids"] = g.download_gids()
+            res["renumbered"] = g.hash_renumber_count()
         res["status"] = g.status()
         g.close()
         out.put((rank, res))
@@ -114,7 +117,8 @@ def test_two_processes_share_one_sharded_map_bit_identical_to_a_single_map(gpu_a
         assert min(two[0]["local_count"], two[1]["local_count"]) > 10_000   # both ranks really own part of the view
 
 
-@pytest.mark.parametrize("cfg", [(160, 120, 0, 7, 0, "hash"), (320, 240, 150_000, 6, 1, "hash")], ids=["from_empty_map", "uploaded_150k_sparse_icp"])
+@pytest.mark.parametrize("cfg", [(160, 120, 0, 7, 0, "hash"), (320, 240, 150_000, 6, 1, "hash"), (160, 120, 0, 8, 0, "hash", 20000)],
+                         ids=["from_empty_map", "uploaded_150k_sparse_icp", "ids_renumbered_across_processes"])
 def test_two_processes_share_one_hash_owned_map_bit_identical_to_a_single_map(gpu_available, cfg):
     """the same with ownership by spatial hash (hrbf_map_shard_init(h, 2)): two-level z-test over the peers' key buffers, the
     smallest id alive travelling with the counts, every rank appending the new surfels of its own cells.  The index image shows
@@ -137,6 +141,8 @@ def test_two_processes_share_one_hash_owned_map_bit_identical_to_a_single_map(gp
     n = single["local_count"]
     assert two[0]["local_count"] + two[1]["local_count"] == n
     assert min(two[0]["local_count"], two[1]["local_count"]) > 0.3 * n        # the hash splits the view, not only the array
+    if len(cfg) > 6:   # the ids were renumbered through the peers' IPC-mapped id planes, on both ranks alike
+        assert two[0]["renumbered"] == two[1]["renumbered"] >= 2
     ids = np.concatenate([two[0]["gids"], two[1]["gids"]])
     assert len(np.unique(ids)) == n and (np.diff(two[0]["gids"].astype(np.int64)) > 0).all() and (np.diff(two[1]["gids"].astype(np.int64)) > 0).all()
     joined = np.concatenate([two[0]["map"].reshape(-1, 20), two[1]["map"].reshape(-1, 20)])[np.argsort(ids, kind="stable")]
