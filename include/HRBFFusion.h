@@ -409,10 +409,11 @@ public:
     hrbf_handle handle() { return h_; }
     /* more than one GPU, one process per GPU sharing ONE sequence: join the communicator whose id
        rank 0 obtained from hrbf_comm_unique_id; shardMap additionally cuts the (still empty) surfel map over the ranks */
-    void joinRanks(int rank, int world, const unsigned char id128[128], bool shardMap)
+    void joinRanks(int rank, int world, const unsigned char id128[128], bool shardMap, bool ownByHash = false)
     {
         if (hrbf_comm_init(h_, rank, world, id128) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
-        if (shardMap && hrbf_map_shard_init(h_, 1) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
+        /* ownByHash: ownership by spatial hash of the surfel's cell instead of contiguous ranges of the global order */
+        if (shardMap && hrbf_map_shard_init(h_, ownByHash ? 2 : 1) != HRBF_OK) throw std::runtime_error(hrbf_last_error());
     }
 
     /* binary little-endian PLY, 13 properties (HRBFFusion.cpp:1737-1853) */
