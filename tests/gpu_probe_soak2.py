@@ -16,6 +16,7 @@ def bits(a):
     return a.view(np.uint8)
 
 n = int(sys.argv[1]); W = int(sys.argv[2]); H = int(sys.argv[3]); use_oracle = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+shards = int(sys.argv[5]) if len(sys.argv) > 5 else 0; partition = sys.argv[6] if len(sys.argv) > 6 else "ranges"   # virtual shards
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 log = open(os.path.join(ROOT, "gpurun_out", "soak2.log"), "a")
 def say(*a):
@@ -24,6 +25,8 @@ say("start", n, W, H, use_oracle, "cpus", len(os.sched_getaffinity(0)))
 p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 21)
 o = oracle_lib.Oracle(p, omp=True) if use_oracle else None
 g = HRBFFusion(p)
+if shards > 1:
+    g.comm_init(-1, shards); g.map_shard_init(True, partition=partition)
 t0 = time.time()
 for k in range(n):
     rgb, d, _ = synth.frame(k, W, H, noise=True)
@@ -37,6 +40,8 @@ for k in range(n):
             say("MISMATCH pose/count frame", k); break
         if k % 10 == 0:
             for name in IMAGES:
+                if name == "INDEX" and partition == "hash":
+                    continue   # ids instead of array positions: names only
                 if not np.array_equal(bits(o.get_image(name)), bits(g.get_image(name))):
                     say("MISMATCH frame", k, name); break
             if not np.array_equal(bits(o.download_map()), bits(g.download_map())):
