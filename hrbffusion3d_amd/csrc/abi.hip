@@ -857,19 +857,23 @@ static int hash_renumber(hrbf_context *c)
     else if (c->peer.enabled && c->peer.img.gid[c->peer.rank]) { for (int g = 0; g < c->G; ++g) ptrs[g] = c->peer.img.gid[g]; }
     else { hrbf_set_error("hash ownership: id renumbering needs the peer-mapped id planes (not HRBF_SHARD_EXCHANGE=records)"); return HRBF_ERR_INVALID; }
     uint32_t *tmp[HRBF_MAX_SHARDS] = {nullptr};
-    for (int k = 0; k < c->nsh; ++k) {
+    int rc = HRBF_OK;
+    for (int k = 0; k < c->nsh && rc == HRBF_OK; ++k) {
         const uint32_t nk = cnt[c->shard_first + k];
-        if (hipMalloc((void **)&tmp[k], sizeof(uint32_t) * (size_t)(nk ? nk : 1)) != hipSuccess) return HRBF_ERR_DEVICE;
+        if (hipMalloc((void **)&tmp[k], sizeof(uint32_t) * (size_t)(nk ? nk : 1)) != hipSuccess) { rc = HRBF_ERR_DEVICE; break; }
         launch_gid_rank(c->stream, ptrs, counts_live(c), c->G, c->sh[k].d_gid, nk, tmp[k]);
     }
-    if (c->shard_real && peer_meet(c)) return HRBF_ERR_COMM;     // every rank has read every plane
-    for (int k = 0; k < c->nsh; ++k) {
+    // a rank whose allocation failed still meets the others (they would wait for it) and reports the error: the shared map is then
+    // inconsistent between the ranks and the run has to stop
+    if (c->shard_real && peer_meet(c)) rc = HRBF_ERR_COMM;          // every rank has read every plane
+    for (int k = 0; k < c->nsh && rc == HRBF_OK; ++k) {
         const uint32_t nk = cnt[c->shard_first + k];
         if (nk) hipMemcpyAsync(c->sh[k].d_gid, tmp[k], sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToDevice, c->stream);
     }
-    if (c->shard_real && peer_meet(c)) return HRBF_ERR_COMM;     // nobody reads a half-written plane in the next pass
+    if (c->shard_real && peer_meet(c)) rc = HRBF_ERR_COMM;          // nobody reads a half-written plane in the next pass
     hipStreamSynchronize(c->stream);
-    for (int k = 0; k < c->nsh; ++k) hipFree(tmp[k]);
+    for (int k = 0; k < c->nsh; ++k) if (tmp[k]) hipFree(tmp[k]);
+    if (rc != HRBF_OK) return rc;
     c->g_next = (uint32_t)total;
     ++c->hash_renumbered;
     return HRBF_OK;
