@@ -84,7 +84,7 @@ __global__ void k_init_scatter(Cam cam, const DevPose *__restrict__ dp, const fl
     int i = py * cam.W + px;
     float4 vl = vertex_raw[i], nl = normal[i];
     f3 pg = xform(pose, xyz(vl));
-    float conf = radial_confidence((float)px + 0.5f, (float)py + 0.5f, cam.cx, cam.cy, cam.max_dist, 1.0f);
+    float conf = radial_confidence(hd_px_attribute(px, cam.W), hd_px_attribute(py, cam.H), cam.cx, cam.cy, cam.max_dist, 1.0f);   // x = texcoord.x * cols of the uv attribute
     if (use_conf_eval > 0) conf = conf * hd_expf(-eps / hd_sqrtf(gradmag[i]));
     f3 ng = rot_mul(pose, xyz(nl));
     out.p0[n] = make_float4(pg.x, pg.y, pg.z, conf);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
     uint32_t best = 0, lbest = HRBF_NO_SURFEL;
     if (px < cam.W && py < cam.H) {
         const int i = py * cam.W + px;
-        const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+        const float x = hd_px_attribute(px, cam.W), y = hd_px_attribute(py, cam.H);   // data.vert:66-67: texcoord (the uv attribute) * cols, rows
         const float zr = depth_metric[i];
         f3 vl = mk3((x - cam.cx) * zr * cam.camz, (y - cam.cy) * zr * cam.camw, zr);
         float4 npca = normal_pca[i];

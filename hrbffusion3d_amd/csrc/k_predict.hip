@@ -418,7 +418,7 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
         for (int d = 0; d < 4; ++d) list[list_slot(n + d)] = (uint16_t)(DUMMY_TEXEL * PTEXEL_BYTES);
     }
 
-    const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    const float x = hd_px_fragment(px, cam.W), y = hd_px_fragment(py, cam.H);   // predict_hrbf.frag:42-43: texcoord * cols, rows
     const float xl = (x - cam.cx) * cam.camz, yl = (y - cam.cy) * cam.camw;
     const f3 ray = normalize3(mk3(xl, yl, 1.0f));
 

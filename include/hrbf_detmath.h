@@ -62,11 +62,10 @@ HD_FN float hd_floorf(float a) { return __builtin_floorf(a); }
  * At power-of-two sizes every quantity above is exact and the loop takes the nominal samples.
  * Callers iterate `for (float i = w.lo; i <= w.hi; i += w.step)` and take texel hd_window_texel(i, n). */
 typedef struct hd_window { float lo, hi, step; } hd_window;
-HD_FN hd_window hd_window_axis(int p, int n, float win)
+HD_FN hd_window hd_window_axis_t(float t, int n, float win)
 {
     hd_window w;
     const float fn = (float)n;
-    const float t = ((float)p + 0.5f) / fn;
     w.step = 1.0f / fn;
     const float reach = w.step * win;
     const float lo = t - reach, hi = t + reach;
@@ -74,6 +73,23 @@ HD_FN hd_window hd_window_axis(int p, int n, float win)
     w.hi = hi < 1.0f ? hi : 1.0f;
     return w;
 }
+HD_FN float hd_uv_fragment(int p, int n) { return ((float)p + 0.5f) / (float)n; }   /* a fragment shader's texcoord, correctly rounded */
+HD_FN hd_window hd_window_axis(int p, int n, float win) { return hd_window_axis_t(hd_uv_fragment(p, n), n, win); }
+/* The texture coordinate a VERTEX shader of the map passes receives for pixel p (data.vert, init_unstableTex.vert): an attribute
+ * the reference's host computes once, `((float)i / (float)width) + 1.0 / (2 * (float)width)` stored as float
+ * (GlobalModel.cpp:88-97) — a float quotient, a double sum, one more rounding.  It equals hd_uv_fragment at power-of-two sizes
+ * and differs from it by an ulp at 171 of 640 columns and 140 of 480 rows; `x = texcoord.x * cols` (data.vert:66) is then not
+ * exactly p + 0.5 at 103 / 118 of them, and the float-stepped loops that start from it (getNormalPCA in data.vert:88) drop
+ * their last sample at other columns than the fragment shader's do.  Found by executing the shaders at 640 x 480
+ * (tests/golden/make_ref_glsl.py --vga-map-report). */
+/* x = texcoord.x * cols as the shaders form it (p + 0.5 exactly at power-of-two sizes) */
+HD_FN float hd_px_fragment(int p, int n) { return hd_uv_fragment(p, n) * (float)n; }
+HD_FN float hd_uv_attribute(int p, int n)
+{
+    const float fn = (float)n;
+    return (float)((double)((float)p / fn) + 1.0 / (double)(2.0f * fn));
+}
+HD_FN float hd_px_attribute(int p, int n) { return hd_uv_attribute(p, n) * (float)n; }
 HD_FN int hd_window_texel(float i, int n)   /* NEAREST filtering, CLAMP_TO_EDGE */
 {
     int t = (int)hd_floorf(i * (float)n);

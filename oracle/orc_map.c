@@ -37,7 +37,7 @@ void orc_initialise(orc_ctx *c)
             int i = py * W + px;
             f4 vl = c->vertex_raw[i];
             f3 pg = xform(c->pose, xyz(vl));
-            float conf = orc_radial_confidence((float)px + 0.5f, (float)py + 0.5f, cx, cy, max_dist, 1.0f);
+            float conf = orc_radial_confidence(hd_px_attribute(px, W), hd_px_attribute(py, H), cx, cy, max_dist, 1.0f);   /* init_unstableTex.vert:53-54: x = texcoord.x * cols of the uv attribute */
             if (c->prm.use_conf_eval > 0) conf = conf * hd_expf(-c->prm.conf_eval_epsilon / sqrtf(c->gradmag[i]));
             f4 nl = c->normal[i];
             f3 ng = rot_mul(c->pose, xyz(nl));
@@ -131,7 +131,7 @@ void orc_fuse(orc_ctx *c)
             if (!(px % 2 == tpar && py % 2 == tpar)) continue;
             int i = py * W + px;
             int q = (px / 2) * QH + (py / 2);
-            float x = (float)px + 0.5f, y = (float)py + 0.5f;
+            float x = hd_px_attribute(px, W), y = hd_px_attribute(py, H);   /* data.vert:66-67: texcoord (the uv attribute) * cols, rows */
             float zr = c->depth_metric[i];
             f3 vl = v3((x - cx) * zr * camz, (y - cy) * zr * camw, zr);
             f4 npca = c->normal_pca[i];

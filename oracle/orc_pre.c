@@ -142,14 +142,14 @@ static f3 compute_roots(float m00, float m10, float m20, float m11, float m21, f
 }
 
 /* geometry.glsl:190-244 getNormalPCA, window = 3 */
-static f3 normal_pca(const float *depth, int W, int H, int px, int py, float zc,
+static f3 normal_pca(const float *depth, int W, int H, float tx, float ty, float zc,
                      float cx, float cy, float camz, float camw)
 {
     /* sample set: interior offsets -3..3; left/top clamp starts on texel 0 with integer
        coordinates (tx_min = max(0, ..) lands on texel boundaries, geometry.glsl:196-200) */
     /* geometry.glsl:198-213: the float-stepped 7 x 7 walk, literally (hd_window_axis); a sample's vertex is formed at the
        float position i * cols, j * rows — the float overload of getVertex (:21-25), unlike the pixel's own vertex */
-    const hd_window wx = hd_window_axis(px, W, 3.0f), wy = hd_window_axis(py, H, 3.0f);
+    const hd_window wx = hd_window_axis_t(tx, W, 3.0f), wy = hd_window_axis_t(ty, H, 3.0f);   /* tx, ty: the shader's texcoord */
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
     int n = 0;
     for (float i = wx.lo; i <= wx.hi; i += wx.step) {
@@ -210,6 +210,23 @@ static f3 normal_cd(const float *depth, int W, int H, int px, int py, f3 vpos, f
     return normalize3(cross3(del_x, del_y));
 }
 
+/* the float overload (geometry.glsl:36-51 with float x, y): data.vert:91-94 passes x = texcoord.x * cols, i.e. half-pixel
+   coordinates, where depth_vertex_normal_radius.frag passes int(x) */
+static f3 normal_cd_float(const float *depth, int W, int H, int px, int py, float x, float y, f3 vpos,
+                          float cx, float cy, float camz, float camw)
+{
+    int xf = clampi(px + 1, 0, W - 1), xb = clampi(px - 1, 0, W - 1);
+    int yf = clampi(py + 1, 0, H - 1), yb = clampi(py - 1, 0, H - 1);
+    float z;
+    z = depth[py * W + xf]; f3 vxf = v3(((x + 1.0f) - cx) * z * camz, (y - cy) * z * camw, z);
+    z = depth[py * W + xb]; f3 vxb = v3(((x - 1.0f) - cx) * z * camz, (y - cy) * z * camw, z);
+    z = depth[yf * W + px]; f3 vyf = v3((x - cx) * z * camz, ((y + 1.0f) - cy) * z * camw, z);
+    z = depth[yb * W + px]; f3 vyb = v3((x - cx) * z * camz, ((y - 1.0f) - cy) * z * camw, z);
+    f3 del_x = sub3(scale3(add3(vxb, vpos), 0.5f), scale3(add3(vxf, vpos), 0.5f));
+    f3 del_y = sub3(scale3(add3(vyb, vpos), 0.5f), scale3(add3(vyf, vpos), 0.5f));
+    return normalize3(cross3(del_x, del_y));
+}
+
 static int check_neighbours(const float *depth, int W, int H, int px, int py)
 {
     if (depth[py * W + clampi(px - 1, 0, W - 1)] == 0.0f) return 0;
@@ -231,19 +248,36 @@ void orc_vertex_normal_radius(orc_ctx *c)
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
             int i = py * W + px;
-            float x = (float)px + 0.5f, y = (float)py + 0.5f;
+            const float tfx = hd_uv_fragment(px, W), tfy = hd_uv_fragment(py, H);
+            float x = tfx * (float)W, y = tfy * (float)H;     /* texcoord * cols: p + 0.5 up to an ulp where the size is no power of two */
             float zr = c->depth_metric[i], zf = c->depth_metric_filtered[i];
             f3 vr = v3(((float)px - cx) * zr * camz, ((float)py - cy) * zr * camw, zr);
             f3 vf = v3(((float)px - cx) * zf * camz, ((float)py - cy) * zf * camw, zf);
             f3 n = v3(0.0f, 0.0f, 0.0f);
             if (c->prm.normal_estimation_pca > 0.0f)
-                n = normal_pca(c->depth_metric_filtered, W, H, px, py, vf.z, cx, cy, camz, camw);
+                n = normal_pca(c->depth_metric_filtered, W, H, tfx, tfy, vf.z, cx, cy, camz, camw);
             else if (check_neighbours(c->depth_metric, W, H, px, py))
                 n = normal_cd(c->depth_metric_filtered, W, H, px, py, vf, 0, 0, cx, cy, camz, camw);
             float radius_init = rm * orc_get_radius(vf.z, n.z, camz, camw);
-            /* build-specific side output: the un-invalidated PCA normal + radius, which data.vert
-               recomputes identically for fusion (data.vert:87-99) */
-            c->normal_pca[i] = v4(n.x, n.y, n.z, radius_init);
+            /* build-specific side output: the normal + radius data.vert RECOMPUTES for a new point (data.vert:83-96), never
+               invalidated.  data.vert is a vertex shader: its texcoord is the host-computed attribute (hd_uv_attribute), its
+               x, y are texcoord * cols / rows as floats — so the PCA window's float-stepped loops start an ulp elsewhere than the
+               fragment shader's at a third of the columns of a 640 x 480 image, and the central differences run on half-pixel
+               coordinates.  Identical to the fragment shader's PCA normal at power-of-two sizes. */
+            {
+                const float tax = hd_uv_attribute(px, W), tay = hd_uv_attribute(py, H);
+                f3 nr = n;
+                if (c->prm.normal_estimation_pca > 0.0f) {
+                    if (tax != tfx || tay != tfy) nr = normal_pca(c->depth_metric_filtered, W, H, tax, tay, zf, cx, cy, camz, camw);
+                } else {
+                    const float xa = tax * (float)W, ya = tay * (float)H;
+                    nr = v3(0.0f, 0.0f, 0.0f);
+                    if (check_neighbours(c->depth_metric, W, H, px, py))
+                        nr = normal_cd_float(c->depth_metric_filtered, W, H, px, py, xa, ya,
+                                             v3((xa - cx) * zf * camz, (ya - cy) * zf * camw, zf), cx, cy, camz, camw);
+                }
+                c->normal_pca[i] = v4(nr.x, nr.y, nr.z, rm * orc_get_radius(zf, nr.z, camz, camw));
+            }
             if (len3(n) < 0.3f || vr.z < 0.3f || vf.z < 0.3f) {
                 vr = v3(0, 0, 0); vf = v3(0, 0, 0); n = v3(0, 0, 0); radius_init = 0.0f;
             }
@@ -338,7 +372,7 @@ void orc_confidence(orc_ctx *c)
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
             int i = py * W + px;
-            float conf = orc_radial_confidence((float)px + 0.5f, (float)py + 0.5f, cx, cy, max_dist, c->weighting);
+            float conf = orc_radial_confidence(hd_px_fragment(px, W), hd_px_fragment(py, H), cx, cy, max_dist, c->weighting);
             if (c->prm.use_conf_eval > 0) conf = conf * hd_expf(-c->prm.conf_eval_epsilon / sqrtf(c->gradmag[i]));
             c->confidence[i] = conf;
         }

@@ -44,7 +44,7 @@ void orc_predict_hrbf(orc_ctx *c)
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
             int pi = py * W + px;
-            float x = (float)px + 0.5f, y = (float)py + 0.5f;
+            float x = hd_px_fragment(px, W), y = hd_px_fragment(py, H);   /* predict_hrbf.frag:42-43: texcoord * cols, rows */
             float xl = (x - cx) * camz, yl = (y - cy) * camw;
             f3 ray = normalize3(v3(xl, yl, 1.0f));
             f4 vc[100], nr[100], ct[100], cmax[100], cmin[100];

@@ -33,12 +33,13 @@ OUT = os.path.join(HERE, "ref_glsl")
 X0, Y0 = 256, 224          # window of the 640 x 480 GPUTest frames
 # scene -> (W, H, fx, fy, cx, cy)
 GEOM = {"pair": (256, 128, 528.0, 528.0, 320.0 - X0, 240.0 - Y0),
-        "sphere": (128, 128, 150.0, 170.0, 60.3, 66.9)}    # fx != fy, off-centre principal point
+        "sphere": (128, 128, 150.0, 170.0, 60.3, 66.9),    # fx != fy, off-centre principal point
+        "vga": (640, 480, 528.0, 528.0, 320.0, 240.0)}     # the whole GPUTest frames: report only (--vga-map-report), no fixture
 
 
 def params(scene, **kw):
     W, H, fx, fy, cx, cy = GEOM[scene]
-    return default_params(width=W, height=H, fx=fx, fy=fy, cx=cx, cy=cy, max_surfels=1 << 17, **kw)
+    return default_params(width=W, height=H, fx=fx, fy=fy, cx=cx, cy=cy, max_surfels=1 << (20 if W * H > (1 << 17) else 17), **kw)
 
 
 def crop(name):
@@ -84,7 +85,8 @@ def run_reference(scene, f1, f2, T2, w2, prm_over=None):
     """the reference's GL passes in processFrame order (HRBFFusion.cpp:991-1260) for two frames; returns {name: array}"""
     from ref_glsl import refgl
     W, H, FX, FY, CX, CY = GEOM[scene]
-    p = refgl.RefPipeline(W, H, FX, FY, CX, CY, 1.0 / 5000.0, prm=prm_over, tex_dim=512, max_surfels=1 << 17)
+    big = W * H > (1 << 17)
+    p = refgl.RefPipeline(W, H, FX, FY, CX, CY, 1.0 / 5000.0, prm=prm_over, tex_dim=1024 if big else 512, max_surfels=1 << (20 if big else 17))
     out = {}
     I4 = np.eye(4, dtype=np.float32)
 
@@ -474,8 +476,34 @@ def vga_report():
     print("   restricted to pixels with the nominal window: median %.2e, p90 %.2e, p99 %.2e" % (np.median(errf), np.percentile(errf, 90), np.percentile(errf, 99)))
 
 
+def vga_map_report():
+    """Every GLSL pass at 640 x 480 — the benchmark's resolution — on the whole GPUTest pair: the reference's shaders on llvmpipe
+    against the oracle, through the same checks as the committed (power-of-two) fixtures, printed instead of asserted: which bounds
+    hold unchanged at a size that is not a power of two, and what the implementation-defined taps cost where they do not."""
+    import ref_glsl_check as R
+    from oracle_lib import Oracle
+    from PIL import Image as _I
+    f1 = (np.array(_I.open(os.path.join(HERE, "1c.png"))), np.array(_I.open(os.path.join(HERE, "1d.png"))))
+    f2 = (np.array(_I.open(os.path.join(HERE, "2c.png"))), np.array(_I.open(os.path.join(HERE, "2d.png"))))
+    o = Oracle(params("vga"), omp=True)
+    o.process_frame(*f1); o.process_frame(*f2)
+    T2, w2 = o.get_pose().astype(np.float32), float(o.get_weighting())
+    o.close()
+    fx = run_reference("vga", f1, f2, T2, w2)
+    print("reference shaders at 640 x 480: %d surfels seeded, %d after frame 2; stable map + outliers %d -> %d; %d predicted pixels" % (
+        fx["f1_map"].shape[0], int(fx["f2_map_count"][0]), fx["f1_map"].shape[0] + fx["x_extra"].shape[0], int(fx["x_map_count"][0]),
+        int((fx["x_PRED_VERTEX"][..., 2] != 0).sum())))
+    o = Oracle(params("vga"), omp=True)
+    rep = R.run(o, fx, R.Report(strict=False, verbose=True), own_pca_normals=True)
+    o.close()
+    bad = [w for w, ok, _ in rep.rows if not ok]
+    print("%d checks, %d outside the bounds of the power-of-two fixtures: %s" % (len(rep.rows), len(bad), bad))
+
+
 if __name__ == "__main__":
-    if "--vga-report" in sys.argv:
+    if "--vga-map-report" in sys.argv:
+        vga_map_report()
+    elif "--vga-report" in sys.argv:
         vga_report()
     else:
         main()

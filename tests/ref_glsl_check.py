@@ -181,7 +181,7 @@ def part_prediction(rep, g, fx, ref_final, P="f2_"):
     fill_checks(rep, g, fx, "x_")
 
 
-def run(impl, fx, rep, has_records=False):
+def run(impl, fx, rep, has_records=False, own_pca_normals=False):
     g, P = impl, "f2_"
     T2, w2 = fx[P + "pose"], float(fx[P + "weighting"])
     part_filter(rep, g, fx, P)
@@ -189,7 +189,17 @@ def run(impl, fx, rep, has_records=False):
     part_curvature(rep, g, fx, P)
     part_confidence(rep, g, fx, P)
     g.set_image("CONFIDENCE", fx[P + "CONFIDENCE"])
-    g.set_image("NORMAL_PCA", fx[P + "NORMAL_P3"])
+    # data.vert recomputes the PCA normal of a new point from the filtered depth (data.vert:83-95) with the texture coordinate
+    # of a VERTEX ATTRIBUTE; the normal image holds the fragment shader's, computed with an INTERPOLATED coordinate.  At
+    # power-of-two sizes the two are the same number and the image can stand in; at other sizes the implementation's own P3
+    # normals (own_pca_normals: correctly rounded coordinates, like the attribute) are the faithful input of the map passes
+    if not own_pca_normals:
+        g.set_image("NORMAL_PCA", fx[P + "NORMAL_P3"])
+    else:
+        g.set_image("DEPTH_METRIC", fx[P + "DEPTH_METRIC"]); g.set_image("DEPTH_METRIC_FILTERED", fx[P + "DEPTH_METRIC_FILTERED"])
+        g.run_stage("VERTEX_NORMAL_RADIUS")
+        for name in ("VERTEX_RAW", "VERTEX_FILTERED", "RADIUS", "NORMAL", "CURV1", "CURV2", "GRADIENT_MAG", "CONFIDENCE"):
+            g.set_image(name, fx[P + name])
 
     # ---- F4 initialise (init_unstableTex.*) from frame 2's images at pose T2 -----------------------------------------------
     g.set_image("VERTEX_RAW", fx[P + "VERTEX_RAW"])
