@@ -838,7 +838,8 @@ static void st_fuse(hrbf_context *c)
                     c->d_normal_pca, c->d_curv1, c->d_curv2, c->d_confidence, c->d_rgb, c->d_idx, c->d_im_vertconf,
                     c->d_im_normrad, c->rec, c->d_rec_flag, c->d_rec_best, c->sh[k].d_slot, c->sh[k].map, shard_ref(c, k),
                     c->sh[k].d_stats, c->prm.curv_valid_threshold, ring ? c->ring_m0[c->ring_head % HRBF_RING] : nullptr,
-                    ring ? c->ring_m1[c->ring_head % HRBF_RING] : nullptr, c->sh[k].d_merged_part);
+                    ring ? c->ring_m1[c->ring_head % HRBF_RING] : nullptr, c->sh[k].d_merged_part,
+                    RecNormalSrc{c->d_depth_metric_f, c->prm.init_radius_multiplier, c->prm.normal_estimation_pca > 0.0f ? 1 : 0});
     c->fuse_tick = c->tick; c->ring_merge_head = c->ring_head;
 }
 // hash ownership: ids are never renumbered by the frame path and grow by Q per clean pass (55 000 frames of VGA fill 32 bits).

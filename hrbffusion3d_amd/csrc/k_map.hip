@@ -17,6 +17,7 @@
 //    of every surviving surfel = 160 B/surfel), order preserving like GL transform feedback.
 #include "common.h"
 #include "kernels.h"
+#include "pca_normal.h"
 
 // ------------------------------------------------------------------------------------------
 // F4: seeding (init_unstableTex.vert:51-98).  Column-major order like the reference's draw;
@@ -392,7 +393,8 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                                                    const float4 *__restrict__ vertconf,
                                                    const float4 *__restrict__ normrad, RecPlanes rec,
                                                    int32_t *__restrict__ rec_flag, uint32_t *__restrict__ rec_best,
-                                                   uint32_t *__restrict__ slot, ShardRef sh, uint32_t *__restrict__ stats)
+                                                   uint32_t *__restrict__ slot, ShardRef sh, uint32_t *__restrict__ stats,
+                                                   RecNormalSrc rn)
 {
     // the pass's statistics words start from zero ([0..3] counts, [4] force-full-check, [5] ticket, [6] moved; [7] is the
     // sticky status): nothing in this kernel reads them and the next kernel (k_apply_merges) is ordered behind it
@@ -405,10 +407,28 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
     const int tiles_x = (QW + 7) / 8;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qx = (tile % tiles_x) * 8 + (lane >> 3), qy = (tile / tiles_x) * 8 + (lane & 7);
+    const int tpar = tick % 2;
+    // The filtered depth under the wave's 16 x 16 pixel block (+ the PCA window's reach of 3) is staged in LDS when any of its
+    // pixels needs data.vert's own normal (see below): 22 x 22 floats per wave, one barrier for the workgroup — before any exit.
+    constexpr int RT = 22;
+    __shared__ float s_zf[4][RT * RT];
+    const int bx0 = (tile % tiles_x) * 16 - 3, by0 = (tile / tiles_x) * 16 - 3;   // image coordinates of tile texel (0, 0)
+    {
+        const int ppx = qx * 2 + tpar, ppy = qy * 2 + tpar;
+        const bool need = rn.use_pca && qx < QW && qy < QH && ppx < cam.W && ppy < cam.H &&
+                          (hd_uv_attribute(ppx, cam.W) != hd_uv_fragment(ppx, cam.W) || hd_uv_attribute(ppy, cam.H) != hd_uv_fragment(ppy, cam.H));
+        if (__ballot(need) != 0ull) {
+            float *t = s_zf[threadIdx.x >> 6];
+            for (int e = lane; e < RT * RT; e += 64) {
+                const int gx = clampi(bx0 + e % RT, 0, cam.W - 1), gy = clampi(by0 + e / RT, 0, cam.H - 1);
+                t[e] = rn.depth_metric_f[gy * cam.W + gx];
+            }
+        }
+    }
+    __syncthreads();
     if (qx >= QW || qy >= QH) return;
     const int q = qx * QH + qy;
     const Rigid pose = dp->pose;
-    const int tpar = tick % 2;
     const int px = qx * 2 + tpar, py = qy * 2 + tpar;
     int flag = 0;
     uint32_t best = 0, lbest = HRBF_NO_SURFEL;
@@ -417,7 +437,54 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
         const float x = hd_px_attribute(px, cam.W), y = hd_px_attribute(py, cam.H);   // data.vert:66-67: texcoord (the uv attribute) * cols, rows
         const float zr = depth_metric[i];
         f3 vl = mk3((x - cam.cx) * zr * cam.camz, (y - cam.cy) * zr * cam.camw, zr);
+        // the 9 + 9 + 9 index-map texels of the association are requested here, before the record's normal is (re)computed:
+        // they do not depend on it, and the arithmetic below runs while they are on their way
+        uint32_t cur[9]; float4 vcf9[9], nr9[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int sx = clampi(px + a - 1, 0, cam.W - 1);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int sy = clampi(py + b - 1, 0, cam.H - 1);
+                const int si = sy * cam.W + sx;
+                cur[a * 3 + b] = idx[si]; vcf9[a * 3 + b] = vertconf[si]; nr9[a * 3 + b] = normrad[si];
+            }
+        }
         float4 npca = normal_pca[i];
+        {
+            // data.vert RECOMPUTES the new point's normal and radius from the filtered depth (data.vert:83-96) with ITS texcoord —
+            // the host-computed uv attribute — and ITS x, y (floats).  The image holds the fragment shader's result; where the
+            // inputs differ (an ulp of texcoord at a third of the columns of a 640 x 480 image; always for central differences,
+            // which then run on half-pixel coordinates) the record's are recomputed here.  Never at power-of-two sizes with PCA.
+            const float tax = hd_uv_attribute(px, cam.W), tay = hd_uv_attribute(py, cam.H);
+            const float zf = rn.depth_metric_f[i];
+            if (rn.use_pca) {
+                if (tax != hd_uv_fragment(px, cam.W) || tay != hd_uv_fragment(py, cam.H)) {
+                    const f3 nr = pca_normal_tile(s_zf[threadIdx.x >> 6], RT, bx0, by0, cam.W, cam.H, tax, tay, zf, cam.cx, cam.cy, cam.camz, cam.camw);
+                    npca = make_float4(nr.x, nr.y, nr.z, rn.radius_mult * get_radius(zf, nr.z, cam.camz, cam.camw));
+                }
+            } else {
+                const int W = cam.W, H = cam.H;
+                f3 nr = mk3(0.0f, 0.0f, 0.0f);
+                const bool ok = depth_metric[py * W + clampi(px - 1, 0, W - 1)] != 0.0f &&
+                                depth_metric[clampi(py - 1, 0, H - 1) * W + px] != 0.0f &&
+                                depth_metric[py * W + clampi(px + 1, 0, W - 1)] != 0.0f &&
+                                depth_metric[clampi(py + 1, 0, H - 1) * W + px] != 0.0f;
+                if (ok) {
+                    const float cx = cam.cx, cy = cam.cy, camz = cam.camz, camw = cam.camw;
+                    const f3 va = mk3((x - cx) * zf * camz, (y - cy) * zf * camw, zf);
+                    float z;
+                    z = rn.depth_metric_f[py * W + clampi(px + 1, 0, W - 1)]; f3 vxf = mk3(((x + 1.0f) - cx) * z * camz, (y - cy) * z * camw, z);
+                    z = rn.depth_metric_f[py * W + clampi(px - 1, 0, W - 1)]; f3 vxb = mk3(((x - 1.0f) - cx) * z * camz, (y - cy) * z * camw, z);
+                    z = rn.depth_metric_f[clampi(py + 1, 0, H - 1) * W + px]; f3 vyf = mk3((x - cx) * z * camz, ((y + 1.0f) - cy) * z * camw, z);
+                    z = rn.depth_metric_f[clampi(py - 1, 0, H - 1) * W + px]; f3 vyb = mk3((x - cx) * z * camz, ((y - 1.0f) - cy) * z * camw, z);
+                    f3 del_x = sub3(scale3(add3(vxb, va), 0.5f), scale3(add3(vxf, va), 0.5f));
+                    f3 del_y = sub3(scale3(add3(vyb, va), 0.5f), scale3(add3(vyf, va), 0.5f));
+                    nr = normalize3(cross3(del_x, del_y));
+                }
+                npca = make_float4(nr.x, nr.y, nr.z, rn.radius_mult * get_radius(zf, nr.z, cam.camz, cam.camw));
+            }
+        }
         f3 nl = xyz(npca);
         float4 k1 = curv1[i], k2 = curv2[i];
         if (len3(nl) > 0.8f && vl.z > 0.3f && vl.z <= maxDepth && k1.w > -300.0f && k1.w < 300.0f &&
@@ -433,17 +500,6 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
             // met a second time offers the same distance and `dist < bestDist` is strict, so revisits (and the extra
             // ones border clamping creates) never change anything: the 9 distinct texels in first-visit order (x outer,
             // y inner) give the same result.  All 9 + 9 + 9 loads are issued before the first test.
-            uint32_t cur[9]; float4 vcf9[9], nr9[9];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int sx = clampi(px + a - 1, 0, cam.W - 1);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int sy = clampi(py + b - 1, 0, cam.H - 1);
-                    const int si = sy * cam.W + sx;
-                    cur[a * 3 + b] = idx[si]; vcf9[a * 3 + b] = vertconf[si]; nr9[a * 3 + b] = normrad[si];
-                }
-            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const uint32_t current = cur[t];
@@ -1237,12 +1293,13 @@ void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, flo
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
-                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr, hipEvent_t m0, hipEvent_t m1, uint32_t *merged_part)
+                 MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr, hipEvent_t m0, hipEvent_t m1, uint32_t *merged_part,
+                 RecNormalSrc rn)
 {
     int Q = (cam.W / 2) * (cam.H / 2);
     hipLaunchKernelGGL(k_associate, dim3(quarter_tile_blocks(cam.W, cam.H)), dim3(256), 0, s, cam, dp, tick, maxDepth, index_submap,
                        depth_metric, normal_pca, curv1, curv2, confidence, rgb, idx, vertconf, normrad, rec, rec_flag,
-                       rec_best, slot, sh, stats);
+                       rec_best, slot, sh, stats, rn);
     if (m0) hipEventRecord(m0, s);   // F2 (update.vert) is part of the roofline-timed fuse: SURVEY §8d "F2+F3"
     hipLaunchKernelGGL(k_apply_merges, dim3(merge_workgroups(Q)), dim3(MERGE_THREADS), 0, s, Q, tick, rec, rec_flag, rec_best, slot, m,
                        sh, stats + 1, curvThr, merged_part);

@@ -119,13 +119,16 @@ void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, Ma
                             uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time,
                             unsigned long long *zpriv = nullptr);
 void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P);
+// what data.vert recomputes a new point's normal and radius from (data.vert:83-96)
+struct RecNormalSrc { const float *depth_metric_f; float radius_mult; int use_pca; };
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
                  const float *depth_metric, const float4 *normal_pca, const float4 *curv1, const float4 *curv2,
                  const float *confidence, const uint8_t *rgb, const uint32_t *idx, const float4 *vertconf,
                  const float4 *normrad, RecPlanes rec, int32_t *rec_flag, uint32_t *rec_best, uint32_t *slot,
                  MapPlanes m, ShardRef sh, uint32_t *stats, float curvThr,
                  hipEvent_t m0, hipEvent_t m1 /* nullable: bracket the merge kernel (F2) */,
-                 uint32_t *merged_part /* merge_workgroups(Q) words: the merged count, one word per workgroup of k_apply_merges */);
+                 uint32_t *merged_part /* merge_workgroups(Q) words: the merged count, one word per workgroup of k_apply_merges */,
+                 RecNormalSrc rn);
 void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, float confThr, float curvThr,
                   int time, float clean_window_multiplier, int full_check, MapPlanes m, RecPlanes rec, int32_t *rec_flag,
                   const uint32_t *count_in, uint32_t *count_out, uint32_t count_ub, uint32_t *stats, uint32_t cap,

@@ -21,6 +21,7 @@
 
 float orc_get_radius(float depth, float norm_z, float camz, float camw);
 float orc_radial_confidence(float x, float y, float cx, float cy, float max_dist, float weighting);
+f4 orc_record_normal(const orc_ctx *c, int px, int py, f4 image);
 
 #define SURF(buf, i, k) ((buf)[(size_t)(i) * 5 + (k)])
 
@@ -134,7 +135,7 @@ void orc_fuse(orc_ctx *c)
             float x = hd_px_attribute(px, W), y = hd_px_attribute(py, H);   /* data.vert:66-67: texcoord (the uv attribute) * cols, rows */
             float zr = c->depth_metric[i];
             f3 vl = v3((x - cx) * zr * camz, (y - cy) * zr * camw, zr);
-            f4 npca = c->normal_pca[i];
+            f4 npca = orc_record_normal(c, px, py, c->normal_pca[i]);   /* data.vert:83-96 recomputes it */
             f3 nl = xyz(npca);
             f4 k1 = c->curv1[i], k2 = c->curv2[i];
             if (!(len3(nl) > 0.8f && vl.z > 0.3f && vl.z <= maxDepth && k1.w > -300.0f && k1.w < 300.0f &&

@@ -236,6 +236,33 @@ static int check_neighbours(const float *depth, int W, int H, int px, int py)
     return 1;
 }
 
+/* data.vert:83-96: the normal and radius of a new point, recomputed by the vertex shader from the filtered depth with ITS
+   texcoord — the host-computed uv attribute (hd_uv_attribute) — and ITS x, y = texcoord * cols, rows as floats.  `image` is what
+   the fragment shader left for this pixel (NORMAL_PCA); it is the answer where the inputs coincide: PCA at every pixel of a
+   power-of-two image and wherever the attribute equals the fragment's coordinate.  Central differences always differ (they
+   run on half-pixel coordinates here, on integer ones in the fragment shader). */
+f4 orc_record_normal(const orc_ctx *c, int px, int py, f4 image)
+{
+    const int W = c->W, H = c->H;
+    const float cx = c->prm.cx, cy = c->prm.cy;
+    const float camz = (float)(1.0 / (double)c->prm.fx), camw = (float)(1.0 / (double)c->prm.fy);
+    const float rm = c->prm.init_radius_multiplier;
+    const float tax = hd_uv_attribute(px, W), tay = hd_uv_attribute(py, H);
+    const float zf = c->depth_metric_filtered[py * W + px];
+    f3 nr;
+    if (c->prm.normal_estimation_pca > 0.0f) {
+        if (tax == hd_uv_fragment(px, W) && tay == hd_uv_fragment(py, H)) return image;
+        nr = normal_pca(c->depth_metric_filtered, W, H, tax, tay, zf, cx, cy, camz, camw);
+    } else {
+        const float xa = tax * (float)W, ya = tay * (float)H;
+        nr = v3(0.0f, 0.0f, 0.0f);
+        if (check_neighbours(c->depth_metric, W, H, px, py))
+            nr = normal_cd_float(c->depth_metric_filtered, W, H, px, py, xa, ya,
+                                 v3((xa - cx) * zf * camz, (ya - cy) * zf * camw, zf), cx, cy, camz, camw);
+    }
+    return v4(nr.x, nr.y, nr.z, rm * orc_get_radius(zf, nr.z, camz, camw));
+}
+
 /* ---- P3: depth_vertex_normal_radius.frag:23-68 -------------------------------------------- */
 void orc_vertex_normal_radius(orc_ctx *c)
 {
@@ -259,25 +286,10 @@ void orc_vertex_normal_radius(orc_ctx *c)
             else if (check_neighbours(c->depth_metric, W, H, px, py))
                 n = normal_cd(c->depth_metric_filtered, W, H, px, py, vf, 0, 0, cx, cy, camz, camw);
             float radius_init = rm * orc_get_radius(vf.z, n.z, camz, camw);
-            /* build-specific side output: the normal + radius data.vert RECOMPUTES for a new point (data.vert:83-96), never
-               invalidated.  data.vert is a vertex shader: its texcoord is the host-computed attribute (hd_uv_attribute), its
-               x, y are texcoord * cols / rows as floats — so the PCA window's float-stepped loops start an ulp elsewhere than the
-               fragment shader's at a third of the columns of a 640 x 480 image, and the central differences run on half-pixel
-               coordinates.  Identical to the fragment shader's PCA normal at power-of-two sizes. */
-            {
-                const float tax = hd_uv_attribute(px, W), tay = hd_uv_attribute(py, H);
-                f3 nr = n;
-                if (c->prm.normal_estimation_pca > 0.0f) {
-                    if (tax != tfx || tay != tfy) nr = normal_pca(c->depth_metric_filtered, W, H, tax, tay, zf, cx, cy, camz, camw);
-                } else {
-                    const float xa = tax * (float)W, ya = tay * (float)H;
-                    nr = v3(0.0f, 0.0f, 0.0f);
-                    if (check_neighbours(c->depth_metric, W, H, px, py))
-                        nr = normal_cd_float(c->depth_metric_filtered, W, H, px, py, xa, ya,
-                                             v3((xa - cx) * zf * camz, (ya - cy) * zf * camw, zf), cx, cy, camz, camw);
-                }
-                c->normal_pca[i] = v4(nr.x, nr.y, nr.z, rm * orc_get_radius(zf, nr.z, camz, camw));
-            }
+            /* build-specific side output: the un-invalidated normal + radius.  data.vert RECOMPUTES both for a new point
+               (data.vert:83-96); where its inputs are the fragment shader's the result is this one, elsewhere the association
+               recomputes (orc_record_normal) */
+            c->normal_pca[i] = v4(n.x, n.y, n.z, radius_init);
             if (len3(n) < 0.3f || vr.z < 0.3f || vf.z < 0.3f) {
                 vr = v3(0, 0, 0); vf = v3(0, 0, 0); n = v3(0, 0, 0); radius_init = 0.0f;
             }
