@@ -459,10 +459,10 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
             const float tax = hd_uv_attribute(px, cam.W), tay = hd_uv_attribute(py, cam.H);
             const float zf = rn.depth_metric_f[i];
             if (rn.use_pca) {
-                if (tax != hd_uv_fragment(px, cam.W) || tay != hd_uv_fragment(py, cam.H)) {
-                    const f3 nr = pca_normal_tile(s_zf[threadIdx.x >> 6], RT, bx0, by0, cam.W, cam.H, tax, tay, zf, cam.cx, cam.cy, cam.camz, cam.camw);
-                    npca = make_float4(nr.x, nr.y, nr.z, rn.radius_mult * get_radius(zf, nr.z, cam.camz, cam.camw));
-                }
+                f3 nr = xyz(npca);
+                if (tax != hd_uv_fragment(px, cam.W) || tay != hd_uv_fragment(py, cam.H))
+                    nr = pca_normal_tile(s_zf[threadIdx.x >> 6], RT, bx0, by0, cam.W, cam.H, tax, tay, zf, cam.cx, cam.cy, cam.camz, cam.camw);
+                npca = make_float4(nr.x, nr.y, nr.z, rn.radius_mult * get_radius(zf, nr.z, cam.camz, cam.camw));   // data.vert:96
             } else {
                 const int W = cam.W, H = cam.H;
                 f3 nr = mk3(0.0f, 0.0f, 0.0f);

@@ -251,8 +251,8 @@ f4 orc_record_normal(const orc_ctx *c, int px, int py, f4 image)
     const float zf = c->depth_metric_filtered[py * W + px];
     f3 nr;
     if (c->prm.normal_estimation_pca > 0.0f) {
-        if (tax == hd_uv_fragment(px, W) && tay == hd_uv_fragment(py, H)) return image;
-        nr = normal_pca(c->depth_metric_filtered, W, H, tax, tay, zf, cx, cy, camz, camw);
+        if (tax == hd_uv_fragment(px, W) && tay == hd_uv_fragment(py, H)) nr = v3(image.x, image.y, image.z);   /* the radius is formed below either way */
+        else nr = normal_pca(c->depth_metric_filtered, W, H, tax, tay, zf, cx, cy, camz, camw);
     } else {
         const float xa = tax * (float)W, ya = tay * (float)H;
         nr = v3(0.0f, 0.0f, 0.0f);

@@ -290,6 +290,17 @@ def run_reference_variants(f1, f2, T2, w2, base):
             p.p.update(kw)
             p.clean(T2, 2)
             out[tag + "x_keep"], out[tag + "x_new_picks"], out[tag + "x_map_count"] = clean_structure(fused_ref, rec, p.download_map())
+        elif part == "fuse":
+            # association + merge + clean with the variant's uniforms in data.vert (the frame's images are the default run's)
+            p.upload_map(xm); p.predict_indices(T2, 2); p.fuse(T2, 2, w2)
+            rec = out[tag + "x_records"] = p.fuse_records()
+            fused = p.download_map()
+            ch = np.nonzero((fused.view(np.uint32) != xm.view(np.uint32)).any(1))[0]
+            out[tag + "x_fused_rows"], out[tag + "x_fused_vals"] = ch.astype(np.uint32), fused[ch]
+            p.predict_indices(T2, 2)
+            out[tag + "x_c_INDEX"] = p.index_images()["INDEX"]
+            p.clean(T2, 2)
+            out[tag + "x_keep"], out[tag + "x_new_picks"], out[tag + "x_map_count"] = clean_structure(fused, rec, p.download_map())
         elif part == "predict":
             p.upload_map(final_ref); p.predict_indices(T2, 2)
             same(p.index_images()["INDEX"], base["x_p_INDEX"], "index map differs from the committed fixture")

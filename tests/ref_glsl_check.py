@@ -243,6 +243,8 @@ VARIANTS = {
     "clean_window_2_25": (dict(clean_window_multiplier=2.25), "clean"),              # ceil(4.5) = 5 samples per axis
     "clean_window_4": (dict(clean_window_multiplier=4.0), "clean"),
     "clean_thresholds": (dict(confidence_threshold=9.0, curv_valid_threshold=40.0), "clean"),
+    "fuse_central_diff": (dict(normal_estimation_pca=0.0), "fuse"),                # data.vert:91-94: central differences on HALF-PIXEL coordinates
+    "fuse_radius_multiplier_3": (dict(init_radius_multiplier=3.0), "fuse"),        # data.vert:96: the record's radius (merge-or-keep branch of update.vert)
     "predict_small": (dict(predict_window_multiplier=2.0, predict_min_neighbors=4, predict_max_neighbors=6), "predict"),
     "fill_frame_to_frame_rgb": (dict(frame_to_frame_rgb=1), "predict"),             # fill_rgb.frag with passthrough: the live image everywhere
     "predict_conf_6_6": (dict(predict_conf_threshold=6.6), "predict"),            # about half of the stable map qualifies
@@ -270,7 +272,9 @@ def run_variant(impl, base, var, name, rep):
         part_curvature(rep, g, fx)
     elif part == "conf":
         part_confidence(rep, g, fx)
-    elif part == "clean":
+    elif part in ("clean", "fuse"):
+        if kw.get("normal_estimation_pca", 1.0) == 0.0:
+            fx["_normal_abs_floor"] = 2e-5
         bind_frame(g, base)
         map_flow(rep, g, fx, "x_", name + ": ", stable_map_with_outliers(base), base["f2_pose"])
     elif part == "predict":
@@ -308,7 +312,8 @@ def map_flow(rep, g, fx, pre, tag, map_in, T2):
     rep.add(tag + "F2 surfels merged with another record", int((~same_rec).sum()) <= 2 * ties, "%d" % int((~same_rec).sum()))
     gv, rv = gv[same_rec], rv[same_rec]
     rep.close_ulp(tag + "F2 merged position + confidence", gv[:, 0:4], rv[:, 0:4], 8)
-    rep.close_ulp(tag + "F2 merged normal + radius", gv[:, 8:12], rv[:, 8:12], 16, abs_floor=1e-6)
+    # (central differences, data.vert:91-94: the cross product of two ~5 mm differences cancels — see part_vertex_normal_radius)
+    rep.close_ulp(tag + "F2 merged normal + radius", gv[:, 8:12], rv[:, 8:12], 16, abs_floor=float(fx.get("_normal_abs_floor", 1e-6)))
     rep.close_ulp(tag + "F2 merged curvature records", gv[:, 12:20], rv[:, 12:20], 16, abs_floor=1e-5)
     g.run_stage("PREDICT_INDICES")
     ic = g.get_image("INDEX")
