@@ -34,7 +34,8 @@ X0, Y0 = 256, 224          # window of the 640 x 480 GPUTest frames
 # scene -> (W, H, fx, fy, cx, cy)
 GEOM = {"pair": (256, 128, 528.0, 528.0, 320.0 - X0, 240.0 - Y0),
         "sphere": (128, 128, 150.0, 170.0, 60.3, 66.9),    # fx != fy, off-centre principal point
-        "vga": (640, 480, 528.0, 528.0, 320.0, 240.0)}     # the whole GPUTest frames: report only (--vga-map-report), no fixture
+        "vga": (640, 480, 528.0, 528.0, 320.0, 240.0),
+        "qqvga_map": (160, 120, 190.0, 200.0, 77.3, 61.9)}  # not a power of two: the vertex shaders' uv attribute differs from the fragment texcoord     # the whole GPUTest frames: report only (--vga-map-report), no fixture
 
 
 def params(scene, **kw):
@@ -57,9 +58,9 @@ def scene_pair():
     return f1, f2, T2.astype(np.float32), float(w2)
 
 
-def scene_sphere():
+def scene_sphere(scene="sphere"):
     import scenes
-    W, H, FX, FY, CX, CY = GEOM["sphere"]
+    W, H, FX, FY, CX, CY = GEOM[scene]
 
     def view(T):
         # depth of a sphere in front of a slanted plane, rendered for camera pose T (camera-to-world)
@@ -401,6 +402,27 @@ def main():
     print("qqvga_pre ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "6-sample columns / rows:", int((q["win_x"] == 6).sum()), int((q["win_y"] == 6).sum()),
           "tie columns / rows:", q["tie_cols"].tolist(), q["tie_rows"].tolist(), "low tap rows:", q["tap_rows_low"].tolist())
     if "--only-nonpow2" in sys.argv:
+        return
+    if "--only-nonpow2-map" in sys.argv:
+        # the map passes of the second frame at 160 x 120: association (data.vert with the host-computed uv attribute), merge,
+        # index map, clean — only what those checks read is kept
+        f1, f2, T2, w2 = scene_sphere("qqvga_map")
+        full = run_reference("qqvga_map", f1, f2, T2, w2)
+        keep = ["f1_map", "f2_rgb", "f2_depth", "f2_pose", "f2_weighting", "f2_DEPTH_FILTERED", "f2_DEPTH_METRIC", "f2_DEPTH_METRIC_FILTERED",
+                "f2_VERTEX_RAW", "f2_VERTEX_FILTERED", "f2_RADIUS", "f2_NORMAL_P3", "f2_NORMAL", "f2_CURV1", "f2_CURV2", "f2_GRADIENT_MAG",
+                "f2_CONFIDENCE", "f2_a_INDEX", "f2_a_INDEX_VERTCONF", "f2_a_INDEX_NORMRAD", "f2_records", "f2_fused_rows", "f2_fused_vals",
+                "f2_c_INDEX", "f2_keep", "f2_new_picks", "f2_map_count", "f2_init_count", "f2_init_head"]
+        out = {k: full[k] for k in keep}
+        out["geom"] = np.array(GEOM["qqvga_map"], np.float64)
+        f = np.float32
+        for n, key in ((160, "uv_cols_differ"), (120, "uv_rows_differ")):
+            i = np.arange(n)
+            ta = ((i.astype(f) / f(n)).astype(np.float64) + 1.0 / (2 * f(n))).astype(f)
+            out[key] = np.nonzero(ta != ((i.astype(f) + f(0.5)) / f(n)).astype(f))[0].astype(np.int32)
+        path = os.path.join(OUT, "qqvga_map.npz")
+        np.savez_compressed(path, **out)
+        print("qqvga_map ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "surfels", out["f1_map"].shape[0], "->", int(out["f2_map_count"][0]),
+              "merge marks", int((out["f2_records"][:, 7] == -1).sum()), "uv attribute differs at", len(out["uv_cols_differ"]), "columns /", len(out["uv_rows_differ"]), "rows")
         return
     if "--only-variants" in sys.argv:
         import ref_glsl_check as R

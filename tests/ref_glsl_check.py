@@ -425,6 +425,32 @@ def fill_checks(rep, g, fx, P):
     rep.close_ulp("H3 FILL_ICPWEIGHT", g.get_image("FILL_ICPWEIGHT"), fx[P + "FILL_ICPWEIGHT"], 16)
 
 
+def run_nonpow2_map(impl, fx, rep):
+    """association, merge, index map and clean of the second frame at 160 x 120 against the executed shaders
+    (tests/golden/ref_glsl/qqvga_map.npz).  Not a power of two: data.vert's texcoord — the uv attribute the host computes as
+    fl(fl(i / w) + 1 / 2w) — differs from the fragment shaders' (i + 0.5) / w by an ulp at 43 of 160 columns and 20 of 120 rows, so its
+    x, y are not exactly i + 0.5 and the PCA normal it recomputes for a new point takes its 7 x 7 window from elsewhere (hd_uv_attribute).
+    The implementation's own P3 normals stand in for the fragment shader's (llvmpipe's interpolated texcoord is an ulp off the
+    correctly rounded one: implementation-defined); everything the map passes do must then hold within the bounds of
+    the power-of-two scenes."""
+    g, P = impl, "f2_"
+    T2 = fx[P + "pose"]
+    g.upload_frame(fx[P + "rgb"], fx[P + "depth"])
+    for name in ("DEPTH_FILTERED", "DEPTH_METRIC", "DEPTH_METRIC_FILTERED"):
+        g.set_image(name, fx[P + name])
+    g.run_stage("VERTEX_NORMAL_RADIUS")            # own NORMAL_PCA (the fragment shader's normal under a correctly rounded texcoord)
+    for name in ("VERTEX_RAW", "VERTEX_FILTERED", "RADIUS", "NORMAL", "CURV1", "CURV2", "GRADIENT_MAG", "CONFIDENCE"):
+        g.set_image(name, fx[P + name])
+    g.set_weighting(float(fx[P + "weighting"]))
+    g.set_pose(T2)
+    g.run_stage("INITIALISE")                      # init_unstableTex.vert: x, y of the radial confidence from the same attribute
+    im = g.download_map()
+    rep.add("F4 surfel count", im.shape[0] == int(fx[P + "init_count"][0]), "%d vs reference %d" % (im.shape[0], int(fx[P + "init_count"][0])))
+    rep.close_ulp("F4 confidence (exp)", im[:4096, 3], fx[P + "init_head"][:, 3], 16)
+    map_flow(rep, g, fx, "f2_", "160 x 120: ", fx["f1_map"], T2)
+    return rep
+
+
 def run_nonpow2_pre(impl, fx, rep):
     """P1-P5 at 160 x 120 against the executed shaders (tests/golden/ref_glsl/qqvga_pre.npz).  Not a power of two: the
     float-stepped window loops take 6 instead of 7 samples at 88 of 160 columns and 17 of 120 rows (hd_window_axis), the bilateral

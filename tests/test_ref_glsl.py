@@ -94,6 +94,31 @@ def test_hip_path_matches_the_executed_shaders_at_a_size_that_is_not_a_power_of_
     assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
 
 
+def test_oracle_matches_the_executed_map_passes_at_a_size_that_is_not_a_power_of_two(oracle_lib_built):
+    """160 x 120: the vertex shaders' host-computed uv attribute is an ulp off the fragment texcoord at 43 columns / 20 rows —
+    data.vert's own normal, position and ray follow the attribute (hd_uv_attribute; found at 640 x 480)"""
+    fx = R.load("qqvga_map")
+    assert len(fx["uv_cols_differ"]) == 43 and len(fx["uv_rows_differ"]) == 20
+    o = oracle_lib_built.Oracle(_nonpow2_params(fx), omp=True)
+    try:
+        rep = R.run_nonpow2_map(o, fx, R.Report(strict=True))
+    finally:
+        o.close()
+    assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_executed_map_passes_at_a_size_that_is_not_a_power_of_two(gpu_available):
+    from hrbffusion3d_amd.api import HRBFFusion
+    fx = R.load("qqvga_map")
+    g = HRBFFusion(_nonpow2_params(fx))
+    try:
+        rep = R.run_nonpow2_map(g, fx, R.Report(strict=True))
+    finally:
+        g.close()
+    assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
+
+
 VARIANT_NAMES = sorted(R.VARIANTS)
 
 
