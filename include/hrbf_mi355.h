@@ -144,7 +144,9 @@ typedef enum hrbf_image {
     HRBF_IMG_VERTEX_RAW,              /* f4 */
     HRBF_IMG_VERTEX_FILTERED,         /* f4 */
     HRBF_IMG_NORMAL,                  /* f4 (after updateNormalRad: NORMAL_OPT) */
-    HRBF_IMG_NORMAL_PCA,              /* f4 build-specific: PCA normal + radius consumed by fuse (data.vert:87-96) */
+    HRBF_IMG_NORMAL_PCA,              /* f4 build-specific: the un-invalidated normal + radius of depth_vertex_normal_radius.frag; the fuse takes it
+                                         for a new point's normal where data.vert's own recomputation (data.vert:83-96) has the same inputs, and
+                                         recomputes elsewhere (sizes that are no power of two; central differences) */
     HRBF_IMG_RADIUS,                  /* f1 */
     HRBF_IMG_CURV1,                   /* f4 */
     HRBF_IMG_CURV2,                   /* f4 */
