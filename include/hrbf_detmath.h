@@ -78,8 +78,8 @@ HD_FN hd_window hd_window_axis(int p, int n, float win) { return hd_window_axis_
 /* The texture coordinate a VERTEX shader of the map passes receives for pixel p (data.vert, init_unstableTex.vert): an attribute
  * the reference's host computes once, `((float)i / (float)width) + 1.0 / (2 * (float)width)` stored as float
  * (GlobalModel.cpp:88-97) — a float quotient, a double sum, one more rounding.  It equals hd_uv_fragment at power-of-two sizes
- * and differs from it by an ulp at 171 of 640 columns and 140 of 480 rows; `x = texcoord.x * cols` (data.vert:66) is then not
- * exactly p + 0.5 at 103 / 118 of them, and the float-stepped loops that start from it (getNormalPCA in data.vert:88) drop
+ * and differs from it by an ulp at 171 of 640 columns and 139 of 480 rows; `x = texcoord.x * cols` (data.vert:66) is then not
+ * exactly p + 0.5 at 103 / 117 of them, and the float-stepped loops that start from it (getNormalPCA in data.vert:88) drop
  * their last sample at other columns than the fragment shader's do.  Found by executing the shaders at 640 x 480
  * (tests/golden/make_ref_glsl.py --vga-map-report). */
 /* x = texcoord.x * cols as the shaders form it (p + 0.5 exactly at power-of-two sizes) */

@@ -314,6 +314,8 @@ int orc_set_image(orc_ctx *c, int which, const void *in, size_t bytes)
     memcpy(p, in, b); return 0;
 }
 
+float orc_uv_attribute(int p, int n) { return hd_uv_attribute(p, n); }
+float orc_uv_fragment(int p, int n) { return hd_uv_fragment(p, n); }
 float orc_expf(float x) { return hd_expf(x); }
 float orc_acosf(float x) { return hd_acosf(x); }
 float orc_atan2f(float y, float x) { return hd_atan2f(y, x); }

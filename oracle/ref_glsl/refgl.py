@@ -402,8 +402,10 @@ class RefPipeline:
         # uv buffer: column-major walk over the image, texel centres (GlobalModel.cpp:82-98)
         ii, jj = np.meshgrid(np.arange(W), np.arange(H), indexing="ij")
         uv = np.empty((W * H, 2), np.float32)
-        uv[:, 0] = (ii.ravel().astype(np.float32) / np.float32(W)).astype(np.float64) + 1.0 / (2 * np.float32(W))
-        uv[:, 1] = (jj.ravel().astype(np.float32) / np.float32(H)).astype(np.float64) + 1.0 / (2 * np.float32(H))
+        # `((float)i / (float)width) + 1.0 / (2 * (float)width)`: a float quotient, a DOUBLE reciprocal (1.0 is a double literal), a
+        # double sum, stored as float.  (float(...) keeps numpy's weak-scalar rules from rounding the reciprocal to float32.)
+        uv[:, 0] = (ii.ravel().astype(np.float32) / np.float32(W)).astype(np.float64) + 1.0 / float(2 * np.float32(W))
+        uv[:, 1] = (jj.ravel().astype(np.float32) / np.float32(H)).astype(np.float64) + 1.0 / float(2 * np.float32(H))
         self.uv_size = W * H
         self.uvo = self._buffer(uv.nbytes, uv, G.GL_STATIC_DRAW)
         self.update_maps = [tex_rgba32f(gl, D, D) for _ in range(5)]

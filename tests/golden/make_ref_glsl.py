@@ -417,7 +417,7 @@ def main():
         f = np.float32
         for n, key in ((160, "uv_cols_differ"), (120, "uv_rows_differ")):
             i = np.arange(n)
-            ta = ((i.astype(f) / f(n)).astype(np.float64) + 1.0 / (2 * f(n))).astype(f)
+            ta = ((i.astype(f) / f(n)).astype(np.float64) + 1.0 / float(2 * f(n))).astype(f)
             out[key] = np.nonzero(ta != ((i.astype(f) + f(0.5)) / f(n)).astype(f))[0].astype(np.int32)
         path = os.path.join(OUT, "qqvga_map.npz")
         np.savez_compressed(path, **out)

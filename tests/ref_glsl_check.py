@@ -428,7 +428,7 @@ def fill_checks(rep, g, fx, P):
 def run_nonpow2_map(impl, fx, rep):
     """association, merge, index map and clean of the second frame at 160 x 120 against the executed shaders
     (tests/golden/ref_glsl/qqvga_map.npz).  Not a power of two: data.vert's texcoord — the uv attribute the host computes as
-    fl(fl(i / w) + 1 / 2w) — differs from the fragment shaders' (i + 0.5) / w by an ulp at 43 of 160 columns and 20 of 120 rows, so its
+    fl(fl(i / w) + 1 / 2w) — differs from the fragment shaders' (i + 0.5) / w by an ulp at 43 of 160 columns and 19 of 120 rows, so its
     x, y are not exactly i + 0.5 and the PCA normal it recomputes for a new point takes its 7 x 7 window from elsewhere (hd_uv_attribute).
     The implementation's own P3 normals stand in for the fragment shader's (llvmpipe's interpolated texcoord is an ulp off the
     correctly rounded one: implementation-defined); everything the map passes do must then hold within the bounds of

@@ -429,3 +429,22 @@ def test_fill_in_selects_and_icp_weight(oracle_lib_built):
     assert np.array_equal(fn[hole], ln[hole]) and np.array_equal(fc1[hole], lc1[hole]) and np.array_equal(fc2[hole], lc2[hole])
     assert np.array_equal(fi[hole][:, :3], rgb[hole])
     o.close()
+
+
+def test_uv_attribute_is_the_hosts_float_double_float_formula(oracle_lib_built):
+    """GlobalModel.cpp:88-97: `((float)i / (float)width) + 1.0 / (2 * (float)width)` stored as float — a float quotient, a double
+    sum, a second rounding.  It equals the fragment shaders' (i + 0.5) / width at power-of-two sizes and differs by an ulp at 171
+    of 640 columns / 139 of 480 rows; texcoord * width is then not exactly i + 0.5 at 103 / 117 of them"""
+    import ctypes as C
+    lib = oracle_lib_built.load()
+    lib.orc_uv_attribute.restype = C.c_float; lib.orc_uv_attribute.argtypes = [C.c_int, C.c_int]
+    lib.orc_uv_fragment.restype = C.c_float; lib.orc_uv_fragment.argtypes = [C.c_int, C.c_int]
+    f = np.float32
+    expect = {640: (171, 103), 480: (139, 117), 160: (43, 26), 120: (19, 14), 256: (0, 0), 128: (0, 0)}
+    for n, (n_t, n_x) in expect.items():
+        i = np.arange(n)
+        ta = np.array([lib.orc_uv_attribute(int(k), n) for k in i], f)
+        tf = np.array([lib.orc_uv_fragment(int(k), n) for k in i], f)
+        ref_a = ((i.astype(f) / f(n)).astype(np.float64) + 1.0 / float(2 * f(n))).astype(f)   # float() : a DOUBLE reciprocal, as in the C++
+        assert np.array_equal(ta, ref_a) and np.array_equal(tf, ((i.astype(f) + f(0.5)) / f(n)).astype(f))
+        assert int((ta != tf).sum()) == n_t and int(((ta * f(n)).astype(f) != i + 0.5).sum()) == n_x, n

@@ -95,10 +95,10 @@ def test_hip_path_matches_the_executed_shaders_at_a_size_that_is_not_a_power_of_
 
 
 def test_oracle_matches_the_executed_map_passes_at_a_size_that_is_not_a_power_of_two(oracle_lib_built):
-    """160 x 120: the vertex shaders' host-computed uv attribute is an ulp off the fragment texcoord at 43 columns / 20 rows —
+    """160 x 120: the vertex shaders' host-computed uv attribute is an ulp off the fragment texcoord at 43 columns / 19 rows —
     data.vert's own normal, position and ray follow the attribute (hd_uv_attribute; found at 640 x 480)"""
     fx = R.load("qqvga_map")
-    assert len(fx["uv_cols_differ"]) == 43 and len(fx["uv_rows_differ"]) == 20
+    assert len(fx["uv_cols_differ"]) == 43 and len(fx["uv_rows_differ"]) == 19
     o = oracle_lib_built.Oracle(_nonpow2_params(fx), omp=True)
     try:
         rep = R.run_nonpow2_map(o, fx, R.Report(strict=True))
