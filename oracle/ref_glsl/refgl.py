@@ -327,7 +327,7 @@ class RefPipeline:
 
     def _cam_inv(self):
         # Eigen::Vector4f(cx, cy, 1.0 / fx, 1.0 / fy): double division, rounded to float by the Vector4f ctor
-        return np.array([self.cx, self.cy, 1.0 / self.fx, 1.0 / self.fy], np.float32)
+        return np.array([self.cx, self.cy, 1.0 / float(self.fx), 1.0 / float(self.fy)], np.float32)   # float(): numpy would divide in float32
 
     def upload_frame(self, rgb, depth):
         """HRBFFusion.cpp:1008-1010: Upload(depth, GL_LUMINANCE_INTEGER_EXT, GL_UNSIGNED_SHORT); Upload(rgb, GL_RGB, ..)."""
@@ -604,7 +604,7 @@ class RefPipeline:
 
     def predict_hrbf(self):
         """IndexMap::predictHRBF(ACTIVE) (IndexMap.cpp:413-518)."""
-        cam = np.array([self.cx, self.cy, 1.0 / self.fx, 1.0 / self.fy], np.float32)
+        cam = np.array([self.cx, self.cy, 1.0 / float(self.fx), 1.0 / float(self.fy)], np.float32)   # double division (IndexMap.cpp:451-452)
         u = [("cam", cam), ("cols", float(self.W)), ("rows", float(self.H)), ("scale", 1.0),
              ("predict_minimum_neighbors", int(self.p["predict_min_neighbors"])),
              ("predict_maximum_neighbors", int(self.p["predict_max_neighbors"])),
