@@ -652,6 +652,7 @@ struct CleanParams {
     int time;
     int nw;        // samples per axis = ceil(2 * clean_window_multiplier) (copy_unstable.vert:106-108, half-pixel steps)
     float w0;      // clean_window_multiplier * 0.5
+    float wm;      // clean_window_multiplier: the walk itself is taken literally in fp32 (hd_halfpixel_walk)
     int full_check;
     const uint8_t *submap_active;   // nullable: KeyFrameIDMap (copy_unstable.vert:98-101)
     int n_active;
@@ -681,20 +682,25 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
     const uint32_t *bits = clean_bits(clean_tex, P);
     (void)ftime;
     if (cp.nw == 4) {
-        // the 4 samples of an axis are non-decreasing with steps <= 1: values s0, s0+1, s0+2 with multiplicities.
+        // the 4 samples of an axis — 5 where the fp32-accumulated coordinate ends an ulp below the bound (hd_halfpixel_walk) — are
+        // non-decreasing with steps <= 1 over [x - 1, x + 1]: texels s0, s0+1, s0+2 with multiplicities.
         // All (<= 9) distinct texels and the three mask rows are requested in one batch, then evaluated.
-        int sxk[4], syk[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sxk[k] = clampi((int)hd_floorf(x + ((float)k * 0.5f - cp.w0)), 0, cam.W - 1);
-            syk[k] = clampi((int)hd_floorf(y + ((float)k * 0.5f - cp.w0)), 0, cam.H - 1);
+        const hd_walk wkx = hd_halfpixel_walk(x, cam.W, cp.wm), wky = hd_halfpixel_walk(y, cam.H, cp.wm);
+        int mx[3] = {0, 0, 0}, my[3] = {0, 0, 0}, sx0 = -1, sy0 = -1;
+        for (float fi = wkx.lo; fi < wkx.hi; fi += wkx.step) {
+            const int t = hd_window_texel(fi, cam.W);
+            if (sx0 < 0) sx0 = t;
+            const int d = t - sx0;
+            mx[0] += d == 0; mx[1] += d == 1; mx[2] += d == 2;
         }
-        int mx[3], my[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            mx[j] = (sxk[0] == sxk[0] + j) + (sxk[1] == sxk[0] + j) + (sxk[2] == sxk[0] + j) + (sxk[3] == sxk[0] + j);
-            my[j] = (syk[0] == syk[0] + j) + (syk[1] == syk[0] + j) + (syk[2] == syk[0] + j) + (syk[3] == syk[0] + j);
+        for (float fj = wky.lo; fj < wky.hi; fj += wky.step) {
+            const int t = hd_window_texel(fj, cam.H);
+            if (sy0 < 0) sy0 = t;
+            const int d = t - sy0;
+            my[0] += d == 0; my[1] += d == 1; my[2] += d == 2;
         }
+        if (sx0 < 0 || sy0 < 0) return true;   // an empty walk (cannot happen for a surfel in view)
+        const int sxk[1] = {sx0}, syk[1] = {sy0};
         float4 ta[9];
         uint32_t upd[3];   // bit jx of upd[jy]: the winner at (sx0 + jx, sy0 + jy) was updated this frame
 #pragma unroll
@@ -725,14 +731,15 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
             }
         return !(count > 8 || zCount > 4);
     }
+    const hd_walk wkx = hd_halfpixel_walk(x, cam.W, cp.wm), wky = hd_halfpixel_walk(y, cam.H, cp.wm);
     int prev_sx = -1, colc = 0, colz = 0;
-    for (int a = 0; a < cp.nw; ++a) {
-        const int sx = clampi((int)hd_floorf(x + ((float)a * 0.5f - cp.w0)), 0, cam.W - 1);
+    for (float fi = wkx.lo; fi < wkx.hi; fi += wkx.step) {
+        const int sx = hd_window_texel(fi, cam.W);
         if (sx != prev_sx) {
             prev_sx = sx; colc = 0; colz = 0;
             int prev_sy = -1, c1 = 0, z1 = 0;
-            for (int b = 0; b < cp.nw; ++b) {
-                const int sy = clampi((int)hd_floorf(y + ((float)b * 0.5f - cp.w0)), 0, cam.H - 1);
+            for (float fj = wky.lo; fj < wky.hi; fj += wky.step) {
+                const int sy = hd_window_texel(fj, cam.H);
                 if (sy != prev_sy) {
                     prev_sy = sy; c1 = 0; z1 = 0;
                     const int si = sy * cam.W + sx;
@@ -1319,7 +1326,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
     CleanParams cp;
     cp.cam = cam; cp.dp = dp; cp.maxDepth = maxDepth; cp.confThr = confThr; cp.curvThr = curvThr; cp.time = time;
-    cp.nw = (int)ceilf(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.full_check = full_check;
+    cp.nw = (int)ceilf(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.wm = clean_window_multiplier; cp.full_check = full_check;
     cp.submap_active = submap_active; cp.n_active = n_active;
     cp.hash_G = gid ? hash_G : 1; cp.hash_me = hash_me; cp.hash_inv_cell = hash_inv_cell;
     const uint32_t items_ub = count_ub + (uint32_t)Q;

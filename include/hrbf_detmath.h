@@ -96,6 +96,28 @@ HD_FN int hd_window_texel(float i, int n)   /* NEAREST filtering, CLAMP_TO_EDGE 
     return t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
 }
 
+/* The half-pixel walk of the clean pass around a surfel's projection x (copy_unstable.vert:85-108, scale = 1):
+ *     step = (1 / cols) * 0.5;  for (i = x / cols - step * wm; i < x / cols + step * wm; i += step)  sample texel floor(i * cols)
+ * is 2 wm samples in exact arithmetic.  In fp32 the accumulated i can end an ulp BELOW the bound, and the loop then takes one more
+ * sample — at x + wm/2, the texel to the right of the window — for roughly a third of the surfels at 640 x 480.  Rounds 1-3 called
+ * that "driver arithmetic" and kept the exact count; but every fp32 implementation takes the extra sample for SOME surfels, so the
+ * exact rule removes systematically fewer surfels than the reference does (`count > 8`, `zCount > 4`): on the 640 x 480 GPUTest
+ * frame the executed shader removes 607 outliers and the exact rule 425.  Taken literally, with IEEE division (GLSL allows a
+ * division 2.5 ulp: which individual surfels get the extra sample is implementation-defined, their share is not).
+ * Callers iterate `for (float i = w.lo; i < w.hi; i += w.step)` and take texel hd_window_texel(i, n). */
+typedef struct hd_walk { float lo, hi, step; } hd_walk;
+HD_FN hd_walk hd_halfpixel_walk(float x, int n, float wm)
+{
+    hd_walk w;
+    const float fn = (float)n;
+    w.step = (1.0f / fn) * 0.5f;
+    const float reach = w.step * wm;
+    const float c = x / fn;
+    w.lo = c - reach;
+    w.hi = c + reach;
+    return w;
+}
+
 /* Where the GL rasteriser places a 1-pixel point (IndexMap::predictIndices, index_map.vert:57-60): the shader emits the
  * normalised device coordinate (u - extent/2) / (extent/2); the fixed-function viewport transform maps it back to a
  * window coordinate, which is snapped to the sub-pixel grid (GL_SUBPIXEL_BITS = 8 on NVIDIA hardware and on Mesa,

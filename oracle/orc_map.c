@@ -232,17 +232,13 @@ static int clean_test(const orc_ctx *c, const float *tinv, f4 vp, f4 *vcol, f4 v
         active = (sm < (uint32_t)c->n_submap_active && c->submap_active[sm]) ? 1.0f : 0.0f;
     }
     if (lp.z < maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)W && y < (float)H) {
-        /* half-pixel steps over [x - w/2, x + w/2) px (copy_unstable.vert:84-108 with FACTOR = 1):
-           samples at x + (k - w)*0.5, k = 0 .. 2w-1 */
-        /* copy_unstable.vert:106-108 steps i from x - wm/2 while i < x + wm/2 in half pixels: ceil(2 wm) samples per axis in exact
-           arithmetic (the shader accumulates i in fp32 texture coordinates; whether rounding ever adds a sample there is
-           driver arithmetic and stays unpinned) */
-        int nw = (int)ceilf(2.0f * c->prm.clean_window_multiplier);
-        float w0 = c->prm.clean_window_multiplier * 0.5f;
-        for (int a = 0; a < nw; ++a) {
-            int sx = clampi((int)floorf(x + ((float)a * 0.5f - w0)), 0, W - 1);
-            for (int b = 0; b < nw; ++b) {
-                int sy = clampi((int)floorf(y + ((float)b * 0.5f - w0)), 0, H - 1);
+        /* copy_unstable.vert:85-141: the half-pixel walk, literally (hd_halfpixel_walk: an fp32-accumulated loop that takes
+           2 wm samples per axis, or one more where the accumulated coordinate ends an ulp below the bound) */
+        const hd_walk wx = hd_halfpixel_walk(x, W, c->prm.clean_window_multiplier), wy = hd_halfpixel_walk(y, H, c->prm.clean_window_multiplier);
+        for (float fi = wx.lo; fi < wx.hi; fi += wx.step) {
+            int sx = hd_window_texel(fi, W);
+            for (float fj = wy.lo; fj < wy.hi; fj += wy.step) {
+                int sy = hd_window_texel(fj, H);
                 int si = sy * W + sx;
                 uint32_t current = c->idx[si];
                 if (current > 0u) {
