@@ -411,7 +411,10 @@ def main():
         keep = ["f1_map", "f2_rgb", "f2_depth", "f2_pose", "f2_weighting", "f2_DEPTH_FILTERED", "f2_DEPTH_METRIC", "f2_DEPTH_METRIC_FILTERED",
                 "f2_VERTEX_RAW", "f2_VERTEX_FILTERED", "f2_RADIUS", "f2_NORMAL_P3", "f2_NORMAL", "f2_CURV1", "f2_CURV2", "f2_GRADIENT_MAG",
                 "f2_CONFIDENCE", "f2_a_INDEX", "f2_a_INDEX_VERTCONF", "f2_a_INDEX_NORMRAD", "f2_records", "f2_fused_rows", "f2_fused_vals",
-                "f2_c_INDEX", "f2_keep", "f2_new_picks", "f2_map_count", "f2_init_count", "f2_init_head"]
+                "f2_c_INDEX", "f2_keep", "f2_new_picks", "f2_map_count", "f2_init_count", "f2_init_head",
+                # the stable map with planted outliers / duplicates / stale surfels: the removal rules of copy_unstable.vert
+                "x_extra", "x_old", "x_a_INDEX", "x_a_INDEX_VERTCONF", "x_a_INDEX_NORMRAD", "x_records", "x_fused_rows", "x_fused_vals",
+                "x_c_INDEX", "x_keep", "x_new_picks", "x_map_count"]
         out = {k: full[k] for k in keep}
         out["geom"] = np.array(GEOM["qqvga_map"], np.float64)
         f = np.float32
@@ -422,7 +425,8 @@ def main():
         path = os.path.join(OUT, "qqvga_map.npz")
         np.savez_compressed(path, **out)
         print("qqvga_map ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "surfels", out["f1_map"].shape[0], "->", int(out["f2_map_count"][0]),
-              "merge marks", int((out["f2_records"][:, 7] == -1).sum()), "uv attribute differs at", len(out["uv_cols_differ"]), "columns /", len(out["uv_rows_differ"]), "rows")
+              "merge marks", int((out["f2_records"][:, 7] == -1).sum()), "| stable flow removed",
+              int((~np.unpackbits(out["x_keep"])[:out["f1_map"].shape[0] + out["x_extra"].shape[0]].astype(bool)).sum()), "| uv attribute differs at", len(out["uv_cols_differ"]), "columns /", len(out["uv_rows_differ"]), "rows")
         return
     if "--only-variants" in sys.argv:
         import ref_glsl_check as R

@@ -302,7 +302,9 @@ def map_flow(rep, g, fx, pre, tag, map_in, T2):
     # Association ties: a candidate whose normal is parallel to the new point's to within ~2e-4 rad has cos = 1 to within an ulp;
     # acos of 1 + ulp is NaN and rejects it (data.vert:150-152 through utils.glsl angleBetween) — which of 1 and 1 + ulp comes out
     # depends on the last bit of the division, so two executions can associate such a pixel with different neighbours (or none).
-    ties = max(2, rows.size // 400)
+    # (at sizes that are no power of two the half-pixel walk's samples on exact texel boundaries are implementation-defined as
+    # well — llvmpipe's fp32 floor lands some of them one texel low, DESIGN.md §8 — : the caller widens the allowance there)
+    ties = int(fx.get("_tie_factor", 1.0) * max(2, rows.size // 400))
     odd = np.setxor1d(ch, rows)
     rep.add(tag + "F1/F2 which surfels were merged into (%d)" % rows.size, odd.size <= 2 * ties,
             "%d surfels merged in one execution only (acos-domain ties; allowed %d)" % (odd.size, 2 * ties))
@@ -434,6 +436,7 @@ def run_nonpow2_map(impl, fx, rep):
     correctly rounded one: implementation-defined); everything the map passes do must then hold within the bounds of
     the power-of-two scenes."""
     g, P = impl, "f2_"
+    fx = dict(fx); fx["_tie_factor"] = 2.0
     T2 = fx[P + "pose"]
     g.upload_frame(fx[P + "rgb"], fx[P + "depth"])
     for name in ("DEPTH_FILTERED", "DEPTH_METRIC", "DEPTH_METRIC_FILTERED"):
@@ -448,6 +451,9 @@ def run_nonpow2_map(impl, fx, rep):
     rep.add("F4 surfel count", im.shape[0] == int(fx[P + "init_count"][0]), "%d vs reference %d" % (im.shape[0], int(fx[P + "init_count"][0])))
     rep.close_ulp("F4 confidence (exp)", im[:4096, 3], fx[P + "init_head"][:, 3], 16)
     map_flow(rep, g, fx, "f2_", "160 x 120: ", fx["f1_map"], T2)
+    # the removal rules: copy_unstable.vert's half-pixel walk is an fp32-accumulated loop that takes one more sample for about a
+    # third of the surfels (hd_halfpixel_walk) — the exact-arithmetic count removes a third fewer of the planted surfels
+    map_flow(rep, g, fx, "x_", "160 x 120, stable map + outliers: ", stable_map_with_outliers(fx), T2)
     return rep
 
 
