@@ -28,7 +28,7 @@ EXPORTS = [
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
     "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts", "hrbf_hash_owner", "hrbf_hash_renumber_count",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
-    "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
+    "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_dense_enough", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
     "hrbf_probe_single_workgroup_iteration", "hrbf_probe_sqrt_rounding", "hrbf_probe_exp_scaling", "hrbf_probe_division", "hrbf_set_fuse_ring_stride",
 ]
@@ -98,6 +98,7 @@ def load_library():
     lib.hrbf_hash_owner.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i32]; lib.hrbf_hash_renumber_count.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
     lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
+    lib.hrbf_dense_enough.argtypes = [vp, vp]
     lib.hrbf_predict_indices.argtypes = [vp, vp, i32, f32, i32]; lib.hrbf_fuse.argtypes = [vp, vp, i32, f32, i32]
     lib.hrbf_clean.argtypes = [vp, vp, i32, f32, f32]
     lib.hrbf_rebalance_plan.argtypes = [vp, i32, vp, vp, vp]
@@ -241,6 +242,12 @@ class HRBFFusion:
 
     def predict_hrbf(self):
         self._check(self.lib.hrbf_predict_hrbf(self.h))
+
+    def dense_enough(self):
+        """Resize::vertex + HRBFFusion::denseEnough on the current PRED_VERTEX image (HRBFFusion.cpp:974-988, 1069-1070)"""
+        d = C.c_int(0)
+        self._check(self.lib.hrbf_dense_enough(self.h, C.byref(d)))
+        return bool(d.value)
 
     def map_shard_init(self, enable=True, partition="ranges"):
         """cut the surfel map over the ranks of comm_init (SURVEY §8e sharding 2); the map must be empty.

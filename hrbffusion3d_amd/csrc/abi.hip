@@ -1797,6 +1797,19 @@ extern "C" int hrbf_predict_hrbf(hrbf_handle c)
     return HRBF_OK;
 }
 
+extern "C" int hrbf_dense_enough(hrbf_handle c, int *dense)
+{
+    if (!c || !dense) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
+    c->fill_flag_fresh = 1;
+    int fill = 0;
+    HIP_CHECK(hipMemcpyAsync(&fill, &c->d_pose->should_fill_in, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    *dense = !fill;
+    return HRBF_OK;
+}
+
 extern "C" int hrbf_comm_unique_id(uint8_t out128[128])
 {
     if (!out128) return HRBF_ERR_INVALID;

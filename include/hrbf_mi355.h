@@ -284,6 +284,11 @@ int hrbf_predict_indices(hrbf_handle h, const float pose16[16], int time, float 
 int hrbf_fuse(hrbf_handle h, const float pose16[16], int time, float depth_cutoff, int index_submap);
 int hrbf_clean(hrbf_handle h, const float pose16[16], int time, float conf_threshold, float max_depth);
 int hrbf_predict_hrbf(hrbf_handle h);
+/* Resize::vertex(indexMap.vertexTexHRBF(), verticesBuff) + HRBFFusion::denseEnough (Shaders/Resize.cpp:106-134, resize.frag,
+ * HRBFFusion.cpp:974-988): *dense = 1 when more than dense_enough_thresh of the (width / 20) x (height / 20) cell centres of the
+ * predicted vertex map hold a depth.  processFrame takes this decision on the device (shouldFillIn = !dense, :1069-1070);
+ * this is the reference's host-side predicate on the context's current PRED_VERTEX image. */
+int hrbf_dense_enough(hrbf_handle h, int *dense);
 int hrbf_set_tick(hrbf_handle h, int tick);
 int hrbf_set_weighting(hrbf_handle h, float w);
 

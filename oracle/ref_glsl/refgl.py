@@ -48,6 +48,8 @@ SOURCE_FIXES = [
      "index_map.vert:43,45 identifier `active` is a reserved word in GLSL 3.30 (Mesa enforces it)"),
     ("copy_unstable.vert", "active", "active_",
      "copy_unstable.vert:101,133 identifier `active` is a reserved word in GLSL 3.30"),
+    ("resize.frag", "texture2D(eSampler, texcoord.xy)", "texture(eSampler, texcoord.xy)",
+     "resize.frag:31 `texture2D` was renamed `texture` in GLSL 1.30 and is gone from the 3.30 core profile (NVIDIA still accepts it); same function"),
 ]
 
 _INC = re.compile(r'^[ \t]*#include[ \t]*"([^"]+)"[ \t]*\r?$', re.M)
@@ -615,6 +617,17 @@ class RefPipeline:
              ("icp_weight_lambda", f32(self.p["icp_curv_weight_lambda"]))]
         self._quad_pass(self.predict_prog, self.predict_fbo,
                         [self.im_index, self.im_vertconf, self.im_colortime, self.im_normrad, self.im_curvmax, self.im_curvmin], u)
+
+    def dense_thumbnail(self):
+        """Resize::vertex(indexMap.vertexTexHRBF(), verticesBuff) (Shaders/Resize.cpp:106-134, resize.frag): the predicted vertex
+        map sampled (NEAREST: vertexTextureHRBF is built with draw = false, IndexMap.cpp:85-87) at the centres of a
+        (W / consSample) x (H / consSample) grid, consSample = 20 (HRBFFusion.cpp:27-31) — what denseEnough counts."""
+        if not hasattr(self, "_resize"):
+            w, h = self.W // 20, self.H // 20
+            self._resize_tex = tex_rgba32f(self.gl, w, h)
+            self._resize = (Program(self.gl, "empty.vert", "resize.frag", "quad.geom"), Fbo(self.gl, w, h, [self._resize_tex]))
+        self._quad_pass(*self._resize, [self.pr_vertex], [("eSampler", 0)])
+        return get_f4(self._resize_tex)
 
     def prediction_images(self):
         return dict(PRED_IMAGE=get_rgba8(self.pr_image), PRED_VERTEX=get_f4(self.pr_vertex), PRED_NORMAL=get_f4(self.pr_normal),

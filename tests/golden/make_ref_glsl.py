@@ -394,8 +394,35 @@ def run_reference_nonpow2():
     return out
 
 
+THUMB_SIZES = [(640, 480), (160, 120), (256, 128), (128, 128)]
+
+
+def run_reference_thumbnail():
+    """Resize::vertex (resize.frag behind quad.geom into a (W / 20) x (H / 20) target, NEAREST) on a predicted vertex map whose
+    texels carry their own coordinates: which texel every cell of denseEnough's thumbnail reads."""
+    from ref_glsl import refgl
+    out = {"sizes": np.array(THUMB_SIZES, np.int32)}
+    for W, H in THUMB_SIZES:
+        p = refgl.RefPipeline(W, H, float(W), float(W), W / 2.0, H / 2.0, 1.0 / 5000.0, tex_dim=64, max_surfels=1024)
+        ys, xs = np.mgrid[0:H, 0:W]
+        v = np.zeros((H, W, 4), np.float32); v[..., 0] = xs; v[..., 1] = ys; v[..., 2] = 1.0; v[..., 3] = xs + ys * W
+        p.pr_vertex.upload(v)
+        t = p.dense_thumbnail()
+        assert t.shape == (H // 20, W // 20, 4) and (t[..., 2] == 1.0).all()
+        assert (t[..., 0] == t[0, :, 0][None]).all() and (t[..., 1] == t[:, 0, 1][:, None]).all()     # separable
+        assert (t[..., 3] == t[..., 0] + t[..., 1] * W).all()                                             # one texel, not a blend
+        out["sx_%dx%d" % (W, H)] = t[0, :, 0].astype(np.int32); out["sy_%dx%d" % (W, H)] = t[:, 0, 1].astype(np.int32)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-thumbnail" in sys.argv:
+        q = run_reference_thumbnail()
+        path = os.path.join(OUT, "thumbnail.npz")
+        np.savez_compressed(path, **q)
+        print("thumbnail ->", path, {k: v.tolist() for k, v in q.items() if k.startswith("sy_")})
+        return
     q = run_reference_nonpow2()
     path = os.path.join(OUT, "qqvga_pre.npz")
     np.savez_compressed(path, **q)

@@ -45,6 +45,7 @@ def load(omp=False):
     lib.orc_rgb_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_get_weighting.argtypes = [C.c_void_p]
+    lib.orc_dense_enough.argtypes = [C.c_void_p]
     lib.orc_get_weighting.restype = C.c_float
     lib.orc_surfel_count.argtypes = [C.c_void_p]
     lib.orc_surfel_count.restype = C.c_uint32
@@ -179,6 +180,9 @@ class Oracle:
         i, dt, ch = IMAGES[name]
         a = np.ascontiguousarray(a, np.dtype(dt))
         assert self.lib.orc_set_image(self.h, i, _p(a), a.nbytes) == 0
+
+    def dense_enough(self):
+        return bool(self.lib.orc_dense_enough(self.h))
 
     def last_icp(self):
         e = C.c_float(); n = C.c_float()

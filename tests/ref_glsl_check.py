@@ -512,3 +512,56 @@ def run_nonpow2_pre(impl, fx, rep):
     no, nor = g.get_image("NORMAL"), fx["NORMAL"]
     rep.close_ulp("P5 NORMAL (HRBF gradient direction)", no[..., :3][ok], nor[..., :3][ok], 64, abs_floor=4e-6)
     return rep
+
+
+# ---- Resize::vertex + denseEnough (H3) ------------------------------------------------------------------------------
+def thumbnail_cells(fx, W, H):
+    """per thumbnail column and row, the texels that contain the cell centre (i + 1/2) * W / (W / 20): one texel, or two when the
+    centre lies exactly ON a texel edge (every cell at 640 x 480) — there NEAREST picks by the rounding of the GL implementation's
+    interpolated coordinate, and llvmpipe reads the lower texel at some rows.  Asserts that the executed resize.frag read one of them."""
+    from fractions import Fraction
+    w, h = W // 20, H // 20
+    cand = []
+    for n_cells, size, key in ((w, W, "sx_%dx%d"), (h, H, "sy_%dx%d")):
+        read = fx[key % (W, H)]
+        axis = []
+        for k in range(n_cells):
+            q = Fraction(2 * k + 1, 2) * size / n_cells
+            c = (int(q) - 1, int(q)) if q.denominator == 1 else (int(q),)
+            assert int(read[k]) in c, ("the executed shader read a texel that does not contain the cell centre", key, k, int(read[k]), q)
+            axis.append(c)
+        cand.append(axis)
+    return cand[0], cand[1]
+
+
+def run_thumbnail(make, fx, rep):
+    """`make(W, H)` returns a context of that size (dense_enough_thresh = 0.75).  The images are built from the texels that contain
+    the cell centres (both texels of an edge cell are set alike, so the rounding at the edge does not enter)."""
+    for W, H in fx["sizes"]:
+        W, H = int(W), int(H)
+        cx, cy = thumbnail_cells(fx, W, H)
+        w, h = W // 20, H // 20
+        n = w * h
+        g = make(W, H)
+        try:
+            def image(cells_on, background, on=1.5):
+                v = np.zeros((H, W, 4), np.float32); v[..., 2] = background
+                for c in range(n):
+                    for y in cy[c // w]:
+                        for x in cx[c % w]:
+                            v[y, x, 2] = on if c in cells_on else 0.0
+                return v
+            k75 = (3 * n) // 4                      # per > 0.75 needs MORE than three quarters of the cells
+            tag = "H3 denseEnough %dx%d: " % (W, H)
+            order = np.random.default_rng(W).permutation(n).tolist()
+            cases = [("only the cell centres hold depth", image(set(range(n)), 0.0), True),
+                     ("everything but the cell centres holds depth", image(set(), 2.0), False),
+                     ("%d of %d cells" % (k75, n), image(set(order[:k75]), 0.0), False),
+                     ("%d of %d cells" % (k75 + 1, n), image(set(order[:k75 + 1]), 0.0), True),
+                     ("negative depth does not count", image(set(range(n)), 0.0, on=-1.5), False)]
+            for name, img, want in cases:
+                g.set_image("PRED_VERTEX", img)
+                rep.exact(tag + name, np.array([g.dense_enough()]), np.array([want]))
+        finally:
+            g.close()
+    return rep

@@ -64,6 +64,26 @@ def test_hip_path_matches_the_executed_reference_shaders(scene, gpu_available):
     assert len(rep.rows) > 60 and all(ok for _, ok, _ in rep.rows)
 
 
+def _thumb_params(W, H):
+    from hrbffusion3d_amd.params import default_params
+    return default_params(width=W, height=H, fx=float(W), fy=float(W), cx=W / 2.0, cy=H / 2.0, max_surfels=1 << 12)
+
+
+def test_oracle_dense_enough_reads_the_texels_the_executed_resize_shader_read(oracle_lib_built):
+    """Resize::vertex + denseEnough: cell size 20, NEAREST at the cell centre, z > 0, `per > 0.75`"""
+    fx = R.load("thumbnail")
+    assert [tuple(s) for s in fx["sizes"].tolist()] == [(640, 480), (160, 120), (256, 128), (128, 128)]
+    rep = R.run_thumbnail(lambda W, H: oracle_lib_built.Oracle(_thumb_params(W, H)), fx, R.Report(strict=True))
+    assert len(rep.rows) == 20 and all(ok for _, ok, _ in rep.rows)
+
+
+@pytest.mark.gpu
+def test_hip_dense_enough_reads_the_texels_the_executed_resize_shader_read(gpu_available):
+    from hrbffusion3d_amd.api import HRBFFusion
+    rep = R.run_thumbnail(lambda W, H: HRBFFusion(_thumb_params(W, H)), R.load("thumbnail"), R.Report(strict=True))
+    assert len(rep.rows) == 20 and all(ok for _, ok, _ in rep.rows)
+
+
 def _nonpow2_params(fx):
     from hrbffusion3d_amd.params import default_params
     W, H, fx_, fy_, cx, cy = fx["geom"]
@@ -161,10 +181,11 @@ def test_hip_path_matches_the_executed_shaders_under_the_references_parameter_va
 
 
 def test_glsl_harness_source_fixes_are_token_level():
-    """the harness may only respell what Mesa's compiler rejects: three spellings, no arithmetic"""
+    """the harness may only respell what Mesa's compiler rejects: four spellings, no arithmetic"""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
     from ref_glsl import refgl      # importing needs neither GL nor the reference
-    assert len(refgl.SOURCE_FIXES) == 3
+    assert len(refgl.SOURCE_FIXES) == 4
     for fname, old, new, why in refgl.SOURCE_FIXES:
-        assert fname in ("hrbfbase.glsl", "index_map.vert", "copy_unstable.vert") and why
-        assert (old, new) == ("active", "active_") or old.replace("return 0;", "return 0.0;") == new
+        assert fname in ("hrbfbase.glsl", "index_map.vert", "copy_unstable.vert", "resize.frag") and why
+        assert (old, new) == ("active", "active_") or old.replace("return 0;", "return 0.0;") == new or \
+            (fname == "resize.frag" and old.replace("texture2D(", "texture(") == new)
