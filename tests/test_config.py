@@ -122,3 +122,85 @@ def test_reference_parameter_file_matches_library_defaults():
     for k, v in kw.items():
         assert getattr(d, k) == pytest.approx(v), k       # the library's defaults ARE the reference's file
     assert len(kw) >= 22
+
+
+# ---- against the reference's OWN reader (oracle/_ref/ref_params, built from Core/src/Utils/{GlobalStateParams,parameterFile}.h) ----
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_params")
+REF_READER = os.path.join(os.path.dirname(GOLD), "..", "..", "oracle", "_ref", "ref_params")
+
+
+def _as_text(typ, v):
+    """a member as the reference's `std::cout << std::setprecision(9) << member` prints it"""
+    import numpy as np
+    if typ == "bool":
+        return str(int(bool(v)))
+    if typ == "int":
+        return str(int(v))
+    if typ == "float":
+        return "%.9g" % np.float32(v)
+    return v
+
+
+def _cases():
+    import json
+    import sys
+    sys.path.insert(0, GOLD)
+    import cases
+    with open(os.path.join(GOLD, "expected.json")) as f:
+        return cases.FILES, json.load(f)
+
+
+def test_parameter_readers_agree_with_the_reference_reader(tmp_path):
+    """every member the reference's reader fills from a file with unusual spellings (`TRUE`, `yes`, `7.9` / `0x10` / `12abc` / `1e2` as
+    ints, `1,5`, `2.5f`, single quotes, unquoted strings, `=` inside a value) and an unusual layout (two statements on a line, repeated
+    keys, missing `;`, unterminated quote, CRLF, tabs, keys in another case) — hrbffusion3d_amd/config.py and include/hrbf_io.h
+    (through tools/hrbf_run --dump-params) read the same value."""
+    import subprocess
+    files, exp = _cases()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "hrbf_dump")
+    from hrbffusion3d_amd import build
+    so = build.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "hrbf_run.cpp"), "-o", exe, so, "-lz",
+                           "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+    checked = 0
+    for name, txt in files.items():
+        path = str(tmp_path / (name + ".txt"))
+        with open(path, "w", newline="") as f:
+            f.write(txt)
+        g = hcfg.load_global_state(path)
+        out = subprocess.run([exe, "--dump-params", "--config", path], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        cpp = {}
+        for line in out.stdout.split("\n"):
+            if "\t" in line:
+                n, v = line.split("\t", 1)
+                cpp[n] = v[1:-1] if v.endswith("]") else v[1:]
+        assert len(exp[name]) >= 18
+        for member, (typ, want) in exp[name].items():
+            if member in g:
+                assert _as_text(typ, g[member]) == want, (name, member, "python")
+                checked += 1
+            if member in cpp:
+                assert cpp[member] == want, (name, member, "c++")
+                checked += 1
+        if os.path.exists(REF_READER):      # the fixture is what the reference's reader prints today
+            import sys
+            sys.path.insert(0, os.path.dirname(GOLD))
+            import make_ref_params as M
+            ref = M.run_reference_reader(path)
+            assert {n: list(tv) for n, tv in ref.items() if n in exp[name]} == exp[name]
+    assert checked >= 110
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference tree exists only in the build container")
+def test_shipped_parameter_file_read_like_the_reference_reader_reads_it():
+    _, exp = _cases()
+    g = hcfg.load_global_state(REF)
+    want = exp["shipped GUI/GlobalStateParam.txt"]
+    n = 0
+    for member, (typ, text) in want.items():
+        if member in g:
+            assert _as_text(typ, g[member]) == text, member
+            n += 1
+    assert n >= 40

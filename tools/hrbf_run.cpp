@@ -46,18 +46,41 @@ int main(int argc, char **argv)
 {
     std::string config, dataDir, cameraFile, out, ply;
     int maxFrames = 0, maxSurfels = 4 * 1024 * 1024;
-    bool selftest = false;
+    bool selftest = false, dumpParams = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "--config") config = next(); else if (a == "--data-dir") dataDir = next(); else if (a == "--camera") cameraFile = next();
         else if (a == "--out") out = next(); else if (a == "--ply") ply = next(); else if (a == "--max-frames") maxFrames = atoi(next().c_str());
         else if (a == "--max-surfels") maxSurfels = atoi(next().c_str()); else if (a == "--selftest") selftest = true;
+        else if (a == "--dump-params") dumpParams = true;
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (config.empty()) { fprintf(stderr, "usage: hrbf_run --config GlobalStateParam.txt [--data-dir D] [--camera Y] [--max-frames N] [--out T] [--ply P]\n"); return 2; }
     try {
         const GlobalState g = GlobalState::fromFile(config);
+        if (dumpParams) {   // every member as read, one "name<TAB>[value]" per line (compared with the reference's own reader in tests/test_config.py)
+#define D_S(n) printf("%s\t[%s]\n", #n, g.n.c_str());
+#define D_I(n) printf("%s\t[%d]\n", #n, (int)g.n);
+#define D_F(n) printf("%s\t[%.9g]\n", #n, (double)g.n);
+            D_S(currentWorkingDirectory) D_I(sensorType) D_S(klgFileName) D_S(AssociationFile) D_S(parameterFileCvFormat)
+            D_I(optimizationUseLocalBA) D_I(optimizationUseGlobalBA) D_I(preprocessingUsebilateralFilter)
+            D_F(preprocessingInitRadiusMultiplier) D_F(preprocessingCurvEstimationWindow) D_F(preprocessingCurvValidThreshold)
+            D_F(preprocessingNormalEstimationPCA) D_I(preprocessingUseConfEval) D_F(preprocessingConfEvalEpsilon)
+            D_I(registrationPreAlignSO3) D_F(registrationJointICPWeight) D_I(registrationICPUseSparseICP)
+            D_I(registrationICPUseCoorespondenceSearch) D_I(registrationICPNeighborSearchRadius) D_I(registrationICPUseWeightedICP)
+            D_F(registrationICPCurvWeightImpactControl) D_I(registrationColorUseRGBGrad) D_F(preictionWindowMultiplier)
+            D_I(preictionMinNeighbors) D_I(preictionMaxNeighbors) D_F(preictionConfThreshold) D_F(fusionCleanWindowMultiplier)
+            D_F(globalConfidenceThreshold) D_F(globalDenseEnoughThresh) D_F(globalDepthCutoff) D_I(globalInputICLNUIMDataset)
+            D_I(globalInputLoadTrajectory) D_S(globalInputTrajectoryFormat) D_S(globalInputTrajectoryFile)
+            D_F(globalOutputSavePointCloudConfThreshold) D_I(globalStartFrame) D_I(globalEndFrame) D_I(globalFrameToSkip)
+            D_F(registrationICPErrorThreshold) D_F(registrationICPCovarianceThreshold) D_F(registrationColorPhotoThreshold)
+            D_I(globalOutputSaveTrjectoryFile) D_S(globalOutputSaveTrjectoryFileType)
+#undef D_S
+#undef D_I
+#undef D_F
+            return 0;
+        }
         const std::string base = dataDir.empty() ? dirOf(config) : dataDir;
         if (cameraFile.empty()) cameraFile = resolve(g, g.parameterFileCvFormat, base);
         const CameraFile cam = CameraFile::fromFile(cameraFile);
