@@ -14,8 +14,7 @@
  *                                      non-interlaced; the five PNG filters; inflate by zlib
  *   KlgReader                          sensorType 2, the .klg raw log (GUI/src/Tools/RawLogReader.cpp:3-140): int32 frame
  *                                      count; per frame int64 timestamp, int32 depthSize, int32 imageSize, depth raw or
- *                                      zlib, colour raw (JPEG colour needs libjpeg headers, absent from this image: the
- *                                      reader reports it instead of guessing)
+ *                                      zlib, colour raw or JPEG (hrbf_jpeg.h: libjpeg's default decode written out, bit for bit)
  *
  * The Python twins live in hrbffusion3d_amd/config.py and hrbffusion3d_amd/io.py; tests/test_cpp_io.py checks the two
  * against each other.  Nothing here touches the GPU.
@@ -36,6 +35,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include "hrbf_jpeg.h"
 
 namespace hrbf_mi355 {
 
@@ -458,7 +458,11 @@ public:
         }
         out.rgb.assign(n * 3, 0);
         if ((size_t)isz == n * 3) std::memcpy(out.rgb.data(), im.data(), n * 3);
-        else if (isz > 0) throw std::runtime_error("klg: JPEG-compressed colour needs libjpeg (headers absent here); re-write the log with raw colour");
+        else if (isz > 0) {   /* JPEG colour (GUI/src/Tools/RawLogReader.cpp -> JPEGLoader.h:46-97): libjpeg's default decode, written out in hrbf_jpeg.h */
+            int jw = 0, jh = 0;
+            out.rgb = JpegDecoder::decodeRGB(im.data(), im.size(), jw, jh);
+            if (jw != W_ || jh != H_) throw std::runtime_error("klg: the JPEG frame is not W x H");
+        }
         if (flip_) for (size_t i = 0; i < n; ++i) std::swap(out.rgb[3 * i], out.rgb[3 * i + 2]);
     }
 private:

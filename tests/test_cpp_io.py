@@ -49,7 +49,7 @@ def _build(tmp):
     return exe
 
 
-def _write_sequence(d, W, H, K, n, sensor):
+def _write_sequence(d, W, H, K, n, sensor, jpeg_quality=None):
     from PIL import Image
     from hrbffusion3d_amd.io import write_klg
     frames = [synth.frame(k, W, H, noise=True, K=K) for k in range(n)]
@@ -61,7 +61,7 @@ def _write_sequence(d, W, H, K, n, sensor):
             Image.fromarray(rgb, "RGB").save(os.path.join(d, "rgb", "%04d.png" % k))
             Image.fromarray(dep).save(os.path.join(d, "depth", "%04d.png" % k))       # 16-bit grey ("I;16")
             f.write("%.6f depth/%04d.png %.6f rgb/%04d.png\n" % (t, k, t, k))
-    write_klg(os.path.join(d, "seq.klg"), [(k * 33333, f[0], f[1]) for k, f in enumerate(frames)], compress_depth=True)
+    write_klg(os.path.join(d, "seq.klg"), [(k * 33333, f[0], f[1]) for k, f in enumerate(frames)], compress_depth=True, jpeg_quality=jpeg_quality)
     with open(os.path.join(d, "cam.yaml"), "w") as f:
         f.write("%%YAML:1.0\n# camera\nCamera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.width: %d\nCamera.height: %d\n"
                 "Camera.RGB: 1\nDepthMapFactor: 5000.0\n" % (K[0], K[1], K[2], K[3], W, H))
@@ -91,6 +91,68 @@ def test_cpp_readers_agree_with_the_python_ones(tmp_path, sensor):
     # the first frame, decoded in C++ (own PNG decoder / zlib), equals the arrays the files were written from
     assert j["rgb_fnv"] == _fnv(frames[0][0].tobytes()) and j["depth_fnv"] == _fnv(frames[0][1].tobytes())
     assert j["timestamp0"] == (int(round(1305031102.175304 * 1e6)) if sensor == 3 else 0)
+
+
+def test_cpp_klg_reader_decodes_jpeg_colour_like_libjpeg(tmp_path):
+    """a .klg log with JPEG colour frames, as Logger2 writes them and RawLogReader reads them through libjpeg (JPEGLoader.h:46-97):
+    the first frame decoded by include/hrbf_jpeg.h equals the Python reader's (Pillow = libjpeg-turbo) byte for byte"""
+    from hrbffusion3d_amd.io import KlgReader
+    exe = _build(str(tmp_path))
+    W, H = 160, 120
+    _write_sequence(str(tmp_path), W, H, (129.325, 129.125, 79.65, 63.825), 3, 2, jpeg_quality=90)
+    out = subprocess.run([exe, "--selftest", "--config", str(tmp_path / "GlobalStateParam.txt")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    j = json.loads(out.stdout)
+    r = KlgReader(str(tmp_path / "seq.klg"), W, H)
+    _, rgb, depth = r.read_frame(0)
+    assert j["frames"] == 3 and j["rgb_fnv"] == _fnv(np.ascontiguousarray(rgb).tobytes()) and j["depth_fnv"] == _fnv(np.ascontiguousarray(depth).tobytes())
+
+
+def test_cpp_jpeg_decoder_is_libjpeg_bit_for_bit(tmp_path, png_pair):
+    """include/hrbf_jpeg.h against Pillow (libjpeg-turbo, the same defaults as the reference's JPEGLoader: islow IDCT, fancy upsampling):
+    every pixel of every case equal — 4:4:4 / 4:2:2 / 4:2:0, qualities 30-100, optimised Huffman tables, restart markers, greyscale,
+    sizes that are not multiples of the MCU, widths whose chroma has <= 2 columns (libjpeg then replicates instead of filtering)"""
+    import io
+    from PIL import Image
+    exe = str(tmp_path / "jpeg_decode")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "jpeg_decode.cpp"), "-o", exe])
+    rng = np.random.default_rng(1)
+    images = [("photo", np.ascontiguousarray(png_pair[0][0][..., :3])), ("synth", synth.frame(3, 320, 240, noise=True)[0]),
+              ("noise", rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)), ("odd", np.ascontiguousarray(png_pair[1][0][3:124, 5:166, :3])),
+              ("1x1", rng.integers(0, 256, (1, 1, 3), dtype=np.uint8))]
+    images += [("w%d" % w, rng.integers(0, 256, (w + 2, w, 3), dtype=np.uint8)) for w in (2, 3, 4, 5, 6, 7, 9, 16, 17)]
+    images.append(("saturated", np.stack([np.tile(np.array([0, 255], np.uint8), (64, 32)), np.tile(np.array([[255], [0]], np.uint8), (32, 64)),
+                                          np.full((64, 64), 255, np.uint8)], -1)))
+
+    def decode(data):
+        f = tmp_path / "t.jpg"
+        f.write_bytes(data)
+        o = subprocess.run([exe, str(f)], capture_output=True, timeout=60)
+        assert o.returncode == 0, o.stderr
+        hdr, raw = o.stdout.split(b"\n", 1)
+        w, h = map(int, hdr.split())
+        return np.frombuffer(raw, np.uint8).reshape(h, w, 3)
+    n = 0
+    for name, img in images:
+        big = img.shape[0] * img.shape[1] > 100000
+        for sub in (0, 1, 2):
+            for q, extra in ((75, {}),) if big else ((30, {}), (75, {"optimize": True}), (95, {"restart_marker_blocks": 3}), (100, {"restart_marker_rows": 1})):
+                b = io.BytesIO()
+                Image.fromarray(img).save(b, format="JPEG", quality=q, subsampling=sub, **extra)
+                ref = np.array(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))
+                got = decode(b.getvalue())
+                assert got.shape == ref.shape and (got == ref).all(), (name, sub, q, extra)
+                n += 1
+        b = io.BytesIO()
+        Image.fromarray(np.array(Image.fromarray(img).convert("L"))).save(b, format="JPEG", quality=80)
+        assert (decode(b.getvalue()) == np.array(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))).all(), (name, "grey")
+        n += 1
+    assert n >= 170
+    b = io.BytesIO()
+    Image.fromarray(images[2][1]).save(b, format="JPEG", progressive=True)
+    (tmp_path / "p.jpg").write_bytes(b.getvalue())
+    o = subprocess.run([exe, str(tmp_path / "p.jpg")], capture_output=True, timeout=60)
+    assert o.returncode == 1 and b"progressive" in o.stderr       # said, not guessed
 
 
 def test_cpp_png_decoder_on_the_reference_fixture(tmp_path, png_pair):
