@@ -361,6 +361,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(1 + Wm, 1 + Wm + K):
         fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), k)
+    t_enqueued = time.perf_counter() - t0       # the host has submitted every frame; the device may still be working
     fus.synchronize(); torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
 
@@ -483,6 +484,7 @@ def main():
                                       else ("%d virtual %s map shards on one GPU" % (args.virtual_shards, "hash-owned" if args.partition == "hash" else "contiguous")) if args.virtual_shards > 1
                                       else ("replicas x%d" % world if world > 1 else "single GPU"),
                        "final_translation_error_mm": err_mm, "pcie_inclusive_fps": pcie_fps,
+                       "host_submit_ms_per_frame": 1e3 * t_enqueued / K,
                        "cpp_shim": shim,
                        "update_model": update_model,
                        "last_frame_region_ms": {"Initialization": float(tm[0]), "Registration": float(tm[1]),
