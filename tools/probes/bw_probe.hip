@@ -66,6 +66,32 @@ __global__ __launch_bounds__(512) void k_copy_tile_planes(const float4 *__restri
         }
     }
 }
+// V4 (round 3): the in-place left shift of pass B — record i + S moves to i inside ONE buffer — record-major (every lane moves its
+// record through the five planes, what k_fuse_stream does) against plane-major (the grid finishes plane 0, then plane 1, ...: two
+// streams at a time).  Bandwidth only: no hazard protocol (S is far larger than what the grid holds in flight).
+template <int IPT>
+__global__ __launch_bounds__(512) void k_shift_record_major(float4 *__restrict__ a, size_t n, size_t plane, size_t S)
+{
+    for (size_t base = (size_t)blockIdx.x * 512 * IPT; base + S < n; base += (size_t)gridDim.x * 512 * IPT) {
+        float4 v[IPT][5];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) for (int q = 0; q < 5; ++q) v[k][q] = a[q * plane + i + S]; }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) for (int q = 0; q < 5; ++q) a[q * plane + i] = v[k][q]; }
+    }
+}
+template <int IPT>
+__global__ __launch_bounds__(512) void k_shift_plane_major(float4 *__restrict__ a, size_t n, size_t plane, size_t S)
+{
+    for (int q = 0; q < 5; ++q)
+        for (size_t base = (size_t)blockIdx.x * 512 * IPT; base + S < n; base += (size_t)gridDim.x * 512 * IPT) {
+            float4 v[IPT];
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) v[k] = a[q * plane + i + S]; }
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) a[q * plane + i] = v[k]; }
+        }
+}
 int main(int argc, char **argv)
 {
     size_t n = argc > 1 ? atoll(argv[1]) : 4343735;
@@ -109,6 +135,17 @@ int main(int argc, char **argv)
     timeit("flat U8 blocks=1024", n * 160.0, [&] { hipLaunchKernelGGL((k_copy_flat<8, false>), dim3(1024), dim3(256), 0, 0, a, b, n * 5); });
     for (int blocks : {256, 512, 1024})
         timeit(("tile2048 planes blocks=" + std::to_string(blocks)).c_str(), n * 160.0, [&] { hipLaunchKernelGGL(k_copy_tile_planes<2048>, dim3(blocks), dim3(512), 0, 0, a, b, n, n); });
+    {
+        const size_t S = 200000;
+        const double bytes = (double)(n - S) * 160.0;
+        for (int blocks : {256, 512, 1024}) {
+            timeit(("shift record-major ipt1 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_record_major<1>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift record-major ipt4 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_record_major<4>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift plane-major  ipt1 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_plane_major<1>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift plane-major  ipt4 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_plane_major<4>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift plane-major  ipt8 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_plane_major<8>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+        }
+    }
     timeit("hipMemcpyDtoD 5 planes", n * 160.0, [&] { hipMemcpyAsync(b, a, n * 80, hipMemcpyDeviceToDevice, 0); });
     return 0;
 }
