@@ -634,14 +634,16 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_apply_merges(int Q, int tick,
 //    writer polls tile_done of the tiles its output range overlaps.  tile_done never waits on
 //    another tile's writes, so there is no serial chain.
 #ifndef FUSE_THREADS
-#define FUSE_THREADS 512
+#define FUSE_THREADS 1024
 #endif
 #ifndef FUSE_WAVES_PER_EU   // register budget of pass B (second __launch_bounds__ argument of hipcc = waves per SIMD)
-#define FUSE_WAVES_PER_EU 3
+#define FUSE_WAVES_PER_EU 4
 #endif
 // workgroups of pass B per CU: while one waits for its loads another one stores
 #define FUSE_WG_PER_CU ((FUSE_WAVES_PER_EU * 4) / (FUSE_THREADS / 64) > 0 ? (FUSE_WAVES_PER_EU * 4) / (FUSE_THREADS / 64) : 1)
-#define FUSE_IPT 4   // the move path below is written out for exactly 4 items per thread
+#ifndef FUSE_IPT
+#define FUSE_IPT 1   // items per thread and tile
+#endif
 #define FUSE_TILE (FUSE_THREADS * FUSE_IPT)
 #define TC_STRIDE 32   // one tile counter per 128-byte line: wave atomics of different tiles never share a line
 
@@ -982,6 +984,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
     // atomics are serialised at the memory side (~8 ns each) and one per wave and tile made the pass atomic-bound
     uint32_t acc_appended = 0, acc_moved = 0;
     for (;;) {
+        // (the next ticket drawn one tile ahead, so that the draw travels under this tile's loads, measured slower twice: with 4 items
+        //  per lane in round 2, with 1 item per lane in round 3 — 34.5 vs 32.2 us headline, 176 vs 172 us at 4.3 M surfels)
         if (threadIdx.x == 0) s_ticket = atomicAdd(&stats[5], 1u);
         __syncthreads();
         const uint32_t tile = first + s_ticket;
@@ -1013,32 +1017,31 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
             __syncthreads();   // s_ticket / s_psum reuse
             continue;
         }
-        MoveSlot s0, s1, s2, s3;
-        s0.it = base + threadIdx.x; s1.it = s0.it + FUSE_THREADS; s2.it = s1.it + FUSE_THREADS; s3.it = s2.it + FUSE_THREADS;
-        s0.keep = s0.it < total && keep_flags[s0.it] != 0; s1.keep = s1.it < total && keep_flags[s1.it] != 0;
-        s2.keep = s2.it < total && keep_flags[s2.it] != 0; s3.keep = s3.it < total && keep_flags[s3.it] != 0;
+        // FUSE_IPT slots, written out by a macro list: an array of MoveSlot went to scratch (64 B / lane) and cost 30 us at 4.3 M surfels
+#if FUSE_IPT == 1
+#define FUSE_SLOTS(X) X(0)
+#elif FUSE_IPT == 2
+#define FUSE_SLOTS(X) X(0) X(1)
+#elif FUSE_IPT == 4
+#define FUSE_SLOTS(X) X(0) X(1) X(2) X(3)
+#else
+#error "FUSE_IPT must be 1, 2 or 4"
+#endif
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned long long b0 = __ballot(s0.keep), b1 = __ballot(s1.keep), b2 = __ballot(s2.keep), b3 = __ballot(s3.keep);
-        if (lane == 0) {
-            s_wcnt[0][wid] = (uint32_t)__popcll(b0); s_wcnt[1][wid] = (uint32_t)__popcll(b1);
-            s_wcnt[2][wid] = (uint32_t)__popcll(b2); s_wcnt[3][wid] = (uint32_t)__popcll(b3);
-        }
+#define X(k) MoveSlot s##k; s##k.it = base + (uint32_t)(k) * FUSE_THREADS + threadIdx.x; s##k.keep = s##k.it < total && keep_flags[s##k.it] != 0; \
+             const unsigned long long b##k = __ballot(s##k.keep); if (lane == 0) s_wcnt[k][wid] = (uint32_t)__popcll(b##k);
+        FUSE_SLOTS(X)
+#undef X
         __syncthreads();
         {   // item order inside the tile: k-major, then wave, then lane
-            uint32_t run = prefix, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o0 = run; run += s_wcnt[0][w]; }
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o1 = run; run += s_wcnt[1][w]; }
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o2 = run; run += s_wcnt[2][w]; }
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) { if (w == wid) o3 = run; run += s_wcnt[3][w]; }
-            s0.o = o0 + (uint32_t)__popcll(b0 & lt); s1.o = o1 + (uint32_t)__popcll(b1 & lt);
-            s2.o = o2 + (uint32_t)__popcll(b2 & lt); s3.o = o3 + (uint32_t)__popcll(b3 & lt);
+            uint32_t run = prefix;
+#define X(k) { uint32_t o = 0; _Pragma("unroll") for (int w = 0; w < NWAVE; ++w) { if (w == wid) o = run; run += s_wcnt[k][w]; } s##k.o = o + (uint32_t)__popcll(b##k & lt); }
+            FUSE_SLOTS(X)
+#undef X
         }
-        move_load(s0, m, rec, N, ftime, gid, g_base); move_load(s1, m, rec, N, ftime, gid, g_base);
-        move_load(s2, m, rec, N, ftime, gid, g_base); move_load(s3, m, rec, N, ftime, gid, g_base);
+#define X(k) move_load(s##k, m, rec, N, ftime, gid, g_base);
+        FUSE_SLOTS(X)
+#undef X
         // every load this tile will ever issue on the map has returned -> publish tile_done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1060,17 +1063,18 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_WAVES_PER_EU) void k_fuse_stream
             }
         }
         __syncthreads();
-        acc_appended += move_store(s0, m, N, cap, gid) + move_store(s1, m, N, cap, gid) + move_store(s2, m, N, cap, gid) +
-                        move_store(s3, m, N, cap, gid);
+#define X(k) acc_appended += move_store(s##k, m, N, cap, gid);
+        FUSE_SLOTS(X)
+#undef X
         if (base + FUSE_TILE > N && rec_flag_rearm) {   // the lanes that handled records re-arm the record flags
-            if (s0.it >= N && s0.it < total) rec_flag_rearm[s0.it - N] = 0;
-            if (s1.it >= N && s1.it < total) rec_flag_rearm[s1.it - N] = 0;
-            if (s2.it >= N && s2.it < total) rec_flag_rearm[s2.it - N] = 0;
-            if (s3.it >= N && s3.it < total) rec_flag_rearm[s3.it - N] = 0;
+#define X(k) if (s##k.it >= N && s##k.it < total) rec_flag_rearm[s##k.it - N] = 0;
+            FUSE_SLOTS(X)
+#undef X
         }
         // statistics: surfels that really changed slot (real traffic = 160 B each)
-        acc_moved += (uint32_t)(s0.keep && s0.it < N && s0.o != s0.it) + (uint32_t)(s1.keep && s1.it < N && s1.o != s1.it) +
-                     (uint32_t)(s2.keep && s2.it < N && s2.o != s2.it) + (uint32_t)(s3.keep && s3.it < N && s3.o != s3.it);
+#define X(k) acc_moved += (uint32_t)(s##k.keep && s##k.it < N && s##k.o != s##k.it);
+        FUSE_SLOTS(X)
+#undef X
         __syncthreads();   // s_wcnt / s_psum / s_ticket reuse
     }
     // one atomic per workgroup and statistic (s_psum / s_first are free again: every path above ended with a barrier)

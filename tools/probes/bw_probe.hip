@@ -80,6 +80,33 @@ __global__ __launch_bounds__(512) void k_shift_record_major(float4 *__restrict__
         for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) for (int q = 0; q < 5; ++q) a[q * plane + i] = v[k][q]; }
     }
 }
+// the same record-major tile, but the 5 x IPT loads of a lane issued plane by plane (IPT consecutive KB of one plane per wave, then
+// the next plane) instead of record by record; SPLIT: loads and stores of one plane back to back (plane-major inside the tile)
+template <int IPT, bool SPLIT>
+__global__ __launch_bounds__(512) void k_shift_tile_plane_order(float4 *__restrict__ a, size_t n, size_t plane, size_t S)
+{
+    for (size_t base = (size_t)blockIdx.x * 512 * IPT; base + S < n; base += (size_t)gridDim.x * 512 * IPT) {
+        float4 v[5][IPT];
+        if (!SPLIT) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) v[q][k] = a[q * plane + i + S]; }
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) a[q * plane + i] = v[q][k]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) v[q][k] = a[q * plane + i + S]; }
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) { size_t i = base + k * 512 + threadIdx.x; if (i + S < n) a[q * plane + i] = v[q][k]; }
+            }
+        }
+    }
+}
 template <int IPT>
 __global__ __launch_bounds__(512) void k_shift_plane_major(float4 *__restrict__ a, size_t n, size_t plane, size_t S)
 {
@@ -141,6 +168,10 @@ int main(int argc, char **argv)
         for (int blocks : {256, 512, 1024}) {
             timeit(("shift record-major ipt1 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_record_major<1>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
             timeit(("shift record-major ipt4 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_record_major<4>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift tile plane-order ipt4 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL((k_shift_tile_plane_order<4, false>), dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift tile plane-split ipt4 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL((k_shift_tile_plane_order<4, true>), dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift tile plane-order ipt2 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL((k_shift_tile_plane_order<2, false>), dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
+            timeit(("shift record-major ipt2 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_record_major<2>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
             timeit(("shift plane-major  ipt1 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_plane_major<1>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
             timeit(("shift plane-major  ipt4 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_plane_major<4>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
             timeit(("shift plane-major  ipt8 b=" + std::to_string(blocks)).c_str(), bytes, [&] { hipLaunchKernelGGL(k_shift_plane_major<8>, dim3(blocks), dim3(512), 0, 0, a, n, n, S); });
