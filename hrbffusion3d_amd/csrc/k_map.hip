@@ -1343,7 +1343,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     if (Q > 0) fblocks += quarter_tile_blocks(cam.W, cam.H);   // ... behind the record workgroups
     hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
                        keep_flags, tile_count, stats);
-    // any grid size is safe (ticketed tiles); one 512-thread workgroup per CU keeps every CU's load/store pipes busy
+    // any grid size is safe (ticketed tiles); one FUSE_THREADS-thread workgroup per CU, one item per lane (more loads in
+    // flight per lane cost bandwidth on this part)
     uint32_t blocks = tiles < 256u * FUSE_WG_PER_CU ? tiles : 256u * FUSE_WG_PER_CU;
     if (blocks == 0) blocks = 1;
     const size_t lds = sizeof(uint32_t) * (size_t)(tiles ? tiles : 1);
