@@ -94,6 +94,7 @@ private:
                 if (u8() != 8) fail("only 8-bit samples are supported");
                 H_ = u16(); W_ = u16(); nc_ = u8();
                 if (W_ <= 0 || H_ <= 0) fail("empty image");
+                if ((long long)W_ * H_ > (1ll << 26)) fail("image larger than 64 M pixels");
                 if (nc_ != 1 && nc_ != 3) fail("only greyscale and YCbCr files are supported");
                 for (int i = 0; i < nc_; ++i) {
                     c_[i].id = u8(); const int hv = u8(); c_[i].h = hv >> 4; c_[i].v = hv & 15; c_[i].tq = u8();
@@ -142,6 +143,7 @@ private:
         for (int l = 1; l <= 16; ++l) {
             h.valptr[l] = k; h.mincode[l] = code;
             for (int i = 0; i < h.bits[l]; ++i) { codes[k] = (uint16_t)code; sizes[k] = (uint8_t)l; ++k; ++code; }
+            if (code > (1 << l)) fail("bad Huffman table");     /* more codes of this length than the length can hold */
             h.maxcode[l] = h.bits[l] ? code - 1 : -1;
             code <<= 1;
         }
@@ -223,8 +225,8 @@ private:
                             std::memset(coef, 0, sizeof(coef));
                             int s = decodeHuff(dc_[c.td]);
                             if (s > 11) fail("bad DC size");
-                            c.pred += s ? extend(getBits(s), s) : 0;
-                            coef[0] = c.pred * qt_[c.tq][0];
+                            c.pred = (int)((unsigned)c.pred + (unsigned)(s ? extend(getBits(s), s) : 0));
+                            coef[0] = (int)((long long)c.pred * qt_[c.tq][0]);
                             for (int k = 1; k < 64;) {
                                 const int rs = decodeHuff(ac_[c.ta]);
                                 const int r = rs >> 4; s = rs & 15;
@@ -242,36 +244,37 @@ private:
             }
     }
 
-    static inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
-    static inline uint8_t clampSample(int x) { x += 128; return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); }
+    typedef long long wide;   /* libjpeg's JLONG: the products of a damaged file must not overflow (undefined behaviour in 32 bits) */
+    static inline wide descale(wide x, int n) { return (x + ((wide)1 << (n - 1))) >> n; }
+    static inline uint8_t clampSample(wide x) { x += 128; return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); }
 
     /* jidctint.c jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2, on already dequantised coefficients */
     static void idctIslow(const int *in, uint8_t *out, int stride)
     {
         enum { CB = 13, P1 = 2 };
-        const int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
-                  F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+        const wide F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+                   F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
         int ws[64];
         for (int pass = 0; pass < 2; ++pass)
             for (int k = 0; k < 8; ++k) {
-                int i0, i1, i2, i3, i4, i5, i6, i7;
+                wide i0, i1, i2, i3, i4, i5, i6, i7;
                 if (pass == 0) { i0 = in[k]; i1 = in[8 + k]; i2 = in[16 + k]; i3 = in[24 + k]; i4 = in[32 + k]; i5 = in[40 + k]; i6 = in[48 + k]; i7 = in[56 + k]; }
                 else { const int *w = ws + 8 * k; i0 = w[0]; i1 = w[1]; i2 = w[2]; i3 = w[3]; i4 = w[4]; i5 = w[5]; i6 = w[6]; i7 = w[7]; }
-                int z1 = (i2 + i6) * F0_541;
-                const int t2 = z1 + i6 * (-F1_847), t3 = z1 + i2 * F0_765;
-                const int t0 = (int)((unsigned)(i0 + i4) << CB), t1 = (int)((unsigned)(i0 - i4) << CB);
-                const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-                int o0 = i7, o1 = i5, o2 = i3, o3 = i1;
-                z1 = o0 + o3; int z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
-                const int z5 = (z3 + z4) * F1_175;
+                wide z1 = (i2 + i6) * F0_541;
+                const wide t2 = z1 + i6 * (-F1_847), t3 = z1 + i2 * F0_765;
+                const wide t0 = (i0 + i4) * ((wide)1 << CB), t1 = (i0 - i4) * ((wide)1 << CB);
+                const wide t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+                wide o0 = i7, o1 = i5, o2 = i3, o3 = i1;
+                z1 = o0 + o3; wide z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
+                const wide z5 = (z3 + z4) * F1_175;
                 o0 *= F0_298; o1 *= F2_053; o2 *= F3_072; o3 *= F1_501;
                 z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
                 z3 += z5; z4 += z5;
                 o0 += z1 + z3; o1 += z2 + z4; o2 += z2 + z3; o3 += z1 + z4;
                 if (pass == 0) {
                     const int n = CB - P1;
-                    ws[k] = descale(t10 + o3, n); ws[56 + k] = descale(t10 - o3, n); ws[8 + k] = descale(t11 + o2, n); ws[48 + k] = descale(t11 - o2, n);
-                    ws[16 + k] = descale(t12 + o1, n); ws[40 + k] = descale(t12 - o1, n); ws[24 + k] = descale(t13 + o0, n); ws[32 + k] = descale(t13 - o0, n);
+                    ws[k] = (int)descale(t10 + o3, n); ws[56 + k] = (int)descale(t10 - o3, n); ws[8 + k] = (int)descale(t11 + o2, n); ws[48 + k] = (int)descale(t11 - o2, n);
+                    ws[16 + k] = (int)descale(t12 + o1, n); ws[40 + k] = (int)descale(t12 - o1, n); ws[24 + k] = (int)descale(t13 + o0, n); ws[32 + k] = (int)descale(t13 - o0, n);
                 } else {
                     const int n = CB + P1 + 3;
                     uint8_t *o = out + (size_t)k * stride;

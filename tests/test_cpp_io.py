@@ -155,6 +155,44 @@ def test_cpp_jpeg_decoder_is_libjpeg_bit_for_bit(tmp_path, png_pair):
     assert o.returncode == 1 and b"progressive" in o.stderr       # said, not guessed
 
 
+def test_cpp_jpeg_decoder_survives_damaged_files(tmp_path):
+    """a .klg log is an external file: truncated, bit-flipped and spliced JPEG payloads end in an exception (exit 1) or in some image
+    (exit 0), never in a memory error or undefined behaviour — the decoder built with -fsanitize=address,undefined"""
+    import io
+    from PIL import Image
+    exe = str(tmp_path / "jpeg_decode_san")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "jpeg_decode.cpp"), "-o", exe])
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    seeds = []
+    for sub in (0, 1, 2):
+        for extra in ({}, {"restart_marker_blocks": 2}, {"optimize": True}):
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, format="JPEG", quality=80, subsampling=sub, **extra)
+            seeds.append(b.getvalue())
+    outcomes = {0: 0, 1: 0}
+    for it in range(320):
+        d = bytearray(seeds[it % len(seeds)])
+        mode = it % 4
+        if mode == 0:
+            d = d[:rng.integers(2, len(d))]
+        elif mode == 1:
+            for _ in range(rng.integers(1, 6)):
+                d[rng.integers(0, len(d))] = rng.integers(0, 256)
+        elif mode == 2:
+            d[rng.integers(2, min(len(d), 700))] = rng.integers(0, 256)       # the tables and the frame header
+        else:
+            a = rng.integers(0, len(d))
+            del d[a:rng.integers(a, min(len(d), a + 40))]
+        f = tmp_path / "f.jpg"
+        f.write_bytes(bytes(d))
+        o = subprocess.run([exe, str(f)], capture_output=True, timeout=60)
+        assert o.returncode in (0, 1) and b"Sanitizer" not in o.stderr and b"runtime error" not in o.stderr, (it, mode, o.stderr[-400:])
+        outcomes[o.returncode] += 1
+    assert outcomes[0] > 20 and outcomes[1] > 20        # both ends of the contract were exercised
+
+
 def test_cpp_png_decoder_on_the_reference_fixture(tmp_path, png_pair):
     """the reference's GPUTest PNGs (RGB 8-bit, grey 16-bit; written by another encoder, other filter choices)"""
     exe = _build(str(tmp_path))
