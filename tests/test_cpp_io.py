@@ -193,6 +193,53 @@ def test_cpp_jpeg_decoder_survives_damaged_files(tmp_path):
     assert outcomes[0] > 20 and outcomes[1] > 20        # both ends of the contract were exercised
 
 
+def test_cpp_readers_survive_damaged_files(tmp_path):
+    """every file the caller loop opens — PNG frames, the .klg log (raw and JPEG colour), the association file, the camera YAML, the
+    parameter file — truncated, bit-flipped and spliced: hrbf_run --selftest (built with -fsanitize=address,undefined) ends with exit
+    0, 1 or 2 and no sanitizer report"""
+    from hrbffusion3d_amd import build
+    so = build.build()
+    exe = str(tmp_path / "hrbf_run_san")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "hrbf_run.cpp"), "-o", exe, so, "-lz", "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    W, H = 160, 120
+    dirs = {}
+    for sensor, jq in ((3, None), (2, None), (2, 85)):
+        sd = tmp_path / ("s%d_%s" % (sensor, jq))
+        sd.mkdir()
+        _write_sequence(str(sd), W, H, (129.325, 129.125, 79.65, 63.825), 2, sensor, jpeg_quality=jq)
+        dirs[(sensor, jq)] = sd
+    rng = np.random.default_rng(3)
+    seen = {}
+    for key, name in (((3, None), "depth/0000.png"), ((3, None), "rgb/0000.png"), ((2, None), "seq.klg"), ((2, 85), "seq.klg"),
+                      ((3, None), "associations.txt"), ((3, None), "cam.yaml"), ((3, None), "GlobalStateParam.txt")):
+        sd = dirs[key]
+        path = sd / name
+        orig = path.read_bytes()
+        cmd = [exe, "--selftest", "--config", str(sd / "GlobalStateParam.txt")]
+        assert subprocess.run(cmd, capture_output=True, timeout=60, env=env).returncode == 0
+        for it in range(28):
+            b = bytearray(orig)
+            mode = it % 4
+            if mode == 0:
+                b = b[:rng.integers(0, len(b))]
+            elif mode == 1:
+                for _ in range(rng.integers(1, 5)):
+                    b[rng.integers(0, len(b))] = rng.integers(0, 256)
+            elif mode == 2:
+                b[rng.integers(0, min(len(b), 120))] = rng.integers(0, 256)
+            else:
+                a = rng.integers(0, len(b))
+                del b[a:rng.integers(a, min(len(b), a + 30))]
+            path.write_bytes(bytes(b))
+            o = subprocess.run(cmd, capture_output=True, timeout=60, env=env)
+            assert o.returncode in (0, 1, 2) and b"Sanitizer" not in o.stderr and b"runtime error" not in o.stderr, (name, it, mode, o.stderr[-400:])
+            seen[o.returncode] = seen.get(o.returncode, 0) + 1
+        path.write_bytes(orig)
+    assert seen.get(0, 0) > 10 and seen.get(1, 0) > 10
+
+
 def test_cpp_png_decoder_on_the_reference_fixture(tmp_path, png_pair):
     """the reference's GPUTest PNGs (RGB 8-bit, grey 16-bit; written by another encoder, other filter choices)"""
     exe = _build(str(tmp_path))
