@@ -1348,7 +1348,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     uint32_t blocks = tiles < 256u * FUSE_WG_PER_CU ? tiles : 256u * FUSE_WG_PER_CU;
     if (blocks == 0) blocks = 1;
     const size_t lds = sizeof(uint32_t) * (size_t)(tiles ? tiles : 1);
-    // maps beyond ~25 M surfels per shard need more than the default 48 KB of dynamic LDS.  The attribute belongs to the current
+    // maps beyond ~12 M surfels per shard need more than the default 48 KB of dynamic LDS (one word per 1024-item tile; the part allows a
+    // workgroup all 160 KiB: ~41 M surfels per shard, beyond which the launch fails and the frame reports HRBF_ERR_DEVICE).  The attribute belongs to the current
     // DEVICE's copy of the function, so it is set whenever it is needed (a process-wide "already raised" flag skipped it for a
     // second context on another device, whose launch then failed): a host-side call per frame, only for such maps
     if (lds > 48 * 1024)
