@@ -381,6 +381,24 @@ __host__ __device__ inline uint32_t quarter_tile_blocks(int W, int H)
     return (tiles + 3u) / 4u;
 }
 
+// Which of the texels {p-1, p, p+1} (clamped to the image) one axis of data.vert's half-pixel walk visits (data.vert:108-138):
+//     step = (1 / (cols * scale)) * 0.5;  for (i = tc - scale * step * 2; i < tc + scale * step * 2; i += step)  texel floor(fl(i * cols))
+// accumulated in fp32 from the uv attribute tc.  Exact arithmetic visits all three; in fp32 the sample at p + 1/2 lands in texel p
+// at about a fifth of the columns of a 640-wide image and, unless the loop then takes a fifth sample, texel p+1 is never looked at.
+// bit a = texel clamp(p + a - 1) is visited.
+__device__ __forceinline__ int assoc_axis_mask(float tc, int n, int p)
+{
+    const float step = (1.0f / ((float)n * 1.0f)) * 0.5f;
+    const float hi = tc + (1.0f * step * 2.0f);
+    int m = 0;
+    for (float i = tc - (1.0f * step * 2.0f); i < hi; i += step) {
+        const int t = hd_window_texel(i, n);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) m |= (t == clampi(p + a - 1, 0, n - 1)) << a;
+    }
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------
 // F1: data association (data.vert:63-198) over the quarter grid; record q = (px/2)*(H/2) + py/2
 // preserves the reference's column-major draw order among active pixels.
@@ -496,13 +514,15 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
             f3 ray = mk3(xl, yl, 1.0f);
             float lray = len3(ray);
             float lnl = len3(nl);
-            // The reference walks a 4x4 half-pixel grid (data.vert:108-160) = offsets {-1, 0, 0, +1} per axis.  A texel
-            // met a second time offers the same distance and `dist < bestDist` is strict, so revisits (and the extra
-            // ones border clamping creates) never change anything: the 9 distinct texels in first-visit order (x outer,
-            // y inner) give the same result.  All 9 + 9 + 9 loads are issued before the first test.
+            // The reference walks a half-pixel grid (data.vert:108-160) whose samples fall in the texels {-1, 0, +1} of each axis —
+            // those the fp32 walk actually reaches (assoc_axis_mask).  A texel met a second time offers the same distance and
+            // `dist < bestDist` is strict, so revisits (and the extra ones border clamping creates) never change anything: the
+            // visited texels in first-visit order (x outer, y inner) give the same result.  All 9 + 9 + 9 loads are issued before
+            // the first test.
+            const int mx = assoc_axis_mask(hd_uv_attribute(px, cam.W), cam.W, px), my = assoc_axis_mask(hd_uv_attribute(py, cam.H), cam.H, py);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const uint32_t current = cur[t];
+                const uint32_t current = ((mx >> (t / 3)) & (my >> (t % 3)) & 1) ? cur[t] : 0u;
                 if (current > 0u) {
                     const float4 vcf = vcf9[t];
                     if (hd_fabsf((vcf.z * lambda) - (vl.z * lambda)) < 0.05f) {

@@ -116,14 +116,15 @@ __global__ __launch_bounds__(256) void k_filter_metric(Cam cam, const uint16_t *
         int tx = i % TW, ty = i / TW;
         int gx = bx + tx - R, gy = by + ty - R;
         float v = 0.0f;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = (float)raw[gy * W + gx] / adj;
+        // a tap's coordinate float(c) / n sits ON the texel's edge; NEAREST reads texel floor(fl(fl(c / n) * n)) (hd_tap_texel:
+        // c - 1 at 7 rows of a 480-high image, c everywhere at 640) — the tile holds what the taps read
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = (float)raw[hd_tap_texel(gy, H) * W + hd_tap_texel(gx, W)] / adj;
         tile[i] = v;
     }
     __syncthreads();
     const int x = bx + threadIdx.x, y = by + threadIdx.y;
     if (x >= W || y >= H) return;
-    const int lx = threadIdx.x + R, ly = threadIdx.y + R;
-    const float value = tile[ly * TW + lx];
+    const float value = (float)raw[y * W + x] / adj;   // the centre is read at the pixel's own texcoord (depth_bilateral.frag:20)
     float out;
     if (value > maxD * 1000.0f || value < 300.0f) out = 0.0f;
     else {

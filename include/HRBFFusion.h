@@ -260,6 +260,17 @@ public:
     }
 };
 
+/* What callers read of the reference's frame-to-model odometry object (Core/src/Utils/RGBDOdometry.h:124-125): two public
+   floats, `getFrameToModel().lastICPError` / `.lastICPCount` (GUI/src/HRBF_fusion.cpp:285-295).  Here they mirror
+   hrbf_last_icp(): HRBFFusion::getFrameToModel() refreshes them (a blocking read of the last finished frame's residual
+   record) and hands out the object, so the caller's lines compile and behave unchanged. */
+class RGBDOdometry {
+public:
+    RGBDOdometry() : lastICPError(0.0f), lastICPCount(0.0f) {}
+    float lastICPError;   // sqrt(residual[0]) / residual[1] of the last ICP iteration (RGBDOdometry.cpp:1135)
+    float lastICPCount;   // residual[1]: number of inlier correspondences (RGBDOdometry.cpp:1136)
+};
+
 class HRBFFusion {
 public:
     HRBFFusion(int width, int height, float fx, float fy, float cx, float cy, float depthScale,
@@ -394,8 +405,10 @@ public:
     void setTick(const int &val) { hrbf_set_tick(h_, val); }
     GlobalModel &getGlobalModel() { return *model_; }
     IndexMap &getIndexMap() { return *index_; }
-    float lastICPError() { float e, c; hrbf_last_icp(h_, &e, &c); return e; }
-    float lastICPCount() { float e, c; hrbf_last_icp(h_, &e, &c); return c; }
+    /* Core/src/HRBFFusion.h:217 */
+    RGBDOdometry &getFrameToModel() { hrbf_last_icp(h_, &frame_to_model_.lastICPError, &frame_to_model_.lastICPCount); return frame_to_model_; }
+    float lastICPError() { return getFrameToModel().lastICPError; }
+    float lastICPCount() { return getFrameToModel().lastICPCount; }
     /* setters applied every GUI frame (GUI/src/HRBF_fusion.cpp:448-456) */
     void setRgbOnly(const bool &val) { hrbf_set_rgb_only(h_, val); }
     void setIcpWeight(const float &val) { hrbf_set_icp_weight(h_, val); }
@@ -463,6 +476,7 @@ private:
     GlobalModel *model_;
     IndexMap *index_;
     Pose curr_;
+    RGBDOdometry frame_to_model_;
     bool load_trajectory_;
     std::vector<bool> pushes_;   // per processed frame: does it contribute to trajectory_manager->poses
     uint32_t synced_;            // frames already folded into trajectory_manager->poses
@@ -478,5 +492,6 @@ using hrbf_mi355::GlobalStateParam;
 using hrbf_mi355::Intrinsics;
 using hrbf_mi355::ParameterFile;
 using hrbf_mi355::Resolution;
+using hrbf_mi355::RGBDOdometry;
 #endif
 #endif

@@ -96,6 +96,14 @@ HD_FN int hd_window_texel(float i, int n)   /* NEAREST filtering, CLAMP_TO_EDGE 
     return t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
 }
 
+/* The texel a NEAREST lookup at texture coordinate float(c) / n reads (depth_bilateral.frag:51-54 and depth_guass.frag: the taps of
+ * the depth filters sit exactly ON a texel's left / upper edge): floor(fl(fl(c / n) * n)).  That is c wherever the fp32 product
+ * rounds back to c — everywhere at 640, 512, 256 ... — and c - 1 where it stays below: rows {63, 125, 126, 127, 250, 252, 254} of a
+ * 480-high image, row 63 of a 120-high one.  Both rasterisers the image has (Mesa llvmpipe and softpipe, independent code for
+ * texture addressing) execute exactly this; rounds 1-3 read texel c ("what a fixed-point texture unit yields") and differed from
+ * the executed shaders within +-6 rows of those. */
+HD_FN int hd_tap_texel(int c, int n) { return hd_window_texel((float)c / (float)n, n); }
+
 /* The half-pixel walk of the clean pass around a surfel's projection x (copy_unstable.vert:85-108, scale = 1):
  *     step = (1 / cols) * 0.5;  for (i = x / cols - step * wm; i < x / cols + step * wm; i += step)  sample texel floor(i * cols)
  * is 2 wm samples in exact arithmetic.  In fp32 the accumulated i can end an ulp BELOW the bound, and the loop then takes one more

@@ -55,6 +55,7 @@ typedef struct orc_ctx {
     /* preprocessing images */
     float *depth_filtered, *depth_metric, *depth_metric_filtered;
     f4 *vertex_raw, *vertex_filtered, *normal, *normal_pca, *normal_opt, *curv1, *curv2;
+    float *frag_tc;   /* test hook (orc_set_fragment_texcoords): the rasteriser's interpolated texcoord per pixel, or NULL = correctly rounded */
     float *radius, *gradmag, *confidence;
     /* index map */
     uint32_t *idx;
@@ -113,6 +114,7 @@ void orc_set_active_submaps(orc_ctx *c, const uint8_t *active, int n);   /* n = 
 /* GlobalModel::updateModel (GlobalModel.cpp:690-767 -> update_delta_trans.vert:41-104) */
 void orc_update_model(orc_ctx *c, const float *delta16_colmajor, int n);
 void orc_set_weighting(orc_ctx *c, float w);
+int orc_set_fragment_texcoords(orc_ctx *c, const float *tc);   /* test hook, see orc_ctx.c */
 float orc_get_weighting(orc_ctx *c);
 uint32_t orc_surfel_count(orc_ctx *c);
 int orc_download_map(orc_ctx *c, float *out, size_t cap);

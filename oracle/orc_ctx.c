@@ -86,7 +86,7 @@ orc_ctx *orc_create(const hrbf_params *p)
 void orc_destroy(orc_ctx *c)
 {
     if (!c) return;
-    free(c->submap_active);
+    free(c->submap_active); free(c->frag_tc);
     free(c->rgb); free(c->depth_raw); free(c->depth_filtered); free(c->depth_metric); free(c->depth_metric_filtered);
     free(c->vertex_raw); free(c->vertex_filtered); free(c->normal); free(c->normal_pca); free(c->normal_opt);
     free(c->curv1); free(c->curv2); free(c->im_vertconf); free(c->im_colortime); free(c->im_normrad);
@@ -314,6 +314,20 @@ int orc_set_image(orc_ctx *c, int which, const void *in, size_t bytes)
     memcpy(p, in, b); return 0;
 }
 
+/* TEST HOOK.  The fragment shaders' `texcoord` is a varying the rasteriser interpolates over the full-screen quad; how it rounds
+   is the GL implementation's (llvmpipe: an ulp off the correctly rounded (p + 0.5) / n at 85 % of the pixels of a 640 x 480 target,
+   softpipe: at other pixels).  The oracle takes it correctly rounded; with the coordinates a rasteriser actually produced handed in
+   here (H x W x 2 floats, NULL to go back) P3 / P4 must reproduce that rasteriser's execution of the shaders at EVERY pixel
+   (tests/test_ref_glsl.py, 640 x 480). */
+int orc_set_fragment_texcoords(orc_ctx *c, const float *tc)
+{
+    free(c->frag_tc); c->frag_tc = NULL;
+    if (!tc) return 0;
+    c->frag_tc = (float *)malloc(sizeof(float) * 2 * (size_t)c->P);
+    if (!c->frag_tc) return -1;
+    memcpy(c->frag_tc, tc, sizeof(float) * 2 * (size_t)c->P);
+    return 0;
+}
 float orc_uv_attribute(int p, int n) { return hd_uv_attribute(p, n); }
 float orc_uv_fragment(int p, int n) { return hd_uv_fragment(p, n); }
 float orc_expf(float x) { return hd_expf(x); }

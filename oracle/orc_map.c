@@ -148,10 +148,19 @@ void orc_fuse(orc_ctx *c)
             float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
             f3 ray = v3(xl, yl, 1.0f);
             float lray = len3(ray);
-            static const int offs[4] = {-1, 0, 0, 1};   /* half-pixel steps under exact floor() */
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) {
-                    int sx = clampi(px + offs[a], 0, W - 1), sy = clampi(py + offs[b], 0, H - 1);
+            /* data.vert:108-138, literally: indexXStep = (1 / (cols * scale)) * 0.5, scale = 1, windowMultiplier = 2;
+                   for (i = texcoord.x - scale * indexXStep * windowMultiplier; i < texcoord.x + ...; i += indexXStep), same in j —
+               half-pixel steps accumulated in fp32 from the uv attribute; every other sample sits ON a texel edge and NEAREST
+               reads texel floor(fl(i * cols)) (hd_window_texel).  In exact arithmetic that is {p-1, p, p, p+1} per axis (what
+               rounds 1-3 walked); in fp32 the sample at p + 1/2 lands in texel p for about a fifth of the columns of a 640-wide
+               image, and unless the accumulated i ends an ulp below the bound (a fifth sample, at p + 1) texel p+1 is never
+               visited.  Both rasterisers of the image execute it this way. */
+            const float stepx = (1.0f / ((float)W * 1.0f)) * 0.5f, stepy = (1.0f / ((float)H * 1.0f)) * 0.5f;
+            const float tcx = hd_uv_attribute(px, W), tcy = hd_uv_attribute(py, H);
+            const float ihi = tcx + (1.0f * stepx * 2.0f), jhi = tcy + (1.0f * stepy * 2.0f);
+            for (float wi = tcx - (1.0f * stepx * 2.0f); wi < ihi; wi += stepx)
+                for (float wj = tcy - (1.0f * stepy * 2.0f); wj < jhi; wj += stepy) {
+                    int sx = hd_window_texel(wi, W), sy = hd_window_texel(wj, H);
                     int si = sy * W + sx;
                     uint32_t current = c->idx[si];
                     if (current > 0u) {

@@ -35,7 +35,9 @@ void orc_filter_depth(orc_ctx *c)
                 float sum1 = 0.0f, sum2 = 0.0f;
                 for (int cy = (y - D / 2 > 0 ? y - D / 2 : 0); cy < ty; ++cy)
                     for (int cx = (x - D / 2 > 0 ? x - D / 2 : 0); cx < tx; ++cx) {
-                        float tmp = (float)c->depth_raw[cy * W + cx] / adj;
+                        /* depth_bilateral.frag:51-54: texture(gSampler, vec2(float(cx) / cols, float(cy) / rows)), NEAREST — a
+                           coordinate exactly ON the texel's edge; the texel is floor(fl(fl(c / n) * n)) (hd_tap_texel) */
+                        float tmp = (float)c->depth_raw[hd_tap_texel(cy, H) * W + hd_tap_texel(cx, W)] / adj;
                         float dx = (float)x - (float)cx, dy = (float)y - (float)cy;
                         float space2 = dx * dx + dy * dy;
                         float dv = value - tmp;
@@ -52,7 +54,7 @@ void orc_filter_depth(orc_ctx *c)
                 float sum1 = 0.0f, sum2 = 0.0f;
                 for (int cy = (y - D / 2 > 0 ? y - D / 2 : 0); cy < ty; ++cy)
                     for (int cx = (x - D / 2 > 0 ? x - D / 2 : 0); cx < tx; ++cx) {
-                        float tmp = (float)c->depth_raw[cy * W + cx] / adj;
+                        float tmp = (float)c->depth_raw[hd_tap_texel(cy, H) * W + hd_tap_texel(cx, W)] / adj;   /* depth_guass.frag:54-58 */
                         if (tmp > 300.0f && fabsf(tmp - value) < 100.0f) {
                             float dx = (float)x - (float)cx, dy = (float)y - (float)cy;
                             float weight = hd_expf(-((dx * dx + dy * dy) / (2.0f * 3.0f * 3.0f)));
@@ -275,7 +277,7 @@ void orc_vertex_normal_radius(orc_ctx *c)
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
             int i = py * W + px;
-            const float tfx = hd_uv_fragment(px, W), tfy = hd_uv_fragment(py, H);
+            const float tfx = c->frag_tc ? c->frag_tc[2 * i] : hd_uv_fragment(px, W), tfy = c->frag_tc ? c->frag_tc[2 * i + 1] : hd_uv_fragment(py, H);
             float x = tfx * (float)W, y = tfy * (float)H;     /* texcoord * cols: p + 0.5 up to an ulp where the size is no power of two */
             float zr = c->depth_metric[i], zf = c->depth_metric_filtered[i];
             f3 vr = v3(((float)px - cx) * zr * camz, ((float)py - cy) * zr * camw, zr);
@@ -318,8 +320,8 @@ void orc_curvature(orc_ctx *c)
                 f4 vc[100], nr[100];
                 int n = 0;
                 /* depth_curvature_gradient.frag:48-73: the float-stepped window, literally (hd_window_axis) */
-                const hd_window wx = hd_window_axis(px, W, c->prm.curv_estimation_window);
-                const hd_window wy = hd_window_axis(py, H, c->prm.curv_estimation_window);
+                const hd_window wx = hd_window_axis_t(c->frag_tc ? c->frag_tc[2 * i] : hd_uv_fragment(px, W), W, c->prm.curv_estimation_window);
+                const hd_window wy = hd_window_axis_t(c->frag_tc ? c->frag_tc[2 * i + 1] : hd_uv_fragment(py, H), H, c->prm.curv_estimation_window);
                 for (float fi = wx.lo; fi <= wx.hi; fi += wx.step) {
                     const int ix = hd_window_texel(fi, W);
                     for (float fj = wy.lo; fj <= wy.hi; fj += wy.step) {

@@ -1,7 +1,7 @@
 // The reference's caller, against this library with only the #include changed.
 //
 // The statements between the BEGIN/END marks are the library-facing statements of MainController's constructor and run()
-// (GUI/src/HRBF_fusion.cpp:35-54,87-100,174-181,190-239,470-497) in their order and spelling: parameter file ->
+// (GUI/src/HRBF_fusion.cpp:35-54,87-100,174-181,190-239,283-297,470-497) in their order and spelling: parameter file ->
 // GlobalStateParam, camera file -> Resolution / Intrinsics, the defaults read back from GlobalStateParam, `new HRBFFusion(...)`
 // with the reference's eight arguments, the start / skip / processFrame sequence, the getters the GUI polls, the export
 // calls.  What is NOT the reference's text: OpenCV's FileStorage (absent here) is replaced by hrbf_mi355::CameraFile, the log
@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <limits>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -33,6 +35,15 @@ struct SyntheticLogReader {   // stands in for RawImageLogReader: rgb / depth / 
         currentFrame++;
     }
     void fastForward(int frame) { currentFrame = frame; }
+};
+
+// stands in for the Pangolin widgets the polled lines write to (GUI/src/Tools/GUI.h): a text variable, a button, a data log
+struct TextVar { std::string s; TextVar &Ref() { return *this; } void Set(const std::string &v) { s = v; } };
+struct Button { bool on; bool Get() const { return on; } };
+struct DataLog { std::vector<float> v, t; void Log(float a, float b) { v.push_back(a); t.push_back(b); } };
+struct GuiStandIn {
+    TextVar inliers_, res_, *trackInliers, *trackRes; Button start_, *start; DataLog resLog, inLog;
+    GuiStandIn() : trackInliers(&inliers_), trackRes(&res_), start_{true}, start(&start_) {}
 };
 
 int main(int argc, char **argv)
@@ -123,6 +134,27 @@ int main(int argc, char **argv)
     hrbfFusion->setIcpWeight(icp);
     hrbfFusion->setSo3(so3);
     hrbfFusion->setFrameToFrameRGB(frameToFrameRGB);
+    GuiStandIn gui_, *gui = &gui_;
+    bool aStep = false;
+    // ---- BEGIN: MainController::run, the tracking read-outs (GUI/src/HRBF_fusion.cpp:283-297) ----------------------------------
+        //Tracking inliers in histgram
+        std::stringstream stri;
+        stri << hrbfFusion->getFrameToModel().lastICPCount;
+        gui->trackInliers->Ref().Set(stri.str());
+        //Tracking ICP error in histgram.
+        std::stringstream stre;
+
+        stre << (std::isnan(hrbfFusion->getFrameToModel().lastICPError) ? 0 : hrbfFusion->getFrameToModel().lastICPError);
+        gui->trackRes->Ref().Set(stre.str());
+
+        if(gui->start->Get()|| aStep) {
+            gui->resLog.Log((std::isnan(hrbfFusion->getFrameToModel().lastICPError) ? std::numeric_limits<float>::max() : hrbfFusion->getFrameToModel().lastICPError), icpErrThresh);
+            gui->inLog.Log(hrbfFusion->getFrameToModel().lastICPCount, icpCountThresh);
+            aStep = false;         
+        }
+    // ---- END ---------------------------------------------------------------------------------------------------------------
+    printf("read-outs: inliers '%s' error '%s' logged %g / %g\n", gui->inliers_.s.c_str(), gui->res_.s.c_str(), gui->resLog.v[0], gui->inLog.v[0]);
+    if (!(gui->inLog.v[0] > 1000.0f) || !(gui->resLog.v[0] > 0.0f && gui->resLog.v[0] < 1e-2f) || gui->inLog.v[0] != hrbfFusion->lastICPCount()) return 22;
     const float *currPose = hrbfFusion->getCurrPoseData();
     printf("tick %d surfels %u icp error %g count %g pose t = %g %g %g\n", hrbfFusion->getTick(), hrbfFusion->getGlobalModel().lastCount(),
            hrbfFusion->lastICPError(), hrbfFusion->lastICPCount(), currPose[12], currPose[13], currPose[14]);

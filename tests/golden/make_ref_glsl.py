@@ -6,7 +6,8 @@ calls the reference's host code makes.  The fixtures are data: per pass, the inp
 surfel buffers the shaders wrote.  tests/test_ref_glsl.py feeds the same inputs to the C oracle (CPU suite) and to the
 HIP library (GPU suite) and compares.
 
-    python tests/golden/make_ref_glsl.py            # writes the fixtures
+    python tests/golden/make_ref_glsl.py            # writes the power-of-two fixtures
+    python tests/golden/make_ref_glsl.py --vga-fixture  # the whole GPUTest pair at 640 x 480 (vga.npz, coded by tests/ref_glsl_vga.py)
     python tests/golden/make_ref_glsl.py --vga-report   # what differs between the two executions at 640 x 480, and why
     python tests/ref_glsl_report.py oracle|hip           # per-pass comparison of an implementation with the fixtures
 
@@ -198,6 +199,7 @@ def run_reference(scene, f1, f2, T2, w2, prm_over=None):
     D[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
     D[:3, 3] = [0.01, -0.02, 0.005]
     p.update_model([D]); out["x_delta"] = D; out["x_map_updated_head"] = p.download_map()[:4096]
+    out["tc"] = interpolated_texcoords(p)
     # initialise from frame 2's images at pose T2 (GlobalModel::initialise takes any init_pose)
     p.initialise(T2)
     im = p.download_map()
@@ -341,6 +343,29 @@ def fp32_window_counts(n, tc, win=3.0):
     return np.array(out)
 
 
+def interpolated_texcoords(p):
+    """the texture coordinate the rasteriser interpolates for every pixel of the full-screen quad (a fragment shader that writes
+    it, behind the reference's quad.geom)"""
+    import ctypes as C
+    from ref_glsl import refgl, glbind as G
+    gl, W, H = p.gl, p.W, p.H
+    src = b"#version 330 core\nin vec2 texcoord; out vec4 o; void main(){ o = vec4(texcoord, 0.0, 1.0); }\n"
+    pid = gl.glCreateProgram()
+    for kind, text in ((G.GL_VERTEX_SHADER, refgl.shader_source("empty.vert").encode()), (G.GL_GEOMETRY_SHADER, refgl.shader_source("quad.geom").encode()),
+                       (G.GL_FRAGMENT_SHADER, src)):
+        sid = gl.glCreateShader(kind); b = C.c_char_p(text); gl.glShaderSource(sid, 1, C.byref(b), None); gl.glCompileShader(sid); gl.glAttachShader(pid, sid)
+    gl.glLinkProgram(pid)
+
+    class P:
+        def bind(self): gl.glUseProgram(pid)
+        def unbind(self): gl.glUseProgram(0)
+        def set(self, k, v): pass
+    t = refgl.tex_rgba32f(gl, W, H)
+    p._quad_pass(P(), refgl.Fbo(gl, W, H, [t]), [], [])
+    tc = refgl.get_f4(t)
+    return np.ascontiguousarray(tc[..., :2])      # (H, W, 2); NOT separable in general: the two triangles of the strip are set up separately
+
+
 def run_reference_nonpow2():
     """P1-P5 at 160 x 120 — NOT a power of two: here the float-stepped window loops of getNormalPCA and the curvature pass take 6
     instead of 7 samples at 88 of the 160 columns and 17 of the 120 rows, and 4 rows of the bilateral filter's taps land a texel
@@ -366,22 +391,8 @@ def run_reference_nonpow2():
     p.compute_curvature_gradient()
     out["CURV1"], out["CURV2"], out["GRADIENT_MAG"] = p.get("PRINCIPAL_CURV1"), p.get("PRINCIPAL_CURV2"), p.get("GRADIENT_MAG")
     p.update_normal_rad(); out["NORMAL"] = p.get("NORMAL")
-    # the interpolated texture coordinate of every pixel (a fragment shader that writes it, behind the reference's quad.geom)
-    gl = p.gl
-    src = b"#version 330 core\nin vec2 texcoord; out vec4 o; void main(){ o = vec4(texcoord, 0.0, 1.0); }\n"
-    pid = gl.glCreateProgram()
-    for kind, text in ((G.GL_VERTEX_SHADER, refgl.shader_source("empty.vert").encode()), (G.GL_GEOMETRY_SHADER, refgl.shader_source("quad.geom").encode()),
-                       (G.GL_FRAGMENT_SHADER, src)):
-        sid = gl.glCreateShader(kind); b = C.c_char_p(text); gl.glShaderSource(sid, 1, C.byref(b), None); gl.glCompileShader(sid); gl.glAttachShader(pid, sid)
-    gl.glLinkProgram(pid)
-
-    class P:
-        def bind(self): gl.glUseProgram(pid)
-        def unbind(self): gl.glUseProgram(0)
-        def set(self, k, v): pass
-    t = refgl.tex_rgba32f(gl, W, H)
-    p._quad_pass(P(), refgl.Fbo(gl, W, H, [t]), [], [])
-    tc = refgl.get_f4(t)
+    tc = interpolated_texcoords(p)
+    assert (tc[..., 0] == tc[0, :, 0][None, :]).all() and (tc[..., 1] == tc[:, 0, 1][:, None]).all()     # separable at this size
     out["tc_x"], out["tc_y"] = tc[0, :, 0].copy(), tc[:, 0, 1].copy()
     f = np.float32
     ideal_x = ((np.arange(W, dtype=f) + f(0.5)) / f(W)).astype(f); ideal_y = ((np.arange(H, dtype=f) + f(0.5)) / f(H)).astype(f)
@@ -589,8 +600,59 @@ def qqvga_variants_report():
         print("%s: %d map-pass checks, %d outside the bounds of the power-of-two fixtures %s" % (kw, len(rows), len(bad), bad))
 
 
+def vga_inputs():
+    """the whole GPUTest pair at 640 x 480 and the pose / weighting the oracle's registration finds for frame 2"""
+    from oracle_lib import Oracle
+    f1 = (np.array(Image.open(os.path.join(HERE, "1c.png"))), np.array(Image.open(os.path.join(HERE, "1d.png"))))
+    f2 = (np.array(Image.open(os.path.join(HERE, "2c.png"))), np.array(Image.open(os.path.join(HERE, "2d.png"))))
+    o = Oracle(params("vga"), omp=True)
+    o.process_frame(*f1); o.process_frame(*f2)
+    T2, w2 = o.get_pose().astype(np.float32), float(o.get_weighting())
+    o.close()
+    return f1, f2, T2, w2
+
+
+def dump_vga(path):
+    """the full, unreduced output of every pass at 640 x 480 (hundreds of MB: scratch, never committed)"""
+    from ref_glsl import refgl
+    f1, f2, T2, w2 = vga_inputs()
+    fx = run_reference("vga", f1, f2, T2, w2)
+    from ref_glsl import glbind as G
+    fx["renderer"] = np.array(G.GL(compat=True).glGetString(G.GL_RENDERER).decode())     # glh_init is idempotent: the run's context
+    print("GL_RENDERER:", fx["renderer"])
+    np.savez(path, **fx)
+    print("vga dump ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6))
+
+
+def vga_fixture():
+    """tests/golden/ref_glsl/vga.npz: every pass on the WHOLE GPUTest pair at 640 x 480 (the benchmark's resolution), coded
+    losslessly by tests/ref_glsl_vga.py (177 MB of arrays -> tens of MB: most are exact functions of the others)."""
+    import ref_glsl_vga as V
+    from ref_glsl import glbind as G
+    f1, f2, T2, w2 = vga_inputs()
+    fx = run_reference("vga", f1, f2, T2, w2)
+    renderer = G.GL(compat=True).glGetString(G.GL_RENDERER).decode()
+    path = os.path.join(OUT, "vga.npz")
+    sizes = V.encode(fx, path, {"renderer": renderer, "scene": "GPUTest 1c/1d -> 2c/2d, 640 x 480, K = (528, 528, 320, 240), pose of frame 2 from the oracle's registration"})
+    kinds = {}
+    for k, (kind, sz, nb, _) in sizes.items():
+        a = kinds.setdefault(kind, [0, 0, 0]); a[0] += 1; a[1] += sz; a[2] += nb
+    print("vga ->", path, "%.1f MB on" % (os.path.getsize(path) / 1e6), renderer, "|", ", ".join("%s: %d arrays, %.1f MB stored for %.1f MB" % (k, v[0], v[1] / 1e6, v[2] / 1e6) for k, v in kinds.items()))
+    back = V.decode(path)
+    for k, v in back.items():
+        if k != "_info":
+            assert np.array_equal(np.ascontiguousarray(v).view(np.uint8).ravel(), np.ascontiguousarray(fx[k]).view(np.uint8).ravel()), k
+    print("decodes to the run's bits: %d arrays; %d surfels seeded, %d after frame 2; stable map + outliers %d -> %d; %d predicted pixels" % (
+        len(fx), fx["f1_map"].shape[0], int(fx["f2_map_count"][0]), fx["f1_map"].shape[0] + fx["x_extra"].shape[0], int(fx["x_map_count"][0]),
+        int((fx["x_PRED_VERTEX"][..., 2] != 0).sum())))
+
+
 if __name__ == "__main__":
-    if "--qqvga-variants-report" in sys.argv:
+    if "--vga-fixture" in sys.argv:
+        vga_fixture()
+    elif "--dump-vga" in sys.argv:
+        dump_vga(sys.argv[sys.argv.index("--dump-vga") + 1])
+    elif "--qqvga-variants-report" in sys.argv:
         qqvga_variants_report()
     elif "--vga-map-report" in sys.argv:
         vga_map_report()

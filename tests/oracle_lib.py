@@ -37,6 +37,7 @@ def load(omp=False):
     lib.orc_get_tick.argtypes = [C.c_void_p]
     lib.orc_set_tick.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_weighting.argtypes = [C.c_void_p, C.c_float]
+    lib.orc_set_fragment_texcoords.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_set_index_submap.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_active_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_update_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -137,6 +138,15 @@ class Oracle:
 
     def set_weighting(self, w):
         self.lib.orc_set_weighting(self.h, w)
+
+    def set_fragment_texcoords(self, tc):
+        """test hook: the texcoord a rasteriser interpolated for every pixel ((H, W, 2) float32), None = correctly rounded"""
+        if tc is None:
+            self.lib.orc_set_fragment_texcoords(self.h, None)
+            return
+        tc = np.ascontiguousarray(tc, np.float32)
+        assert tc.shape == (self.H, self.W, 2)
+        assert self.lib.orc_set_fragment_texcoords(self.h, _p(tc)) == 0
 
     def set_index_submap(self, idx):
         self.lib.orc_set_index_submap(self.h, int(idx))

@@ -181,8 +181,11 @@ def test_free_space_violation_removes_a_surfel_in_front_of_fresh_stable_ones(ora
     was updated THIS frame, lies more than 1 cm behind it, and its own normal faces the camera (|n_z| > 0.85).  Scene: a
     stable wall at 2 m re-observed this frame, plus intruder surfels floating at 1.5 m in front of it (never observed:
     the depth image shows the wall) — they must go; the same intruders with a grazing normal (|n_z| < 0.85) must stay."""
-    W, H = 96, 72
-    f, cx, cy = 79.0, 48.0, 36.0
+    # a power-of-two size: there the fp32 half-pixel walks of data.vert / copy_unstable.vert are exact and visit the nominal texels
+    # (at 96 x 72 the association reaches texel p + 1 at fewer pixels — as the executed shaders do, DESIGN.md §8 — fewer surfels are
+    # updated per frame and a third of the intruders survive)
+    W, H = 128, 64
+    f, cx, cy = 79.0, 64.0, 32.0
     # fusion samples a quarter of the pixels per frame (x % 2 == y % 2 == time % 2), so at the default window (4 x 4 half-pixel
     # samples) at most 4 samples can show a surfel updated THIS frame and "zCount > 4" cannot fire; fusionCleanWindowMultiplier
     # = 4 (8 x 8 samples over 5 x 5 texels) is the smallest setting where the rule is live

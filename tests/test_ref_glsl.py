@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import ref_glsl_check as R  # noqa: E402
 
+sys.path.insert(0, HERE)
 SCENES = ["pair", "sphere"]
 
 
@@ -137,6 +138,68 @@ def test_hip_path_matches_the_executed_map_passes_at_a_size_that_is_not_a_power_
     finally:
         g.close()
     assert len(rep.rows) > 15 and all(ok for _, ok, _ in rep.rows)
+
+
+# ---- 640 x 480: the size BASELINE's metric is quoted on ---------------------------------------------------------------------------
+_VGA = {}
+
+
+def _vga():
+    if not _VGA:
+        import ref_glsl_vga as V
+        _VGA.update(V.decode())
+    return _VGA
+
+
+def _vga_params():
+    from hrbffusion3d_amd.params import default_params
+    return default_params(max_surfels=1 << 20)        # 640 x 480, K = (528, 528, 320, 240), 1 / 5000: the GPUTest pair
+
+
+def test_vga_fixture_decodes_to_the_recorded_bits_and_covers_every_pass():
+    """tests/ref_glsl_vga.py rebuilds 177 MB of shader outputs from 29 MB (predictors + XOR residuals) and checks a CRC per array"""
+    fx = _vga()
+    assert "llvmpipe" in fx["_info"]["renderer"]
+    assert fx["f2_depth"].shape == (480, 640) and fx["f1_map"].shape[0] > 250000
+    for k in ("f2_DEPTH_FILTERED", "f2_NORMAL_P3", "f2_CURV1", "f2_CONFIDENCE", "f2_a_INDEX", "f2_records", "f2_fused_vals", "f2_keep", "x_keep",
+              "x_p_INDEX_CURVMAX", "x_PRED_VERTEX", "x_FILL_ICPWEIGHT", "x_map_updated_head", "f2_init_head", "tc"):
+        assert k in fx, k
+    removed = int((~np.unpackbits(fx["x_keep"])[:fx["f1_map"].shape[0] + fx["x_extra"].shape[0]].astype(bool)).sum())
+    assert removed >= 500 and int((fx["f2_records"][:, 7] == -1).sum()) > 60000 and int((fx["x_PRED_VERTEX"][..., 2] != 0).sum()) > 250000
+
+
+def test_oracle_matches_the_executed_reference_shaders_at_640x480(oracle_lib_built):
+    fx = _vga()
+    o = oracle_lib_built.Oracle(_vga_params(), omp=True)
+    try:
+        rep = R.run_vga(o, fx, R.Report(strict=True))
+    finally:
+        o.close()
+    assert len(rep.rows) > 90 and all(ok for _, ok, _ in rep.rows)
+
+
+def test_oracle_matches_every_pixel_at_640x480_given_the_rasterisers_texcoords(oracle_lib_built):
+    """the one implementation-defined input of the fragment passes — the interpolated texcoord — taken from the execution (test hook
+    orc_set_fragment_texcoords): no mask is left, all 307 200 pixels of P3 / P4 meet the power-of-two bounds"""
+    fx = _vga()
+    o = oracle_lib_built.Oracle(_vga_params(), omp=True)
+    try:
+        rep = R.run_vga(o, fx, R.Report(strict=True), rasteriser_texcoords=True)
+    finally:
+        o.close()
+    assert len(rep.rows) > 80 and all(ok for _, ok, _ in rep.rows)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_executed_reference_shaders_at_640x480(gpu_available):
+    from hrbffusion3d_amd.api import HRBFFusion
+    fx = _vga()
+    g = HRBFFusion(_vga_params())
+    try:
+        rep = R.run_vga(g, fx, R.Report(strict=True))
+    finally:
+        g.close()
+    assert len(rep.rows) > 90 and all(ok for _, ok, _ in rep.rows)
 
 
 VARIANT_NAMES = sorted(R.VARIANTS)
