@@ -154,7 +154,8 @@ int main(int argc, char **argv)
         }
     // ---- END ---------------------------------------------------------------------------------------------------------------
     printf("read-outs: inliers '%s' error '%s' logged %g / %g\n", gui->inliers_.s.c_str(), gui->res_.s.c_str(), gui->resLog.v[0], gui->inLog.v[0]);
-    if (!(gui->inLog.v[0] > 1000.0f) || !(gui->resLog.v[0] > 0.0f && gui->resLog.v[0] < 1e-2f) || gui->inLog.v[0] != hrbfFusion->lastICPCount()) return 22;
+    /* the synthetic source repeats one frame: every pixel is an inlier and the residual is zero */
+    if (!(gui->inLog.v[0] > 1000.0f) || !(gui->resLog.v[0] >= 0.0f && gui->resLog.v[0] < 1e-2f) || gui->inLog.v[0] != hrbfFusion->lastICPCount()) return 22;
     const float *currPose = hrbfFusion->getCurrPoseData();
     printf("tick %d surfels %u icp error %g count %g pose t = %g %g %g\n", hrbfFusion->getTick(), hrbfFusion->getGlobalModel().lastCount(),
            hrbfFusion->lastICPError(), hrbfFusion->lastICPCount(), currPose[12], currPose[13], currPose[14]);
