@@ -8,9 +8,15 @@ A "step" = one hrbf_process_frame over one synthetic 640x480 RGB-D frame (pre-pr
 compact + append, HRBF ray-cast prediction + fill-in) against a map pre-seeded to >= 1 M surfels.
 Inputs are resident in HBM before the timed region (torch tensors; PyTorch is plumbing only).
 
-N > 1: one process per GPU (torchrun), each an independent replica of the same sequence
-(SURVEY.md §8e last row: the per-frame path of one sequence does not shard below VGA); no data-path
-collective, "scaling": "weak", value = frames all ranks processed / max-over-ranks time.
+N > 1: one process per GPU, each an independent replica of the same sequence (SURVEY.md §8e last row: the
+per-frame path of one sequence does not shard below VGA); no data-path collective, "scaling": "weak",
+value = frames all ranks processed / max-over-ranks time.  Started by hand (`python bench.py --gpus N`, no
+WORLD_SIZE in the environment) it re-executes itself under `python -m torch.distributed.run`, one rank per GPU; under
+the driver's launcher it checks WORLD_SIZE == N.  The line carries the rank count RCCL itself saw (`ranks_observed`).
+At N > 1 a second leg times the SHARDED design — all ranks on ONE sequence, the surfel map owned by
+spatial hash, registration row-sharded, RCCL all-reduce of the 6 x 6 limb sums: BASELINE config 4 (640 x 480, 4.3 M
+surfels) at N = 2..7, config 5 (1280 x 960, 8.8 M) at N = 8 — in child processes with a time limit, so that nothing
+there can take the replica line down (`sharded_one_sequence`, "scaling": "strong", per-rank fuse-pass times).
 
 One JSON line on rank 0, with `roofline` (fuse streaming kernel, HIP events on the library's own
 stream) and `cpu_baseline` (the CPU oracle on a bounded sample; baseline, not target).
@@ -68,6 +74,12 @@ def parse():
     ap.add_argument("--ring-stride", type=int, default=4,
                     help="bracket the fuse pass with HIP events on every n-th frame of the timed region (each bracketed frame costs the stream ~22 us)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the one-sequence sharded leg (child processes)")
+    ap.add_argument("--sharded-leg-timeout", type=float, default=420.0, help="seconds the sharded leg's child processes may take")
+    ap.add_argument("--one-sequence-child", action="store_true", help=argparse.SUPPRESS)   # set by the parent for the sharded leg
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: start the ranks (gloo), run the barrier / max-over-ranks / rank-count plumbing and the child-leg "
+                         "launch, print the line's skeleton (tests/test_multigpu_gloo.py)")
     return ap.parse_args()
 
 
@@ -284,14 +296,134 @@ def worst_case_leg(args, local_rank):
             "real_bytes_source": "model (fuse_real_bytes in bench.py); PMC FETCH_SIZE + WRITE_SIZE of the same command: profiles/"}
 
 
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` by hand: become `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`"""
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def sharded_leg_command(args, world):
+    """the one-sequence sharded leg: BASELINE config 4 at 2..7 ranks, config 5 at 8"""
+    if world >= 8:
+        shape = ["--width", "1280", "--height", "960", "--surfels", "8800000"]
+        name = "BASELINE config 5: synthetic 1280x960 stream, 8.8 M surfels hash-owned over %d ranks" % world
+    else:
+        shape = ["--width", "640", "--height", "480", "--surfels", "4300000"]
+        name = "BASELINE config 4: synthetic 640x480 stream, 4.3 M surfels hash-owned over %d ranks" % world
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--one-sequence-child", "--shard-map", "--partition", "hash",
+           "--shard-odometry", "--steps", str(min(args.steps, 50)), "--warmup", str(min(args.warmup, 10)), "--cpu-frames", "0",
+           "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-sharded-leg"] + shape
+    if args.dry_run:
+        cmd.append("--dry-run")
+    return cmd, name
+
+
+def sharded_leg(args, rank, world, barrier):
+    """Every rank starts ONE child (same RANK / LOCAL_RANK / WORLD_SIZE, its own rendezvous port) and waits for it with a time limit;
+    the children form their own communicator, so a failure or a hang in there ends with the limit and an `error` entry — the parent's
+    process group is never inside the children's collectives.  Returns the child line (rank 0) or {"error": ...}."""
+    import subprocess
+    cmd, name = sharded_leg_command(args, world)
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    for k in [k for k in env if k.startswith("TORCHELASTIC")]:      # the children rendezvous on their own TCP store, not the agent's
+        del env[k]
+    barrier()
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.sharded_leg_timeout)
+        res = {"error": "child exit code %d: %s" % (r.returncode, (r.stderr or "")[-400:])} if r.returncode else None
+        if rank == 0 and res is None:
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            res = json.loads(line[-1]) if line else {"error": "no line from the child: " + (r.stderr or "")[-400:]}
+    except subprocess.TimeoutExpired:
+        res = {"error": "time limit of %.0f s" % args.sharded_leg_timeout}
+    except Exception as e:
+        res = {"error": repr(e)}
+    barrier()
+    if rank != 0:
+        return None
+    res = dict(res or {})
+    res["workload"] = name
+    res["wall_s_incl_setup"] = time.perf_counter() - t0
+    return res
+
+
+def collective_latencies(dist, torch, W, H, world, iters=50):
+    """microseconds of the collectives one sharded frame issues, timed on this communicator with torch.distributed calls of the same
+    sizes and types (the library issues its own through librccl on its stream; this is the wire + launch cost, not a trace of them)"""
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t) / iters
+    keys = torch.zeros(W * H, dtype=torch.int64, device="cuda")
+    limbs = torch.zeros(29 * 3, dtype=torch.int64, device="cuda")
+    word = torch.zeros(1, dtype=torch.int64, device="cuda")
+    counts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+    out = {"allreduce_min_keys_us": timed(lambda: dist.all_reduce(keys, op=dist.ReduceOp.MIN)),
+           "allreduce_sum_limbs_us": timed(lambda: dist.all_reduce(limbs)),
+           "allreduce_one_word_us": timed(lambda: dist.all_reduce(word)),
+           "allgather_counts_us": timed(lambda: dist.all_gather(counts, word))}
+    # per frame (DESIGN.md §7): 3 projections (key min-reduce + one meeting word each), 1 counts all-gather, 19 Gauss-Newton
+    # iterations x 2 limb all-reduces + <= 10 SO3 iterations x 1
+    out["per_frame_us_estimate"] = 3 * (out["allreduce_min_keys_us"] + out["allreduce_one_word_us"]) + out["allgather_counts_us"] + \
+        (19 * 2 + 10) * out["allreduce_sum_limbs_us"]
+    out["what"] = "same-size torch.distributed collectives on this RCCL communicator, %d iterations each" % iters
+    return out
+
+
+def dry_run(args, rank, world):
+    """the N-rank plumbing without a GPU (gloo): rank count, barrier + max-over-ranks, and the sharded leg's child launch"""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    one = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(one)
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sharded = None
+    if world > 1 and not args.one_sequence_child and not args.no_sharded_leg:
+        sharded = sharded_leg(args, rank, world, barrier)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_observed": int(one.item()), "max_over_ranks_s": float(t.item()),
+                          "one_sequence_child": bool(args.one_sequence_child), "scaling": "strong" if args.one_sequence_child else "weak",
+                          "sharded_one_sequence": sharded}))
+        sys.stdout.flush()
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.only_worst:
         print(json.dumps({"roofline_worst_case": worst_case_leg(args, int(os.environ.get("LOCAL_RANK", "0")))}))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.virtual_shards <= 1:
+        respawn_under_launcher(args.gpus)          # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus) and args.virtual_shards <= 1:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE = %d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     t_gen = time.perf_counter()
     gen = _frames(range(1 + args.warmup + args.steps), args.width, args.height, args.noise)   # forked workers: before the HIP runtime starts
     import torch
@@ -303,6 +435,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ranks_observed = 1
+    if dist is not None:       # what RCCL itself connects: one contribution per rank
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(one)
+        ranks_observed = int(one.item())
+        if ranks_observed != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but RCCL sees %d ranks" % (args.gpus, ranks_observed))
 
     from hrbffusion3d_amd import synth
     from hrbffusion3d_amd.api import HRBFFusion
@@ -469,6 +608,29 @@ def main():
         except Exception as e:   # the extra leg must never take the bench line down
             big = {"error": repr(e)}
 
+    per_rank_fuse_ms = None
+    coll = None
+    if dist is not None:
+        mine = torch.tensor([fuse_ms, merge_ms, float(count1)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_fuse_ms = [[float(x) for x in a.tolist()] for a in allr]
+        if one_sequence:
+            try:
+                coll = collective_latencies(dist, torch, W, H, world)
+            except Exception as e:
+                coll = {"error": repr(e)}
+    sharded = None
+    if dist is not None and not one_sequence and not args.no_sharded_leg:
+        fus.synchronize(); torch.cuda.synchronize()
+        sharded = sharded_leg(args, rank, world, barrier)
+        if sharded is not None and "error" not in sharded:      # keep what the leg is for; the rest of the child's line repeats this one's
+            sharded = {k: sharded.get(k) for k in ("workload", "value", "unit", "ms_per_step", "scaling", "n_gpus", "ranks_observed", "steps", "warmup",
+                                                   "per_rank_fuse_ms", "collectives", "wall_s_incl_setup")} | {
+                "parallelism": sharded.get("config", {}).get("parallelism"), "surfels_end_rank0": sharded.get("config", {}).get("surfels_end"),
+                "final_translation_error_mm": sharded.get("config", {}).get("final_translation_error_mm"),
+                "status": sharded.get("roofline", {}).get("status")}
+
     if rank == 0:
         out = {
             "metric": "frames/sec at 640x480, 1M-surfel map, 1 MI355X",
@@ -505,6 +667,10 @@ def main():
                          "moved_per_frame": float(st[ok][:, 6].mean()) if ok.any() else 0.0, "status": status},
             "roofline_worst_case": worst,
             "config5_single_gpu": big,
+            "ranks_observed": ranks_observed,
+            "per_rank_fuse_ms": per_rank_fuse_ms,      # [fuse pass ms, of which merge ms, live surfels] per rank
+            "collectives": coll,
+            "sharded_one_sequence": sharded,
         }
         if args.cpu_frames > 0 and world == 1:
             try:

@@ -26,7 +26,7 @@ EXPORTS = [
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
-    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts", "hrbf_hash_owner", "hrbf_hash_renumber_count",
+    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_peer_release_id", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts", "hrbf_hash_owner", "hrbf_hash_renumber_count", "hrbf_shard_exchange_mode",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_dense_enough", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
@@ -92,10 +92,10 @@ def load_library():
     lib.hrbf_icp_step_sparse.argtypes = [vp] + [vp] * 6 + [vp] * 2 + [f32] * 4 + [vp] * 5 + [i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
     lib.hrbf_update_lambda_map.argtypes = [vp] + [vp] * 9 + [i32, i32]
     lib.hrbf_comm_unique_id.argtypes = [vp]; lib.hrbf_comm_init.argtypes = [vp, i32, i32, vp]
-    lib.hrbf_peer_unique_id.argtypes = [vp]; lib.hrbf_comm_init_peer.argtypes = [vp, i32, i32, vp]
+    lib.hrbf_peer_unique_id.argtypes = [vp]; lib.hrbf_comm_init_peer.argtypes = [vp, i32, i32, vp]; lib.hrbf_peer_release_id.argtypes = [vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
     lib.hrbf_download_gids.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_shard_counts.argtypes = [vp, vp]
-    lib.hrbf_hash_owner.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i32]; lib.hrbf_hash_renumber_count.argtypes = [vp]
+    lib.hrbf_hash_owner.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i32]; lib.hrbf_hash_renumber_count.argtypes = [vp]; lib.hrbf_shard_exchange_mode.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
     lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
     lib.hrbf_dense_enough.argtypes = [vp, vp]
@@ -218,6 +218,12 @@ class HRBFFusion:
             raise HrbfError(lib.hrbf_last_error().decode())
         return bytes(buf)
 
+    @staticmethod
+    def peer_release_id(unique_id):
+        """remove a rendezvous segment that will not be used (rank 0's context does it otherwise); False if it is already gone"""
+        lib = load_library()
+        return lib.hrbf_peer_release_id((C.c_uint8 * 128).from_buffer_copy(unique_id)) == 0
+
     def comm_init_peer(self, rank, world, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self.lib.hrbf_comm_init_peer(self.h, int(rank), int(world), buf))
@@ -265,6 +271,10 @@ class HRBFFusion:
 
     def hash_renumber_count(self):
         return int(self.lib.hrbf_hash_renumber_count(self.h))
+
+    def shard_exchange_mode(self):
+        """0 not sharded over ranks, 1 peer-mapped images, 2 packed records on request, 3 packed records agreed by the ranks"""
+        return int(self.lib.hrbf_shard_exchange_mode(self.h))
 
     def download_gids(self):
         """hash ownership, one shard per rank: the global-order ids of the rank's surfels (order of download_map)"""

@@ -83,6 +83,9 @@ struct ShardScratch {
 #define PEER_BUFS 8   // z-buffer + six image planes (+ the id plane of a hash-owned map: only then exchanged)
 struct PeerShm {
     volatile uint32_t arrived;                  // monotone barrier counter
+    volatile uint32_t failed;                   // a rank ran into an error (stream, IPC mapping): published BEFORE the barrier it still arrives at
+    volatile uint32_t map_failed;               // a rank could not map its peers' images (agreed on after the mapping barrier)
+    volatile uint32_t attached;                 // contexts that joined: a segment serves ONE rendezvous of `world` ranks (its barrier counter is never reset)
     volatile uint32_t counts[2][HRBF_PEER_MAX]; // live surfel counts, double buffered by barrier generation
     hipIpcMemHandle_t handles[HRBF_PEER_MAX][PEER_BUFS];
 };
@@ -134,6 +137,8 @@ struct hrbf_context {
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
     // ownership by spatial hash: the next free global-order id (the same on every rank: seed size, then + Q per clean pass),
     // 1 / cell size, the device word holding the smallest id alive, scratch of the hashed seeding
+    int peer_fallback;          // the ranks agreed to exchange packed records because a rank could not map its peers (hrbf_shard_exchange_mode)
+    int renumber_failed;        // hash ownership: the id renumbering failed; frames fail fast until the status is cleared
     int hash_mode; uint32_t g_next, g_renumber_at, hash_renumbered; float hash_inv_cell; uint32_t *d_gfirst; uint32_t *d_init_flags2, *d_init_offs2, *d_gtotal;
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
     uint32_t *d_init_flags, *d_init_offs;
@@ -525,12 +530,19 @@ static void st_conf(hrbf_context *c)
 static int peer_barrier_host(hrbf_context *c)
 {
     PeerLink &pl = c->peer;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) { hrbf_set_error("peer barrier: stream error"); return HRBF_ERR_DEVICE; }
+    // a rank in trouble still ARRIVES (its generation counter stays aligned with the shared one) and says so in the segment: every
+    // rank leaves this barrier with the same verdict instead of the healthy ones spinning for a minute (round-3 advice)
+    const bool bad = hipStreamSynchronize(c->stream) != hipSuccess;
+    if (bad) { pl.shm->failed = 1u; __sync_synchronize(); }
     const uint32_t target = ++pl.gen * (uint32_t)pl.world;
     __sync_fetch_and_add(&pl.shm->arrived, 1u);
     struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint32_t spins = 0;; ++spins) {
-        if ((int32_t)(__atomic_load_n(&pl.shm->arrived, __ATOMIC_ACQUIRE) - target) >= 0) return HRBF_OK;
+        if ((int32_t)(__atomic_load_n(&pl.shm->arrived, __ATOMIC_ACQUIRE) - target) >= 0) {
+            if (bad) { hrbf_set_error("peer barrier: stream error"); return HRBF_ERR_DEVICE; }
+            if (pl.shm->failed) { hrbf_set_error("peer barrier: a rank reported a failure"); return HRBF_ERR_COMM; }
+            return HRBF_OK;
+        }
         if ((spins & 63u) == 63u) {
             struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
             if (t1.tv_sec - t0.tv_sec > 60) { hrbf_set_error("peer barrier: a rank did not arrive within 60 s"); c->status |= HRBF_STATUS_INTERNAL_BOUND; return HRBF_ERR_COMM; }
@@ -561,56 +573,91 @@ static void peer_shm_release(hrbf_context *c)
     pl.shm_mode = 0; pl.shm_owner = 0; pl.shm_name[0] = 0;
 }
 // exchange the IPC handles of this rank's z-buffer and six index-map planes and map everybody else's
-static int peer_map_images(hrbf_context *c)
+static int peer_map_images(hrbf_context *c, int *all_mapped)
 {
+    *all_mapped = 0;
     PeerLink &pl = c->peer;
     const int G = pl.world, me = pl.rank;
     void *mine[PEER_BUFS] = {c->d_zbuf, c->d_im_vertconf, c->d_im_normrad, c->d_im_colortime, c->d_im_curvmax, c->d_im_curvmin, c->d_clean_tex, c->sh[0].d_gid};
     const int NB = c->sh[0].d_gid ? PEER_BUFS : PEER_BUFS - 1;   // the id plane exists under hash ownership only
     hipIpcMemHandle_t all[HRBF_PEER_MAX][PEER_BUFS];
     memset(all, 0, sizeof(all));
+    // A rank that fails locally (no IPC handle, a handle that does not open: another node, another IPC namespace) still goes
+    // through EVERY meeting point below, and the outcome is agreed on by all ranks — a rank that left early would make the others
+    // issue collectives it never joins (round-3 advice).  *all_mapped = 0: nobody keeps a mapping (the caller falls back to the
+    // packed-record exchange on the RCCL transport; the shm transport has no other path and fails on every rank alike).
+    int fail = 0;
     for (int b = 0; b < NB; ++b) {
         const hipError_t e = hipIpcGetMemHandle(&all[me][b], mine[b]);
-        if (e != hipSuccess) { hrbf_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+        if (e != hipSuccess) { hrbf_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e)); fail = 1; memset(&all[me][b], 0, sizeof(all[me][b])); }
     }
+    uint32_t *d = nullptr;   // RCCL transport: device staging of the handle bytes (448 B per rank) + the agreement word
+    const size_t words = sizeof(all[0]) / 4;
     if (pl.shm_mode) {
         memcpy((void *)pl.shm->handles[me], all[me], sizeof(all[me]));
+        if (fail) pl.shm->map_failed = 1u;
         __sync_synchronize();
         int r = peer_barrier_host(c);
         if (r) return r;
         memcpy(all, (const void *)pl.shm->handles, sizeof(all));
     } else {
-        // all-gather of the handle bytes through the communicator (device staging, 448 B per rank)
-        uint32_t *d = nullptr;
-        const size_t words = sizeof(all[0]) / 4;
-        if (hipMalloc((void **)&d, sizeof(all)) != hipSuccess) return HRBF_ERR_DEVICE;
-        hipMemcpyAsync(d + (size_t)me * words, all[me], sizeof(all[me]), hipMemcpyHostToDevice, c->stream);
-        const int e = rccl_allgather_u32(c->comm.comm, d + (size_t)me * words, d, words, c->stream);
-        hipMemcpyAsync(all, d, sizeof(all[0]) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
+        if (hipMalloc((void **)&d, sizeof(all) + sizeof(uint32_t)) != hipSuccess) { d = nullptr; fail = 1; }
+        int e = 0;
+        if (d) {
+            hipMemcpyAsync(d + (size_t)me * words, all[me], sizeof(all[me]), hipMemcpyHostToDevice, c->stream);
+            e = rccl_allgather_u32(c->comm.comm, d + (size_t)me * words, d, words, c->stream);
+            hipMemcpyAsync(all, d, sizeof(all[0]) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
+        }
         const hipError_t se = hipStreamSynchronize(c->stream);
-        hipFree(d);
-        if (e != 0 || se != hipSuccess) { hrbf_set_error("peer link: handle all-gather failed"); return HRBF_ERR_COMM; }
+        if (!d || e != 0 || se != hipSuccess) { hrbf_set_error("peer link: handle all-gather failed"); if (d) hipFree(d); return HRBF_ERR_COMM; }   // the communicator itself is broken: nothing to agree over
     }
     PeerImages &pi = pl.img;
     memset(&pi, 0, sizeof(pi));
     pi.world = G; pi.me = me;
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < G && !fail; ++g) {
         void *q[PEER_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NB && !fail; ++b) {
             if (g == me) { q[b] = mine[b]; continue; }
             const hipError_t e = hipIpcOpenMemHandle(&q[b], all[g][b], hipIpcMemLazyEnablePeerAccess);
-            if (e != hipSuccess) { hrbf_set_error("hipIpcOpenMemHandle(rank %d, buffer %d): %s", g, b, hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+            if (e != hipSuccess) { hrbf_set_error("hipIpcOpenMemHandle(rank %d, buffer %d): %s", g, b, hipGetErrorString(e)); fail = 1; break; }
             pl.opened[g][b] = q[b];
         }
         pi.zbuf[g] = (unsigned long long *)q[0]; pi.vertconf[g] = (float4 *)q[1]; pi.normrad[g] = (float4 *)q[2];
         pi.colortime[g] = (float4 *)q[3]; pi.curvmax[g] = (float4 *)q[4]; pi.curvmin[g] = (float4 *)q[5]; pi.clean[g] = (float4 *)q[6]; pi.gid[g] = (uint32_t *)q[7];
+    }
+    const char *forced = getenv("HRBF_TEST_FAIL_PEER_MAP");   // tests: this rank pretends its mapping failed ("all" or a rank number)
+    if (forced && (!strcmp(forced, "all") || atoi(forced) == me)) fail = 1;
+    uint32_t failed_ranks = 0;
+    if (pl.shm_mode) {
+        if (fail) { pl.shm->map_failed = 1u; __sync_synchronize(); }
+        const int r = peer_barrier_host(c);    // nobody touches a peer's memory before everybody has mapped it — or has said it cannot
+        if (r) return r;
+        failed_ranks = pl.shm->map_failed;
+    } else {
+        const uint32_t f = (uint32_t)fail;
+        uint32_t *w = d + (size_t)HRBF_PEER_MAX * words;
+        hipMemcpyAsync(w, &f, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        const int e = rccl_allreduce_sum_u32(c->comm.comm, w, 1, c->stream);
+        hipMemcpyAsync(&failed_ranks, w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        const hipError_t se = hipStreamSynchronize(c->stream);
+        hipFree(d);
+        if (e != 0 || se != hipSuccess) { hrbf_set_error("peer link: agreement all-reduce failed"); return HRBF_ERR_COMM; }
+    }
+    if (failed_ranks) {
+        for (int g = 0; g < HRBF_PEER_MAX; ++g)
+            for (int b = 0; b < PEER_BUFS; ++b)
+                if (pl.opened[g][b]) { hipIpcCloseMemHandle(pl.opened[g][b]); pl.opened[g][b] = nullptr; }
+        memset(&pi, 0, sizeof(pi));
+        *all_mapped = 0;
+        return HRBF_OK;
     }
     if (!pl.shm_mode) {
         if (hipMalloc((void **)&pl.d_token, sizeof(uint32_t)) != hipSuccess) return HRBF_ERR_DEVICE;
         hipMemsetAsync(pl.d_token, 0, sizeof(uint32_t), c->stream);
     }
     pl.enabled = 1;
-    return pl.shm_mode ? peer_barrier_host(c) : HRBF_OK;   // nobody touches a peer's memory before everybody has mapped it
+    *all_mapped = 1;
+    return HRBF_OK;
 }
 
 static void refresh_count_ub(hrbf_context *c)
@@ -643,7 +690,7 @@ static void shard_allgather_counts(hrbf_context *c, uint32_t *row)
         PeerLink &pl = c->peer;
         uint32_t mine = 0;
         hipMemcpyAsync(&mine, row + pl.rank, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+        (void)hipStreamSynchronize(c->stream);      // an error here is reported by the barrier below, which this rank still reaches
         const int slot = (int)((pl.gen + 1u) & 1u);
         pl.shm->counts[slot][pl.rank] = mine;
         __sync_synchronize();
@@ -669,7 +716,7 @@ static void hash_refresh_gfirst(hrbf_context *c, const uint32_t *counts_row)
     if (c->peer.shm_mode) {   // through the rendezvous segment, like the counts
         PeerLink &pl = c->peer;
         hipMemcpyAsync(&mine, c->d_gfirst, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+        (void)hipStreamSynchronize(c->stream);      // reported by the barrier below
         const int slot = (int)((pl.gen + 1u) & 1u);
         pl.shm->counts[slot][pl.rank] = mine;
         __sync_synchronize();
@@ -856,9 +903,22 @@ static int hash_renumber(hrbf_context *c)
     const uint32_t *ptrs[HRBF_MAX_SHARDS] = {nullptr};
     if (!c->shard_real) { for (int k = 0; k < c->nsh; ++k) ptrs[k] = c->sh[k].d_gid; }
     else if (c->peer.enabled && c->peer.img.gid[c->peer.rank]) { for (int g = 0; g < c->G; ++g) ptrs[g] = c->peer.img.gid[g]; }
-    else { hrbf_set_error("hash ownership: id renumbering needs the peer-mapped id planes (not HRBF_SHARD_EXCHANGE=records)"); return HRBF_ERR_INVALID; }
-    uint32_t *tmp[HRBF_MAX_SHARDS] = {nullptr};
+    uint32_t *gathered = nullptr;
     int rc = HRBF_OK;
+    if (c->shard_real && !(c->peer.enabled && c->peer.img.gid[c->peer.rank])) {
+        // packed-record transport (no peer-mapped planes): all-gather the id planes, padded to the longest (every plane has room
+        // for c->cap ids; the padding is never read: the counts say where a plane ends)
+        uint32_t maxc = 1;
+        for (int g = 0; g < c->G; ++g) maxc = cnt[g] > maxc ? cnt[g] : maxc;
+        if (!c->comm.comm) { hrbf_set_error("hash ownership: id renumbering without a communicator"); return HRBF_ERR_INVALID; }
+        // (out of device memory here ends the job: this rank returns the error and its peers' all-gather runs into RCCL's own time-out)
+        if (hipMalloc((void **)&gathered, sizeof(uint32_t) * (size_t)maxc * (size_t)c->G) != hipSuccess) { hrbf_set_error("hash ownership: id renumbering: out of device memory"); return HRBF_ERR_DEVICE; }
+        uint32_t *dst = gathered;
+        hipMemcpyAsync(dst + (size_t)c->comm.rank * maxc, c->sh[0].d_gid, sizeof(uint32_t) * (size_t)maxc, hipMemcpyDeviceToDevice, c->stream);
+        if (rccl_allgather_u32(c->comm.comm, dst + (size_t)c->comm.rank * maxc, dst, maxc, c->stream) != 0) rc = HRBF_ERR_COMM;
+        for (int g = 0; g < c->G; ++g) ptrs[g] = dst + (size_t)g * maxc;
+    }
+    uint32_t *tmp[HRBF_MAX_SHARDS] = {nullptr};
     for (int k = 0; k < c->nsh && rc == HRBF_OK; ++k) {
         const uint32_t nk = cnt[c->shard_first + k];
         if (hipMalloc((void **)&tmp[k], sizeof(uint32_t) * (size_t)(nk ? nk : 1)) != hipSuccess) { rc = HRBF_ERR_DEVICE; break; }
@@ -866,25 +926,33 @@ static int hash_renumber(hrbf_context *c)
     }
     // a rank whose allocation failed still meets the others (they would wait for it) and reports the error: the shared map is then
     // inconsistent between the ranks and the run has to stop
-    if (c->shard_real && peer_meet(c)) rc = HRBF_ERR_COMM;          // every rank has read every plane
+    if (c->shard_real && !gathered && peer_meet(c)) rc = HRBF_ERR_COMM;          // every rank has read every plane
     for (int k = 0; k < c->nsh && rc == HRBF_OK; ++k) {
         const uint32_t nk = cnt[c->shard_first + k];
         if (nk) hipMemcpyAsync(c->sh[k].d_gid, tmp[k], sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToDevice, c->stream);
     }
-    if (c->shard_real && peer_meet(c)) rc = HRBF_ERR_COMM;          // nobody reads a half-written plane in the next pass
+    if (c->shard_real && !gathered && peer_meet(c)) rc = HRBF_ERR_COMM;          // nobody reads a half-written plane in the next pass
     hipStreamSynchronize(c->stream);
     for (int k = 0; k < c->nsh; ++k) if (tmp[k]) hipFree(tmp[k]);
+    if (gathered) hipFree(gathered);
     if (rc != HRBF_OK) return rc;
     c->g_next = (uint32_t)total;
     ++c->hash_renumbered;
     return HRBF_OK;
 }
-static void st_clean(hrbf_context *c)
+static int st_clean(hrbf_context *c)
 {
     // the clean texels carry the confidence threshold and the time they were resolved with; a caller that changed
     // either since (stage API / named operators) gets a fresh projection instead of a stale test
     if (c->clean_thr != c->prm.confidence_threshold || c->clean_time != c->tick) st_indices(c, true, 7);
-    if (c->hash_mode && c->g_next > c->g_renumber_at) (void)hash_renumber(c);   // the same decision on every rank: g_next is
+    if (c->hash_mode && c->g_next > c->g_renumber_at) {
+        // ids must never run past g_renumber_at: a pass that cannot renumber does not run (the map stays as the merge left it), the
+        // condition is sticky (HRBF_STATUS_ID_SPACE) and every later frame fails at once instead of retrying a host-synchronous,
+        // allocating operation per frame (round-3 advice) — until the caller clears the status
+        const int rr = c->renumber_failed ? HRBF_ERR_DEVICE : hash_renumber(c);
+        if (rr != HRBF_OK) { c->renumber_failed = 1; c->status |= HRBF_STATUS_ID_SPACE; return rr; }
+    }
+    // (the same decision on every rank: g_next is a pure function of the frames processed)
     const bool ring = ring_frame(c);
     for (int k = 0; k < c->nsh; ++k) {
         const int gk = c->shard_first + k;
@@ -921,6 +989,7 @@ static void st_clean(hrbf_context *c)
     c->target = 1 - c->target;
     c->map_dirty = 0;
     c->ub_growth_since += (uint32_t)c->Q;
+    return HRBF_OK;
 }
 // with_fill_in: the frame path — the ray-cast kernel fills in from the live frame as well (FILL_* images), so what is left
 // of FillIn is the end-of-frame bookkeeping (st_end_of_frame)
@@ -971,6 +1040,8 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
 static int process_frame_resident(hrbf_context *c, float wmul)
 {
     hipSetDevice(c->device);
+    if (c->renumber_failed) { hrbf_set_error("hash ownership: the id space is exhausted and renumbering failed (HRBF_STATUS_ID_SPACE); clear the status to retry"); return HRBF_ERR_DEVICE; }
+    int frame_rc = HRBF_OK;
     refresh_count_ub(c);
     TIMER(0);
     st_filter(c); st_vnr(c);
@@ -992,7 +1063,7 @@ static int process_frame_resident(hrbf_context *c, float wmul)
             TIMER(4);
             st_indices(c, true, 4);      // the clean test reads the packed texels only
             TIMER(5);
-            st_clean(c);
+            frame_rc = st_clean(c);
             TIMER(6);
         } else { TIMER(3); TIMER(4); TIMER(5); TIMER(6); }
     }
@@ -1006,7 +1077,7 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     c->tick++; c->frames_enqueued++;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hrbf_set_error("launch: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
-    return HRBF_OK;
+    return frame_rc;   // the frame ran, but its clean pass did not (id renumbering failed): the caller must not go on
 }
 
 extern "C" int hrbf_upload_frame(hrbf_handle c, const uint8_t *rgb, const uint16_t *depth)
@@ -1098,7 +1169,7 @@ extern "C" int hrbf_run_stage(hrbf_handle c, int stage)
         case HRBF_STAGE_INITIALISE: st_init(c); break;
         case HRBF_STAGE_PREDICT_INDICES: st_indices(c); break;
         case HRBF_STAGE_FUSE: st_fuse(c); break;
-        case HRBF_STAGE_CLEAN: st_clean(c); break;
+        case HRBF_STAGE_CLEAN: { const int r = st_clean(c); if (r) return r; } break;
         case HRBF_STAGE_PREDICT_HRBF: st_predict(c); break;
         case HRBF_STAGE_FILLIN: st_fillin(c); break;
         case HRBF_STAGE_ODOMETRY: st_odometry(c); break;
@@ -1303,6 +1374,15 @@ extern "C" int hrbf_download_gids(hrbf_handle c, uint32_t *out, size_t cap_surfe
     if (n) HIP_CHECK(hipMemcpyAsync(out, c->sh[0].d_gid, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return HRBF_OK;
+}
+// how a sharded map's ranks exchange the index map: 0 not sharded over ranks, 1 peer-mapped images (owner-side scatter),
+// 2 packed records because HRBF_SHARD_EXCHANGE=records asked for them, 3 packed records because the ranks AGREED that somebody
+// cannot map its peers (another node / IPC namespace)
+extern "C" int hrbf_shard_exchange_mode(hrbf_handle c)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    if (!c->shard_real) return 0;
+    return c->peer.enabled ? 1 : (c->peer_fallback ? 3 : 2);
 }
 // hash ownership: how often the ids were renumbered (hash_renumber: when the next pass could exhaust 32 bits; HRBF_HASH_RENUMBER_AT)
 extern "C" int hrbf_hash_renumber_count(hrbf_handle c) { return c ? (int)c->hash_renumbered : HRBF_ERR_INVALID; }
@@ -1617,6 +1697,7 @@ extern "C" int hrbf_get_status(hrbf_handle c, uint32_t *flags, int clear)
         if (so3 > 0) c->status |= HRBF_STATUS_SO3_TIMEOUT;
     }
     *flags = c->status;
+    if (clear) c->renumber_failed = 0;     // the caller takes note and may retry the renumbering with the next frame
     if (clear) {
         c->status = 0;
         for (int k = 0; k < c->nsh; ++k) HIP_CHECK(hipMemsetAsync(c->sh[k].d_stats + 7, 0, sizeof(uint32_t), c->stream));
@@ -1784,7 +1865,8 @@ extern "C" int hrbf_clean(hrbf_handle c, const float pose16[16], int time, float
     op_set_pose_time(c, pose16, time);
     if (conf_threshold >= 0.0f) c->prm.confidence_threshold = conf_threshold;
     if (max_depth > 0.0f) c->prm.max_depth_processed = max_depth;
-    st_clean(c);
+    const int r = st_clean(c);
+    if (r) return r;
     HIP_CHECK(hipGetLastError());
     return HRBF_OK;
 }
@@ -1859,6 +1941,13 @@ extern "C" int hrbf_peer_unique_id(uint8_t out128[128])
     if (r != 0) { shm_unlink((const char *)out128); hrbf_set_error("ftruncate of the rendezvous segment failed"); return HRBF_ERR_COMM; }
     return HRBF_OK;   // zero-filled by the kernel; rank 0 of hrbf_comm_init_peer unlinks it when its context goes away
 }
+// a rendezvous that is abandoned before rank 0 joined it (rank 0's context unlinks the segment when it goes away): remove the name
+extern "C" int hrbf_peer_release_id(const uint8_t id128[128])
+{
+    if (!id128 || id128[0] != '/') return HRBF_ERR_INVALID;
+    char name[64]; memcpy(name, id128, 63); name[63] = 0;
+    return shm_unlink(name) == 0 ? HRBF_OK : HRBF_ERR_COMM;
+}
 extern "C" int hrbf_comm_init_peer(hrbf_handle c, int rank, int world, const uint8_t id128[128])
 {
     if (!c || !id128 || world < 2 || world > HRBF_PEER_MAX || rank < 0 || rank >= world || id128[0] != '/') return HRBF_ERR_INVALID;
@@ -1875,6 +1964,12 @@ extern "C" int hrbf_comm_init_peer(hrbf_handle c, int rank, int world, const uin
     close(fd);
     if (m == MAP_FAILED) { hrbf_set_error("mmap of the rendezvous segment failed"); return HRBF_ERR_COMM; }
     pl.shm = (PeerShm *)m; pl.shm_mode = 1; pl.shm_owner = rank == 0; pl.rank = rank; pl.world = world; pl.gen = 0;
+    // the barrier counter of a segment is never reset: a second set of contexts on the same id would walk through every barrier
+    if (__sync_fetch_and_add(&pl.shm->attached, 1u) >= (uint32_t)world) {
+        pl.shm_owner = 0; peer_shm_release(c);
+        hrbf_set_error("comm_init_peer: this rendezvous id has already served its %d ranks; take a new one from hrbf_peer_unique_id", world);
+        return HRBF_ERR_INVALID;
+    }
     c->rows_replicated = 1;   // no communicator for the registration sums: every rank reduces the whole image
     return peer_barrier_host(c);
 }
@@ -1949,14 +2044,23 @@ extern "C" int hrbf_map_shard_init(hrbf_handle c, int enable)
         c->hash_mode = 1;
     }
     peer_close(c);
+    c->peer_fallback = 0; c->renumber_failed = 0;
     if (real) {
         // the index-map images of all ranks are mapped into every rank (the owner of a winner writes them, st_indices).
         // HRBF_SHARD_EXCHANGE=records keeps the packed-record exchange over ncclSend / ncclRecv instead (RCCL transport only).
         const char *ex = getenv("HRBF_SHARD_EXCHANGE");
         if (c->peer.shm_mode || !(ex && !strcmp(ex, "records"))) {
             if (!c->peer.shm_mode) { c->peer.rank = c->comm.rank; c->peer.world = c->comm.world; }
-            const int r = peer_map_images(c);
+            int all_mapped = 0;
+            const int r = peer_map_images(c, &all_mapped);
             if (r) return r;
+            if (!all_mapped) {
+                // agreed by every rank: somebody cannot map its peers (ranks on different nodes, no shared IPC namespace).  The RCCL
+                // transport then exchanges packed winner records over ncclSend / ncclRecv on EVERY rank (HRBF_SHARD_EXCHANGE=records,
+                // single-node restriction lifted at the price of the pack / unpack kernels); the shm transport has nothing else.
+                if (c->peer.shm_mode) { hrbf_set_error("map_shard_init: a rank could not map its peers' images (shared-memory transport: no fallback)"); return HRBF_ERR_COMM; }
+                c->peer_fallback = 1;
+            }
         }
     }
     for (int k = 0; k < nsh; ++k) c->sh[k].count_ub = 0;

@@ -248,7 +248,10 @@ int hrbf_set_load_trajectory(hrbf_handle h, int v);
 #define HRBF_STATUS_INTERNAL_BOUND 2u  /* a fuse pass was launched with a stale host bound on the surfel count and refused to run */
 #define HRBF_STATUS_SO3_TIMEOUT 4u     /* the SO3 pre-alignment kernel ran into its poll bound: that frame's pose is NaN */
 #define HRBF_STATUS_FUSE_TIMEOUT 8u    /* the in-place compaction ran into its (bounded) tile wait: the map of that frame is not trustworthy */
+#define HRBF_STATUS_ID_SPACE 16u       /* hash-owned map: the 32-bit order ids were about to run out and renumbering failed: that frame's clean
+                                          pass did not run, hrbf_process_frame returned the error and keeps failing until this is cleared */
 int hrbf_get_status(hrbf_handle h, uint32_t *flags, int clear);
+int hrbf_shard_exchange_mode(hrbf_handle h);   /* see "How the ranks exchange the index map" below */
 /* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
 int hrbf_get_fuse_stats(hrbf_handle h, uint32_t out[4]);
 
@@ -352,8 +355,11 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  *                              appends the new surfels of its own cells; images (up to the names in the index image),
  *                              pose, and the map merged by id are the single-GPU ones bit for bit.  No re-cut is ever
  *                              needed (hrbf_map_rebalance is a no-op).  Ids grow by W*H/4 per frame; before 32 bits run out
- *                              every id is replaced by its rank in the global order (peer-mapped id planes; not with
- *                              HRBF_SHARD_EXCHANGE=records) — the order, hence every result, is unchanged.  hrbf_download_map of a rank returns its own
+ *                              every id is replaced by its rank in the global order (peer-mapped id planes; all-gathered
+ *                              planes under the packed-record exchange) — the order, hence every result, is unchanged.  Should
+ *                              that fail (allocation, communicator) the frame's clean pass does not run, hrbf_process_frame
+ *                              returns the error, HRBF_STATUS_ID_SPACE is set and later frames fail at once until the status is
+ *                              cleared: ids never run past the limit.  hrbf_download_map of a rank returns its own
  *                              surfels, hrbf_download_gids their ids; one process playing all shards returns the merged map.
  *   hrbf_upload_map            always takes the WHOLE map; a rank keeps its slice.
  *   hrbf_surfel_count          global count; hrbf_local_surfel_count / hrbf_download_map: the local range(s).
@@ -364,6 +370,11 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  * ranks of one node) and the OWNER of a pixel's z-test winner writes the winner's attributes straight into every rank's
  * images — no packing, no count exchange, no host read-back; per projection the ranks meet twice on the stream (key
  * min-reduce, "everybody has written").  HRBF_SHARD_EXCHANGE=records selects the older packed-record ncclSend / ncclRecv.
+ * Peer mapping needs all ranks on ONE node in one IPC namespace.  Whether it worked is decided COLLECTIVELY at
+ * hrbf_map_shard_init: every rank reaches every meeting point whatever failed locally, a one-word all-reduce counts the ranks
+ * that could not map, and if there is one ALL ranks drop their mappings and use the packed-record exchange (which has no such
+ * restriction) — never some ranks on one transport and some on the other.  hrbf_shard_exchange_mode tells which: 0 not sharded
+ * over ranks, 1 peer images, 2 records on request, 3 records by that agreement.
  *
  * hrbf_peer_unique_id / hrbf_comm_init_peer: the same sharded map WITHOUT RCCL — rendezvous, surfel counts and the meeting
  * points go through a POSIX shared-memory segment (the id is its name), the key min-reduce reads the peers' z-buffers.  It
@@ -372,6 +383,9 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  * row-sharded (every rank reduces the whole image) and hrbf_map_rebalance is unavailable. */
 int hrbf_peer_unique_id(uint8_t out128[128]);
 int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
+/* a rendezvous id that will not be used after all (rank 0's context removes the segment when it goes away; if rank 0 never
+ * joins, this does).  An id serves ONE rendezvous: a second set of contexts on it is refused. */
+int hrbf_peer_release_id(const uint8_t id128[128]);
 int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ranges | 2 spatial hash */
 int hrbf_hash_renumber_count(hrbf_handle h);   /* hash ownership: times the 32-bit ids were renumbered to ranks (every ~55 000 VGA frames; order unchanged) */
 int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards);   /* shard of a surfel inserted at (x, y, z); host code */

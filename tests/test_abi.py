@@ -106,3 +106,15 @@ def test_rebalance_plan_is_an_exact_recut():
             for a, b, so, do, ln in moves:
                 out[b][do:do + ln] = shards[a][so:so + ln]
             assert np.array_equal(np.concatenate(out) if out else seq, seq)
+
+
+def test_an_abandoned_peer_rendezvous_can_be_released():
+    """hrbf_peer_unique_id creates a POSIX shared-memory segment that rank 0's context removes when it goes away; a rendezvous
+    that is given up before rank 0 joined would leak it (round-3 advice): hrbf_peer_release_id removes the name (no GPU needed)"""
+    import os
+    from hrbffusion3d_amd.api import HRBFFusion
+    uid = HRBFFusion.peer_unique_id()
+    name = uid.split(b"\0")[0].decode()
+    assert name.startswith("/hrbf_peer_") and os.path.exists("/dev/shm" + name)
+    assert HRBFFusion.peer_release_id(uid) and not os.path.exists("/dev/shm" + name)
+    assert not HRBFFusion.peer_release_id(uid)

@@ -96,11 +96,37 @@ def test_hash_owned_map_rccl_world1(pair, exchange, monkeypatch):
     p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
     o, g = pair(p)
     g.comm_init(0, 1, HRBFFusion.comm_unique_id()); g.map_shard_init(True, partition="hash")
+    assert g.shard_exchange_mode() == (1 if exchange == "images" else 2)
     for k in range(5):
         rgb, d, _ = synth.frame(k, W, H, noise=True)
         o.process_frame(rgb, d); g.process_frame(rgb, d)
         same_up_to_names(o, g, "hash rccl1 %s frame %d" % (exchange, k))
     assert g.status() == 0 and np.array_equal(g.download_gids().astype(np.int64), np.sort(g.download_gids().astype(np.int64)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("why", ["records on request", "a rank cannot map its peers"])
+def test_hash_owned_map_renumbers_its_ids_under_the_packed_record_exchange(pair, why, monkeypatch):
+    """round-3 advice: under the record exchange hash_renumber failed by design and st_clean swallowed the failure.  Now the id
+    planes are all-gathered through the communicator (world size 1 here: the collective is issued, in place), and the choice of
+    the exchange is COLLECTIVE: a rank whose hipIpc mapping fails (forced) makes every rank fall back to records (mode 3)."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    monkeypatch.setenv("HRBF_HASH_RENUMBER_AT", "20000")
+    if why == "records on request":
+        monkeypatch.setenv("HRBF_SHARD_EXCHANGE", "records")
+    else:
+        monkeypatch.setenv("HRBF_TEST_FAIL_PEER_MAP", "all")
+    W, H = 160, 120
+    fx, fy, cx, cy = synth.intrinsics(W, H)
+    p = default_params(W, H, fx, fy, cx, cy, max_surfels=1 << 17)
+    o, g = pair(p)
+    g.comm_init(0, 1, HRBFFusion.comm_unique_id()); g.map_shard_init(True, partition="hash")
+    assert g.shard_exchange_mode() == (2 if why == "records on request" else 3)
+    for k in range(9):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        same_up_to_names(o, g, "records, renumbered, frame %d" % k)
+    assert g.hash_renumber_count() >= 3 and g.status() == 0
 
 
 @pytest.mark.gpu

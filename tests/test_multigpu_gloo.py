@@ -269,3 +269,42 @@ def test_bench_json_contract_fields():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "workload", "achieved", "peak",
                 "frac", "traffic", "cores", "kind", "sample"):
         assert '"%s"' % key in src, key
+
+
+def _bench_line(cmd):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("form", ["by hand", "driver"])
+def test_bench_gpus_2_starts_two_ranks_and_times_the_sharded_design_in_children(form):
+    """`bench.py --gpus N` must USE N ranks (round-3 verdict: the flag was parsed and never read).  By hand it re-executes itself under
+    torch.distributed.run; under the driver's launcher it checks WORLD_SIZE.  Either way the line carries the rank count the
+    communicator saw, and at N > 1 the one-sequence sharded leg runs in child processes with their own rendezvous (dry mode: gloo,
+    no GPU work)."""
+    import socket
+    if form == "by hand":
+        cmd = [sys.executable, "bench.py", "--gpus", "2", "--dry-run"]
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"]
+    line = _bench_line(cmd)
+    assert line["n_gpus"] == 2 and line["ranks_observed"] == 2 and line["scaling"] == "weak"
+    child = line["sharded_one_sequence"]
+    assert "error" not in child, child
+    assert child["n_gpus"] == 2 and child["ranks_observed"] == 2 and child["scaling"] == "strong" and child["one_sequence_child"]
+    assert "config 4" in child["workload"] and "hash" in child["workload"]
+
+
+def test_bench_refuses_a_launcher_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr

@@ -147,3 +147,41 @@ def test_two_processes_share_one_hash_owned_map_bit_identical_to_a_single_map(gp
     assert len(np.unique(ids)) == n and (np.diff(two[0]["gids"].astype(np.int64)) > 0).all() and (np.diff(two[1]["gids"].astype(np.int64)) > 0).all()
     joined = np.concatenate([two[0]["map"].reshape(-1, 20), two[1]["map"].reshape(-1, 20)])[np.argsort(ids, kind="stable")]
     assert np.array_equal(joined, single["map"].reshape(-1, 20))
+
+
+def _run_failing_map(rank, world, uid, out):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    import time
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion, HrbfError
+    from hrbffusion3d_amd.params import default_params
+    os.environ["HRBF_TEST_FAIL_PEER_MAP"] = "1"        # rank 1 pretends hipIpcOpenMemHandle failed
+    W, H = 160, 120
+    g = HRBFFusion(default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 16))
+    t = time.time()
+    try:
+        g.comm_init_peer(rank, world, uid)
+        g.map_shard_init(True)
+        out.put((rank, "no error", time.time() - t))
+    except HrbfError as e:
+        out.put((rank, str(e), time.time() - t))
+    g.close()
+
+
+def test_a_rank_that_cannot_map_its_peers_fails_every_rank_at_once(gpu_available):
+    """round-3 advice: a rank whose IPC mapping failed returned early and left its peers spinning in the barrier (60 s), or on the
+    other transport.  Now it still reaches every meeting point and the outcome is shared: on the shared-memory transport (no other
+    exchange to fall back to) BOTH ranks get the error from hrbf_map_shard_init, within seconds; an id serves one rendezvous only."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = HRBFFusion.peer_unique_id()
+    procs = [ctx.Process(target=_run_failing_map, args=(r, 2, uid, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict((r, (msg, dt)) for r, msg, dt in (q.get(timeout=120) for _ in range(2)))
+    for pr in procs:
+        pr.join(timeout=60)
+    for r in (0, 1):
+        assert "could not map its peers" in got[r][0], got
+        assert got[r][1] < 30.0, got
