@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--ring-stride", type=int, default=4,
                     help="bracket the fuse pass with HIP events on every n-th frame of the timed region (each bracketed frame costs the stream ~22 us)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes that measure the fuse pass's HBM traffic")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the one-sequence sharded leg (child processes)")
     ap.add_argument("--sharded-leg-timeout", type=float, default=420.0, help="seconds the sharded leg's child processes may take")
     ap.add_argument("--one-sequence-child", action="store_true", help=argparse.SUPPRESS)   # set by the parent for the sharded leg
@@ -294,6 +295,58 @@ def worst_case_leg(args, local_rank):
             "bytes_per_launch": B_alg, "achieved": B_alg / t / 1e9, "frac": B_alg / t / 1e9 / 8000.0,
             "real_bytes": B_real, "achieved_real": B_real / t / 1e9, "frac_real": B_real / t / 1e9 / 8000.0,
             "real_bytes_source": "model (fuse_real_bytes in bench.py); PMC FETCH_SIZE + WRITE_SIZE of the same command: profiles/"}
+
+
+FUSE_KERNELS = ("k_apply_merges", "k_clean_flags", "k_fuse_stream")
+
+
+def pmc_fuse_traffic(child_args, last_n, timeout_s=300.0, skip=None):
+    """HBM-side bytes of the fuse pass's three kernels, MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    cannot share one: 3 + 2 of the 4 TCC slots, /opt/skills/guides/MI355X_MICROARCH.md) over a short child of this script, nothing
+    but --pmc in each.  Returns {kernel: {"FETCH_KB": mean per dispatch over the last `last_n` dispatches — or, with `skip`, over
+    dispatches skip .. skip + last_n of the kernel, i.e. the timed frames behind the warm-up —, "WRITE_KB": ...}} or
+    {"error": ...}; None when rocprofv3 is not on the box.  Counter values are KB (1024 B) per dispatch."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None
+    out = {k: {} for k in FUSE_KERNELS}
+    env = dict(os.environ, TMPDIR="/tmp", HRBF_BENCH_GEN_PROCS="1")     # no forked frame generators under the profiler
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    tmp = tempfile.mkdtemp(prefix="hrbf_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "x", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": "rocprofv3 --pmc %s: exit code %d, %d csv files: %s" % (counter, r.returncode, len(files), (r.stderr or "")[-300:])}
+            per = {k: [] for k in FUSE_KERNELS}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].split("(")[0]
+                    if name in per and row["Counter_Name"] == counter:
+                        per[name].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            for k in FUSE_KERNELS:
+                v = [x for _, x in sorted(per[k])]
+                v = v[-last_n:] if skip is None else v[skip:skip + last_n]
+                if not v:
+                    return {"error": "no %s dispatches of %s in the profile" % (counter, k)}
+                out[k][counter.split("_")[0] + "_KB"] = float(np.mean(v))
+                out[k]["dispatches"] = len(v)
+    except subprocess.TimeoutExpired:
+        return {"error": "rocprofv3 pass ran into its %.0f s limit" % timeout_s}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def respawn_under_launcher(n):
@@ -568,14 +621,27 @@ def main():
     # and committed with its calibration under profiles/ (null if the file is missing)
     traffic = None
     traffic_src = None
-    for name in ("r03_fuse_traffic.json", "r02_fuse_traffic.json", "r01_fuse_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = float(json.load(f)["traffic_bytes_per_launch"])
-            traffic_src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; not measured in this run)"
-            break
-        except Exception:
-            traffic = None
+    traffic_kernels = None
+    if rank == 0 and world == 1 and args.virtual_shards <= 1 and not one_sequence and not args.no_traffic:
+        fus.synchronize()
+        kp = min(K, 10)
+        traffic_kernels = pmc_fuse_traffic(["--steps", str(kp), "--warmup", "3", "--surfels", str(args.surfels), "--width", str(W), "--height", str(H),
+                                            "--cpu-frames", "0", "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-traffic"] +
+                                           (["--noise"] if args.noise else []), last_n=kp, skip=3)
+        if traffic_kernels is not None and "error" not in traffic_kernels:
+            # raw counters, no gfx950 x2: pass A mixes a 16-B stream with scattered texel gathers and the 86 MB map is resident in the
+            # 256 MiB Infinity Cache at this size (the guide's x2 is calibrated for wide coalesced streams; see roofline_worst_case)
+            traffic = 1024.0 * sum(v["FETCH_KB"] + v["WRITE_KB"] for v in traffic_kernels.values())
+            traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over a %d-frame child of this command, mean per dispatch of the three kernels" % kp
+    if traffic is None:      # no profiler on the box (or a failed pass): the figure committed with its calibration, and say so
+        for name in ("r04_fuse_traffic.json", "r03_fuse_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = float(json.load(f)["traffic_bytes_per_launch"])
+                traffic_src = "profiles/" + name + " (not measured in this run%s)" % (": " + traffic_kernels["error"] if traffic_kernels else ": no rocprofv3 on this box")
+                break
+            except Exception:
+                traffic = None
     shim = None
     if rank == 0 and world == 1 and args.virtual_shards <= 1 and not one_sequence and not args.no_cpp_shim:
         fus.synchronize()
@@ -588,15 +654,30 @@ def main():
         fus.synchronize()
         try:
             worst = worst_case_leg(args, local_rank)
-            try:    # HBM bytes of this very leg from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process)
-                with open(os.path.join(ROOT, "profiles", "r03_fuse_traffic.json")) as f:
-                    tw = float(json.load(f)["worst_case_leg_4.34M_surfels_all_moved"]["traffic_bytes_per_launch"])
-                if args.worst_surfels == 4_300_000 and abs(args.worst_frac - 0.05) < 1e-9 and (W, H) == (640, 480):
-                    worst["traffic"] = tw
-                    worst["achieved_traffic"] = tw / (worst["avg_kernel_ms"] * 1e-3) / 1e9
-                    worst["traffic_source"] = "profiles/r03_fuse_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --only-worst`)"
-            except Exception:
-                pass
+            wk = None if args.no_traffic else pmc_fuse_traffic(
+                ["--only-worst", "--worst-samples", "3", "--worst-surfels", str(args.worst_surfels), "--worst-frac", str(args.worst_frac),
+                 "--width", str(W), "--height", str(H)], last_n=1)
+            if wk is not None and "error" not in wk:
+                # the LAST dispatch of each kernel is the measured frame (the whole map moves).  k_fuse_stream's reads are a wide
+                # coalesced stream: FETCH_SIZE tallies its 128-B requests at 64 B on gfx950 -> x2 (MI355X_MICROARCH.md, HBM);
+                # writes and the other two kernels (gathers, sparse updates) as counted
+                tw = 1024.0 * (2.0 * wk["k_fuse_stream"]["FETCH_KB"] + wk["k_fuse_stream"]["WRITE_KB"] +
+                               sum(wk[k]["FETCH_KB"] + wk[k]["WRITE_KB"] for k in ("k_apply_merges", "k_clean_flags")))
+                worst["traffic"] = tw
+                worst["achieved_traffic"] = tw / (worst["avg_kernel_ms"] * 1e-3) / 1e9
+                worst["frac_traffic"] = worst["achieved_traffic"] / 8000.0
+                worst["traffic_kernels_KB"] = wk
+                worst["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --only-worst --worst-samples 3`, last dispatch of each kernel; k_fuse_stream FETCH x2 (gfx950 correction for coalesced streams)"
+            else:
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r03_fuse_traffic.json")) as f:
+                        tw = float(json.load(f)["worst_case_leg_4.34M_surfels_all_moved"]["traffic_bytes_per_launch"])
+                    if args.worst_surfels == 4_300_000 and abs(args.worst_frac - 0.05) < 1e-9 and (W, H) == (640, 480):
+                        worst["traffic"] = tw
+                        worst["achieved_traffic"] = tw / (worst["avg_kernel_ms"] * 1e-3) / 1e9
+                        worst["traffic_source"] = "profiles/r03_fuse_traffic.json (not measured in this run%s)" % (": " + wk["error"] if wk else "")
+                except Exception:
+                    pass
         except Exception as e:   # the second leg must never take the bench line down
             worst = {"error": repr(e)}
 
@@ -653,7 +734,7 @@ def main():
                                                 "Integration": float(tm[2]), "Prediction": float(tm[3]),
                                                 "fuse_stream_pass": float(tm[4])}},
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_kernels_KB": traffic_kernels,
                          "kernel": "k_apply_merges + k_clean_flags + k_fuse_stream (F2 + F3, every kernel of the pass)",
                          "avg_kernel_ms": fuse_ms, "merge_ms": merge_ms, "clean_compact_ms": fuse_ms - merge_ms,
                          "launches_timed": int(ok.sum()), "timed_every_nth_frame": max(1, args.ring_stride),

@@ -681,6 +681,17 @@ struct CleanParams {
     int hash_G, hash_me; float hash_inv_cell;   // hash ownership (hash_G > 1): a shard appends the new surfels whose cell is its own
 };
 
+#ifdef CLEAN_DIAG
+// diagnostic build: [0] in-view items that reach the window test, [1] of them those with NO visited texel behind
+// them (`vcf.z > lp.z` false everywhere: a max-winner-depth image would settle them with one 4-byte gather), [2] dropped
+__device__ unsigned long long g_clean_diag[4];
+extern "C" int hrbf_probe_clean_diag(unsigned long long out[4], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clean_diag), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clean_diag), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 // window part of the test; returns false when the surfel must be dropped.
 // The reference walks a 4x4 half-pixel grid (copy_unstable.vert:104-141) = 2..3 DISTINCT texels per axis,
 // some visited twice.  Each distinct texel is fetched once from the packed clean texture (2 x float4,
@@ -751,6 +762,16 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
                     if (((upd[jy] >> jx) & 1u) && vcf.z - lp.z > 0.01f && nz_ok) zCount += wgt;
                 }
             }
+#ifdef CLEAN_DIAG
+        {
+            bool behind = false;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) behind |= (mx[t / 3] * my[t % 3] > 0) && ta[t].z > lp.z;
+            atomicAdd(&g_clean_diag[0], 1ull);
+            if (!behind) atomicAdd(&g_clean_diag[1], 1ull);
+            if (count > 8 || zCount > 4) atomicAdd(&g_clean_diag[2], 1ull);
+        }
+#endif
         return !(count > 8 || zCount > 4);
     }
     const hd_walk wkx = hd_halfpixel_walk(x, cam.W, cp.wm), wky = hd_halfpixel_walk(y, cam.H, cp.wm);
