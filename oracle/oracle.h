@@ -93,6 +93,12 @@ typedef struct orc_ctx {
     int16_t *corres;          /* P * 6 : zero.x zero.y one.x one.y valid pad ; diff in corres_diff */
     float *corres_diff;
     double timings_ms[8];
+    /* test hook (tests/test_registration_fp64.py): per Gauss-Newton iteration of the last orc_odo_track {level, iteration, A_icp[36],
+       b_icp[6], A_rgb[36], b_rgb[6], increment[6], icp inliers, rgb count, rgb sigma, icp residual} = 96 doubles, then the state the
+       iteration STARTED from: resultRt[16] (row-major), Rcurr[9], tcurr[3]; SO3 iterations {-1, iteration, jtj[9], jtr[3], residual,
+       count} and resultR[9] at [96..105) */
+    double odo_trace[40][128];
+    int odo_trace_n;
 } orc_ctx;
 
 #ifdef __cplusplus
@@ -115,6 +121,11 @@ void orc_set_active_submaps(orc_ctx *c, const uint8_t *active, int n);   /* n = 
 void orc_update_model(orc_ctx *c, const float *delta16_colmajor, int n);
 void orc_set_weighting(orc_ctx *c, float w);
 int orc_set_fragment_texcoords(orc_ctx *c, const float *tc);   /* test hook, see orc_ctx.c */
+int orc_get_odo_trace(const orc_ctx *c, double *out, int max_rows);   /* test hook: rows of 128 doubles, returns the count */
+/* test hook: a level of the registration pyramids as orc_odo_init_* left them.  which: 0-3 model v / n / k1 / k2 (global frame), 4-7 live
+   v / n / k1 / k2 (planar 4 x rows x cols floats), 8 icp weight, 9 last depth, 10 next depth (floats), 11 last / 12 next / 13 previous
+   intensity (bytes), 14 dIdx, 15 dIdy (int16, valid after a track).  Returns the byte count, 0 if `bytes` is too small. */
+size_t orc_get_pyramid(const orc_ctx *c, int which, int level, void *out, size_t bytes);
 float orc_get_weighting(orc_ctx *c);
 uint32_t orc_surfel_count(orc_ctx *c);
 int orc_download_map(orc_ctx *c, float *out, size_t cap);

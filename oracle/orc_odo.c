@@ -761,8 +761,35 @@ static void project_cloud(const float *depth, int rows, int cols, float fx, floa
 }
 
 /* ------------------------------------------------------------------ O6: getIncrementalTransformation */
+int orc_get_odo_trace(const orc_ctx *c, double *out, int max_rows)
+{
+    const int n = c->odo_trace_n < max_rows ? c->odo_trace_n : max_rows;
+    memcpy(out, c->odo_trace, sizeof(double) * 128 * (size_t)n);
+    return n;
+}
+size_t orc_get_pyramid(const orc_ctx *c, int which, int level, void *out, size_t bytes)
+{
+    if (level < 0 || level >= ORC_NUM_PYRS) return 0;
+    const size_t n = (size_t)(c->H >> level) * (size_t)(c->W >> level);
+    const orc_planar *pl[8] = {c->vmap_g, c->nmap_g, c->ck1_g, c->ck2_g, c->vmap_c, c->nmap_c, c->ck1_c, c->ck2_c};
+    const void *src = NULL; size_t b = 0;
+    if (which >= 0 && which < 8) { src = pl[which][level].p; b = 16 * n; }
+    else if (which == 8) { src = c->icpw[level]; b = 4 * n; }
+    else if (which == 9) { src = c->last_depth[level]; b = 4 * n; }
+    else if (which == 10) { src = c->next_depth[level]; b = 4 * n; }
+    else if (which == 11) { src = c->last_image[level]; b = n; }
+    else if (which == 12) { src = c->next_image[level]; b = n; }
+    else if (which == 13) { src = c->last_next_image[level]; b = n; }
+    else if (which == 14) { src = c->dIdx[level]; b = 2 * n; }
+    else if (which == 15) { src = c->dIdy[level]; b = 2 * n; }
+    if (!src || bytes < b) return 0;
+    memcpy(out, src, b);
+    return b;
+}
+
 void orc_odo_track(orc_ctx *c)
 {
+    c->odo_trace_n = 0;
     const int rgbOnly = c->prm.rgb_only;
     const float icpWeight = c->prm.icp_weight;
     const int icp = !rgbOnly && icpWeight > 0.0f;
@@ -797,6 +824,15 @@ void orc_odo_track(orc_ctx *c)
                     float value = (float)s[shift++];
                     if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
                 }
+            if (c->odo_trace_n < 40) {
+                double *tr = c->odo_trace[c->odo_trace_n++];
+                memset(tr, 0, sizeof(double) * 128);
+                tr[0] = -1; tr[1] = it;
+                for (int k = 0; k < 9; ++k) tr[96 + k] = resultR[k];
+                for (int k = 0; k < 9; ++k) tr[2 + k] = jtj[k];
+                for (int k = 0; k < 3; ++k) tr[11 + k] = jtr[k];
+                tr[14] = s[9]; tr[15] = s[10];
+            }
             float res0 = (float)s[9], res1 = (float)s[10];
             float so3err = sqrtf(res0) / res1, so3cnt = res1;
             if (so3err < lastError && lastCount == so3cnt) break;
@@ -847,6 +883,10 @@ void orc_odo_track(orc_ctx *c)
         orc_sparse sp = {c->sp_lambda[i], c->sp_z[i], c->sp_corres[i], &c->sp_shrunk};
         if (sparse) memset(sp.lambda, 0, sizeof(f3) * (size_t)(c->H >> i) * (c->W >> i));   /* RGBDOdometry.cpp:964-977 */
         for (int j = 0; j < iterations[i]; ++j) {
+            double state0[28];
+            memcpy(state0, Rt, sizeof(Rt));
+            for (int k = 0; k < 9; ++k) state0[16 + k] = Rcurr[k];
+            state0[25] = tcurr.x; state0[26] = tcurr.y; state0[27] = tcurr.z;
             /* Rt = resultRt.inverse() (rigid: cofactor inverse of the linear part) */
             double L[9], Li[9], ti[3];
             for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) L[r * 3 + k] = Rt[r * 4 + k];
@@ -904,6 +944,14 @@ void orc_odo_track(orc_ctx *c)
                 for (int k = 0; k < 6; ++k) lastb[k] = b_rgb[k];
             }
             ldlt_d(6, lastA, lastb, result);
+            if (c->odo_trace_n < 40) {
+                double *tr = c->odo_trace[c->odo_trace_n++];
+                tr[0] = i; tr[1] = j;
+                for (int k = 0; k < 36; ++k) { tr[2 + k] = A_icp[k]; tr[44 + k] = A_rgb[k]; }
+                for (int k = 0; k < 6; ++k) { tr[38 + k] = b_icp[k]; tr[80 + k] = b_rgb[k]; tr[86 + k] = result[k]; }
+                tr[92] = res_icp[1]; tr[93] = (double)rgbSize; tr[94] = (double)sigma; tr[95] = res_icp[0];
+                memcpy(tr + 96, state0, sizeof(state0));
+            }
             /* computeUpdateSE3 OdometryProvider.h:73-93 */
             double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];
             rodrigues(rv, Ru);

@@ -38,6 +38,8 @@ def load(omp=False):
     lib.orc_set_tick.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_weighting.argtypes = [C.c_void_p, C.c_float]
     lib.orc_set_fragment_texcoords.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_get_odo_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_get_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]; lib.orc_get_pyramid.restype = C.c_size_t
     lib.orc_set_index_submap.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_active_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_update_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -138,6 +140,26 @@ class Oracle:
 
     def set_weighting(self, w):
         self.lib.orc_set_weighting(self.h, w)
+
+    PYRAMIDS = {"vmap_g": 0, "nmap_g": 1, "ck1_g": 2, "ck2_g": 3, "vmap_c": 4, "nmap_c": 5, "ck1_c": 6, "ck2_c": 7, "icpw": 8, "last_depth": 9,
+                "next_depth": 10, "last_image": 11, "next_image": 12, "prev_image": 13, "dIdx": 14, "dIdy": 15}
+
+    def odo_trace(self):
+        """test hook: one row of 128 doubles per SO3 / Gauss-Newton iteration of the last registration (oracle.h)"""
+        out = np.zeros((40, 128), np.float64)
+        n = self.lib.orc_get_odo_trace(self.h, _p(out), 40)
+        return out[:n]
+
+    def pyramid(self, name, level):
+        """test hook: a level of the registration pyramids; maps come back as (rows, cols, 4)"""
+        which = self.PYRAMIDS[name]
+        r, c = self.H >> level, self.W >> level
+        if which < 8:
+            a = np.zeros((4, r, c), np.float32)
+        else:
+            a = np.zeros((r, c), np.float32 if which <= 10 else (np.uint8 if which <= 13 else np.int16))
+        assert self.lib.orc_get_pyramid(self.h, which, level, _p(a), a.nbytes) == a.nbytes
+        return np.ascontiguousarray(np.moveaxis(a, 0, -1)) if which < 8 else a
 
     def set_fragment_texcoords(self, tc):
         """test hook: the texcoord a rasteriser interpolated for every pixel ((H, W, 2) float32), None = correctly rounded"""
