@@ -71,6 +71,20 @@ def load_trajectory_tum(path):
     return np.array(stamps), poses
 
 
+def reference_trajectory_stamp(token):
+    """the integer TrajectoryManager::LoadFromFile reads from a TUM / CoRBS time stamp (TrajectoryManager.cpp:166-168): std::remove
+    closes the gap the '.' leaves but does not shorten the string, so "1305031102.175304" parses (%llu) as 13050311021753044 — the
+    digits without the dot and the last digit once more"""
+    kept = token.replace(".", "")
+    kept += token[len(kept):]
+    digits = ""
+    for ch in kept:
+        if not ch.isdigit():
+            break
+        digits += ch
+    return int(digits) if digits else 0
+
+
 def load_trajectory_file(path, fmt="TUM"):
     """the pose files TrajectoryManager::LoadFromFile replays (Core/src/Utils/TrajectoryManager.cpp:61-282): TUM / CoRBS,
     zhou (re-based on the first pose), ICL_NUIM_RT (x mirrored on the left, y on the right); returns a list of 4x4 T_wc"""
@@ -83,6 +97,8 @@ def load_trajectory_file(path, fmt="TUM"):
             v = line.split()
             if len(v) != 8 or line.startswith("#"):
                 continue
+            if not line.endswith("\n"):      # `if(file.eof()) break;` before the push_back (TrajectoryManager.cpp:170,207): a last
+                break                        # line without a trailing newline is read and dropped
             x, y, z, qx, qy, qz, qw = (f(float(a)) for a in v[1:8])
             tx, ty, tz = f(2) * qx, f(2) * qy, f(2) * qz
             twx, twy, twz, txx, txy, txz = tx * qw, ty * qw, tz * qw, tx * qx, ty * qx, tz * qx

@@ -315,7 +315,14 @@ public:
         index_ = new IndexMap(h_);
         trajectory_manager = new TrajectoryManager();
         trajectory_manager->sync = [this]() { this->syncTrajectory(); };
-        if (load_trajectory_) loadTrajectory(g.globalInputTrajectoryFile, g.globalInputTrajectoryFormat);
+        if (load_trajectory_) {
+            try { loadTrajectory(g.globalInputTrajectoryFile, g.globalInputTrajectoryFormat); }
+            catch (...) {       // a constructor that throws runs no destructor: release what was acquired, then pass the error on
+                delete trajectory_manager; delete index_; delete model_; hrbf_destroy(h_);
+                trajectory_manager = nullptr; index_ = nullptr; model_ = nullptr; h_ = nullptr;
+                throw;
+            }
+        }
     }
     /* globalInputLoadTrajectory: TrajectoryManager::LoadFromFile + `currPose = poses[0]` (HRBFFusion.cpp:55-59); from then on
        processFrame sets currPose = poses[tick - 1] instead of registering (HRBFFusion.cpp:1105-1108) */

@@ -248,11 +248,24 @@ inline std::vector<PoseCM> loadTrajectoryFile(const std::string &filename, const
     auto fromRows = [](const float r[16]) { PoseCM p; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) p.m[j * 4 + i] = r[i * 4 + j]; return p; };
     if (format == "TUM" || format == "CoRBS") {
         std::string line;
-        while (std::getline(f, line)) {
+        while (!f.eof()) {
+            std::getline(f, line);
             if (line.empty() || line[0] == '#') continue;
-            std::istringstream is(line);
-            double ts; float x, y, z, qx, qy, qz, qw;
-            if (!(is >> ts >> x >> y >> z >> qx >> qy >> qz >> qw)) continue;
+            // TrajectoryManager.cpp:163-171,199-208: `if(file.eof()) break;` sits between the parse and the push_back, so a last
+            // line WITHOUT a trailing newline is read and dropped — kept
+            if (f.eof()) break;
+            // the time stamp: std::remove(begin, begin + first_space, '.') closes the gaps inside the token but does not shorten
+            // the string, so the token's tail keeps its old characters: "1305031102.175304" is parsed (%llu) as
+            // 13050311021753044 — the digits without the dot and the last digit once more.  Reproduced, since the stamps are
+            // written back by SaveTrajectoryToFile.
+            const size_t sp = line.find_first_of(" ");
+            std::string tok = line.substr(0, sp == std::string::npos ? line.size() : sp), kept;
+            for (char ch : tok) if (ch != '.') kept.push_back(ch);
+            for (size_t i = kept.size(); i < tok.size(); ++i) kept.push_back(tok[i]);
+            unsigned long long utime = 0;
+            float x, y, z, qx, qy, qz, qw;
+            const std::string rest = kept + (sp == std::string::npos ? std::string() : line.substr(sp));
+            if (sscanf(rest.c_str(), "%llu %f %f %f %f %f %f %f", &utime, &x, &y, &z, &qx, &qy, &qz, &qw) != 8) continue;   // the reference asserts n == 8
             // Eigen::Quaternionf(qw, qx, qy, qz) -> Isometry3f::rotate (TrajectoryManager.cpp:225-231): fp32, the quaternion is
             // used as read (not normalised), Eigen's toRotationMatrix operation order
             const float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
@@ -262,7 +275,7 @@ inline std::vector<PoseCM> loadTrajectoryFile(const std::string &filename, const
                                  txy + twz, 1.0f - (txx + tzz), tyz - twx, y,
                                  txz - twy, tyz + twx, 1.0f - (txx + tyy), z, 0, 0, 0, 1};
             out.push_back(fromRows(R));
-            if (stamps) stamps->push_back((int64_t)(ts * 1e6));
+            if (stamps) stamps->push_back((int64_t)utime);
         }
     } else if (format == "zhou") {
         int a, b, c;
@@ -272,6 +285,8 @@ inline std::vector<PoseCM> loadTrajectoryFile(const std::string &filename, const
             out.push_back(fromRows(r));
         }
         if (!out.empty()) {
+            // poses[i] = poses[0].inverse() * poses[i] (TrajectoryManager.cpp:86-90): Eigen's general 4x4 inverse there, the rigid
+            // inverse here — the same matrix up to fp32 rounding for the rigid poses such a file holds
             float inv0[16]; rigidInverseCm(out[0].m, inv0);
             for (size_t i = 1; i < out.size(); ++i) { PoseCM t; mul44cm(inv0, out[i].m, t.m); out[i] = t; }
             const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

@@ -624,6 +624,44 @@ def dump_vga(path):
     print("vga dump ->", path, "%.1f MB" % (os.path.getsize(path) / 1e6))
 
 
+def vga_rasteriser_report():
+    """Every GLSL pass at 640 x 480 on the rasteriser GALLIUM_DRIVER selects (llvmpipe by default, softpipe: Mesa's second software
+    rasteriser — C code, no JIT, its own texture addressing, interpolation and point rasterisation) against the oracle, through the
+    checks of the committed fixture (ref_glsl_check.run_vga), printed instead of asserted.  What the two executions agree on is evidence
+    about the reference; where they differ from each other the behaviour is the GL implementation's."""
+    import ref_glsl_check as R
+    from oracle_lib import Oracle
+    from ref_glsl import glbind as G
+    f1, f2, T2, w2 = vga_inputs()
+    fx = run_reference("vga", f1, f2, T2, w2)
+    renderer = G.GL(compat=True).glGetString(G.GL_RENDERER).decode()
+    print("GL_RENDERER:", renderer)
+    W, H = 640, 480
+    f = np.float32
+    ys, xs = np.mgrid[0:H, 0:W]
+    ideal = np.stack([(xs.astype(f) + f(0.5)) / f(W), (ys.astype(f) + f(0.5)) / f(H)], -1).astype(f)
+    tc = fx["tc"]
+    u = lambda a, b: np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32))
+    print("interpolated texcoord vs the correctly rounded (p + 0.5) / n: x differs at %d pixels (max %d ulp), y at %d (max %d ulp); both exact at %.1f%%" % (
+        int((tc[..., 0] != ideal[..., 0]).sum()), int(u(tc[..., 0], ideal[..., 0]).max()), int((tc[..., 1] != ideal[..., 1]).sum()),
+        int(u(tc[..., 1], ideal[..., 1]).max()), 100 * (tc == ideal).all(-1).mean()))
+    ids = fx["f2_a_INDEX"]
+    print("index map: largest surfel id drawn %d of %d surfels%s" % (int(ids.max()), fx["f1_map"].shape[0],
+          "  <-- gl_VertexID restarts every 4096 vertices on this rasteriser: its map passes are not comparable" if ids.max() < fx["f1_map"].shape[0] // 2 else ""))
+    for mode in (False, True):
+        print("---- oracle %s" % ("given this rasteriser's interpolated texcoords (test hook)" if mode else "with correctly rounded texcoords + the exact-texcoord mask"))
+        o = Oracle(params("vga"), omp=True)
+        try:
+            rep = R.run_vga(o, fx, R.Report(strict=False, verbose=True), rasteriser_texcoords=mode)
+        except Exception as e:      # a rasteriser whose map passes are broken can trip the checks' own assumptions
+            print("   (stopped: %r)" % (e,))
+            rep = None
+        o.close()
+        if rep is not None:
+            bad = [w for w, ok, _ in rep.rows if not ok]
+            print("%d checks, %d outside the bounds: %s" % (len(rep.rows), len(bad), bad))
+
+
 def vga_fixture():
     """tests/golden/ref_glsl/vga.npz: every pass on the WHOLE GPUTest pair at 640 x 480 (the benchmark's resolution), coded
     losslessly by tests/ref_glsl_vga.py (177 MB of arrays -> tens of MB: most are exact functions of the others)."""
@@ -650,6 +688,8 @@ def vga_fixture():
 if __name__ == "__main__":
     if "--vga-fixture" in sys.argv:
         vga_fixture()
+    elif "--vga-rasteriser-report" in sys.argv:
+        vga_rasteriser_report()
     elif "--dump-vga" in sys.argv:
         dump_vga(sys.argv[sys.argv.index("--dump-vga") + 1])
     elif "--qqvga-variants-report" in sys.argv:

@@ -305,6 +305,35 @@ def test_trajectory_file_readers_agree(tmp_path):
         hio.load_trajectory_file(str(tmp_path / "t.log"), "lefloch")
 
 
+def test_tum_trajectory_reader_keeps_the_references_stamp_and_eof_behaviour(tmp_path):
+    """TrajectoryManager::LoadFromFile (TrajectoryManager.cpp:163-171,199-233): the stamp is parsed after std::remove has squeezed the
+    '.' out of the token WITHOUT shortening it (the last digit appears twice), and a last line without a trailing newline is read
+    but not pushed.  The C++ reader (include/hrbf_io.h) and the Python reader agree with that reading, not with a tidied one."""
+    from hrbffusion3d_amd import build
+    from hrbffusion3d_amd import io as hio
+    build.build()
+    exe = str(tmp_path / "trajectory_reader")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "trajectory_reader.cpp"),
+                           "-o", exe, "-lz"])
+    body = ("# ground truth trajectory\n1305031102.175304 1.3405 0.6266 1.6575 0.6574 0.6126 -0.2949 -0.3248\n"
+            "1305031102.211214 1.3303 0.6256 1.6464 0.6579 0.6161 -0.2932 -0.3189\n\n42 0.5 0.25 0.125 0 0 0 1\n"
+            "1305031102.275326 1.3160 0.6254 1.6302 0.6609 0.6199 -0.2893 -0.3086")          # no newline at the end: dropped
+    (tmp_path / "gt.txt").write_text(body)
+    out = subprocess.run([exe, str(tmp_path / "gt.txt"), "TUM"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert lines[0] == "3"
+    assert [int(l.split()[0]) for l in lines[1:]] == [13050311021753044, 13050311022112144, 42]
+    assert hio.reference_trajectory_stamp("1305031102.175304") == 13050311021753044 and hio.reference_trajectory_stamp("42") == 42
+    back = hio.load_trajectory_file(str(tmp_path / "gt.txt"), "TUM")
+    assert len(back) == 3 and np.allclose(back[2][:3, 3], [0.5, 0.25, 0.125])
+    assert np.allclose([float(x) for x in lines[1].split()[1:]], back[0][:3, 3], atol=1e-6)
+    (tmp_path / "gt_nl.txt").write_text(body + "\n")
+    assert len(hio.load_trajectory_file(str(tmp_path / "gt_nl.txt"), "TUM")) == 4
+    out = subprocess.run([exe, str(tmp_path / "gt_nl.txt"), "CoRBS"], capture_output=True, text=True, timeout=60)
+    assert out.stdout.split("\n")[0] == "4"
+
+
 @pytest.mark.gpu
 def test_runners_agree_on_start_skip_end_and_trajectory_replay(tmp_path, gpu_available):
     """the frame selection of MainController::run (globalStartFrame / globalFrameToSkip / globalEndFrame) and
