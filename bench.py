@@ -375,11 +375,14 @@ def sharded_leg_command(args, world):
     return cmd, name
 
 
-def sharded_leg(args, rank, world, barrier):
-    """Every rank starts ONE child (same RANK / LOCAL_RANK / WORLD_SIZE, its own rendezvous port) and waits for it with a time limit;
-    the children form their own communicator, so a failure or a hang in there ends with the limit and an `error` entry — the parent's
-    process group is never inside the children's collectives.  Returns the child line (rank 0) or {"error": ...}."""
+def sharded_leg(args, rank, world, barrier, any_rank):
+    """Every rank starts ONE child (same RANK / LOCAL_RANK / WORLD_SIZE, its own rendezvous port) and watches it; the children form
+    their own communicator, so a failure or a hang in there ends with an `error` entry — the parent's process group is never inside
+    the children's collectives.  The parents poll: every 2 s they agree (any_rank: a max-all-reduce over the parents) on whether some
+    child has failed or the time limit has passed — then every parent kills its child at once instead of waiting for the limit
+    while its child sits in a collective with a dead peer.  Returns the child line (rank 0) or {"error": ...}."""
     import subprocess
+    import tempfile
     cmd, name = sharded_leg_command(args, world)
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
@@ -388,19 +391,40 @@ def sharded_leg(args, rank, world, barrier):
         del env[k]
     barrier()
     t0 = time.perf_counter()
+    res = None
+    fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.sharded_leg_timeout)
-        res = {"error": "child exit code %d: %s" % (r.returncode, (r.stderr or "")[-400:])} if r.returncode else None
-        if rank == 0 and res is None:
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            res = json.loads(line[-1]) if line else {"error": "no line from the child: " + (r.stderr or "")[-400:]}
-    except subprocess.TimeoutExpired:
-        res = {"error": "time limit of %.0f s" % args.sharded_leg_timeout}
+        child = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, text=True)
     except Exception as e:
-        res = {"error": repr(e)}
+        child, res = None, {"error": repr(e)}
+    while True:
+        rc = child.poll() if child is not None else 1
+        late = time.perf_counter() - t0 > args.sharded_leg_timeout
+        failed = child is None or (rc is not None and rc != 0) or late
+        stop = any_rank(1 if failed else 0)            # somebody's child failed (or the limit passed): everybody stops
+        running = any_rank(1 if (rc is None) else 0)
+        if stop or not running:
+            break
+        time.sleep(2.0)
+    if child is not None and child.poll() is None:
+        child.kill(); child.wait()
+        res = {"error": "time limit of %.0f s" % args.sharded_leg_timeout if time.perf_counter() - t0 > args.sharded_leg_timeout
+               else "stopped: another rank's child failed"}
+    if child is not None and res is None:
+        fo.seek(0); fe.seek(0)
+        so, se = fo.read(), fe.read()
+        if child.returncode:
+            res = {"error": "child exit code %d: %s" % (child.returncode, se[-400:])}
+        elif rank == 0:
+            line = [l for l in so.splitlines() if l.startswith("{")]
+            res = json.loads(line[-1]) if line else {"error": "no line from the child: " + se[-400:]}
+    # rank 0 reports; if its own child was fine but another rank's failed, say so
+    worst = any_rank(1 if (res is not None and "error" in res) else 0)
     barrier()
     if rank != 0:
         return None
+    if worst and not (res and "error" in res):
+        res = {"error": "a rank's child failed or was stopped"}
     res = dict(res or {})
     res["workload"] = name
     res["wall_s_incl_setup"] = time.perf_counter() - t0
@@ -439,6 +463,11 @@ def dry_run(args, rank, world):
     """the N-rank plumbing without a GPU (gloo): rank count, barrier + max-over-ranks, and the sharded leg's child launch"""
     import torch
     import torch.distributed as dist
+    fault = os.environ.get("HRBF_BENCH_TEST_CHILD", "") if args.one_sequence_child else ""     # tests: what the parents do when the
+    if fault == "fail" and rank == world - 1:                                                   # sharded leg breaks or hangs
+        raise SystemExit("injected failure of the sharded leg's rank %d" % rank)
+    if fault == "hang":
+        time.sleep(3600)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -452,7 +481,11 @@ def dry_run(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sharded = None
     if world > 1 and not args.one_sequence_child and not args.no_sharded_leg:
-        sharded = sharded_leg(args, rank, world, barrier)
+        def any_rank(v):
+            t = torch.tensor([int(v)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item())
+        sharded = sharded_leg(args, rank, world, barrier, any_rank)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_observed": int(one.item()), "max_over_ranks_s": float(t.item()),
                           "one_sequence_child": bool(args.one_sequence_child), "scaling": "strong" if args.one_sequence_child else "weak",
@@ -704,7 +737,11 @@ def main():
     sharded = None
     if dist is not None and not one_sequence and not args.no_sharded_leg:
         fus.synchronize(); torch.cuda.synchronize()
-        sharded = sharded_leg(args, rank, world, barrier)
+        def any_rank(v):
+            t = torch.tensor([int(v)], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item())
+        sharded = sharded_leg(args, rank, world, barrier, any_rank)
         if sharded is not None and "error" not in sharded:      # keep what the leg is for; the rest of the child's line repeats this one's
             sharded = {k: sharded.get(k) for k in ("workload", "value", "unit", "ms_per_step", "scaling", "n_gpus", "ranks_observed", "steps", "warmup",
                                                    "per_rank_fuse_ms", "collectives", "wall_s_incl_setup")} | {
