@@ -662,6 +662,32 @@ def vga_rasteriser_report():
             print("%d checks, %d outside the bounds: %s" % (len(rep.rows), len(bad), bad))
 
 
+VGA_VARIANTS = QQVGA_VARIANTS + [dict(use_bilateral=0), dict(curv_estimation_window=2.0), dict(use_conf_eval=1), dict(depth_cutoff=1.5),
+                                 dict(confidence_threshold=9.0, curv_valid_threshold=40.0), dict(predict_conf_threshold=6.6)]
+
+
+def vga_variants_report():
+    """The reference's switches x the benchmark's resolution: the whole GPUTest pair at 640 x 480 through the reference's shaders with
+    each variant's uniforms, against the oracle with the same parameters, through run_vga's checks (the oracle is given the
+    rasteriser's texcoords, so no mask) — printed, not a fixture (the committed variants live on a 128 x 128 scene)."""
+    import ref_glsl_check as R
+    from oracle_lib import Oracle
+    f1, f2, T2, w2 = vga_inputs()
+    for kw in VGA_VARIANTS:
+        fx = run_reference("vga", f1, f2, T2, w2, prm_over={k: v for k, v in kw.items()})
+        if "normal_estimation_pca" in kw:
+            fx["_normal_abs_floor"] = 2e-5
+        o = Oracle(params("vga", **kw), omp=True)
+        try:
+            rep = R.run_vga(o, fx, R.Report(strict=False, verbose=False), rasteriser_texcoords=True)
+            rows = rep.rows
+            bad = [(w, d) for w, ok, d in rows if not ok]
+            print("%s: %d checks, %d outside the bounds %s" % (kw, len(rows), len(bad), bad))
+        except Exception as e:
+            print("%s: stopped: %r" % (kw, e))
+        o.close()
+
+
 def vga_fixture():
     """tests/golden/ref_glsl/vga.npz: every pass on the WHOLE GPUTest pair at 640 x 480 (the benchmark's resolution), coded
     losslessly by tests/ref_glsl_vga.py (177 MB of arrays -> tens of MB: most are exact functions of the others)."""
@@ -690,6 +716,8 @@ if __name__ == "__main__":
         vga_fixture()
     elif "--vga-rasteriser-report" in sys.argv:
         vga_rasteriser_report()
+    elif "--vga-variants-report" in sys.argv:
+        vga_variants_report()
     elif "--dump-vga" in sys.argv:
         dump_vga(sys.argv[sys.argv.index("--dump-vga") + 1])
     elif "--qqvga-variants-report" in sys.argv:

@@ -103,8 +103,9 @@ def part_vertex_normal_radius(rep, g, fx, P="f2_", pca=True):
     # carry ~1e-5 absolute of rounding, and llvmpipe contracts the cross product's a*b - c*d where the oracle may not)
     rep.close_ulp("P3 NORMAL (%s) xyz" % ("PCA" if pca else "central differences"), n3[..., :3], fx[P + "NORMAL_P3"][..., :3], 64,
                   abs_floor=2e-6 if pca else 2e-5)
-    rep.close_ulp("P3 NORMAL w = RADIUS", n3[..., 3], fx[P + "NORMAL_P3"][..., 3], 64)
-    rep.close_ulp("P3 RADIUS", g.get_image("RADIUS"), fx[P + "RADIUS"], 64)
+    # (the radius divides by |n_z|: it inherits the central-difference normal's cancellation noise — 1e-4 relative of ~1 cm)
+    rep.close_ulp("P3 NORMAL w = RADIUS", n3[..., 3], fx[P + "NORMAL_P3"][..., 3], 64, abs_floor=0.0 if pca else 4e-6)
+    rep.close_ulp("P3 RADIUS", g.get_image("RADIUS"), fx[P + "RADIUS"], 64, abs_floor=0.0 if pca else 4e-6)
 
 
 def part_curvature(rep, g, fx, P="f2_"):
@@ -341,7 +342,8 @@ def map_flow(rep, g, fx, pre, tag, map_in, T2):
     a, b = final[found], ref_final[pos[found]]
     rep.exact(tag + "F3 colour / submap / init time / time of every common row", a[:, 4:8], b[:, 4:8])
     rep.close_ulp(tag + "F3 map positions + confidence", a[:, 0:4], b[:, 0:4], 16, frac_within=1.0 - (4.0 * ties + 1) / max(1, a.shape[0]))
-    rep.close_ulp(tag + "F3 map normals + radii", a[:, 8:12], b[:, 8:12], 64, abs_floor=2e-6, frac_within=1.0 - (4.0 * ties + 1) / max(1, a.shape[0]))
+    rep.close_ulp(tag + "F3 map normals + radii", a[:, 8:12], b[:, 8:12], 64, abs_floor=max(2e-6, float(fx.get("_normal_abs_floor", 0.0))),
+                  frac_within=1.0 - (4.0 * ties + 1) / max(1, a.shape[0]))
     rep.close_ulp(tag + "F3 map curvature records", a[:, 12:20], b[:, 12:20], 64, abs_floor=1e-5, frac_within=1.0 - (8.0 * ties + 1) / max(1, a.shape[0]))
     removed_ref = int((~keep).sum())
     rep.add(tag + "F3 removals", abs((map_in.shape[0] + new.shape[0] - removed_ref) - final.shape[0]) <= 2 * ties,
@@ -400,9 +402,12 @@ def prediction_checks(rep, g, fx, P):
     rep.add("H2 PRED_VERTEX xyz", dp.max() <= 4e-5 and np.percentile(dp, 99) <= 1e-6, "|dp| max %.2e m, p99 %.2e, identical %.1f%%" % (
         dp.max(), np.percentile(dp, 99), 100 * (dp == 0).mean()))
     n, nr = g.get_image("PRED_NORMAL"), fx[P + "PRED_NORMAL"]
-    dn = np.linalg.norm((n[..., :3] - nr[..., :3]).astype(np.float64), axis=-1)[both]
-    rep.add("H2 PRED_NORMAL xyz", dn.max() <= 1e-2 and np.percentile(dn, 99) <= 2e-4, "|dn| max %.2e, p99 %.2e, median %.2e" % (
-        dn.max(), np.percentile(dn, 99), np.median(dn)))
+    # (a vanishing gradient normalises to NaN in both executions — 1 pixel of 250 000 with the radius multiplier at 3: same pixels)
+    nan_a, nan_b = np.isnan(n[..., :3]).any(-1)[both], np.isnan(nr[..., :3]).any(-1)[both]
+    dn = np.linalg.norm((n[..., :3] - nr[..., :3]).astype(np.float64), axis=-1)[both][~nan_a & ~nan_b]
+    rep.add("H2 PRED_NORMAL xyz", dn.max() <= 1e-2 and np.percentile(dn, 99) <= 2e-4 and int((nan_a != nan_b).sum()) <= 1,
+            "|dn| max %.2e, p99 %.2e, median %.2e; NaN normals %d / %d, %d in one execution only" % (
+                dn.max(), np.percentile(dn, 99), np.median(dn), int(nan_a.sum()), int(nan_b.sum()), int((nan_a != nan_b).sum())))
     # attributes of the neighbour nearest to the predicted point: exact unless two neighbours are equally near (<= 0.02 % of pixels)
     near = np.ones(both.sum(), bool)
     for k, cols in (("PRED_VERTEX", slice(3, 4)), ("PRED_NORMAL", slice(3, 4)), ("PRED_CURV1", slice(0, 4)), ("PRED_CURV2", slice(0, 4)),
@@ -541,7 +546,7 @@ def run_vga(impl, fx, rep, rasteriser_texcoords=False):
     part_filter(rep, g, fx, P)
     if rasteriser_texcoords:
         g.set_fragment_texcoords(fx["tc"])
-        part_vertex_normal_radius(rep, g, fx, P)
+        part_vertex_normal_radius(rep, g, fx, P, pca="_normal_abs_floor" not in fx)
         part_curvature(rep, g, fx, P)
         g.set_fragment_texcoords(None)
     else:
