@@ -236,7 +236,7 @@ def test_long_sequence_trajectory_and_determinism(gpu_available):
     est, m = run()
     gt = [f[2] for f in frames]
     ate = synth.ate_rmse(est, gt)
-    assert ate < 0.10, ate
+    assert 0.03 < ate < 0.08, ate          # 0.0596 in round 4 (0.058 in round 3): the photometric term's saturating offset, see the docstring
     assert len(m) > 0.8 * W * H
     est2, m2 = run()
     assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(est, est2))
