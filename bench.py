@@ -314,6 +314,12 @@ def pmc_fuse_traffic(child_args, last_n, timeout_s=300.0, skip=None):
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if prof is None:
         return None
+    # this process is itself being profiled (somebody ran `rocprofv3 ... bench.py`): no counter passes underneath a tracing tool
+    # (the pool refuses --pmc combined with trace domains for a reason), and its tool libraries must not leak into a child
+    tooling = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) or
+               (k in ("HSA_TOOLS_LIB", "LD_PRELOAD") and "rocprof" in os.environ[k].lower())]
+    if tooling:
+        return {"error": "bench.py is running under a profiler (%s): counter passes skipped" % ", ".join(sorted(tooling)[:3])}
     out = {k: {} for k in FUSE_KERNELS}
     env = dict(os.environ, TMPDIR="/tmp", HRBF_BENCH_GEN_PROCS="1")     # no forked frame generators under the profiler
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
