@@ -709,12 +709,12 @@ def main():
                 worst["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --only-worst --worst-samples 3`, last dispatch of each kernel; k_fuse_stream FETCH x2 (gfx950 correction for coalesced streams)"
             else:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r03_fuse_traffic.json")) as f:
+                    with open(os.path.join(ROOT, "profiles", "r04_fuse_traffic.json")) as f:
                         tw = float(json.load(f)["worst_case_leg_4.34M_surfels_all_moved"]["traffic_bytes_per_launch"])
                     if args.worst_surfels == 4_300_000 and abs(args.worst_frac - 0.05) < 1e-9 and (W, H) == (640, 480):
                         worst["traffic"] = tw
                         worst["achieved_traffic"] = tw / (worst["avg_kernel_ms"] * 1e-3) / 1e9
-                        worst["traffic_source"] = "profiles/r03_fuse_traffic.json (not measured in this run%s)" % (": " + wk["error"] if wk else "")
+                        worst["traffic_source"] = "profiles/r04_fuse_traffic.json (not measured in this run%s)" % (": " + wk["error"] if wk else "")
                 except Exception:
                     pass
         except Exception as e:   # the second leg must never take the bench line down
