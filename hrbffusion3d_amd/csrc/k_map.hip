@@ -877,7 +877,13 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
             const uint32_t q = qx * QH + qy;
             const float4 rp = rec.p0[q];
             const bool mine = cp.hash_G <= 1 || hash_owner(rp.x, rp.y, rp.z, cp.hash_inv_cell, cp.hash_G) == (uint32_t)cp.hash_me;
+            // flag 1 = a merge mark (colour word w = -1): copy_unstable.vert:159-162 drops it whatever the window says — its test
+            // (a normal load and <= 12 gathers for 61 000 of the headline stream's 63 600 records) is not run; flag 2 = a new surfel
+#ifndef CLEAN_TEST_MERGE_MARKS
+            const bool keep = rec_flag[q] == 2 && mine && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex, rp);
+#else
             const bool keep = rec_flag[q] != 0 && mine && clean_item(cp, tinv, ftime, m, rec, false, q, clean_tex, rp);
+#endif
             keep_flags[N + q] = keep ? 1 : 0;
             if (keep) {
                 const uint32_t tl = (N + q) / FUSE_TILE;
