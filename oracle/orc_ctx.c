@@ -328,6 +328,24 @@ int orc_set_fragment_texcoords(orc_ctx *c, const float *tc)
     memcpy(c->frag_tc, tc, sizeof(float) * 2 * (size_t)c->P);
     return 0;
 }
+/* the literal-rule helpers of include/hrbf_detmath.h, exported so that tests can hold each of them to an independent numpy emulation
+   at every column / row of the sizes in use (tests/test_detmath.py) — oracle and kernels share them, so oracle == kernel cannot */
+int orc_tap_texel(int c, int n) { return hd_tap_texel(c, n); }
+int orc_window_samples(float t, int n, float win, int *texels /* >= 16 */)
+{
+    const hd_window w = hd_window_axis_t(t, n, win);
+    int k = 0;
+    for (float i = w.lo; i <= w.hi; i += w.step) { if (k < 16) texels[k] = hd_window_texel(i, n); ++k; }
+    return k;
+}
+int orc_halfpixel_walk_samples(float x, int n, float wm, int *texels /* >= 16 */)
+{
+    const hd_walk w = hd_halfpixel_walk(x, n, wm);
+    int k = 0;
+    for (float i = w.lo; i < w.hi; i += w.step) { if (k < 16) texels[k] = hd_window_texel(i, n); ++k; }
+    return k;
+}
+float orc_gl_point_window_coord(float u, float extent, int *clipped) { return hd_gl_point_window_coord(u, extent, clipped); }
 float orc_uv_attribute(int p, int n) { return hd_uv_attribute(p, n); }
 float orc_uv_fragment(int p, int n) { return hd_uv_fragment(p, n); }
 float orc_expf(float x) { return hd_expf(x); }
