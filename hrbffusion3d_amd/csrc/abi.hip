@@ -97,12 +97,19 @@ struct PeerLink {
     uint32_t gen;           // barriers passed
     PeerImages img;
     void *opened[HRBF_PEER_MAX][PEER_BUFS];   // what hipIpcOpenMemHandle returned (to close)
-    uint32_t *d_token;      // one word all-reduced as the on-stream meeting point (transport a)
+    uint32_t *d_token;      // one word all-reduced as the on-stream meeting point (transport a); lives in the context's d_comm_scratch
 };
 
+// device scratch of a communicator, allocated ONCE by hrbf_comm_init (round-4 advice: no allocation may stand between a rank and a
+// collective its peers are about to issue): [the ranks' IPC handle bytes][vote word][meeting token]
+#define COMM_SCRATCH_HANDLES 0
+#define COMM_SCRATCH_VOTE ((size_t)HRBF_PEER_MAX * PEER_BUFS * sizeof(hipIpcMemHandle_t) / 4)
+#define COMM_SCRATCH_TOKEN (COMM_SCRATCH_VOTE + 1)
+#define COMM_SCRATCH_WORDS (COMM_SCRATCH_TOKEN + 1)
 struct hrbf_context {
     hrbf_params prm;
     PeerLink peer;
+    uint32_t *d_comm_scratch;
     int device;
     hipStream_t stream;
     Cam cam;
@@ -450,6 +457,7 @@ extern "C" void hrbf_destroy(hrbf_handle c)
     if (c->d_stats_ring) hipFree(c->d_stats_ring);
     peer_close(c); peer_shm_release(c);
     if (c->comm.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm.comm);
+    if (c->d_comm_scratch) { hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; }
     if (c->d_submap_active) hipFree(c->d_submap_active);
     if (c->d_delta) hipFree(c->d_delta);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -562,7 +570,7 @@ static void peer_close(hrbf_context *c)
     for (int g = 0; g < HRBF_PEER_MAX; ++g)
         for (int b = 0; b < PEER_BUFS; ++b)
             if (pl.opened[g][b]) { hipIpcCloseMemHandle(pl.opened[g][b]); pl.opened[g][b] = nullptr; }
-    if (pl.d_token) { hipFree(pl.d_token); pl.d_token = nullptr; }
+    pl.d_token = nullptr;   // part of d_comm_scratch, which lives as long as the communicator
     pl.enabled = 0;
 }
 static void peer_shm_release(hrbf_context *c)
@@ -601,7 +609,7 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
         if (r) return r;
         memcpy(all, (const void *)pl.shm->handles, sizeof(all));
     } else {
-        if (hipMalloc((void **)&d, sizeof(all) + sizeof(uint32_t)) != hipSuccess) { d = nullptr; fail = 1; }
+        d = c->d_comm_scratch;      // allocated with the communicator: a local out-of-memory cannot keep this rank out of the collectives below
         int e = 0;
         if (d) {
             hipMemcpyAsync(d + (size_t)me * words, all[me], sizeof(all[me]), hipMemcpyHostToDevice, c->stream);
@@ -609,7 +617,7 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
             hipMemcpyAsync(all, d, sizeof(all[0]) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
         }
         const hipError_t se = hipStreamSynchronize(c->stream);
-        if (!d || e != 0 || se != hipSuccess) { hrbf_set_error("peer link: handle all-gather failed"); if (d) hipFree(d); return HRBF_ERR_COMM; }   // the communicator itself is broken: nothing to agree over
+        if (!d || e != 0 || se != hipSuccess) { hrbf_set_error("peer link: handle all-gather failed"); return HRBF_ERR_COMM; }   // the communicator itself is broken: nothing to agree over
     }
     PeerImages &pi = pl.img;
     memset(&pi, 0, sizeof(pi));
@@ -635,12 +643,11 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
         failed_ranks = pl.shm->map_failed;
     } else {
         const uint32_t f = (uint32_t)fail;
-        uint32_t *w = d + (size_t)HRBF_PEER_MAX * words;
+        uint32_t *w = d + COMM_SCRATCH_VOTE;
         hipMemcpyAsync(w, &f, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
         const int e = rccl_allreduce_sum_u32(c->comm.comm, w, 1, c->stream);
         hipMemcpyAsync(&failed_ranks, w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         const hipError_t se = hipStreamSynchronize(c->stream);
-        hipFree(d);
         if (e != 0 || se != hipSuccess) { hrbf_set_error("peer link: agreement all-reduce failed"); return HRBF_ERR_COMM; }
     }
     if (failed_ranks) {
@@ -651,8 +658,8 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
         *all_mapped = 0;
         return HRBF_OK;
     }
-    if (!pl.shm_mode) {
-        if (hipMalloc((void **)&pl.d_token, sizeof(uint32_t)) != hipSuccess) return HRBF_ERR_DEVICE;
+    if (!pl.shm_mode) {      // no allocation after the agreement: the ranks cannot end up on different transports
+        pl.d_token = c->d_comm_scratch + COMM_SCRATCH_TOKEN;
         hipMemsetAsync(pl.d_token, 0, sizeof(uint32_t), c->stream);
     }
     pl.enabled = 1;
@@ -894,48 +901,94 @@ static void st_fuse(hrbf_context *c)
 // shards: a sum of lower bounds over the shards' ascending id planes — the peers' planes are IPC-mapped like their images), and
 // g_next restarts at the surfel count.  Order, hence every result, is unchanged; only the names in the index image change.
 static int read_counts(hrbf_context *c, uint32_t out[HRBF_MAX_SHARDS]);
+// One verdict on every rank of a sharded map: > 0 when ANY rank says `fail` (or, on the shared-memory transport, ever said so: the
+// segment's flag is sticky), 0 when none does, < 0 when the transport itself is broken.  Every rank must call it, whatever
+// happened to it locally — that is the point.  One process playing all shards: the local answer.
+static int peer_vote(hrbf_context *c, int fail)
+{
+    if (!c->shard_real) return fail ? 1 : 0;
+    if (c->peer.shm_mode) {
+        if (fail) { c->peer.shm->failed = 1u; __sync_synchronize(); }
+        return peer_barrier_host(c) != HRBF_OK ? 1 : 0;
+    }
+    if (!c->comm.comm || !c->d_comm_scratch) return -1;
+    uint32_t f = fail ? 1u : 0u, any = 0;
+    uint32_t *w = c->d_comm_scratch + COMM_SCRATCH_VOTE;
+    hipMemcpyAsync(w, &f, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    const int e = rccl_allreduce_sum_u32(c->comm.comm, w, 1, c->stream);
+    hipMemcpyAsync(&any, w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e != 0 || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    return any ? 1 : 0;
+}
+// All ranks commit the new ids or none does (round-4 advice).  Phase A is local (counts, every allocation) and ends in a vote: a
+// rank that failed there has not touched a collective yet and its peers learn it BEFORE they issue one it could not join (the
+// size of the all-gather depends on counts the failing rank may not have).  Phase B (all-gather / rank kernels / copy-back, with
+// the two meeting points) ends in a second vote on the stream's and the communicator's health; only then g_next is reset.
+// With one shard per rank a failure is final for the map: the ranks could not line their meeting points up again in a retry
+// that only some of them need (hrbf_get_status(clear) re-arms a retry for a single process only).
 static int hash_renumber(hrbf_context *c)
 {
-    uint32_t cnt[HRBF_MAX_SHARDS];
-    if (read_counts(c, cnt)) return HRBF_ERR_DEVICE;
+    uint32_t cnt[HRBF_MAX_SHARDS] = {0};
+    int rc = HRBF_OK;
+    const char *inject = getenv("HRBF_TEST_FAIL_RENUMBER");      // tests: this rank pretends an allocation failed
+    if (inject && atoi(inject) == c->comm.rank) { hrbf_set_error("hash ownership: id renumbering: injected failure"); rc = HRBF_ERR_DEVICE; }
+    if (rc == HRBF_OK && read_counts(c, cnt)) { hrbf_set_error("hash ownership: id renumbering: the counts could not be read"); rc = HRBF_ERR_DEVICE; }
     uint64_t total = 0;
     for (int g = 0; g < c->G; ++g) total += cnt[g];
+    const bool mapped = c->shard_real && c->peer.enabled && c->peer.img.gid[c->peer.rank];
+    const bool records = c->shard_real && !mapped;            // no peer-mapped id planes: they are all-gathered
+    if (records && !c->comm.comm) { hrbf_set_error("hash ownership: id renumbering without a communicator"); return HRBF_ERR_INVALID; }   // the same on every rank
     const uint32_t *ptrs[HRBF_MAX_SHARDS] = {nullptr};
     if (!c->shard_real) { for (int k = 0; k < c->nsh; ++k) ptrs[k] = c->sh[k].d_gid; }
-    else if (c->peer.enabled && c->peer.img.gid[c->peer.rank]) { for (int g = 0; g < c->G; ++g) ptrs[g] = c->peer.img.gid[g]; }
-    uint32_t *gathered = nullptr;
-    int rc = HRBF_OK;
-    if (c->shard_real && !(c->peer.enabled && c->peer.img.gid[c->peer.rank])) {
-        // packed-record transport (no peer-mapped planes): all-gather the id planes, padded to the longest (every plane has room
-        // for c->cap ids; the padding is never read: the counts say where a plane ends)
-        uint32_t maxc = 1;
-        for (int g = 0; g < c->G; ++g) maxc = cnt[g] > maxc ? cnt[g] : maxc;
-        if (!c->comm.comm) { hrbf_set_error("hash ownership: id renumbering without a communicator"); return HRBF_ERR_INVALID; }
-        // (out of device memory here ends the job: this rank returns the error and its peers' all-gather runs into RCCL's own time-out)
-        if (hipMalloc((void **)&gathered, sizeof(uint32_t) * (size_t)maxc * (size_t)c->G) != hipSuccess) { hrbf_set_error("hash ownership: id renumbering: out of device memory"); return HRBF_ERR_DEVICE; }
-        uint32_t *dst = gathered;
-        hipMemcpyAsync(dst + (size_t)c->comm.rank * maxc, c->sh[0].d_gid, sizeof(uint32_t) * (size_t)maxc, hipMemcpyDeviceToDevice, c->stream);
-        if (rccl_allgather_u32(c->comm.comm, dst + (size_t)c->comm.rank * maxc, dst, maxc, c->stream) != 0) rc = HRBF_ERR_COMM;
-        for (int g = 0; g < c->G; ++g) ptrs[g] = dst + (size_t)g * maxc;
+    else if (mapped) { for (int g = 0; g < c->G; ++g) ptrs[g] = c->peer.img.gid[g]; }
+    uint32_t *gathered = nullptr, *tmp[HRBF_MAX_SHARDS] = {nullptr};
+    uint32_t maxc = 1;      // the planes are padded to the longest (every plane has room for c->cap ids; the padding is never read)
+    for (int g = 0; g < c->G; ++g) maxc = cnt[g] > maxc ? cnt[g] : maxc;
+    // ---- phase A: everything that can fail locally
+    if (rc == HRBF_OK && records && hipMalloc((void **)&gathered, sizeof(uint32_t) * (size_t)maxc * (size_t)c->G) != hipSuccess) {
+        gathered = nullptr; hrbf_set_error("hash ownership: id renumbering: out of device memory"); rc = HRBF_ERR_DEVICE;
     }
-    uint32_t *tmp[HRBF_MAX_SHARDS] = {nullptr};
     for (int k = 0; k < c->nsh && rc == HRBF_OK; ++k) {
         const uint32_t nk = cnt[c->shard_first + k];
-        if (hipMalloc((void **)&tmp[k], sizeof(uint32_t) * (size_t)(nk ? nk : 1)) != hipSuccess) { rc = HRBF_ERR_DEVICE; break; }
-        launch_gid_rank(c->stream, ptrs, counts_live(c), c->G, c->sh[k].d_gid, nk, tmp[k]);
+        if (hipMalloc((void **)&tmp[k], sizeof(uint32_t) * (size_t)(nk ? nk : 1)) != hipSuccess) {
+            tmp[k] = nullptr; hrbf_set_error("hash ownership: id renumbering: out of device memory"); rc = HRBF_ERR_DEVICE;
+        }
     }
-    // a rank whose allocation failed still meets the others (they would wait for it) and reports the error: the shared map is then
-    // inconsistent between the ranks and the run has to stop
-    if (c->shard_real && !gathered && peer_meet(c)) rc = HRBF_ERR_COMM;          // every rank has read every plane
-    for (int k = 0; k < c->nsh && rc == HRBF_OK; ++k) {
-        const uint32_t nk = cnt[c->shard_first + k];
-        if (nk) hipMemcpyAsync(c->sh[k].d_gid, tmp[k], sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToDevice, c->stream);
+    auto release = [&]() { for (int k = 0; k < c->nsh; ++k) if (tmp[k]) hipFree(tmp[k]); if (gathered) hipFree(gathered); };
+    const int v1 = peer_vote(c, rc != HRBF_OK);
+    if (v1 != 0) {
+        release();
+        if (rc == HRBF_OK) { hrbf_set_error(v1 < 0 ? "hash ownership: id renumbering: the ranks could not vote" : "hash ownership: id renumbering failed on another rank"); rc = HRBF_ERR_COMM; }
+        return rc;      // nobody has issued a collective of phase B, nobody has changed an id
     }
-    if (c->shard_real && !gathered && peer_meet(c)) rc = HRBF_ERR_COMM;          // nobody reads a half-written plane in the next pass
-    hipStreamSynchronize(c->stream);
-    for (int k = 0; k < c->nsh; ++k) if (tmp[k]) hipFree(tmp[k]);
-    if (gathered) hipFree(gathered);
-    if (rc != HRBF_OK) return rc;
+    // ---- phase B
+    if (records) {
+        hipMemcpyAsync(gathered + (size_t)c->comm.rank * maxc, c->sh[0].d_gid, sizeof(uint32_t) * (size_t)maxc, hipMemcpyDeviceToDevice, c->stream);
+        if (rccl_allgather_u32(c->comm.comm, gathered + (size_t)c->comm.rank * maxc, gathered, maxc, c->stream) != 0) rc = HRBF_ERR_COMM;
+        for (int g = 0; g < c->G; ++g) ptrs[g] = gathered + (size_t)g * maxc;
+    }
+    for (int k = 0; k < c->nsh; ++k)
+        launch_gid_rank(c->stream, ptrs, counts_live(c), c->G, c->sh[k].d_gid, cnt[c->shard_first + k], tmp[k]);
+    if (mapped && peer_meet(c)) rc = HRBF_ERR_COMM;          // every rank has read every plane
+    int committed_copy = 0;
+    if (rc == HRBF_OK) {
+        for (int k = 0; k < c->nsh; ++k) {
+            const uint32_t nk = cnt[c->shard_first + k];
+            if (nk) hipMemcpyAsync(c->sh[k].d_gid, tmp[k], sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToDevice, c->stream);
+        }
+        committed_copy = 1;
+    }
+    if (mapped && peer_meet(c)) rc = HRBF_ERR_COMM;          // nobody reads a half-written plane in the next pass
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = HRBF_ERR_DEVICE;
+    release();
+    // the second verdict: a failure in here is a broken stream or communicator — the ids of this map are no longer trustworthy on
+    // any rank (committed_copy may differ between them), and every rank says so
+    const int v2 = peer_vote(c, rc != HRBF_OK);
+    if (v2 != 0 || rc != HRBF_OK) {
+        if (rc == HRBF_OK) rc = HRBF_ERR_COMM;
+        hrbf_set_error("hash ownership: id renumbering broke down between the ranks (stream or communicator error%s)", committed_copy ? "; ids partly rewritten" : "");
+        return rc;
+    }
     c->g_next = (uint32_t)total;
     ++c->hash_renumbered;
     return HRBF_OK;
@@ -1040,7 +1093,7 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
 static int process_frame_resident(hrbf_context *c, float wmul)
 {
     hipSetDevice(c->device);
-    if (c->renumber_failed) { hrbf_set_error("hash ownership: the id space is exhausted and renumbering failed (HRBF_STATUS_ID_SPACE); clear the status to retry"); return HRBF_ERR_DEVICE; }
+    if (c->renumber_failed) { hrbf_set_error("hash ownership: the id space is exhausted and renumbering failed (HRBF_STATUS_ID_SPACE)%s", c->shard_real ? "; final for a map shared by ranks" : "; clear the status to retry"); return HRBF_ERR_DEVICE; }
     int frame_rc = HRBF_OK;
     refresh_count_ub(c);
     TIMER(0);
@@ -1385,6 +1438,7 @@ extern "C" int hrbf_shard_exchange_mode(hrbf_handle c)
     return c->peer.enabled ? 1 : (c->peer_fallback ? 3 : 2);
 }
 // hash ownership: how often the ids were renumbered (hash_renumber: when the next pass could exhaust 32 bits; HRBF_HASH_RENUMBER_AT)
+extern "C" int hrbf_gn_graph_captures(hrbf_handle c) { return c ? (int)c->odo.gn_graph_captures : HRBF_ERR_INVALID; }
 extern "C" int hrbf_hash_renumber_count(hrbf_handle c) { return c ? (int)c->hash_renumbered : HRBF_ERR_INVALID; }
 // the shard a surfel at (x, y, z) is inserted into under hash ownership (host code: no device needed)
 extern "C" int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards)
@@ -1697,7 +1751,8 @@ extern "C" int hrbf_get_status(hrbf_handle c, uint32_t *flags, int clear)
         if (so3 > 0) c->status |= HRBF_STATUS_SO3_TIMEOUT;
     }
     *flags = c->status;
-    if (clear) c->renumber_failed = 0;     // the caller takes note and may retry the renumbering with the next frame
+    if (clear && !c->shard_real) c->renumber_failed = 0;   // a single process may retry the renumbering with the next frame; a rank of a sharded
+                                                            // map may not (the retry is a collective only some ranks would enter): the map has to be rebuilt
     if (clear) {
         c->status = 0;
         for (int k = 0; k < c->nsh; ++k) HIP_CHECK(hipMemsetAsync(c->sh[k].d_stats + 7, 0, sizeof(uint32_t), c->stream));
@@ -1911,6 +1966,7 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     hipSetDevice(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
+    if (c->d_comm_scratch) { hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; }
     peer_close(c); peer_shm_release(c);
     c->comm.rank = 0; c->comm.world = 1; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
     if (rank < 0) { c->comm.virtual_world = world > 1 ? world : 0; return HRBF_OK; }
@@ -1919,9 +1975,14 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     if (r) return r;
     RcclId128 id;
     memcpy(id.b, id128, 128);
+    // everything a later collective needs on the device is allocated here; a rank that cannot still joins the communicator
+    // (its peers are inside ncclCommInitRank) and leaves it again
+    const bool have = hipMalloc((void **)&c->d_comm_scratch, sizeof(uint32_t) * COMM_SCRATCH_WORDS) == hipSuccess;
+    if (!have) c->d_comm_scratch = nullptr; else hipMemset(c->d_comm_scratch, 0, sizeof(uint32_t) * COMM_SCRATCH_WORDS);
     void *comm = nullptr;
     const int e = g_rccl.CommInitRank(&comm, world, id, rank);
-    if (e != 0 || !comm) { hrbf_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
+    if (e != 0 || !comm) { if (have) hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; hrbf_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
+    if (!have) { g_rccl.CommDestroy(comm); hrbf_set_error("hrbf_comm_init: out of device memory"); return HRBF_ERR_DEVICE; }
     c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world; c->comm.allreduce_i64 = rccl_allreduce_i64;
     return HRBF_OK;
 }
@@ -1954,6 +2015,7 @@ extern "C" int hrbf_comm_init_peer(hrbf_handle c, int rank, int world, const uin
     hipSetDevice(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
+    if (c->d_comm_scratch) { hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; }
     peer_close(c); peer_shm_release(c);
     c->comm.rank = rank; c->comm.world = world; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
     PeerLink &pl = c->peer;

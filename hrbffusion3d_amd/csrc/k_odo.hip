@@ -383,9 +383,10 @@ __device__ __forceinline__ uint8_t pyrdown_u8(const uint8_t *__restrict__ src, i
 
 // one pyramid level; blockIdx.y selects the map, so the 13 independent resamplings run side by side
 #define ODO_DOWN_TASKS 13
-__global__ void k_odo_downsample(OdoLevel I, OdoLevel O)
+__global__ void k_odo_downsample(OdoLevel I, OdoLevel O, DevPose *dp, float frame_wmul)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dp && i == 0 && blockIdx.y == 0) dp->frame_wmul = frame_wmul;   // rides along: read by the captured k_gn_solve / k_odo_end
     if (i >= O.rows * O.cols) return;
     int y = i / O.cols, x = i - y * O.cols;
     switch (blockIdx.y) {
@@ -1603,20 +1604,21 @@ __global__ void k_residual_to_slot0(const long long *__restrict__ totals2, long 
 __global__ __launch_bounds__(256) void k_gn_solve(OdoState *st, long long *__restrict__ icp_part,
                                                    long long *__restrict__ rgb_part, long long *__restrict__ res_part,
                                                    long long *__restrict__ totals, int do_reduce, OdoConfig cfg,
-                                                   int next_level, int level_changes, DevPose *dp, float weight_multiplier)
+                                                   int next_level, int level_changes, DevPose *dp, int weighting)
 {
     gn_solve_block(st, icp_part, rgb_part, res_part, totals, do_reduce, totals[174], totals[175], cfg, next_level,
                    level_changes, dp);
-    // last iteration of the registration: the frame's velocity weighting rides along (no separate launch)
-    if (threadIdx.x == 0 && dp && weight_multiplier >= 0.0f) frame_weighting_state(dp, weight_multiplier);
+    // last iteration of the registration: the frame's velocity weighting rides along (no separate launch); the multiplier is
+    // the device word k_odo_downsample wrote this frame, NOT a launch argument: the captured graph stays valid whatever the caller passes
+    if (threadIdx.x == 0 && dp && weighting) frame_weighting_state(dp, dp->frame_wmul);
 }
 
 // registration without any Gauss-Newton iteration configured: only the guard + publish
-__global__ void k_odo_end(OdoState *st, DevPose *dp, OdoConfig cfg, float weight_multiplier)
+__global__ void k_odo_end(OdoState *st, DevPose *dp, OdoConfig cfg, int weighting)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     odo_end_state(st, dp, cfg);
-    if (weight_multiplier >= 0.0f) frame_weighting_state(dp, weight_multiplier);
+    if (weighting) frame_weighting_state(dp, dp->frame_wmul);
 }
 
 // ------------------------------------------------------------------------------------------ pose bookkeeping
@@ -1750,7 +1752,8 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                            cfg.curv_thr);
     for (int i = 1; i < HRBF_NUM_PYRS; ++i) {
         int n = ob.lv[i].rows * ob.lv[i].cols;
-        hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256, ODO_DOWN_TASKS), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i]);
+        hipLaunchKernelGGL(k_odo_downsample, dim3((n + 255) / 256, ODO_DOWN_TASKS), dim3(256), 0, s, ob.lv[i - 1], ob.lv[i],
+                           i == 1 ? dp : (DevPose *)nullptr, weight_multiplier);
     }
     // the slot rows (icp | rgb | res | so3) are zeroed once at allocation; every fold re-zeroes what it read
     int iterations[3] = {cfg.fast_odom ? 3 : 10, cfg.pyramid ? 5 : 0, cfg.pyramid ? 4 : 0};
@@ -1820,10 +1823,11 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
     // current) is captured once into a hipGraph and replayed: one submission instead of 57.
     static const bool use_graph = getenv("HRBF_NO_GN_GRAPH") == nullptr;
     const int par = ob.swap_parity & 1;
+    const int weighting = weight_multiplier >= 0.0f ? 1 : 0;   // < 0: a caller that does its own frame weighting (operator seams)
     bool replayed = false, capturing = false;
     if (use_graph && !sharded) {
         if (ob.gn_graph_exec[par] && memcmp(&ob.gn_graph_cfg[par], &cfg, sizeof(cfg)) == 0 &&
-            ob.gn_graph_wmul[par] == weight_multiplier && ob.gn_graph_dp[par] == (void *)dp) {
+            ob.gn_graph_weighting[par] == weighting && ob.gn_graph_dp[par] == (void *)dp) {
             replayed = hipGraphLaunch((hipGraphExec_t)ob.gn_graph_exec[par], s) == hipSuccess;
         } else {
             if (ob.gn_graph_exec[par]) { hipGraphExecDestroy((hipGraphExec_t)ob.gn_graph_exec[par]); ob.gn_graph_exec[par] = nullptr; }
@@ -1875,7 +1879,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                 allreduce(ob.totals, 174);
                 hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
                                    ob.totals, 0, cfg, next_level, last_of_level ? 1 : 0,
-                                   last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
+                                   last_of_all ? dp : (DevPose *)nullptr, weighting);
                 continue;
             }
             hipLaunchKernelGGL(k_icp_res, dim3(2 * nb), dim3(RB), 0, s, L, A, ob.state, nb, icp, rgb, minScale,
@@ -1887,7 +1891,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                                ob.totals, 0, L.rows * L.cols);
             hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, ob.state, ob.icp_part, ob.rgb_part, ob.res_part,
                                ob.totals, 1, cfg, next_level, last_of_level ? 1 : 0,
-                               last_of_all ? dp : (DevPose *)nullptr, weight_multiplier);
+                               last_of_all ? dp : (DevPose *)nullptr, weighting);
         }
     }
     };
@@ -1898,13 +1902,14 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         const bool ok = hipStreamEndCapture(s, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
         if (g) hipGraphDestroy(g);
         if (ok) {
-            ob.gn_graph_exec[par] = (void *)ge; ob.gn_graph_cfg[par] = cfg; ob.gn_graph_wmul[par] = weight_multiplier;
+            ob.gn_graph_exec[par] = (void *)ge; ob.gn_graph_cfg[par] = cfg; ob.gn_graph_weighting[par] = weighting;
+            ob.gn_graph_captures++;
             ob.gn_graph_dp[par] = (void *)dp;
             replayed = hipGraphLaunch(ge, s) == hipSuccess;
         } else (void)hipGetLastError();
     }
     if (!replayed) enqueue_gn();   // sharded path, graphs switched off, or capture / replay refused: plain launches
-    if (last_level < 0) hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg, weight_multiplier);
+    if (last_level < 0) hipLaunchKernelGGL(k_odo_end, dim3(1), dim3(1), 0, s, ob.state, dp, cfg, weighting);
     if (cfg.so3)   // swap NextImage <-> lastNextImage (RGBDOdometry.cpp:1239-1245): pointer swap, no copy
     {
         for (int i = 0; i < HRBF_NUM_PYRS; ++i) { uint8_t *t = ob.lv[i].last_next_image; ob.lv[i].last_next_image = ob.lv[i].next_image; ob.lv[i].next_image = t; }

@@ -43,6 +43,8 @@ struct DevPose {
     float weighting;   // velocity weighting (HRBFFusion.cpp:1112-1123)
     float last_icp_error, last_icp_count;
     int should_fill_in;
+    float frame_wmul;  // processFrame's weightMultiplier of the frame being registered: a device word, so that the captured
+                       // Gauss-Newton graph does not depend on a value the caller changes per frame (GUI/src/HRBF_fusion.cpp:225)
 };
 
 // trajectory log in pinned, device-mapped host memory: the end-of-frame kernel appends the frame's pose and publishes
@@ -219,7 +221,8 @@ struct OdoBuffers {
     long long *totals;      // 87 + 87 + 2 + 33 (all-reduce buffer)
     int max_blocks;
     // the 57 launches of the Gauss-Newton loop replayed as one hipGraph (one instance per image-pointer parity)
-    void *gn_graph_exec[2]; OdoConfig gn_graph_cfg[2]; float gn_graph_wmul[2]; void *gn_graph_dp[2]; int swap_parity;
+    void *gn_graph_exec[2]; OdoConfig gn_graph_cfg[2]; int gn_graph_weighting[2]; void *gn_graph_dp[2]; int swap_parity;
+    unsigned int gn_graph_captures;   // how often a graph was (re-)captured: 2 in a steady run, one per parity
 };
 
 struct OdoSources {   // images the odometry is initialised from (selected on device by should_fill_in)

@@ -387,6 +387,8 @@ int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[
  * joins, this does).  An id serves ONE rendezvous: a second set of contexts on it is refused. */
 int hrbf_peer_release_id(const uint8_t id128[128]);
 int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ranges | 2 spatial hash */
+int hrbf_gn_graph_captures(hrbf_handle h);    /* times the Gauss-Newton loop was captured into a hipGraph: 2 in a steady run (one per image parity) whatever
+                                                weightMultiplier the caller passes per frame (GUI/src/HRBF_fusion.cpp:225); re-captured only when a setter changes the configuration */
 int hrbf_hash_renumber_count(hrbf_handle h);   /* hash ownership: times the 32-bit ids were renumbered to ranks (every ~55 000 VGA frames; order unchanged) */
 int hrbf_hash_owner(float x, float y, float z, float cell_metres, int n_shards);   /* shard of a surfel inserted at (x, y, z); host code */
 int hrbf_shard_counts(hrbf_handle h, uint32_t out[8]);   /* live counts of all shards; returns 0 one map | 1 ranges | 2 hash (negative: error) */

@@ -107,6 +107,36 @@ def test_png_pair_variants_match_golden_digests(gpu_available, png_pair):
         g.close()
 
 
+def test_per_frame_weight_multiplier_never_recaptures_the_gn_graph(pair):
+    """the reference's caller passes weightMultiplier = framesToSkip + 1, a different value on any frame (GUI/src/HRBF_fusion.cpp:225).
+    The captured Gauss-Newton graph reads it from a device word, not from a launch argument: 20 frames with 1, 2, 1, 3, ... are
+    bit-identical to the oracle and the loop is captured exactly twice (once per image-pointer parity), never again;
+    a setter that changes the configuration does re-capture (once per parity)."""
+    W, H = 320, 240
+    seed = synth.seed_map(100_000, width=W)
+    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=seed.shape[0] + 400_000)
+    o, g = pair(p)
+    rgb, d, T = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
+    wm = [1.0, 2.0, 1.0, 3.0]
+    for k in range(1, 21):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d, k, wm[k % 4]); g.process_frame(rgb, d, k, wm[k % 4])
+        assert bits(np.float32(o.get_weighting())) == bits(np.float32(g.get_weighting())), k
+        if k in (1, 2, 3, 4, 12, 20):
+            assert_same_state(o, g, "frame %d (weightMultiplier %g)" % (k, wm[k % 4]))
+        if k >= 2:
+            assert g.gn_graph_captures() == 2, (k, g.gn_graph_captures())
+    assert np.array_equal(bits(o.download_map()), bits(g.download_map()))
+    g.set_fast_odom(True)       # 3 instead of 10 iterations on level 0: another graph (the oracle has no live setters)
+    for k in range(21, 25):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        g.process_frame(rgb, d, k, wm[k % 4])
+    assert g.gn_graph_captures() == 4 and g.status() == 0
+    assert np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3]) < 0.05
+
+
 @pytest.mark.parametrize("noise", [False, True])
 def test_tracked_synthetic_stream(pair, noise):
     """QVGA synthetic stream against a pre-seeded map, tracking ON: 10 frames, every image, the map

@@ -185,3 +185,59 @@ def test_a_rank_that_cannot_map_its_peers_fails_every_rank_at_once(gpu_available
     for r in (0, 1):
         assert "could not map its peers" in got[r][0], got
         assert got[r][1] < 30.0, got
+
+
+def _run_failing_renumber(rank, world, uid, out):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    import time
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion, HrbfError
+    from hrbffusion3d_amd.params import default_params
+    os.environ["HRBF_HASH_RENUMBER_AT"] = "20000"
+    os.environ["HRBF_TEST_FAIL_RENUMBER"] = "1"        # rank 1 pretends an allocation of the renumbering failed
+    W, H = 160, 120
+    g = HRBFFusion(default_params(W, H, *synth.intrinsics(W, H), max_surfels=300_000))
+    g.comm_init_peer(rank, world, uid)
+    g.map_shard_init(True, partition="hash")
+    failed_at, msg, t = None, "", time.time()
+    for k in range(8):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        try:
+            g.process_frame(rgb, d)
+        except HrbfError as e:
+            failed_at, msg = k, str(e)
+            break
+    st = g.status()
+    again = None
+    try:                                   # clearing the status does not re-arm a retry on a rank of a shared map
+        g.status(clear=True)
+        rgb, d, _ = synth.frame(7, W, H, noise=True)
+        g.process_frame(rgb, d)
+        again = "ran"
+    except HrbfError as e:
+        again = str(e)
+    out.put((rank, failed_at, msg, st, g.hash_renumber_count(), again, time.time() - t))
+    g.close()
+
+
+def test_a_rank_whose_renumbering_fails_stops_every_rank_at_the_same_frame(gpu_available):
+    """round-4 advice: hash_renumber's outcome is AGREED between the ranks.  Rank 1 fails locally before any collective of the
+    renumbering; both ranks return the error from the same frame within seconds, neither has renumbered an id, both carry
+    HRBF_STATUS_ID_SPACE, and a cleared status does not let one rank walk into a collective retry alone."""
+    from hrbffusion3d_amd.api import HRBFFusion
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = HRBFFusion.peer_unique_id()
+    procs = [ctx.Process(target=_run_failing_renumber, args=(r, 2, uid, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict((r[0], r[1:]) for r in (q.get(timeout=180) for _ in range(2)))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert got[0][0] is not None and got[0][0] == got[1][0], got          # the same frame
+    assert "injected" in got[1][1] and "another rank" in got[0][1], got
+    for r in (0, 1):
+        assert got[r][2] & 16, got                                        # HRBF_STATUS_ID_SPACE
+        assert got[r][3] == 0, got                                        # nobody renumbered
+        assert "final for a map shared by ranks" in got[r][4], got
+        assert got[r][5] < 60.0, got

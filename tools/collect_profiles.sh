@@ -3,7 +3,7 @@
 # reproduced without subtracting legs.  Run on the GPU box:  bash tools/collect_profiles.sh <outdir>
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; export HRBF_BENCH_GEN_PROCS=1   # no forked frame generators under the profiler
-OUT=${1:-gpurun_out/r04/prof}; mkdir -p "$OUT"
+OUT=${1:-gpurun_out/r05/prof}; mkdir -p "$OUT"
 leg() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -o x -- "$@" > "$OUT/$name.log" 2>&1 || echo "leg $name failed";
         f=$(find "$OUT/$name" -name '*kernel_trace.csv' | head -1); python tools/prof_summary.py "$f" 40 "$OUT/${name}_kernel_stats.csv" > "$OUT/${name}_summary.txt";
         s=$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1); [ -n "$s" ] && cp "$s" "$OUT/${name}_rocprof_stats.csv"; }
