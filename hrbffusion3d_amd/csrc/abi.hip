@@ -955,10 +955,12 @@ static int hash_renumber(hrbf_context *c)
         }
     }
     auto release = [&]() { for (int k = 0; k < c->nsh; ++k) if (tmp[k]) hipFree(tmp[k]); if (gathered) hipFree(gathered); };
+    char why[160]; snprintf(why, sizeof(why), "%s", rc != HRBF_OK ? hrbf_last_error() : "");   // the vote's transport may set its own text
     const int v1 = peer_vote(c, rc != HRBF_OK);
     if (v1 != 0) {
         release();
         if (rc == HRBF_OK) { hrbf_set_error(v1 < 0 ? "hash ownership: id renumbering: the ranks could not vote" : "hash ownership: id renumbering failed on another rank"); rc = HRBF_ERR_COMM; }
+        else hrbf_set_error("%s", why);
         return rc;      // nobody has issued a collective of phase B, nobody has changed an id
     }
     // ---- phase B

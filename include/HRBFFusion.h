@@ -36,6 +36,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -413,7 +414,18 @@ public:
     GlobalModel &getGlobalModel() { return *model_; }
     IndexMap &getIndexMap() { return *index_; }
     /* Core/src/HRBFFusion.h:217 */
-    RGBDOdometry &getFrameToModel() { hrbf_last_icp(h_, &frame_to_model_.lastICPError, &frame_to_model_.lastICPCount); return frame_to_model_; }
+    /* the read-out synchronises the stream: done once per processed frame however often the caller asks (the reference's GUI
+       reads lastICPError / lastICPCount six times per frame); after a failed read the values are NaN, not the previous frame's */
+    RGBDOdometry &getFrameToModel()
+    {
+        const unsigned int now = hrbf_frames_enqueued(h_);
+        if (!icp_cached_ || icp_cached_at_ != now) {
+            if (hrbf_last_icp(h_, &frame_to_model_.lastICPError, &frame_to_model_.lastICPCount) != HRBF_OK)
+                frame_to_model_.lastICPError = frame_to_model_.lastICPCount = std::numeric_limits<float>::quiet_NaN();
+            icp_cached_ = true; icp_cached_at_ = now;
+        }
+        return frame_to_model_;
+    }
     float lastICPError() { return getFrameToModel().lastICPError; }
     float lastICPCount() { return getFrameToModel().lastICPCount; }
     /* setters applied every GUI frame (GUI/src/HRBF_fusion.cpp:448-456) */
@@ -484,6 +496,7 @@ private:
     IndexMap *index_;
     Pose curr_;
     RGBDOdometry frame_to_model_;
+    bool icp_cached_ = false; unsigned int icp_cached_at_ = 0;
     bool load_trajectory_;
     std::vector<bool> pushes_;   // per processed frame: does it contribute to trajectory_manager->poses
     uint32_t synced_;            // frames already folded into trajectory_manager->poses

@@ -250,6 +250,9 @@ inline std::vector<PoseCM> loadTrajectoryFile(const std::string &filename, const
         std::string line;
         while (!f.eof()) {
             std::getline(f, line);
+            // a stream that went bad without reaching its end (a directory opened as a file, a read error) would never set eof:
+            // the reference's loop spins forever there; this one reports it
+            if (f.bad() || (f.fail() && !f.eof())) throw std::runtime_error(filename + ": read error in the trajectory file");
             if (line.empty() || line[0] == '#') continue;
             // TrajectoryManager.cpp:163-171,199-208: `if(file.eof()) break;` sits between the parse and the push_back, so a last
             // line WITHOUT a trailing newline is read and dropped — kept

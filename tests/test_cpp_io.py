@@ -332,6 +332,10 @@ def test_tum_trajectory_reader_keeps_the_references_stamp_and_eof_behaviour(tmp_
     assert len(hio.load_trajectory_file(str(tmp_path / "gt_nl.txt"), "TUM")) == 4
     out = subprocess.run([exe, str(tmp_path / "gt_nl.txt"), "CoRBS"], capture_output=True, text=True, timeout=60)
     assert out.stdout.split("\n")[0] == "4"
+    # a DIRECTORY passes is_open() on Linux and never reaches eof: the reference's `while(!file.eof())` would spin forever;
+    # the reader reports a read error instead (round-4 advice) — here: an uncaught exception ends the process, within the timeout
+    out = subprocess.run([exe, str(tmp_path), "TUM"], capture_output=True, text=True, timeout=20)
+    assert out.returncode != 0 and "read error in the trajectory file" in out.stderr
 
 
 @pytest.mark.gpu
