@@ -27,10 +27,12 @@ def _stale():
 
 
 def build(force=False, verbose=False, defines=(), out=None):
-    """defines/out: experiment variants, e.g. build(True, defines=["-DFUSE_IPT=4"], out="libhrbf_v1.so")"""
+    """defines/out: experiment variants, e.g. build(True, defines=["-DFUSE_IPT=4"], out="libhrbf_v1.so") — they land in
+    hrbffusion3d_amd/_build/ (git-ignored), never next to the product library (load one with HRBF_LIB=<path>)"""
     global OUT
     if out is not None:
-        return _build_to(os.path.join(HERE, out), list(defines), verbose, "_" + os.path.splitext(out)[0])
+        os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+        return _build_to(os.path.join(HERE, "_build", os.path.basename(out)), list(defines), verbose, "_" + os.path.splitext(os.path.basename(out))[0])
     if not force and not _stale():
         return OUT
     return _build_to(OUT, [], verbose, "")

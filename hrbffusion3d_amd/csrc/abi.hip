@@ -1097,6 +1097,7 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     hipSetDevice(c->device);
     if (c->renumber_failed) { hrbf_set_error("hash ownership: the id space is exhausted and renumbering failed (HRBF_STATUS_ID_SPACE)%s", c->shard_real ? "; final for a map shared by ranks" : "; clear the status to retry"); return HRBF_ERR_DEVICE; }
     int frame_rc = HRBF_OK;
+    char frame_err[200] = "";
     refresh_count_ub(c);
     TIMER(0);
     st_filter(c); st_vnr(c);
@@ -1119,6 +1120,7 @@ static int process_frame_resident(hrbf_context *c, float wmul)
             st_indices(c, true, 4);      // the clean test reads the packed texels only
             TIMER(5);
             frame_rc = st_clean(c);
+            if (frame_rc) snprintf(frame_err, sizeof(frame_err), "%s", hrbf_last_error());   // later stages (peer barriers) may set their own text
             TIMER(6);
         } else { TIMER(3); TIMER(4); TIMER(5); TIMER(6); }
     }
@@ -1132,6 +1134,7 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     c->tick++; c->frames_enqueued++;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hrbf_set_error("launch: %s", hipGetErrorString(e)); return HRBF_ERR_DEVICE; }
+    if (frame_rc) hrbf_set_error("%s", frame_err);
     return frame_rc;   // the frame ran, but its clean pass did not (id renumbering failed): the caller must not go on
 }
 

@@ -252,12 +252,23 @@ __device__ __forceinline__ f3 hrbf_gradient(const float4 *__restrict__ tile, con
 //   phase 2: 10 steps of 0.4 mm back        phase 3: <= 10 bisections        phase 4: finished
 // The first coarse sample (i = 0) is `closest` itself: its value is v0, which cannot flip the sign, so the
 // march starts at i = 1.  Returns whether a surface point was found (in p_temp).
+#ifdef PREDICT_TRIP_STATS
+struct TripStats { float v0, v1; int k1, k2, k3; };   // measurement build: first two values, samples per phase
+#define TS(x) x
+#else
+#define TS(x)
+#endif
 template <bool SAFE>
 __device__ __forceinline__ bool ray_march(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n, int minn,
-                                          const f3 closest, const f3 ray, f3 &p_temp, int &trips)
+                                          const f3 closest, const f3 ray, f3 &p_temp, int &trips
+#ifdef PREDICT_TRIP_STATS
+                                          , TripStats &ts
+#endif
+                                          )
 {
     bool found = false;
     trips = 0;
+    TS(ts.v0 = 0.0f; ts.v1 = 0.0f; ts.k1 = ts.k2 = ts.k3 = 0;)
     f3 sp = mk3(0, 0, 0), ep = mk3(0, 0, 0), q = closest;
     int phase = 4, it = 1;
     bool pos = false;   // sign class of v0
@@ -265,6 +276,7 @@ __device__ __forceinline__ bool ray_march(const float4 *__restrict__ tile, const
         int nsup;
         const float v0 = hrbf_value<SAFE, true>(tile, list, n, closest, nsup);
         trips = 1;
+        TS(ts.v0 = v0;)
         if (nsup > minn) {
             pos = v0 > 0.0f;
             if (pos) ep = closest; else sp = closest;
@@ -276,6 +288,7 @@ __device__ __forceinline__ bool ray_march(const float4 *__restrict__ tile, const
         int unused;
         const float v = hrbf_value<SAFE, false>(tile, list, n, q, unused);
         ++trips;
+        TS(if (trips == 2) ts.v1 = v; if (phase == 1) ++ts.k1; else if (phase == 2) ++ts.k2; else ++ts.k3;)
         if (phase == 1) {
             if (pos ? v < 0.0f : v > 0.0f) {
                 if (pos) sp = q; else ep = q;
@@ -434,8 +447,14 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
 
     f3 p_temp = mk3(0, 0, 0);
     int trips;   // samples of the implicit this ray took (statistics builds only; dead otherwise)
+#ifdef PREDICT_TRIP_STATS
+    TripStats ts;
+    const bool found = s_untame ? ray_march<true>(tile, list, n, minn, closest, ray, p_temp, trips, ts)
+                                : ray_march<false>(tile, list, n, minn, closest, ray, p_temp, trips, ts);
+#else
     const bool found = s_untame ? ray_march<true>(tile, list, n, minn, closest, ray, p_temp, trips)
                                 : ray_march<false>(tile, list, n, minn, closest, ray, p_temp, trips);
+#endif
 
     uchar4 img = make_uchar4(0, 0, 0, 0);
     f3 p_surface = mk3(0, 0, 0), p_normal = mk3(0, 0, 0);
@@ -475,8 +494,10 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
     pr_vertex[pi] = make_float4(p_surface.x, p_surface.y, p_surface.z, confidence);
     pr_normal[pi] = make_float4(p_normal.x, p_normal.y, p_normal.z, radius);
     pr_curv1[pi] = cmx; pr_curv2[pi] = cmn;
-#ifdef PREDICT_TRIP_STATS   // measurement build: samples | neighbours << 8 | found << 16 instead of the time stamp
-    tm = (uint32_t)trips | ((uint32_t)n << 8) | (found ? 1u << 16 : 0u);
+#ifdef PREDICT_TRIP_STATS   // measurement build: samples | neighbours << 8 | found << 16 | k1 << 17 | k2 << 22 | k3 << 26 instead of the
+    // time stamp; the first two values of the implicit in the curvature image's direction words (tests/gpu_probe_predict_trips.py)
+    tm = (uint32_t)trips | ((uint32_t)n << 8) | (found ? 1u << 16 : 0u) | ((uint32_t)ts.k1 << 17) | ((uint32_t)ts.k2 << 22) | ((uint32_t)ts.k3 << 26);
+    pr_curv1[pi] = make_float4(ts.v0, ts.v1, 0.0f, cmx.w);
 #endif
     pr_time[pi] = tm;
     pr_icpw[pi] = icpw;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of experiment builds on the GPU box: quick bench legs (headline stream + worst-case fuse leg), no CPU baseline.
-# usage: tools/ab_bench.sh [--reps N] default <variant> ...   where <variant> names hrbffusion3d_amd/libhrbf_v_<variant>.so
+# usage: tools/ab_bench.sh [--reps N] default <variant> ...   where <variant> names hrbffusion3d_amd/_build/libhrbf_v_<variant>.so
 # (build with hrbffusion3d_amd.build.build(True, defines=[...], out="libhrbf_v_<variant>.so")); runs alternate to average drift out.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -9,7 +9,7 @@ if [ "$1" = "--reps" ]; then REPS=$2; shift 2; fi
 Q="--steps 120 --warmup 20 --cpu-frames 0 --cpu-frames-1t 0 --big-surfels 0 --no-cpp-shim"
 for r in $(seq 1 $REPS); do
   for v in "$@"; do
-    if [ "$v" = default ]; then lib=libhrbf_mi355.so; else lib=libhrbf_v_$v.so; fi
+    if [ "$v" = default ]; then lib=libhrbf_mi355.so; else lib=_build/libhrbf_v_$v.so; fi
     HRBF_LIB=$lib python bench.py $Q > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
     python - "$v" <<'PY'
 import json, sys

@@ -1,4 +1,4 @@
-"""DESIGN.md §5 diagnostic (needs a -DCLEAN_DIAG build: HRBF_LIB=libhrbf_v_cleandiag.so): what share of the in-view items of the clean
+"""DESIGN.md §5 diagnostic (needs a -DCLEAN_DIAG build: HRBF_LIB=_build/libhrbf_v_cleandiag.so): what share of the in-view items of the clean
 pass has NO index-map winner behind it in its window — the items a dilated max-winner-depth image would settle with one 4-byte gather
 instead of <= 9 sixteen-byte ones (round-3 verdict item 4).  Both bench legs: the headline stream and the 4.3 M-surfel worst case."""
 import ctypes as C
