@@ -80,6 +80,7 @@ struct ShardScratch {
 // (b) a POSIX shared-memory rendezvous (hrbf_peer_unique_id / hrbf_comm_init_peer) — handles, counts and barriers go through
 // the segment, the key min-reduce reads the peers' z-buffers.  (b) needs no RCCL and also runs with several ranks on ONE GPU
 // (RCCL refuses that: "Duplicate GPU detected"), which is how the path is tested on a single device.
+#define PEER_RED_WORDS 176   // 87 + 87 + 2 limb sums at most per all-reduce (launch_odometry)
 #define PEER_BUFS 8   // z-buffer + six image planes (+ the id plane of a hash-owned map: only then exchanged)
 struct PeerShm {
     volatile uint32_t arrived;                  // monotone barrier counter
@@ -88,6 +89,7 @@ struct PeerShm {
     volatile uint32_t attached;                 // contexts that joined: a segment serves ONE rendezvous of `world` ranks (its barrier counter is never reset)
     volatile uint32_t counts[2][HRBF_PEER_MAX]; // live surfel counts, double buffered by barrier generation
     hipIpcMemHandle_t handles[HRBF_PEER_MAX][PEER_BUFS];
+    volatile long long red[2][HRBF_PEER_MAX][PEER_RED_WORDS];   // the ranks' int64 limb sums of a registration all-reduce (double buffered)
 };
 struct PeerLink {
     int enabled;            // images are peer-mapped (either transport)
@@ -557,6 +559,30 @@ static int peer_barrier_host(hrbf_context *c)
             usleep(20);
         }
     }
+}
+// The registration's int64 all-reduce on the shared-memory transport (hrbf_comm_init_peer + hrbf_set_row_sharding(h, 1)): the
+// sums make a round trip through the host segment — slow, and only there so that the row-sharded registration of REAL ranks
+// (strips, fold, all-reduce, stand-alone solve: launch_odometry's sharded path) runs between processes on the one GPU a test
+// box has, where RCCL refuses a second rank.  Integer sums: the result does not depend on the order of the ranks.
+static int shm_allreduce_i64(void *ctx, long long *buf, size_t n, hipStream_t s)
+{
+    hrbf_context *c = (hrbf_context *)ctx;
+    PeerLink &pl = c->peer;
+    if (!pl.shm_mode || n > PEER_RED_WORDS) return -1;
+    long long mine[PEER_RED_WORDS];
+    hipMemcpyAsync(mine, buf, sizeof(long long) * n, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);              // an error here is reported by the barrier below, which this rank still reaches
+    const int slot = (int)((pl.gen + 1u) & 1u);
+    for (size_t i = 0; i < n; ++i) pl.shm->red[slot][pl.rank][i] = mine[i];
+    __sync_synchronize();
+    if (peer_barrier_host(c)) return -1;
+    for (size_t i = 0; i < n; ++i) {
+        long long t = 0;
+        for (int g = 0; g < pl.world; ++g) t += pl.shm->red[slot][g][i];
+        mine[i] = t;
+    }
+    hipMemcpyAsync(buf, mine, sizeof(long long) * n, hipMemcpyHostToDevice, s);
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;    // `mine` lives on this stack
 }
 // the point after which every rank's writes into this rank's images are complete
 static int peer_meet(hrbf_context *c)
@@ -1085,7 +1111,7 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
         launch_should_fill_in(c->stream, c->cam, c->d_pr_vertex, c->prm.dense_enough_thresh, &c->d_pose->should_fill_in);
     OdoSources src = make_sources(c);
     OdoConfig cfg = make_cfg(c);
-    const bool sharded = (c->comm.comm != nullptr || c->comm.virtual_world > 1) && !c->rows_replicated;
+    const bool sharded = (c->comm.allreduce_i64 != nullptr || c->comm.virtual_world > 1) && !c->rows_replicated;
     launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier, c->level0_done);
     c->level0_done = 0;
 }
@@ -1988,7 +2014,7 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     const int e = g_rccl.CommInitRank(&comm, world, id, rank);
     if (e != 0 || !comm) { if (have) hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; hrbf_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return HRBF_ERR_COMM; }
     if (!have) { g_rccl.CommDestroy(comm); hrbf_set_error("hrbf_comm_init: out of device memory"); return HRBF_ERR_DEVICE; }
-    c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world; c->comm.allreduce_i64 = rccl_allreduce_i64;
+    c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world; c->comm.allreduce_i64 = rccl_allreduce_i64; c->comm.ar_ctx = comm;
     return HRBF_OK;
 }
 
@@ -2037,7 +2063,10 @@ extern "C" int hrbf_comm_init_peer(hrbf_handle c, int rank, int world, const uin
         hrbf_set_error("comm_init_peer: this rendezvous id has already served its %d ranks; take a new one from hrbf_peer_unique_id", world);
         return HRBF_ERR_INVALID;
     }
-    c->rows_replicated = 1;   // no communicator for the registration sums: every rank reduces the whole image
+    // the registration sums: every rank reduces the whole image unless hrbf_set_row_sharding(h, 1) asks for the strips + the
+    // (host round trip) all-reduce of this transport
+    c->comm.allreduce_i64 = shm_allreduce_i64; c->comm.ar_ctx = c;
+    c->rows_replicated = 1;
     return peer_barrier_host(c);
 }
 

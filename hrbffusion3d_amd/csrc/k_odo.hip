@@ -1732,7 +1732,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
                      const OdoComm *oc, float weight_multiplier, int level0_done)
 {
     // sharded = the slot rows of this process do not hold the whole image: fold -> all-reduce -> stand-alone solve
-    const bool sharded = oc != nullptr && (oc->comm != nullptr || oc->virtual_world > 1);
+    const bool sharded = oc != nullptr && (oc->allreduce_i64 != nullptr || oc->virtual_world > 1);
     const int vworld = sharded ? (oc->virtual_world > 1 ? oc->virtual_world : oc->world) : 1;
     const int vfirst = sharded && oc->virtual_world <= 1 ? oc->rank : 0;            // ranks this process plays
     const int vlast = sharded && oc->virtual_world <= 1 ? oc->rank + 1 : vworld;
@@ -1741,7 +1741,7 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         p1 = (int)((long long)L.rows * (r + 1) / vworld) * L.cols;
     };
     auto allreduce = [&](long long *buf, size_t n) {
-        if (sharded && oc->comm && oc->allreduce_i64) oc->allreduce_i64(oc->comm, buf, n, s);
+        if (sharded && oc->allreduce_i64) oc->allreduce_i64(oc->ar_ctx, buf, n, s);
     };
     const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
     const int icp = !cfg.rgb_only && cfg.icp_weight > 0.0f;

@@ -329,7 +329,8 @@ struct OdoComm {
     void *comm;
     int rank, world;
     int virtual_world;
-    int (*allreduce_i64)(void *comm, long long *buf, size_t count, hipStream_t s);
+    int (*allreduce_i64)(void *ar_ctx, long long *buf, size_t count, hipStream_t s);   // in place, on the stream (or synchronously)
+    void *ar_ctx;       // its first argument: the RCCL communicator, or the context itself on the shared-memory transport
 };
 // weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well.
 // level0_done: launch_curvature_level0 has written level 0 of the pyramids for this frame already (1), and the packed

@@ -380,7 +380,11 @@ int hrbf_comm_init(hrbf_handle h, int rank, int world, const uint8_t id128[128])
  * points go through a POSIX shared-memory segment (the id is its name), the key min-reduce reads the peers' z-buffers.  It
  * exists because RCCL refuses two ranks on one GPU ("Duplicate GPU detected"): with it the whole sharded-map path runs as
  * two PROCESSES on ONE device, bit-identical to the single map (tests/test_peer_shards_gpu.py).  Registration is then not
- * row-sharded (every rank reduces the whole image) and hrbf_map_rebalance is unavailable. */
+ * row-sharded by default (every rank reduces the whole image); hrbf_set_row_sharding(h, 1) switches the strips on, with the
+ * int64 limb sums all-reduced through the segment (a host round trip per reduction: a correctness path for one-device
+ * boxes, not a fast one).  hrbf_map_rebalance is unavailable on this transport.
+ * A failed id renumbering (HRBF_STATUS_ID_SPACE) is AGREED between the ranks — all commit the new ids or none — and is final
+ * for a map shared by ranks (clearing the status re-arms a retry for a single process only). */
 int hrbf_peer_unique_id(uint8_t out128[128]);
 int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[128]);
 /* a rendezvous id that will not be used after all (rank 0's context removes the segment when it goes away; if rank 0 never
