@@ -1442,7 +1442,8 @@ __device__ __forceinline__ void gn_step_from_totals(S *st, const long long *s_to
     }
     __syncthreads();
     if (tid == 0) {
-        const long long c = res_c, sg = res_s;
+        // the reference sums diff^2 in a 32-bit int (reduce.cu:985-1046, RGBDOdometry.cpp:994-1018): the sum wraps beyond 2^31
+        const long long c = res_c, sg = (long long)(int)(unsigned int)(unsigned long long)res_s;
         if (rgb) {
             float rgbError = (float)(hd_sqrt((double)sg) / (double)(c == 0 ? 1 : c));
             if (rgbOnly && rgbError > st->lastRGBError) st->gn_break = 1;
@@ -1529,6 +1530,7 @@ __device__ __forceinline__ void fold_residual(const long long *__restrict__ res_
     if (threadIdx.x == 0) {
         long long c = 0, s = 0;
         for (int w = 0; w < RB / 64; ++w) { c += s_c[w]; s += s_s[w]; }
+        s = (long long)(int)(unsigned int)(unsigned long long)s;   // the reference's `int sigma`: wraps beyond 2^31 (reduce.cu:985-1046)
         float sigmaVal = hd_sqrtf((((float)s / (float)c) == 0.0f) ? 1.0f : (float)c);
         int brk = gn_break;
         if (rgb_only) {   // only this mode consults the error here (an fp64 sqrt + division on every workgroup's critical path)

@@ -900,10 +900,13 @@ void orc_odo_track(orc_ctx *c)
             for (int r = 0; r < 3; ++r) Ktd[r] = (K[r * 3] * ti[0] + K[r * 3 + 1] * ti[1]) + K[r * 3 + 2] * ti[2];
             f3 kt = v3((float)Ktd[0], (float)Ktd[1], (float)Ktd[2]);
 
-            int64_t sigma = 0, rgbSize = 0;
+            int64_t sigma = 0, rgbSize = 0, sigma_unwrapped = 0;
             if (rgb) {
                 float minScale = (float)(((double)minGrad[i] * (double)minGrad[i]) / (sobelScale * sobelScale));
                 rgb_residual(c, i, minScale, krk, kt, &rgbSize, &sigma);
+                /* `int sigma` (RGBDOdometry.cpp:994) summed in int2 on the device (reduce.cu:985-1046): wraps beyond 2^31 */
+                sigma_unwrapped = sigma;
+                sigma = (int64_t)(int32_t)(uint32_t)(uint64_t)sigma;
             }
             /* RGBDOdometry.cpp:1017-1018 incl. the precedence quirk */
             float sigmaVal = sqrtf(((float)sigma / (float)rgbSize == 0.0f) ? 1.0f : (float)rgbSize);
@@ -951,6 +954,7 @@ void orc_odo_track(orc_ctx *c)
                 for (int k = 0; k < 6; ++k) { tr[38 + k] = b_icp[k]; tr[80 + k] = b_rgb[k]; tr[86 + k] = result[k]; }
                 tr[92] = res_icp[1]; tr[93] = (double)rgbSize; tr[94] = (double)sigma; tr[95] = res_icp[0];
                 memcpy(tr + 96, state0, sizeof(state0));
+                tr[124] = (double)sigma_unwrapped;
             }
             /* computeUpdateSE3 OdometryProvider.h:73-93 */
             double rv[3] = {result[3], result[4], result[5]}, Ru[9], U[16], N[16];

@@ -162,7 +162,49 @@ def test_icp_term_alone_recovers_the_motion_in_the_corner(oracle_lib_built):
     assert np.linalg.norm(e[:3, 3]) < 1.0e-3 and rs.rot_angle_deg(e[:3, :3]) < 0.05
 
 
+# ------------------------------------------------------------------------------------------------------------------ (viii)
+def _inverted_pair(kind, **mode):
+    """the same view twice: frame A almost white, frame B dark with the texture's gradients: |diff| ~ 190 on ~140 k correspondences"""
+    import reg_cases
+    W, H = VGA
+    K = rc.intrinsics(W, H)
+    scene, TA = rc.VIEWS["room"]
+    a = rs.render(TA, W, H, K, scene, wavelength=0.15)
+    b = (np.where(a[0] > 0, 1.0 + (a[0].astype(np.float64) - 20.0) * 0.55, 0).astype(np.uint8), a[1])
+    a = (np.where(a[0] > 0, 250, 0).astype(np.uint8), a[1])
+    from hrbffusion3d_amd.params import default_params
+    e = reg_cases.make_engine(kind, default_params(W, H, *K, max_surfels=1 << 20, **mode))
+    try:
+        e.process_frame(a[0], a[1]); e.process_frame(b[0], b[1])
+        P = e.get_pose()
+        tr = e.odo_trace() if kind == "oracle" else None
+    finally:
+        e.close()
+    return np.ascontiguousarray(P, np.float32).view(np.uint32).copy(), tr
+
+
+def test_the_residual_sum_is_a_32_bit_int_like_the_references(oracle_lib_built):
+    """`int sigma` (RGBDOdometry.cpp:994), summed as int2 on the device (reduce.cu:985-1046, 1141-1153): beyond 2^31 it wraps, and
+    with it `sqrt(sigma)` of the rgbOnly error test can be NaN (never greater than the last error: no early exit).  A white and a
+    dark view push the sum of squares past 2^31; the oracle carries the wrapped value."""
+    _, tr = _inverted_pair("oracle", rgb_only=1, so3=0)
+    rows = [r for r in tr if r[0] >= 0 and r[93] > 0]
+    assert rows and max(r[124] for r in rows) > 2.0 ** 31
+    for r in rows:
+        wrapped = ((int(r[124]) + 2 ** 31) % 2 ** 32) - 2 ** 31
+        assert int(r[94]) == wrapped and -2 ** 31 <= r[94] < 2 ** 31
+
+
 # ================================================================================================================== GPU twins
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [dict(rgb_only=1, so3=0), dict()], ids=["rgb_only", "joint"])
+def test_hip_wraps_the_residual_sum_like_the_oracle(gpu_available, oracle_lib_built, mode):
+    g, _ = _inverted_pair("hip", **mode)
+    o, _ = _inverted_pair("oracle", **mode)
+    assert np.array_equal(g, o)
+
+
+
 GPU_CASES = [
     ("rgb_only_room_5px", VGA, "room", "5px", dict(rgb_only=1, so3=0), 0.5),
     ("rgb_only_plane_2px", VGA, "plane", "2px", dict(rgb_only=1, so3=0), 0.5),

@@ -4,7 +4,7 @@
 # counter collection combined with the trace domains).  Run on the GPU box:  bash tools/collect_pmc.sh <outdir> [lib]
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; export HRBF_BENCH_GEN_PROCS=1   # no forked frame generators under the profiler
-OUT=${1:-gpurun_out/r04/pmc}; mkdir -p "$OUT"
+OUT=${1:-gpurun_out/r05/pmc}; mkdir -p "$OUT"
 [ -n "${2:-}" ] && export HRBF_LIB=$2
 CMD="python bench.py --steps 10 --warmup 3 --cpu-frames 0 --worst-surfels 0 --big-surfels 0 --no-cpp-shim --no-traffic"
 run() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o x -- $CMD > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
