@@ -75,6 +75,7 @@ def parse():
                     help="bracket the fuse pass with HIP events on every n-th frame of the timed region (each bracketed frame costs the stream ~22 us)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes that measure the fuse pass's HBM traffic")
+    ap.add_argument("--no-fit-leg", action="store_true", help="skip the extension leg (true Hermite-RBF fit on the matrix core)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the one-sequence sharded leg (child processes)")
     ap.add_argument("--sharded-leg-timeout", type=float, default=420.0, help="seconds the sharded leg's child processes may take")
     ap.add_argument("--one-sequence-child", action="store_true", help=argparse.SUPPRESS)   # set by the parent for the sharded leg
@@ -415,7 +416,7 @@ def sharded_leg_command(args, world):
         name = "BASELINE config 4: synthetic 640x480 stream, 4.3 M surfels hash-owned over %d ranks" % world
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--one-sequence-child", "--shard-map", "--partition", "hash",
            "--shard-odometry", "--steps", str(min(args.steps, 50)), "--warmup", str(min(args.warmup, 10)), "--cpu-frames", "0",
-           "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-sharded-leg"] + shape
+           "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-sharded-leg", "--no-fit-leg"] + shape
     if args.dry_run:
         cmd.append("--dry-run")
     return cmd, name
@@ -719,7 +720,7 @@ def main():
         fus.synchronize()
         kp = min(K, 10)
         traffic_kernels = pmc_fuse_traffic(["--steps", str(kp), "--warmup", "3", "--surfels", str(args.surfels), "--width", str(W), "--height", str(H),
-                                            "--cpu-frames", "0", "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-traffic"] +
+                                            "--cpu-frames", "0", "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-traffic", "--no-fit-leg"] +
                                            (["--noise"] if args.noise else []), last_n=kp, skip=3)
         if traffic_kernels is not None and "error" not in traffic_kernels:
             # raw counters, no gfx950 x2: pass A mixes a 16-B stream with scattered texel gathers and the 86 MB map is resident in the
@@ -781,6 +782,32 @@ def main():
             big = big_leg(args, local_rank)
         except Exception as e:   # the extra leg must never take the bench line down
             big = {"error": repr(e)}
+
+    # EXTENSION leg (no reference counterpart, not part of `value`): the true Hermite-RBF fit on the matrix core over the live frame
+    # the context holds (hrbf_fit_curvature, csrc/k_fit.hip) — BASELINE config 5's "batched-HRBF small-GEMM on MFMA"
+    fit = None
+    if rank == 0 and world == 1 and args.virtual_shards <= 1 and not one_sequence and not args.no_fit_leg:
+        try:
+            fus.synchronize()
+            fus.fit_curvature(timed=True)
+            ts = [fus.fit_curvature(timed=True) for _ in range(5)]
+            c1 = fus.get_image("FIT_CURV1")
+            fitted = int((c1[..., 3] != 1000.0).sum())
+            ms_fit = float(np.mean(ts))
+            n_sys = 100                      # 25 centres x 4 unknowns (+ the right-hand-side row; padded to 7 x 7 blocks of 16)
+            flops_alg = fitted * (n_sys ** 3 / 3.0 + 2.0 * n_sys ** 2)      # Cholesky + two triangular solves of the 100 x 100 system
+            flops_mfma = fitted * 56 * 2.0 * 16 ** 3                        # what the matrix core executes: 56 block products of 16 x 16 x 16
+            fit = {"what": "EXTENSION, no reference counterpart: Hermite-RBF fit (5x5 window, 100x100 SPD system per pixel, blocked Cholesky, "
+                           "trailing updates on v_mfma_f32_16x16x4_f32) over the %dx%d live frame; never part of processFrame or of `value`" % (W, H),
+                   "ms_per_call": ms_fit, "pixels_fitted": fitted, "systems_per_s": fitted / (ms_fit * 1e-3),
+                   "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": flops_alg / (ms_fit * 1e-3) / 1e12,
+                                "frac": flops_alg / (ms_fit * 1e-3) / 1e12 / 157.3,
+                                "achieved_executed_mfma": flops_mfma / (ms_fit * 1e-3) / 1e12,
+                                "note": "f32-input MFMA peak (= the f32 vector peak); `achieved` counts the algorithm's flops (n^3/3 + 2n^2, n = 100), "
+                                        "`achieved_executed_mfma` the padded 16-blocks the matrix core really multiplies; the kernel is bound by the "
+                                        "sequential column recurrences of the factorisation (one wave per system), not by the matrix core"}}
+        except Exception as e:
+            fit = {"error": repr(e)}
 
     per_rank_fuse_ms = None
     coll = None
@@ -850,6 +877,7 @@ def main():
                          "moved_per_frame": float(st[ok][:, 6].mean()) if ok.any() else 0.0, "status": status},
             "roofline_worst_case": worst,
             "config5_single_gpu": big,
+            "extension_hrbf_fit_mfma": fit,
             "ranks_observed": ranks_observed,
             "per_rank_fuse_ms": per_rank_fuse_ms,      # [fuse pass ms, of which merge ms, live surfels] per rank
             "collectives": coll,

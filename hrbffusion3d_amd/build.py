@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhrbf_mi355.so")
-SOURCES = ["abi.hip", "k_pre.hip", "k_map.hip", "k_predict.hip", "k_odo.hip"]
+SOURCES = ["abi.hip", "k_pre.hip", "k_map.hip", "k_predict.hip", "k_odo.hip", "k_fit.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 

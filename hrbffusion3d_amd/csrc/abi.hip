@@ -112,6 +112,7 @@ struct hrbf_context {
     hrbf_params prm;
     PeerLink peer;
     uint32_t *d_comm_scratch;
+    float4 *d_fit_curv1, *d_fit_curv2, *d_fit_normal;   // extension (hrbf_fit_curvature): allocated on first use
     int device;
     hipStream_t stream;
     Cam cam;
@@ -457,6 +458,9 @@ extern "C" void hrbf_destroy(hrbf_handle c)
         free(r);
     }
     if (c->d_stats_ring) hipFree(c->d_stats_ring);
+    if (c->d_fit_curv1) hipFree(c->d_fit_curv1);
+    if (c->d_fit_curv2) hipFree(c->d_fit_curv2);
+    if (c->d_fit_normal) hipFree(c->d_fit_normal);
     peer_close(c); peer_shm_release(c);
     if (c->comm.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm.comm);
     if (c->d_comm_scratch) { hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; }
@@ -1469,6 +1473,29 @@ extern "C" int hrbf_shard_exchange_mode(hrbf_handle c)
     return c->peer.enabled ? 1 : (c->peer_fallback ? 3 : 2);
 }
 // hash ownership: how often the ids were renumbered (hash_renumber: when the next pass could exhaust 32 bits; HRBF_HASH_RENUMBER_AT)
+// extension: true Hermite-RBF fit per pixel on the matrix core (k_fit.hip); see include/hrbf_mi355.h
+extern "C" int hrbf_fit_curvature(hrbf_handle c, int window, float support, float ridge, float jump, float *ms)
+{
+    if (!c || window < 1 || window > 2 || !(support > 1.0f) || !(ridge >= 0.0f) || !(jump > 0.0f)) { hrbf_set_error("fit_curvature: window 1..2, support > 1, ridge >= 0, jump > 0"); return HRBF_ERR_INVALID; }
+    hipSetDevice(c->device);
+    if (!c->d_fit_curv1) {
+        float4 **q[3] = {&c->d_fit_curv1, &c->d_fit_curv2, &c->d_fit_normal};
+        for (int i = 0; i < 3; ++i)
+            if (hipMalloc((void **)q[i], sizeof(float4) * (size_t)c->P) != hipSuccess) { *q[i] = nullptr; hrbf_set_error("fit_curvature: out of device memory"); return HRBF_ERR_DEVICE; }
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); hipEventRecord(e0, c->stream); }
+    launch_hrbf_fit(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, window, support, ridge, jump, c->d_fit_curv1, c->d_fit_curv2, c->d_fit_normal);
+    if (ms) {
+        hipEventRecord(e1, c->stream);
+        const hipError_t e = hipEventSynchronize(e1);
+        if (e == hipSuccess) hipEventElapsedTime(ms, e0, e1);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        HIP_CHECK(e);
+    }
+    HIP_CHECK(hipGetLastError());
+    return HRBF_OK;
+}
 extern "C" int hrbf_gn_graph_captures(hrbf_handle c) { return c ? (int)c->odo.gn_graph_captures : HRBF_ERR_INVALID; }
 extern "C" int hrbf_hash_renumber_count(hrbf_handle c) { return c ? (int)c->hash_renumbered : HRBF_ERR_INVALID; }
 // the shard a surfel at (x, y, z) is inserted into under hash ownership (host code: no device needed)
@@ -1599,6 +1626,7 @@ static void *img_ptr(hrbf_context *c, int which, size_t *bytes)
         I1(HRBF_IMG_PRED_ICPWEIGHT, d_pr_icpw)
         I1(HRBF_IMG_FILL_IMAGE, d_fi_image) I4(HRBF_IMG_FILL_VERTEX, d_fi_vertex) I4(HRBF_IMG_FILL_NORMAL, d_fi_normal)
         I4(HRBF_IMG_FILL_CURV1, d_fi_curv1) I4(HRBF_IMG_FILL_CURV2, d_fi_curv2) I1(HRBF_IMG_FILL_ICPWEIGHT, d_fi_icpw)
+        I4(HRBF_IMG_FIT_CURV1, d_fit_curv1) I4(HRBF_IMG_FIT_CURV2, d_fit_curv2) I4(HRBF_IMG_FIT_NORMAL, d_fit_normal)
 #undef I1
 #undef I4
         default: *bytes = 0; return nullptr;

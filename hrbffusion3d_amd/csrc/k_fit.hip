@@ -1,0 +1,335 @@
+// k_fit.hip — OPTIONAL extension, not part of processFrame: a true Hermite-RBF fit per pixel, the "batched-HRBF small-GEMM on
+// MFMA" BASELINE config 5 names.  NO counterpart in the reference: hrbfbase.glsl:132,153,173 use the closed-form coefficients
+// 10 * n_i where a Hermite-RBF interpolant solves a (4k x 4k) symmetric positive definite system over its k centres.  The default
+// path (k_curvature) is untouched; this operator (hrbf_fit_curvature) is held to a float64 numpy statement of the same algorithm
+// (oracle/hrbf_fit_ref.py) within a tolerance and to analytic plane / sphere / cylinder answers (tests/test_hrbf_fit.py).
+//
+// One WAVE per pixel (64-thread workgroups, no cross-wave hand-over), everything out of LDS:
+//   gather   the valid pixels of the (2w+1)^2 window (w <= 2: k <= 25 centres), common support rho = support * max |p_q - p_c|,
+//            dimensionless coordinates u = (p - p_c) / rho
+//   assemble the 4k x 4k system of Wendland-C4 blocks [[psi, -grad psi^T], [grad psi, -H psi]](u_i - u_j) + ridge, padded with an
+//            identity to 112 = 7 x 7 blocks of 16 x 16 (3 x 3 for the 3 x 3 window), lower triangle only (28 blocks, rows padded to
+//            17 floats: bank-conflict-free for the MFMA operand reads; 31 KB: five waves per CU); the right-hand side rides as the
+//            LAST ROW of the matrix, so the forward substitution L y = b is done by the factorisation itself
+//   factor   right-looking blocked Cholesky.  A lane owns one ROW (16 registers): lanes 0..15 the diagonal block's rows, lanes
+//            16..63 the rows of three panel blocks; column j of all of them is the same recurrence s = a_ij - sum_{t<j} l_it l_jt,
+//            l_jt broadcast from lane j by v_readlane_b32 — the panel's triangular solve costs nothing beside the factorisation.
+//            Trailing updates C(ib, jb) -= X(ib) X(jb)^T are 16 x 16 x 16 products on v_mfma_f32_16x16x4_f32 (exact f32:
+//            bit-for-bit a k-ordered fmaf chain), accumulators loaded from / stored to LDS in the C/D register layout.
+//            (First version: 32 x 32 blocks on v_mfma_f32_32x32x2_f32, 43 KB and three waves per CU: 26.7 ms per 640 x 480 frame —
+//            small blocks move the flops from the lanes' recurrences into the matrix core and fit more systems on a CU.)
+//   solve    back substitution L^T c = y block by block (the lane that owns an unknown keeps its residual)
+//   evaluate gradient and Hessian of the interpolant at the pixel's own point, shape operator, principal curvatures + directions
+#include "common.h"
+#include "kernels.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define FIT_B 16                        // block edge (v_mfma_f32_16x16x4_f32)
+#define FIT_LD 17                       // floats per block row in LDS (odd: the MFMA operand reads of 16 lanes hit 16 banks)
+#define FIT_BLK (FIT_B * FIT_LD)        // floats per block
+#define FIT_MAXK 25
+#define FIT_MIN_CENTRES 8
+#define FIT_SENTINEL 1000.0f
+
+__device__ __forceinline__ int fit_blk(int I, int J) { return (I * (I + 1) / 2 + J) * FIT_BLK; }
+__device__ __forceinline__ float &fit_at(float *A, int r, int c)   // element (r, c), r >= c
+{
+    return A[fit_blk(r >> 4, c >> 4) + (r & 15) * FIT_LD + (c & 15)];
+}
+__device__ __forceinline__ float fit_readlane(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// Wendland C4: phi(r) = (1 - r)^6 (35 r^2 + 18 r + 3) / 3;  F = phi'/r, G = F'/r, K = G'/r
+__device__ __forceinline__ void fit_wendland(float r, float &phi, float &F, float &G, float &K)
+{
+    if (!(r < 1.0f)) { phi = F = G = K = 0.0f; return; }
+    const float t = 1.0f - r, t2 = t * t, t3 = t2 * t, t4 = t2 * t2;
+    phi = t4 * t2 * (35.0f * r * r + 18.0f * r + 3.0f) * (1.0f / 3.0f);
+    F = -(56.0f / 3.0f) * t4 * t * (5.0f * r + 1.0f);
+    G = 560.0f * t4;
+    K = r > 0.0f ? -2240.0f * t3 / r : 0.0f;
+}
+
+// Columns 0..15 of up to four block rows at once: a lane owns one ROW (16 registers); lanes 0..15 hold the rows of the diagonal
+// block, lanes 16..63 the rows of three panel blocks.  FACTOR: the diagonal block is being factored in the same sweep; otherwise
+// lanes 0..15 hold its finished rows and only broadcast.  Column j of every row is the same recurrence
+// s = a_ij - sum_{t<j} l_it l_jt, l_jt broadcast from lane j (v_readlane_b32): the panel's triangular solve costs nothing beside
+// the factorisation.  Four columns advance together — four INDEPENDENT chains over t < j0 (a wave has at most one partner on its
+// SIMD to hide a dependent chain behind) — and are then finished one by one.  Each element takes its terms in ascending t.
+template <bool FACTOR>
+__device__ __forceinline__ void fit_finish(float (&row)[FIT_B], int lane, int j, float s)
+{
+    float inv;
+    if (FACTOR) inv = 1.0f / sqrtf(fit_readlane(s, j));
+    else inv = 1.0f / fit_readlane(row[j], j);
+    const float val = s * inv;
+    if (FACTOR) { if (lane >= j) row[j] = val; }       // lane j: pivot / sqrt(pivot) = l_jj
+    else if (lane >= FIT_B) row[j] = val;
+}
+template <bool FACTOR>
+__device__ __forceinline__ void fit_columns(float (&row)[FIT_B], int lane)
+{
+#pragma unroll
+    for (int j0 = 0; j0 < FIT_B; j0 += 4) {
+        float s[4] = {row[j0], row[j0 + 1], row[j0 + 2], row[j0 + 3]};
+#pragma unroll
+        for (int t = 0; t < j0; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = fmaf(-row[t], fit_readlane(row[t], j0 + q), s[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = j0; t < j0 + q; ++t) s[q] = fmaf(-row[t], fit_readlane(row[t], j0 + q), s[q]);
+            fit_finish<FACTOR>(row, lane, j0 + q, s[q]);
+        }
+    }
+}
+
+__device__ __forceinline__ void fit_load_row(const float *blk, int lane, bool lower_only, float (&row)[FIT_B])
+{
+    const int r = lane & 15;
+#pragma unroll
+    for (int c = 0; c < FIT_B; ++c) row[c] = (!lower_only || c <= r) ? blk[r * FIT_LD + c] : 0.0f;
+}
+__device__ __forceinline__ void fit_store_row(float *blk, int lane, const float (&row)[FIT_B])
+{
+    const int r = lane & 15;
+#pragma unroll
+    for (int c = 0; c < FIT_B; ++c) blk[r * FIT_LD + c] = row[c];
+}
+
+// C(ib, jb) -= X(ib, kb) * X(jb, kb)^T on the matrix core: 4 x v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain)
+__device__ __forceinline__ void fit_update(float *A, int ib, int jb, int kb, int lane)
+{
+    const float *Xi = A + fit_blk(ib, kb), *Xj = A + fit_blk(jb, kb);
+    float *C = A + fit_blk(ib, jb);
+    const int col = lane & 15, quad = lane >> 4;
+    floatx4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = C[(4 * quad + r) * FIT_LD + col];          // C/D: row = 4 * (lane >> 4) + reg, col = lane & 15
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float a = -Xi[col * FIT_LD + 4 * s + quad];       // A[i = lane & 15][k = lane >> 4]
+        const float b = Xj[col * FIT_LD + 4 * s + quad];        // B[k = lane >> 4][j = lane & 15] = X(jb)[j][k]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(4 * quad + r) * FIT_LD + col] = acc[r];
+}
+
+// NBR block rows of 16: 7 for the 5 x 5 window (4 * 25 unknowns + the right-hand-side row <= 112), 3 for the 3 x 3 window (<= 48)
+template <int NBR>
+__global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__restrict__ normal,
+                                                 int w, float support, float ridge, float jump, float4 *__restrict__ out_c1,
+                                                 float4 *__restrict__ out_c2, float4 *__restrict__ out_n)
+{
+    constexpr int NBLK = NBR * (NBR + 1) / 2, NPAD = NBR * FIT_B, RHS = NPAD - 1;
+    __shared__ float A[NBLK * FIT_BLK];
+    __shared__ float s_u[FIT_MAXK][3], s_n[FIT_MAXK][3];
+    __shared__ float s_coef[NPAD];
+    const int lane = threadIdx.x, pi = blockIdx.x;
+    const int W = cam.W, H = cam.H;
+    const int px = pi % W, py = pi / W;
+    const int side = 2 * w + 1, nwin = side * side, tc = nwin / 2;
+
+    // ---- gather
+    float4 v = make_float4(0, 0, 0, 0), nn = make_float4(0, 0, 0, 0);
+    bool ok = false;
+    if (lane < nwin) {
+        const int qx = px + lane % side - w, qy = py + lane / side - w;
+        if (qx >= 0 && qy >= 0 && qx < W && qy < H) {
+            v = vertex[qy * W + qx]; nn = normal[qy * W + qx];
+            const float nl = sqrtf((nn.x * nn.x + nn.y * nn.y) + nn.z * nn.z);
+            ok = v.z > 0.0f && isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(nl) && nl > 0.5f;
+        }
+    }
+    const float pcx = fit_readlane(v.x, tc), pcy = fit_readlane(v.y, tc), pcz = fit_readlane(v.z, tc);
+    const bool okc = (__ballot(ok) >> tc) & 1ull;
+    const float dx = v.x - pcx, dy = v.y - pcy, dz = v.z - pcz;
+    const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+    ok = ok && dist <= jump * (float)w * pcz * cam.camz;
+    const unsigned long long mask = __ballot(ok);
+    const int k = __popcll(mask);
+    float maxd = ok ? dist : 0.0f;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) maxd = fmaxf(maxd, __shfl_xor(maxd, d));
+    const float rho = support * maxd;
+    if (!okc || k < FIT_MIN_CENTRES || !(rho > 0.0f)) {
+        if (lane == 0) {
+            out_c1[pi] = make_float4(0, 0, 0, FIT_SENTINEL); out_c2[pi] = make_float4(0, 0, 0, FIT_SENTINEL);
+            out_n[pi] = make_float4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+    if (ok) {
+        s_u[slot][0] = dx / rho; s_u[slot][1] = dy / rho; s_u[slot][2] = dz / rho;
+        s_n[slot][0] = nn.x; s_n[slot][1] = nn.y; s_n[slot][2] = nn.z;
+    }
+    for (int i = lane; i < NBLK * FIT_BLK; i += 64) A[i] = 0.0f;
+    __syncthreads();
+
+    // ---- assemble (lower triangle), identity padding, the right-hand side as the last row
+    const int n4 = 4 * k;
+    for (int r = n4 + lane; r < RHS; r += 64) fit_at(A, r, r) = 1.0f;
+    if (lane == 0) fit_at(A, RHS, RHS) = 1.0e30f;      // its pivot is never used; keep it finite
+    for (int c = lane; c < n4; c += 64) fit_at(A, RHS, c) = (c & 3) ? s_n[c >> 2][(c & 3) - 1] : 0.0f;
+    const int npairs = k * (k + 1) / 2;
+    for (int p = lane; p < npairs; p += 64) {
+        int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+        while (i * (i + 1) / 2 > p) --i;
+        while ((i + 1) * (i + 2) / 2 <= p) ++i;
+        const int j = p - i * (i + 1) / 2;
+        if (i == j) {
+            fit_at(A, 4 * i, 4 * i) = 1.0f + ridge;
+#pragma unroll
+            for (int a = 1; a < 4; ++a) fit_at(A, 4 * i + a, 4 * i + a) = 56.0f / 3.0f + ridge;
+            continue;
+        }
+        const float d[3] = {s_u[i][0] - s_u[j][0], s_u[i][1] - s_u[j][1], s_u[i][2] - s_u[j][2]};
+        const float r = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        float phi, F, G, K;
+        fit_wendland(r, phi, F, G, K);
+        fit_at(A, 4 * i, 4 * j) = phi;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            fit_at(A, 4 * i, 4 * j + 1 + a) = -F * d[a];
+            fit_at(A, 4 * i + 1 + a, 4 * j) = F * d[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) fit_at(A, 4 * i + 1 + a, 4 * j + 1 + b) = -((a == b ? F : 0.0f) + G * d[a] * d[b]);
+        }
+    }
+    __syncthreads();
+
+    // ---- blocked Cholesky, right-looking over block columns
+    const int grp = lane >> 4;
+    for (int kb = 0; kb < NBR; ++kb) {
+        float row[FIT_B];
+        {   // the diagonal block is factored while the first three panel blocks below it are solved
+            const int ib = kb + grp;
+            if (grp == 0) fit_load_row(A + fit_blk(kb, kb), lane, true, row);
+            else if (ib < NBR) fit_load_row(A + fit_blk(ib, kb), lane, false, row);
+            else {
+#pragma unroll
+                for (int c = 0; c < FIT_B; ++c) row[c] = 0.0f;
+            }
+            fit_columns<true>(row, lane);
+            if (ib < NBR) fit_store_row(A + fit_blk(ib, kb), lane, row);
+        }
+        for (int base = kb + 4; base < NBR; base += 3) {   // further panel blocks: lanes 0..15 keep L(kb, kb) and broadcast
+            const int ib = base + grp - 1;
+            if (grp > 0) {
+                if (ib < NBR) fit_load_row(A + fit_blk(ib, kb), lane, false, row);
+                else {
+#pragma unroll
+                    for (int c = 0; c < FIT_B; ++c) row[c] = 0.0f;
+                }
+            }
+            fit_columns<false>(row, lane);
+            if (grp > 0 && ib < NBR) fit_store_row(A + fit_blk(ib, kb), lane, row);
+        }
+        __syncthreads();
+        for (int ib = kb + 1; ib < NBR; ++ib)
+            for (int jb = kb + 1; jb <= ib; ++jb) fit_update(A, ib, jb, kb, lane);
+        __syncthreads();
+    }
+
+    // ---- back substitution L^T c = y, y = the last row of L (columns < 4k); lanes 0..15 own the unknowns of a block
+    float racc[NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) {
+        const int c = FIT_B * b + (lane & 15);
+        racc[b] = (lane < FIT_B && c < n4) ? A[fit_blk(NBR - 1, b) + (FIT_B - 1) * FIT_LD + (c & 15)] : 0.0f;
+    }
+#pragma unroll
+    for (int kb = NBR - 1; kb >= 0; --kb) {
+        const float *D = A + fit_blk(kb, kb);
+        const int l15 = lane & 15, grow = FIT_B * kb + l15;
+        const float dinv = (lane < FIT_B && grow < n4) ? 1.0f / D[l15 * FIT_LD + l15] : 0.0f;
+        float r = racc[kb], cval = 0.0f;
+#pragma unroll
+        for (int i = FIT_B - 1; i >= 0; --i) {
+            const float ci = fit_readlane(r * dinv, i);
+            if (lane == i) cval = ci;
+            if (lane < i) r = fmaf(-D[i * FIT_LD + l15], ci, r);
+        }
+        if (lane < FIT_B) s_coef[grow] = cval;
+#pragma unroll
+        for (int jb = 0; jb < NBR - 1; ++jb) {
+            if (jb >= kb) continue;
+            const float *B = A + fit_blk(kb, jb);
+            float acc = racc[jb];
+#pragma unroll
+            for (int i = 0; i < FIT_B; ++i) acc = fmaf(-B[i * FIT_LD + l15], fit_readlane(cval, i), acc);
+            racc[jb] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- gradient and Hessian of the interpolant at the pixel's own point (u = 0)
+    float g[3] = {0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};     // h: xx xy xz yy yz zz
+    if (lane < k) {
+        const float al = s_coef[4 * lane], be[3] = {s_coef[4 * lane + 1], s_coef[4 * lane + 2], s_coef[4 * lane + 3]};
+        const float d[3] = {-s_u[lane][0], -s_u[lane][1], -s_u[lane][2]};
+        const float r = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        float phi, F, G, K;
+        fit_wendland(r, phi, F, G, K);
+        const float db = (d[0] * be[0] + d[1] * be[1]) + d[2] * be[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] = al * F * d[a] - (F * be[a] + G * d[a] * db);
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) {
+                const float dl = a == b ? 1.0f : 0.0f;
+                h[q++] = al * (F * dl + G * d[a] * d[b]) - (G * (db * dl + be[a] * d[b] + d[a] * be[b]) + K * d[a] * d[b] * db);
+            }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] += __shfl_xor(g[a], s);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) h[a] += __shfl_xor(h[a], s);
+    }
+    if (lane != 0) return;
+    const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+    if (!(gn > 0.0f) || !isfinite(gn)) {
+        out_c1[pi] = make_float4(0, 0, 0, FIT_SENTINEL); out_c2[pi] = make_float4(0, 0, 0, FIT_SENTINEL); out_n[pi] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const f3 n = mk3(g[0] / gn, g[1] / gn, g[2] / gn);
+    const f3 ax = fabsf(n.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0);
+    const f3 t1 = normalize3(cross3(n, ax)), t2 = cross3(n, t1);
+    const float sc = 1.0f / (rho * gn);       // H_x = H_u / rho; shape operator = tangential H_x / |grad|
+    auto Hv = [&](f3 x) { return mk3((h[0] * x.x + h[1] * x.y) + h[2] * x.z, (h[1] * x.x + h[3] * x.y) + h[4] * x.z, (h[2] * x.x + h[4] * x.y) + h[5] * x.z); };
+    const f3 H1 = Hv(t1), H2 = Hv(t2);
+    const float m00 = dot3(t1, H1) * sc, m01 = dot3(t1, H2) * sc, m11 = dot3(t2, H2) * sc;
+    const float mean = 0.5f * (m00 + m11), diff = 0.5f * (m00 - m11), rad = sqrtf(diff * diff + m01 * m01);
+    const float kmax = mean + rad, kmin = mean - rad;
+    float vx, vy;       // eigenvector of kmax in the (t1, t2) basis
+    if (fabsf(m01) > 1.0e-12f * (fabsf(m00) + fabsf(m11) + 1.0e-30f)) { vx = m01; vy = kmax - m00; }
+    else if (diff >= 0.0f) { vx = 1.0f; vy = 0.0f; }
+    else { vx = 0.0f; vy = 1.0f; }
+    const float vl = sqrtf(vx * vx + vy * vy);
+    vx /= vl; vy /= vl;
+    const f3 dmax = add3(scale3(t1, vx), scale3(t2, vy)), dmin = add3(scale3(t1, -vy), scale3(t2, vx));
+    out_c1[pi] = make_float4(dmax.x, dmax.y, dmax.z, kmax);
+    out_c2[pi] = make_float4(dmin.x, dmin.y, dmin.z, kmin);
+    out_n[pi] = make_float4(n.x, n.y, n.z, gn);
+}
+
+void launch_hrbf_fit(hipStream_t s, const Cam &cam, const float4 *vertex, const float4 *normal, int w, float support, float ridge,
+                     float jump, float4 *out_c1, float4 *out_c2, float4 *out_n)
+{
+    if (w >= 2)
+        hipLaunchKernelGGL(k_hrbf_fit<7>, dim3(cam.W * cam.H), dim3(64), 0, s, cam, vertex, normal, w, support, ridge, jump, out_c1,
+                           out_c2, out_n);
+    else
+        hipLaunchKernelGGL(k_hrbf_fit<3>, dim3(cam.W * cam.H), dim3(64), 0, s, cam, vertex, normal, w, support, ridge, jump, out_c1,
+                           out_c2, out_n);
+}

@@ -57,6 +57,10 @@ struct PoseLog {
     PoseRecord poses[POSE_LOG_CAP];     // frame f at poses[f % POSE_LOG_CAP]
 };
 
+// ---- k_fit.hip (optional extension: true Hermite-RBF fit on the matrix core; not part of processFrame)
+void launch_hrbf_fit(hipStream_t s, const Cam &cam, const float4 *vertex, const float4 *normal, int w, float support, float ridge,
+                     float jump, float4 *out_c1, float4 *out_c2, float4 *out_n);
+
 // ---- k_pre.hip
 void launch_filter_metric(hipStream_t s, const Cam &cam, const uint16_t *raw, float *filtered, float *metric,
                           float *metric_f, float depthFactor, float maxD, int bilateral, const uint8_t *ride_src = nullptr,

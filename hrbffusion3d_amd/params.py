@@ -81,6 +81,9 @@ _img = [
 ]
 for _i, (_n, _d, _c) in enumerate(_img):
     IMAGES[_n] = (_i, _d, _c)
+# images of the optional extension (hrbf_fit_curvature; allocated on first use, not part of the reference's set): kept out of
+# IMAGES so that loops over the reference's images do not meet them
+EXT_IMAGES = {"FIT_CURV1": (len(_img), "f4", 4), "FIT_CURV2": (len(_img) + 1, "f4", 4), "FIT_NORMAL": (len(_img) + 2, "f4", 4)}
 
 STAGES = {n: i for i, n in enumerate([
     "FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS", "CURVATURE", "CONFIDENCE", "INITIALISE",

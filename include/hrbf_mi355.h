@@ -171,6 +171,9 @@ typedef enum hrbf_image {
     HRBF_IMG_FILL_CURV1,              /* f4 */
     HRBF_IMG_FILL_CURV2,              /* f4 */
     HRBF_IMG_FILL_ICPWEIGHT,          /* f1 */
+    HRBF_IMG_FIT_CURV1,               /* f4 extension (hrbf_fit_curvature): direction of kmax, kmax; w = 1000 where no fit */
+    HRBF_IMG_FIT_CURV2,               /* f4 extension: direction of kmin, kmin */
+    HRBF_IMG_FIT_NORMAL,              /* f4 extension: normalised gradient of the fitted interpolant, its length */
     HRBF_IMG_COUNT
 } hrbf_image;
 size_t hrbf_image_bytes(hrbf_handle h, int which);
@@ -391,6 +394,14 @@ int hrbf_comm_init_peer(hrbf_handle h, int rank, int world, const uint8_t id128[
  * joins, this does).  An id serves ONE rendezvous: a second set of contexts on it is refused. */
 int hrbf_peer_release_id(const uint8_t id128[128]);
 int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ranges | 2 spatial hash */
+/* EXTENSION with NO counterpart in the reference (BASELINE config 5's "batched-HRBF small-GEMM on MFMA"; the reference uses the closed
+ * form 10 * n_i, hrbfbase.glsl:132): a true Hermite-RBF fit over every pixel's (2 * window + 1)^2 window (window 1 or 2) of the
+ * context's VERTEX_FILTERED / NORMAL images — a (4k x 4k) symmetric positive definite Wendland-C4 system per pixel, factored by a
+ * blocked Cholesky whose trailing updates run on v_mfma_f32_16x16x4_f32 — and the principal curvatures of the fitted level set at the
+ * pixel (images HRBF_IMG_FIT_CURV1 / FIT_CURV2 / FIT_NORMAL).  support: common support radius in units of the window's largest
+ * centre distance (1.25); ridge: added to the diagonal (1e-6); jump: centres farther than jump * window pixel footprints from the
+ * pixel are left out (3).  ms (nullable): kernel time by HIP events.  Not called by hrbf_process_frame; never changes its results. */
+int hrbf_fit_curvature(hrbf_handle h, int window, float support, float ridge, float jump, float *ms);
 int hrbf_gn_graph_captures(hrbf_handle h);    /* times the Gauss-Newton loop was captured into a hipGraph: 2 in a steady run (one per image parity) whatever
                                                 weightMultiplier the caller passes per frame (GUI/src/HRBF_fusion.cpp:225); re-captured only when a setter changes the configuration */
 int hrbf_hash_renumber_count(hrbf_handle h);   /* hash ownership: times the 32-bit ids were renumbered to ranks (every ~55 000 VGA frames; order unchanged) */

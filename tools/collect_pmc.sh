@@ -6,7 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; export HRBF_BENCH_GEN_PROCS=1   # no forked frame generators under the profiler
 OUT=${1:-gpurun_out/r05/pmc}; mkdir -p "$OUT"
 [ -n "${2:-}" ] && export HRBF_LIB=$2
-CMD="python bench.py --steps 10 --warmup 3 --cpu-frames 0 --worst-surfels 0 --big-surfels 0 --no-cpp-shim --no-traffic"
+CMD="python bench.py --steps 10 --warmup 3 --cpu-frames 0 --worst-surfels 0 --big-surfels 0 --no-cpp-shim --no-traffic --no-fit-leg"
 run() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o x -- $CMD > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
 run s1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY
 run s2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
