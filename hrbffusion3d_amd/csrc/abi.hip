@@ -579,7 +579,7 @@ static int shm_allreduce_i64(void *ctx, long long *buf, size_t n, hipStream_t s)
     const int slot = (int)((pl.gen + 1u) & 1u);
     for (size_t i = 0; i < n; ++i) pl.shm->red[slot][pl.rank][i] = mine[i];
     __sync_synchronize();
-    if (peer_barrier_host(c)) return -1;
+    if (peer_barrier_host(c)) { c->status |= HRBF_STATUS_INTERNAL_BOUND; return -1; }   // the caller (launch_odometry) cannot stop a frame half way: the status bit says its pose is not to be trusted
     for (size_t i = 0; i < n; ++i) {
         long long t = 0;
         for (int g = 0; g < pl.world; ++g) t += pl.shm->red[slot][g][i];

@@ -18,8 +18,10 @@
 //            bit-for-bit a k-ordered fmaf chain), accumulators loaded from / stored to LDS in the C/D register layout.
 //            (First version: 32 x 32 blocks on v_mfma_f32_32x32x2_f32, 43 KB and three waves per CU: 26.7 ms per 640 x 480 frame —
 //            small blocks move the flops from the lanes' recurrences into the matrix core and fit more systems on a CU.)
-//   solve    back substitution L^T c = y block by block (the lane that owns an unknown keeps its residual)
-//   evaluate gradient and Hessian of the interpolant at the pixel's own point, shape operator, principal curvatures + directions
+//   read out the gradient (3) and Hessian (6) of the interpolant at the pixel are LINEAR functionals e_m of the coefficients; their
+//            rows ride in the matrix below the right-hand side, so e_m^T A^-1 b = (L^-1 e_m) . (L^-1 b) is computed by the
+//            factorisation's own trailing updates and stands in L[RB + 1 + m][RB] afterwards: no back substitution (it was 22 %
+//            of the kernel), then the shape operator, principal curvatures + directions on one lane
 #include "common.h"
 #include "kernels.h"
 
@@ -61,9 +63,11 @@ __device__ __forceinline__ void fit_wendland(float r, float &phi, float &F, floa
 template <bool FACTOR>
 __device__ __forceinline__ void fit_finish(float (&row)[FIT_B], int lane, int j, float s)
 {
+    // v_rsq_f32 / v_rcp_f32 (1 ulp) instead of the IEEE sqrt + division (~25 instructions per column): this operator is held to a
+    // tolerance against a float64 statement, not to bits
     float inv;
-    if (FACTOR) inv = 1.0f / sqrtf(fit_readlane(s, j));
-    else inv = 1.0f / fit_readlane(row[j], j);
+    if (FACTOR) inv = __builtin_amdgcn_rsqf(fit_readlane(s, j));
+    else inv = __builtin_amdgcn_rcpf(fit_readlane(row[j], j));
     const float val = s * inv;
     if (FACTOR) { if (lane >= j) row[j] = val; }       // lane j: pivot / sqrt(pivot) = l_jj
     else if (lane >= FIT_B) row[j] = val;
@@ -120,20 +124,66 @@ __device__ __forceinline__ void fit_update(float *A, int ib, int jb, int kb, int
     for (int r = 0; r < 4; ++r) C[(4 * quad + r) * FIT_LD + col] = acc[r];
 }
 
+// two blocks of block row ib at once: X(ib) is read once and the two dependent MFMA chains (40 cycles per link) interleave.
+// (Requesting block jb + 1's operands and accumulator before block jb's MFMAs — one chain, software-pipelined over a whole block
+//  row — measured SLOWER: 580 against 440 cycles per block update; the pairs stay.)
+__device__ __forceinline__ void fit_update2(float *A, int ib, int jb, int kb, int lane)
+{
+    const float *Xi = A + fit_blk(ib, kb), *Xj0 = A + fit_blk(jb, kb), *Xj1 = A + fit_blk(jb + 1, kb);
+    float *C0 = A + fit_blk(ib, jb), *C1 = A + fit_blk(ib, jb + 1);
+    const int col = lane & 15, quad = lane >> 4;
+    floatx4 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc0[r] = C0[(4 * quad + r) * FIT_LD + col]; acc1[r] = C1[(4 * quad + r) * FIT_LD + col]; }
+    float a[4], b0[4], b1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = -Xi[col * FIT_LD + 4 * s + quad]; b0[s] = Xj0[col * FIT_LD + 4 * s + quad]; b1[s] = Xj1[col * FIT_LD + 4 * s + quad];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { C0[(4 * quad + r) * FIT_LD + col] = acc0[r]; C1[(4 * quad + r) * FIT_LD + col] = acc1[r]; }
+}
+
+#ifdef FIT_TIMING   // measurement build: cycles per phase and wave, plain stores (tools/probes/fit_phases.py sums them)
+#define FIT_TIMING_WAVES (640 * 480)
+__device__ unsigned int g_fit_phase_w[FIT_TIMING_WAVES * 8];
+extern "C" int hrbf_probe_fit_phases(unsigned int *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fit_phase_w), sizeof(unsigned int) * FIT_TIMING_WAVES * 8) != hipSuccess) return -1;
+    if (reset) { void *p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fit_phase_w)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned int) * FIT_TIMING_WAVES * 8) != hipSuccess) return -1; }
+    return 0;
+}
+#define FIT_T(i) do { const unsigned long long t_now = __builtin_readcyclecounter(); if (lane == 0 && pi < FIT_TIMING_WAVES) g_fit_phase_w[pi * 8 + (i)] += (unsigned int)(t_now - t_last); t_last = t_now; } while (0)
+#else
+#define FIT_T(i)
+#endif
+
 // NBR block rows of 16: 7 for the 5 x 5 window (4 * 25 unknowns + the right-hand-side row <= 112), 3 for the 3 x 3 window (<= 48)
 template <int NBR>
 __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__restrict__ normal,
                                                  int w, float support, float ridge, float jump, float4 *__restrict__ out_c1,
                                                  float4 *__restrict__ out_c2, float4 *__restrict__ out_n)
 {
-    constexpr int NBLK = NBR * (NBR + 1) / 2, NPAD = NBR * FIT_B, RHS = NPAD - 1;
-    __shared__ float A[NBLK * FIT_BLK];
+    // rows: [0, 4k) the unknowns, identity padding up to RB, row RB the right-hand side b, rows RB + 1 .. RB + 9 the nine linear
+    // functionals that read the interpolant's gradient (3) and Hessian (6) at the pixel, two rows of padding.  After the
+    // factorisation row RB of L is y = L^-1 b and row RB + 1 + m is z_m = L^-1 e_m, so the wanted values q_m = e_m^T A^-1 b =
+    // z_m . y appear — with a minus sign, divided by the pivot of column RB — at L[RB + 1 + m][RB]: the factorisation's own
+    // trailing updates compute them and NO back substitution is needed (it was 22 % of the kernel: dependent steps on 16 lanes).
+    constexpr int NBLK = NBR * (NBR + 1) / 2, NPAD = NBR * FIT_B, RB = NPAD - 12;
+    __shared__ __attribute__((aligned(16))) float A[NBLK * FIT_BLK];
     __shared__ float s_u[FIT_MAXK][3], s_n[FIT_MAXK][3];
-    __shared__ float s_coef[NPAD];
     const int lane = threadIdx.x, pi = blockIdx.x;
     const int W = cam.W, H = cam.H;
     const int px = pi % W, py = pi / W;
     const int side = 2 * w + 1, nwin = side * side, tc = nwin / 2;
+#ifdef FIT_TIMING
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
 
     // ---- gather
     float4 v = make_float4(0, 0, 0, 0), nn = make_float4(0, 0, 0, 0);
@@ -145,6 +195,11 @@ __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restri
             const float nl = sqrtf((nn.x * nn.x + nn.y * nn.y) + nn.z * nn.z);
             ok = v.z > 0.0f && isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(nl) && nl > 0.5f;
         }
+    }
+    {   // the matrix is zeroed while the window's loads are in flight
+        static_assert((NBLK * FIT_BLK) % 4 == 0, "block storage is a multiple of 16 bytes");
+        float4 *A4 = reinterpret_cast<float4 *>(A);
+        for (int i = lane; i < NBLK * FIT_BLK / 4; i += 64) A4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const float pcx = fit_readlane(v.x, tc), pcy = fit_readlane(v.y, tc), pcz = fit_readlane(v.z, tc);
     const bool okc = (__ballot(ok) >> tc) & 1ull;
@@ -169,14 +224,39 @@ __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restri
         s_u[slot][0] = dx / rho; s_u[slot][1] = dy / rho; s_u[slot][2] = dz / rho;
         s_n[slot][0] = nn.x; s_n[slot][1] = nn.y; s_n[slot][2] = nn.z;
     }
-    for (int i = lane; i < NBLK * FIT_BLK; i += 64) A[i] = 0.0f;
     __syncthreads();
+    FIT_T(0);
 
     // ---- assemble (lower triangle), identity padding, the right-hand side as the last row
     const int n4 = 4 * k;
-    for (int r = n4 + lane; r < RHS; r += 64) fit_at(A, r, r) = 1.0f;
-    if (lane == 0) fit_at(A, RHS, RHS) = 1.0e30f;      // its pivot is never used; keep it finite
-    for (int c = lane; c < n4; c += 64) fit_at(A, RHS, c) = (c & 3) ? s_n[c >> 2][(c & 3) - 1] : 0.0f;
+    for (int r = n4 + lane; r < RB; r += 64) fit_at(A, r, r) = 1.0f;
+    if (lane < 12) fit_at(A, RB + lane, RB + lane) = lane < 10 ? 1.0e30f : 1.0f;   // pivots of the extra rows: large, so that they stay positive
+    for (int c = lane; c < n4; c += 64) fit_at(A, RB, c) = (c & 3) ? s_n[c >> 2][(c & 3) - 1] : 0.0f;
+    if (lane < k) {   // the nine functionals at u = 0: centre `lane` contributes its four columns to each
+        const int j = lane;
+        const float d[3] = {-s_u[j][0], -s_u[j][1], -s_u[j][2]};
+        const float r = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        float phi, F, G, K;
+        fit_wendland(r, phi, F, G, K);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {          // gradient component a
+            fit_at(A, RB + 1 + a, 4 * j) = F * d[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) fit_at(A, RB + 1 + a, 4 * j + 1 + b) = -((a == b ? F : 0.0f) + G * d[a] * d[b]);
+        }
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) {      // Hessian entry (a, b): xx xy xz yy yz zz
+                const float dl = a == b ? 1.0f : 0.0f;
+                fit_at(A, RB + 4 + m, 4 * j) = F * dl + G * d[a] * d[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    fit_at(A, RB + 4 + m, 4 * j + 1 + c) = -(G * (d[c] * dl + (a == c ? d[b] : 0.0f) + (b == c ? d[a] : 0.0f)) + K * d[a] * d[b] * d[c]);
+                ++m;
+            }
+    }
     const int npairs = k * (k + 1) / 2;
     for (int p = lane; p < npairs; p += 64) {
         int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
@@ -203,6 +283,7 @@ __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restri
         }
     }
     __syncthreads();
+    FIT_T(1);
 
     // ---- blocked Cholesky, right-looking over block columns
     const int grp = lane >> 4;
@@ -232,70 +313,29 @@ __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restri
             if (grp > 0 && ib < NBR) fit_store_row(A + fit_blk(ib, kb), lane, row);
         }
         __syncthreads();
-        for (int ib = kb + 1; ib < NBR; ++ib)
-            for (int jb = kb + 1; jb <= ib; ++jb) fit_update(A, ib, jb, kb, lane);
+        FIT_T(2);
+        for (int ib = kb + 1; ib < NBR; ++ib) {
+            int jb = kb + 1;
+            for (; jb + 1 <= ib; jb += 2) fit_update2(A, ib, jb, kb, lane);
+            if (jb <= ib) fit_update(A, ib, jb, kb, lane);
+        }
         __syncthreads();
+        FIT_T(3);
     }
 
-    // ---- back substitution L^T c = y, y = the last row of L (columns < 4k); lanes 0..15 own the unknowns of a block
-    float racc[NBR];
+    // ---- read the nine values out of the factor: q_m = -L[RB + 1 + m][RB] * L[RB][RB]
+    FIT_T(4);
+    float g[3], h[6];
+    {
+        const float *D = A + fit_blk(NBR - 1, NBR - 1);
+        constexpr int lc = RB - FIT_B * (NBR - 1);            // local column of the b row in the last diagonal block
+        const float piv = D[lc * FIT_LD + lc];
 #pragma unroll
-    for (int b = 0; b < NBR; ++b) {
-        const int c = FIT_B * b + (lane & 15);
-        racc[b] = (lane < FIT_B && c < n4) ? A[fit_blk(NBR - 1, b) + (FIT_B - 1) * FIT_LD + (c & 15)] : 0.0f;
+        for (int a = 0; a < 3; ++a) g[a] = -D[(lc + 1 + a) * FIT_LD + lc] * piv;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) h[a] = -D[(lc + 4 + a) * FIT_LD + lc] * piv;
     }
-#pragma unroll
-    for (int kb = NBR - 1; kb >= 0; --kb) {
-        const float *D = A + fit_blk(kb, kb);
-        const int l15 = lane & 15, grow = FIT_B * kb + l15;
-        const float dinv = (lane < FIT_B && grow < n4) ? 1.0f / D[l15 * FIT_LD + l15] : 0.0f;
-        float r = racc[kb], cval = 0.0f;
-#pragma unroll
-        for (int i = FIT_B - 1; i >= 0; --i) {
-            const float ci = fit_readlane(r * dinv, i);
-            if (lane == i) cval = ci;
-            if (lane < i) r = fmaf(-D[i * FIT_LD + l15], ci, r);
-        }
-        if (lane < FIT_B) s_coef[grow] = cval;
-#pragma unroll
-        for (int jb = 0; jb < NBR - 1; ++jb) {
-            if (jb >= kb) continue;
-            const float *B = A + fit_blk(kb, jb);
-            float acc = racc[jb];
-#pragma unroll
-            for (int i = 0; i < FIT_B; ++i) acc = fmaf(-B[i * FIT_LD + l15], fit_readlane(cval, i), acc);
-            racc[jb] = acc;
-        }
-    }
-    __syncthreads();
-
-    // ---- gradient and Hessian of the interpolant at the pixel's own point (u = 0)
-    float g[3] = {0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};     // h: xx xy xz yy yz zz
-    if (lane < k) {
-        const float al = s_coef[4 * lane], be[3] = {s_coef[4 * lane + 1], s_coef[4 * lane + 2], s_coef[4 * lane + 3]};
-        const float d[3] = {-s_u[lane][0], -s_u[lane][1], -s_u[lane][2]};
-        const float r = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-        float phi, F, G, K;
-        fit_wendland(r, phi, F, G, K);
-        const float db = (d[0] * be[0] + d[1] * be[1]) + d[2] * be[2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) g[a] = al * F * d[a] - (F * be[a] + G * d[a] * db);
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = a; b < 3; ++b) {
-                const float dl = a == b ? 1.0f : 0.0f;
-                h[q++] = al * (F * dl + G * d[a] * d[b]) - (G * (db * dl + be[a] * d[b] + d[a] * be[b]) + K * d[a] * d[b] * db);
-            }
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) g[a] += __shfl_xor(g[a], s);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) h[a] += __shfl_xor(h[a], s);
-    }
+    FIT_T(5);
     if (lane != 0) return;
     const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
     if (!(gn > 0.0f) || !isfinite(gn)) {
