@@ -20,6 +20,8 @@ code states, written down before looking at any output of the oracle, on analyti
        and its null space is {in-plane translations, rotation about the normal through the camera} with the normal expressed in that
        camera's frame — not in the tracker's world frame.
  (vii) ICP term alone on the three-wall corner recovers the motion to a fraction of the photometric bound.
+ (viii) the residual's sum of squares is a 32-bit int that wraps, like the reference's.
+ (ix)  time reversal and photometric / joint agreement on the reference's own GPUTest frames (the only real data there is).
 
 GPU twins (-m gpu): the HIP library on the same frames meets the same bounds and returns the oracle's pose bit for bit.
 DESIGN.md §8 ("The drift ...") rests on (i): the photometric term works to its half-pixel bound, and no better."""
@@ -195,7 +197,51 @@ def test_the_residual_sum_is_a_32_bit_int_like_the_references(oracle_lib_built):
         assert int(r[94]) == wrapped and -2 ** 31 <= r[94] < 2 ** 31
 
 
+# ------------------------------------------------------------------------------------------------------------------ (ix)
+def _png_pair_estimate(kind, png_pair, first, second, **mode):
+    import reg_cases
+    from hrbffusion3d_amd.params import default_params
+    e = reg_cases.make_engine(kind, default_params(640, 480, 528.0, 528.0, 320.0, 240.0, max_surfels=1 << 21, **mode))
+    try:
+        e.process_frame(*png_pair[first]); e.process_frame(*png_pair[second])
+        return e.get_pose().astype(np.float64)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("mode", [dict(), dict(icp_weight=100.0), dict(rgb_only=1)], ids=["joint", "icp_only", "rgb_only"])
+def test_time_reversal_on_the_references_own_frames(oracle_lib_built, png_pair, mode):
+    """the only REAL frames there are (GPUTest/1c,1d,2c,2d.png: a hand-held sensor, 9.4 px of mean image motion): frame 2 against
+    frame 1 and frame 1 against frame 2 must be inverse motions — on real texture and sensor noise the sub-pixel phases are not
+    aligned from pixel to pixel and the loop closes far inside the half-pixel bounds"""
+    K = (528.0, 528.0, 320.0, 240.0)
+    z = png_pair[1][1].astype(np.float64) / 5000.0
+    f = _png_pair_estimate("oracle", png_pair, 0, 1, **mode)
+    b = _png_pair_estimate("oracle", png_pair, 1, 0, **mode)
+    assert rs.reprojection_px(np.eye(4), f, z, K) > 8.0                     # the frames did move
+    assert rs.reprojection_px(f @ b, np.eye(4), z, K) < 0.15, mode            # measured 0.02-0.05 px, 0.1-0.2 mm
+    assert np.linalg.norm((f @ b)[:3, 3]) < 5e-4
+
+
+def test_photometric_and_joint_estimates_agree_on_the_references_own_frames(oracle_lib_built, png_pair):
+    K = (528.0, 528.0, 320.0, 240.0)
+    z = png_pair[1][1].astype(np.float64) / 5000.0
+    joint = _png_pair_estimate("oracle", png_pair, 0, 1)
+    rgb = _png_pair_estimate("oracle", png_pair, 0, 1, rgb_only=1)
+    assert rs.reprojection_px(joint, rgb, z, K) < 0.5                          # two estimators, one motion: within the photometric bound
+
+
 # ================================================================================================================== GPU twins
+@pytest.mark.gpu
+def test_hip_time_reversal_on_the_references_own_frames(gpu_available, oracle_lib_built, png_pair):
+    K = (528.0, 528.0, 320.0, 240.0)
+    z = png_pair[1][1].astype(np.float64) / 5000.0
+    f = _png_pair_estimate("hip", png_pair, 0, 1)
+    b = _png_pair_estimate("hip", png_pair, 1, 0)
+    assert rs.reprojection_px(f @ b, np.eye(4), z, K) < 0.15
+    assert np.array_equal(f.astype(np.float32).view(np.uint32), _png_pair_estimate("oracle", png_pair, 0, 1).astype(np.float32).view(np.uint32))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [dict(rgb_only=1, so3=0), dict()], ids=["rgb_only", "joint"])
 def test_hip_wraps_the_residual_sum_like_the_oracle(gpu_available, oracle_lib_built, mode):
