@@ -10,6 +10,13 @@
  *  - LDLT = diagonal-pivoted LDL^T written here; 3x3/4x4 inverses by cofactors;
  *  - sin/cos/acos = hd_* ; normalized(n) = n * (1/sqrt(n.n)).
  */
+/* ORC_MUTANT (default 0 = the oracle): deliberate MISREADINGS of the reference, one per value, compiled only into
+   oracle/_build/liboracle_mutant_<k>.so by `make mutants` — never into the oracle.  tools/mutation_report.py runs the metamorphic
+   tests of tests/test_registration_metamorphic.py against each of them: a test suite that is meant to catch a misread Jacobian
+   column, sign, weight or frame has to FAIL on these (profiles/r05_metamorphic_mutation_report.txt says which do). */
+#ifndef ORC_MUTANT
+#define ORC_MUTANT 0
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
@@ -410,7 +417,11 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
     if (!found) return;
     f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
     f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
+#if ORC_MUTANT == 1      /* the matched normal left in the tracker's world frame */
+    f3 n_cp = bn;
+#else
     f3 n_cp = m33_mul(Rpi, bn);
+#endif
     if (sp) {   /* sparse ICP (reduce.cu:479-492): the target moves by the shrunk residual minus the scaled multiplier */
         const int k = y * cols + x;
         sp->corres[2 * k] = bx; sp->corres[2 * k + 1] = by;
@@ -432,7 +443,11 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
     float row[7];
     f3 cr = cross3(s_cp, n_cp);
     row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
+#if ORC_MUTANT == 2      /* residual n . (d - s) instead of n . (s - d) */
+    row[6] = dot3(n_cp, sub3(d_cp, s_cp));
+#else
     row[6] = dot3(n_cp, sub3(s_cp, d_cp));
+#endif
     int k = 0;
     for (int i = 0; i < 6; ++i) for (int j = i; j < 7; ++j) out[k++] = weight * row[i] * row[j];
     out[27] = weight * row[6] * row[6];
@@ -588,7 +603,11 @@ static void rgb_residual_core(int rows, int cols, const int16_t *dIdx, const int
             float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + kt.x) / td1;
             float fv = (d1 * ((krk[3] * (float)x + krk[4] * (float)y) + krk[5]) + kt.y) / td1;
             if (!(fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f)) continue;
+#if ORC_MUTANT == 4      /* the model image looked up at the truncated instead of the nearest texel */
+            int u0 = (int)floorf(fu), v0 = (int)floorf(fv);
+#else
             int u0 = (int)rintf(fu), v0 = (int)rintf(fv);
+#endif
             if (!(u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows)) continue;
             float d0 = lastDepth[v0 * cols + u0];
             if (d0 > 0.0f && fabsf(td1 - d0) <= maxDepthDelta && lastImage[v0 * cols + u0] != 0) {
@@ -614,7 +633,11 @@ static void rgb_step_core(int rows, int cols, const int16_t *corres, const float
                           const int16_t *dIdxl, const int16_t *dIdyl, float sigma, float fx, float fy, int use_grad,
                           double sums[29])
 {
+#if ORC_MUTANT == 5      /* Sobel scale 1 / 2^2 instead of 1 / 2^3 */
+    const float sobelScale = 0.25f;
+#else
     const float sobelScale = 0.125f;
+#endif
     acc29 tot; for (int i = 0; i < 29; ++i) hd_acc_zero(&tot.a[i]);
 #pragma omp parallel
     {
@@ -631,14 +654,26 @@ static void rgb_step_core(int rows, int cols, const int16_t *corres, const float
             row[6] = -w * diff;
             f3 cp = cloud[co[1] * cols + co[0]];
             float invz = 1.0f / cp.z;
+#if ORC_MUTANT == 12     /* the gradient read at the model pixel (`zero`) instead of the live pixel (`one`) */
+            float dIx = w * sobelScale * (float)dIdxl[co[1] * cols + co[0]];
+            float dIy = w * sobelScale * (float)dIdyl[co[1] * cols + co[0]];
+#else
             float dIx = w * sobelScale * (float)dIdxl[co[3] * cols + co[2]];
             float dIy = w * sobelScale * (float)dIdyl[co[3] * cols + co[2]];
+#endif
             float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
             float v2 = -(v0 * cp.x + v1 * cp.y) * invz;
             row[0] = v0; row[1] = v1; row[2] = v2;
+#if ORC_MUTANT == 3      /* the rotational columns of the photometric row with the cross product the other way round */
+            row[3] = cp.z * v1 - cp.y * v2;
+#else
             row[3] = -cp.z * v1 + cp.y * v2;
+#endif
             row[4] = cp.z * v0 - cp.x * v2;
             row[5] = -cp.y * v0 + cp.x * v1;
+#if ORC_MUTANT == 3
+            row[4] = -row[4]; row[5] = -row[5];
+#endif
             float rw = 1.0f;
             if (use_grad) {
                 float gm = sqrtf(dIx * dIx + dIy * dIy);
@@ -698,7 +733,11 @@ static void so3_step(const uint8_t *lastImage, const uint8_t *nextImage, int row
                        (((point.z * (f * gy + cc * gx)) - (gy * i_ * fyp)) - (gx * i_ * fxp)) / z2);
             f3 jr = cross3(lp, point);
             float row[4] = {jr.x, jr.y, jr.z,
+#if ORC_MUTANT == 11     /* SO3 residual last - next ... with the sign of next - last */
+                            ((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x])};
+#else
                             -((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x])};
+#endif
             int q = 0;
             for (int i = 0; i < 3; ++i) for (int j = i; j < 4; ++j) hd_acc_add_f32(&tot[q++], row[i] * row[j]);
             hd_acc_add_f32(&tot[9], row[3] * row[3]);
@@ -873,7 +912,11 @@ void orc_odo_track(orc_ctx *c)
 
     for (int i = ORC_NUM_PYRS - 1; i >= 0; --i) {
         const int div = 1 << i;
+#if ORC_MUTANT == 10     /* the principal point not divided by 2^level */
+        const float fxl = c->prm.fx / div, fyl = c->prm.fy / div, cxl = c->prm.cx, cyl = c->prm.cy;
+#else
         const float fxl = c->prm.fx / div, fyl = c->prm.fy / div, cxl = c->prm.cx / div, cyl = c->prm.cy / div;
+#endif
         if (rgb) project_cloud(c->last_depth[i], c->H >> i, c->W >> i, fxl, fyl, cxl, cyl, c->cloud[i]);
         double K[9] = {0}, Kinv[9];
         K[0] = fxl; K[4] = fyl; K[2] = cxl; K[5] = cyl; K[8] = 1;
@@ -909,7 +952,11 @@ void orc_odo_track(orc_ctx *c)
                 sigma = (int64_t)(int32_t)(uint32_t)(uint64_t)sigma;
             }
             /* RGBDOdometry.cpp:1017-1018 incl. the precedence quirk */
+#if ORC_MUTANT == 8      /* sigma as the rms residual: what the expression looks like it means, not what its precedence says */
+            float sigmaVal = sqrtf((float)sigma / (float)(rgbSize == 0 ? 1 : rgbSize));
+#else
             float sigmaVal = sqrtf(((float)sigma / (float)rgbSize == 0.0f) ? 1.0f : (float)rgbSize);
+#endif
             float rgbError = (float)(sqrt((double)sigma) / (double)(rgbSize == 0 ? 1 : rgbSize));
             if (rgbOnly && rgbError > lastRGBError) break;
             lastRGBError = rgbError;
@@ -937,8 +984,16 @@ void orc_odo_track(orc_ctx *c)
             double lastA[36], lastb[6], result[6];
             if (icp && rgb) {
                 double w = icpWeight, ww = w * w;
+#if ORC_MUTANT == 6      /* A_rgb + w A_icp (the weight not squared on the matrix) */
+                for (int k = 0; k < 36; ++k) lastA[k] = (double)A_rgb[k] + w * (double)A_icp[k];
+#else
                 for (int k = 0; k < 36; ++k) lastA[k] = (double)A_rgb[k] + ww * (double)A_icp[k];
+#endif
+#if ORC_MUTANT == 7      /* b_rgb + w^2 b_icp (a consistent weighting: NOT what the reference does) */
+                for (int k = 0; k < 6; ++k) lastb[k] = (double)b_rgb[k] + ww * (double)b_icp[k];
+#else
                 for (int k = 0; k < 6; ++k) lastb[k] = (double)b_rgb[k] + w * (double)b_icp[k];
+#endif
             } else if (icp) {
                 for (int k = 0; k < 36; ++k) lastA[k] = A_icp[k];
                 for (int k = 0; k < 6; ++k) lastb[k] = b_icp[k];
@@ -968,8 +1023,13 @@ void orc_odo_track(orc_ctx *c)
             for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }
             /* currentT = [Rprev|tprev] * rgbOdom.inverse(); inverse = (R^T, -R^T t) */
             float iR[9], it_[3];
+#if ORC_MUTANT == 9      /* T_prev * dT instead of T_prev * dT^-1 */
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[r * 3 + k];
+            for (int r = 0; r < 3; ++r) it_[r] = ot[r];
+#else
             for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) iR[r * 3 + k] = oR[k * 3 + r];
             for (int r = 0; r < 3; ++r) it_[r] = -((iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1]) + iR[r * 3 + 2] * ot[2]);
+#endif
             mul3f(Rprev, iR, Rcurr);
             f3 rt = m33_mul(Rprev, v3(it_[0], it_[1], it_[2]));
             tcurr = add3(rt, tprev);

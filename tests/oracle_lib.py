@@ -21,6 +21,9 @@ def load(omp=False):
         os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, len(os.sched_getaffinity(0)))))
     name = "liboracle_omp.so" if omp else "liboracle.so"
     path = os.path.join(_ODIR, "_build", name)
+    # tools/mutation_report.py only: a deliberately MISREAD oracle (oracle/Makefile `mutants`), to show that the metamorphic tests fail on it
+    if os.environ.get("HRBF_ORACLE_MUTANT"):
+        path = os.path.join(_ODIR, "_build", "liboracle_mutant_%d.so" % int(os.environ["HRBF_ORACLE_MUTANT"]))
     if not os.path.exists(path):
         build()
     lib = C.CDLL(path)
