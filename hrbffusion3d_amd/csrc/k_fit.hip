@@ -105,48 +105,79 @@ __device__ __forceinline__ void fit_store_row(float *blk, int lane, const float 
     for (int c = 0; c < FIT_B; ++c) blk[r * FIT_LD + c] = row[c];
 }
 
-// C(ib, jb) -= X(ib, kb) * X(jb, kb)^T on the matrix core: 4 x v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain)
-__device__ __forceinline__ void fit_update(float *A, int ib, int jb, int kb, int lane)
+// C(ib, jb .. jb + N - 1) -= X(ib, kb) * X(jb .., kb)^T on the matrix core: N x 4 v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered
+// fmaf chain).  N blocks of one block row at a time: X(ib) is read once, the N dependent accumulator chains (40 cycles per link,
+// 32 per issue) interleave, and the LDS round trips in front of and behind the MFMAs are paid once per N blocks (measured: 440
+// cycles per block update in pairs).  Requesting block jb + 1's operands before block jb's MFMAs — ONE chain, software-pipelined
+// over a block row — measured slower (580).
+template <int N>
+__device__ __forceinline__ void fit_update_n(float *A, int ib, int jb, int kb, int lane)
 {
-    const float *Xi = A + fit_blk(ib, kb), *Xj = A + fit_blk(jb, kb);
-    float *C = A + fit_blk(ib, jb);
+    const float *Xi = A + fit_blk(ib, kb);
     const int col = lane & 15, quad = lane >> 4;
-    floatx4 acc;
+    floatx4 acc[N];
+    float a[4], b[N][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = C[(4 * quad + r) * FIT_LD + col];          // C/D: row = 4 * (lane >> 4) + reg, col = lane & 15
+    for (int n = 0; n < N; ++n) {
+        const float *C = A + fit_blk(ib, jb + n), *Xj = A + fit_blk(jb + n, kb);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float a = -Xi[col * FIT_LD + 4 * s + quad];       // A[i = lane & 15][k = lane >> 4]
-        const float b = Xj[col * FIT_LD + 4 * s + quad];        // B[k = lane >> 4][j = lane & 15] = X(jb)[j][k]
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) acc[n][r] = C[(4 * quad + r) * FIT_LD + col];      // C/D: row = 4 * (lane >> 4) + reg, col = lane & 15
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[n][s] = Xj[col * FIT_LD + 4 * s + quad];         // B[k = lane >> 4][j = lane & 15] = X(jb)[j][k]
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) C[(4 * quad + r) * FIT_LD + col] = acc[r];
+    for (int s = 0; s < 4; ++s) a[s] = -Xi[col * FIT_LD + 4 * s + quad];               // A[i = lane & 15][k = lane >> 4]
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[n][s], acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float *C = A + fit_blk(ib, jb + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(4 * quad + r) * FIT_LD + col] = acc[n][r];
+    }
+}
+__device__ __forceinline__ void fit_update_row(float *A, int ib, int kb, int lane)
+{
+    int jb = kb + 1;
+    for (; jb + 3 <= ib; jb += 4) fit_update_n<4>(A, ib, jb, kb, lane);
+    const int left = ib - jb + 1;
+    if (left == 3) fit_update_n<3>(A, ib, jb, kb, lane);
+    else if (left == 2) fit_update_n<2>(A, ib, jb, kb, lane);
+    else if (left == 1) fit_update_n<1>(A, ib, jb, kb, lane);
 }
 
-// two blocks of block row ib at once: X(ib) is read once and the two dependent MFMA chains (40 cycles per link) interleave.
-// (Requesting block jb + 1's operands and accumulator before block jb's MFMAs — one chain, software-pipelined over a whole block
-//  row — measured SLOWER: 580 against 440 cycles per block update; the pairs stay.)
-__device__ __forceinline__ void fit_update2(float *A, int ib, int jb, int kb, int lane)
+// Panel blocks beyond the two that ride in the factor sweep: X(ib) = P(ib) * W with W = L(kb, kb)^-T, which the sweep produced as
+// the "panel solve" of an identity block (X L^T = I) and left in the diagonal block's place (with the functional rows there is no
+// back substitution, so L(kb, kb) itself is never read again).  In place, N blocks at a time, W read once.
+template <int N>
+__device__ __forceinline__ void fit_trsm_n(float *A, int ib, int kb, int lane)
 {
-    const float *Xi = A + fit_blk(ib, kb), *Xj0 = A + fit_blk(jb, kb), *Xj1 = A + fit_blk(jb + 1, kb);
-    float *C0 = A + fit_blk(ib, jb), *C1 = A + fit_blk(ib, jb + 1);
+    const float *Wb = A + fit_blk(kb, kb);
     const int col = lane & 15, quad = lane >> 4;
-    floatx4 acc0, acc1;
+    floatx4 acc[N];
+    float a[N][4], b[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc0[r] = C0[(4 * quad + r) * FIT_LD + col]; acc1[r] = C1[(4 * quad + r) * FIT_LD + col]; }
-    float a[4], b0[4], b1[4];
+    for (int s = 0; s < 4; ++s) b[s] = Wb[(4 * s + quad) * FIT_LD + col];              // B[k][j] = W[k][j]
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a[s] = -Xi[col * FIT_LD + 4 * s + quad]; b0[s] = Xj0[col * FIT_LD + 4 * s + quad]; b1[s] = Xj1[col * FIT_LD + 4 * s + quad];
+    for (int n = 0; n < N; ++n) {
+        const float *P = A + fit_blk(ib + n, kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[n][s] = P[col * FIT_LD + 4 * s + quad];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] = 0.0f;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
-    }
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { C0[(4 * quad + r) * FIT_LD + col] = acc0[r]; C1[(4 * quad + r) * FIT_LD + col] = acc1[r]; }
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n][s], b[s], acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float *P = A + fit_blk(ib + n, kb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(4 * quad + r) * FIT_LD + col] = acc[n][r];
+    }
 }
 
 #ifdef FIT_TIMING   // measurement build: cycles per phase and wave, plain stores (tools/probes/fit_phases.py sums them)
@@ -289,7 +320,8 @@ __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restri
     const int grp = lane >> 4;
     for (int kb = 0; kb < NBR; ++kb) {
         float row[FIT_B];
-        {   // the diagonal block is factored while the first three panel blocks below it are solved
+        const int nb = NBR - 1 - kb;                     // panel blocks below the diagonal block
+        if (nb <= 3) {   // the diagonal block is factored while all panel blocks below it are solved in the same sweep
             const int ib = kb + grp;
             if (grp == 0) fit_load_row(A + fit_blk(kb, kb), lane, true, row);
             else if (ib < NBR) fit_load_row(A + fit_blk(ib, kb), lane, false, row);
@@ -299,26 +331,29 @@ __global__ __launch_bounds__(64) void k_hrbf_fit(Cam cam, const float4 *__restri
             }
             fit_columns<true>(row, lane);
             if (ib < NBR) fit_store_row(A + fit_blk(ib, kb), lane, row);
-        }
-        for (int base = kb + 4; base < NBR; base += 3) {   // further panel blocks: lanes 0..15 keep L(kb, kb) and broadcast
-            const int ib = base + grp - 1;
-            if (grp > 0) {
-                if (ib < NBR) fit_load_row(A + fit_blk(ib, kb), lane, false, row);
-                else {
+            __syncthreads();
+        } else {         // more panels than lanes: lanes 16..31 solve an IDENTITY block (-> W = L^-T), lanes 32..63 two panels,
+                         // the other nb - 2 panels are multiplied by W on the matrix core (one sweep per block column, not two)
+            if (grp == 0) fit_load_row(A + fit_blk(kb, kb), lane, true, row);
+            else if (grp == 1) {
 #pragma unroll
-                    for (int c = 0; c < FIT_B; ++c) row[c] = 0.0f;
-                }
-            }
-            fit_columns<false>(row, lane);
-            if (grp > 0 && ib < NBR) fit_store_row(A + fit_blk(ib, kb), lane, row);
+                for (int c = 0; c < FIT_B; ++c) row[c] = c == (lane & 15) ? 1.0f : 0.0f;
+            } else fit_load_row(A + fit_blk(kb + grp - 1, kb), lane, false, row);
+            fit_columns<true>(row, lane);
+            __syncthreads();                              // every lane has read its rows: the diagonal block's place is free
+            if (grp == 1) fit_store_row(A + fit_blk(kb, kb), lane, row);
+            else if (grp > 1) fit_store_row(A + fit_blk(kb + grp - 1, kb), lane, row);
+            __syncthreads();
+            int ib = kb + 3;
+            for (; ib + 3 < NBR; ib += 4) fit_trsm_n<4>(A, ib, kb, lane);
+            const int left = NBR - ib;
+            if (left == 3) fit_trsm_n<3>(A, ib, kb, lane);
+            else if (left == 2) fit_trsm_n<2>(A, ib, kb, lane);
+            else if (left == 1) fit_trsm_n<1>(A, ib, kb, lane);
+            __syncthreads();
         }
-        __syncthreads();
         FIT_T(2);
-        for (int ib = kb + 1; ib < NBR; ++ib) {
-            int jb = kb + 1;
-            for (; jb + 1 <= ib; jb += 2) fit_update2(A, ib, jb, kb, lane);
-            if (jb <= ib) fit_update(A, ib, jb, kb, lane);
-        }
+        for (int ib = kb + 1; ib < NBR; ++ib) fit_update_row(A, ib, kb, lane);
         __syncthreads();
         FIT_T(3);
     }
