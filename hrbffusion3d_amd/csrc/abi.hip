@@ -113,6 +113,7 @@ struct hrbf_context {
     PeerLink peer;
     uint32_t *d_comm_scratch;
     float4 *d_fit_curv1, *d_fit_curv2, *d_fit_normal;   // extension (hrbf_fit_curvature): allocated on first use
+    int fit_in_frame;           // extension (hrbf_set_hrbf_fit): processFrame takes the live frame's curvatures from the fitted interpolant
     int device;
     hipStream_t stream;
     Cam cam;
@@ -1131,7 +1132,9 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     refresh_count_ub(c);
     TIMER(0);
     st_filter(c); st_vnr(c);
-    st_curv(c, c->tick > 1 && !c->prm.load_trajectory && c->fill_flag_fresh);
+    st_curv(c, c->tick > 1 && !c->prm.load_trajectory && c->fill_flag_fresh && !c->fit_in_frame);
+    if (c->fit_in_frame)   // EXTENSION, off by default (hrbf_set_hrbf_fit): PRINCIPAL_CURV1 / 2 of the live frame from the true Hermite-RBF fit
+        launch_hrbf_fit(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, 2, 1.25f, 0.1f, 3.0f, c->d_curv1, c->d_curv2, c->d_fit_normal);   // ridge 0.1: an exact interpolant of noisy normals amplifies the noise
     TIMER(1);
     if (c->tick == 1) {
         st_init(c);
@@ -1474,15 +1477,27 @@ extern "C" int hrbf_shard_exchange_mode(hrbf_handle c)
 }
 // hash ownership: how often the ids were renumbered (hash_renumber: when the next pass could exhaust 32 bits; HRBF_HASH_RENUMBER_AT)
 // extension: true Hermite-RBF fit per pixel on the matrix core (k_fit.hip); see include/hrbf_mi355.h
+static int fit_alloc(hrbf_context *c)
+{
+    if (c->d_fit_curv1) return HRBF_OK;
+    float4 **q[3] = {&c->d_fit_curv1, &c->d_fit_curv2, &c->d_fit_normal};
+    for (int i = 0; i < 3; ++i)
+        if (hipMalloc((void **)q[i], sizeof(float4) * (size_t)c->P) != hipSuccess) { *q[i] = nullptr; hrbf_set_error("hrbf fit: out of device memory"); return HRBF_ERR_DEVICE; }
+    return HRBF_OK;
+}
+extern "C" int hrbf_set_hrbf_fit(hrbf_handle c, int enable)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (enable) { const int r = fit_alloc(c); if (r) return r; }
+    c->fit_in_frame = enable ? 1 : 0;
+    return HRBF_OK;
+}
 extern "C" int hrbf_fit_curvature(hrbf_handle c, int window, float support, float ridge, float jump, float *ms)
 {
     if (!c || window < 1 || window > 2 || !(support > 1.0f) || !(ridge >= 0.0f) || !(jump > 0.0f)) { hrbf_set_error("fit_curvature: window 1..2, support > 1, ridge >= 0, jump > 0"); return HRBF_ERR_INVALID; }
     hipSetDevice(c->device);
-    if (!c->d_fit_curv1) {
-        float4 **q[3] = {&c->d_fit_curv1, &c->d_fit_curv2, &c->d_fit_normal};
-        for (int i = 0; i < 3; ++i)
-            if (hipMalloc((void **)q[i], sizeof(float4) * (size_t)c->P) != hipSuccess) { *q[i] = nullptr; hrbf_set_error("fit_curvature: out of device memory"); return HRBF_ERR_DEVICE; }
-    }
+    { const int r = fit_alloc(c); if (r) return r; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ms) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); hipEventRecord(e0, c->stream); }
     launch_hrbf_fit(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, window, support, ridge, jump, c->d_fit_curv1, c->d_fit_curv2, c->d_fit_normal);

@@ -402,6 +402,11 @@ int hrbf_map_shard_init(hrbf_handle h, int enable);   /* 0 off | 1 contiguous ra
  * centre distance (1.25); ridge: added to the diagonal (1e-6); jump: centres farther than jump * window pixel footprints from the
  * pixel are left out (3).  ms (nullable): kernel time by HIP events.  Not called by hrbf_process_frame; never changes its results. */
 int hrbf_fit_curvature(hrbf_handle h, int window, float support, float ridge, float jump, float *ms);
+/* the same fit INSIDE the frame path, as an option beside the closed form (default 0 = the reference's closed form; with 1 the results
+ * are no longer the reference's): hrbf_process_frame then takes the live frame's principal curvatures (HRBF_IMG_CURV1 / CURV2: ICP
+ * weights, curvature validity, the records of the fusion) from the fitted interpolant, 5 x 5 window, ridge 0.1 (an exact interpolant
+ * of noisy normals amplifies their noise), at ~7 ms per 640 x 480 frame */
+int hrbf_set_hrbf_fit(hrbf_handle h, int enable);
 int hrbf_gn_graph_captures(hrbf_handle h);    /* times the Gauss-Newton loop was captured into a hipGraph: 2 in a steady run (one per image parity) whatever
                                                 weightMultiplier the caller passes per frame (GUI/src/HRBF_fusion.cpp:225); re-captured only when a setter changes the configuration */
 int hrbf_hash_renumber_count(hrbf_handle h);   /* hash ownership: times the 32-bit ids were renumbered to ranks (every ~55 000 VGA frames; order unchanged) */

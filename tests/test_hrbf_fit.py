@@ -166,3 +166,45 @@ def test_hip_fit_on_a_preprocessed_frame_with_holes_and_edges(gpu_available):
         assert np.array_equal(g.get_image("CURV1").view(np.uint32), before.view(np.uint32))
     finally:
         g.close()
+
+
+@pytest.mark.gpu
+def test_fit_as_an_option_inside_the_frame_path(gpu_available):
+    """hrbf_set_hrbf_fit(1): processFrame takes the live frame's curvatures from the fitted interpolant instead of the closed form
+    (off by default; the results are then not the reference's).  A tracked noisy sequence stays on the trajectory, the live
+    curvature images are the fit's, the map keeps growing; switched off again the closed form is back (same images as a context
+    that never switched it on, given the same frame)."""
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion
+    from hrbffusion3d_amd.params import default_params
+    W2, H2 = 320, 240
+    p = default_params(W2, H2, *synth.intrinsics(W2, H2), max_surfels=1 << 19)
+    g, ref = HRBFFusion(p), HRBFFusion(p)
+    try:
+        g.set_hrbf_fit(True)
+        for k in range(12):
+            rgb, d, T = synth.frame(k, W2, H2, noise=True)
+            if k == 0:
+                g.set_pose(T); ref.set_pose(T)
+            g.process_frame(rgb, d); ref.process_frame(rgb, d)
+        assert g.status() == 0 and g.surfel_count() > 70_000
+        assert np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3]) < 0.05 and np.linalg.norm(ref.get_pose()[:3, 3] - T[:3, 3]) < 0.05
+        c1, c1_ref = g.get_image("CURV1"), ref.get_image("CURV1")
+        both = (c1[..., 3] != 1000.0) & (np.abs(c1_ref[..., 3]) < 300.0)
+        assert both.mean() > 0.5
+        # an interpolant of NOISY Hermite samples amplifies the noise (median |k| 58 / m with ridge 1e-6 on this stream, 22 with the
+        # in-frame ridge of 0.1, against 4 for the closed form, which smooths; 4.0 against 4.2 on noise-free frames): bounded, not small
+        assert np.median(np.abs(c1[..., 3][both])) < 40.0
+        assert not np.array_equal(c1.view(np.uint32), c1_ref.view(np.uint32))
+        g.set_hrbf_fit(False)
+        rgb, d, _ = synth.frame(12, W2, H2, noise=True)
+        fresh = HRBFFusion(p)
+        try:
+            g.upload_frame(rgb, d); fresh.upload_frame(rgb, d)
+            for st in ("FILTER_DEPTH", "METRICISE", "VERTEX_NORMAL_RADIUS", "CURVATURE"):
+                g.run_stage(st); fresh.run_stage(st)
+            assert np.array_equal(g.get_image("CURV1").view(np.uint32), fresh.get_image("CURV1").view(np.uint32))
+        finally:
+            fresh.close()
+    finally:
+        g.close(); ref.close()
