@@ -37,7 +37,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define FIT_MIN_CENTRES 8
 #define FIT_SENTINEL 1000.0f
 #ifndef FIT_WAVES
-#define FIT_WAVES 3                     // waves per SIMD the register budget is cut for (168 registers)
+#define FIT_WAVES 4                     // waves per SIMD the register budget is cut for (128 registers)
 #endif
 
 __device__ __forceinline__ constexpr int fit_blk(int I, int J) { return I * (I + 1) / 2 + J; }
@@ -175,16 +175,14 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
     __syncthreads();
     FIT_T(0);
 
-    // ---- assemble: lane (rr, g) computes M[rr][4g .. 4g + 3] of every block (I, J), J <= I.  Its row is component p = rr & 3 of
-    // centre 4I + (rr >> 2); its four columns are the components of centre 4J + g: with d = u_row - u_col, c0 = [p == 0] and
-    // w = onehot(p - 1), dp = w . d, the row of the sub-block is
+    // ---- assemble, LAZILY: block (I, J) is computed when the factorisation reaches block column J (below).  Lane (rr, g) computes
+    // M[rr][4g .. 4g + 3].  Its row is component p = rr & 3 of centre 4I + (rr >> 2); its four columns are the components of centre
+    // 4J + g: with d = u_row - u_col, c0 = [p == 0] and w = onehot(p - 1), dp = w . d, the row of the sub-block is
     //     [ c0 phi + F dp ,  -( (G dp + c0 F) d + w F ) ]
     // — no selects.  In the last block row the rows rr >= LC are the right-hand side (rr = LC), the gradient functionals (the same
     // sub-block rows 1..3 with u_row = 0), the six Hessian functionals and two rows of padding (c0 = 0, w = 0: zeros).
     const int rr = lane & 15, g = lane >> 4, p = rr & 3;
-    floatx4 C[NBLK];
-#pragma unroll
-    for (int I = 0; I < NBR; ++I) {
+    auto assemble = [&](const int I, const float4 ub4, const float4 nb, const bool diagonal) -> floatx4 {
         const bool tail = I == NBR - 1 && rr >= LC;                   // a row below the unknowns
         const int tr = rr - LC;                                       // tail row: 0 b, 1..3 gradient, 4..9 Hessian, 10..11 padding
         const int pp = tail ? (tr < 4 ? tr : -1) : p;                 // sub-block row this lane evaluates (-1: none)
@@ -192,54 +190,66 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
         const float w0 = pp == 1 ? 1.0f : 0.0f, w1 = pp == 2 ? 1.0f : 0.0f, w2 = pp == 3 ? 1.0f : 0.0f;
         const float4 ua4 = *reinterpret_cast<const float4 *>(s_u[4 * I + (rr >> 2)]);
         const f3 ua = tail ? mk3(0.0f, 0.0f, 0.0f) : mk3(ua4.x, ua4.y, ua4.z);
-        const bool hess = tail && tr >= 4 && tr < 10;
-        const int hm = tr - 4;                                        // xx xy xz yy yz zz
-        const int ha = hm < 3 ? 0 : hm < 5 ? 1 : 2, hb = hm < 3 ? hm : hm < 5 ? hm - 2 : 2;
-        // the diagonal entry of this row is column p of quarter rr >> 2 of block (I, I)
-        const float dg = g != (rr >> 2) ? 0.0f : tail ? (tr < 10 ? 1.0e30f : 1.0f) : ridge;   // extra rows: large pivots, so that they stay positive
-#pragma unroll
-        for (int J = 0; J <= I; ++J) {
-            const float4 ub4 = *reinterpret_cast<const float4 *>(s_u[4 * J + g]);
-            const float d0 = ua.x - ub4.x, d1 = ua.y - ub4.y, d2 = ua.z - ub4.z;
-            const float r = __builtin_amdgcn_sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
-            float phi, F, G, t;
-            fit_wendland(r, phi, F, G, t);
-            const float dp = fmaf(w2, d2, fmaf(w1, d1, w0 * d0));
-            const float c0F = c0 * F, nA = fmaf(-G, dp, -c0F);
-            floatx4 e;
-            e[0] = fmaf(F, dp, c0 * phi);
-            e[1] = fmaf(nA, d0, -(w0 * F));
-            e[2] = fmaf(nA, d1, -(w1 * F));
-            e[3] = fmaf(nA, d2, -(w2 * F));
-            if (I == NBR - 1) {
-                if (tail && tr == 0) {                                // b: the normals
-                    const float4 nb = *reinterpret_cast<const float4 *>(s_n[4 * J + g]);
-                    e[0] = 0.0f; e[1] = nb.x; e[2] = nb.y; e[3] = nb.z;
-                }
-                if (hess) {
-                    const float K = r > 0.0f ? -2240.0f * (t * t * t) * __builtin_amdgcn_rcpf(r) : 0.0f;
-                    const float da = ha == 0 ? d0 : ha == 1 ? d1 : d2, db = hb == 0 ? d0 : hb == 1 ? d1 : d2;
-                    const float dl = ha == hb ? 1.0f : 0.0f, Kab = K * da * db;
-                    e[0] = fmaf(G * da, db, F * dl);
-                    e[1] = -fmaf(Kab, d0, G * (fmaf(d0, dl, (ha == 0 ? db : 0.0f)) + (hb == 0 ? da : 0.0f)));
-                    e[2] = -fmaf(Kab, d1, G * (fmaf(d1, dl, (ha == 1 ? db : 0.0f)) + (hb == 1 ? da : 0.0f)));
-                    e[3] = -fmaf(Kab, d2, G * (fmaf(d2, dl, (ha == 2 ? db : 0.0f)) + (hb == 2 ? da : 0.0f)));
-                }
+        const float d0 = ua.x - ub4.x, d1 = ua.y - ub4.y, d2 = ua.z - ub4.z;
+        const float r = __builtin_amdgcn_sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+        float phi, F, G, t;
+        fit_wendland(r, phi, F, G, t);
+        const float dp = fmaf(w2, d2, fmaf(w1, d1, w0 * d0));
+        const float c0F = c0 * F, nA = fmaf(-G, dp, -c0F);
+        floatx4 e;
+        e[0] = fmaf(F, dp, c0 * phi);
+        e[1] = fmaf(nA, d0, -(w0 * F));
+        e[2] = fmaf(nA, d1, -(w1 * F));
+        e[3] = fmaf(nA, d2, -(w2 * F));
+        if (I == NBR - 1) {
+            if (tail && tr == 0) { e[0] = 0.0f; e[1] = nb.x; e[2] = nb.y; e[3] = nb.z; }      // b: the normals
+            if (tail && tr >= 4 && tr < 10) {
+                const int hm = tr - 4;                                // xx xy xz yy yz zz
+                const int ha = hm < 3 ? 0 : hm < 5 ? 1 : 2, hb = hm < 3 ? hm : hm < 5 ? hm - 2 : 2;
+                const float K = r > 0.0f ? -2240.0f * (t * t * t) * __builtin_amdgcn_rcpf(r) : 0.0f;
+                const float da = ha == 0 ? d0 : ha == 1 ? d1 : d2, db = hb == 0 ? d0 : hb == 1 ? d1 : d2;
+                const float dl = ha == hb ? 1.0f : 0.0f, Kab = K * da * db;
+                e[0] = fmaf(G * da, db, F * dl);
+                e[1] = -fmaf(Kab, d0, G * (fmaf(d0, dl, (ha == 0 ? db : 0.0f)) + (hb == 0 ? da : 0.0f)));
+                e[2] = -fmaf(Kab, d1, G * (fmaf(d1, dl, (ha == 1 ? db : 0.0f)) + (hb == 1 ? da : 0.0f)));
+                e[3] = -fmaf(Kab, d2, G * (fmaf(d2, dl, (ha == 2 ? db : 0.0f)) + (hb == 2 ? da : 0.0f)));
             }
-            if (I == J) {
-                e[0] += p == 0 ? dg : 0.0f; e[1] += p == 1 ? dg : 0.0f; e[2] += p == 2 ? dg : 0.0f; e[3] += p == 3 ? dg : 0.0f;
-            }
-            C[fit_blk(I, J)] = e;
         }
-    }
-    FIT_T(1);
+        if (diagonal) {   // the diagonal entry of this row is column p of quarter rr >> 2; extra rows: large pivots, so that they stay positive
+            const float dg = g != (rr >> 2) ? 0.0f : tail ? (tr < 10 ? 1.0e30f : 1.0f) : ridge;
+            e[0] += p == 0 ? dg : 0.0f; e[1] += p == 1 ? dg : 0.0f; e[2] += p == 2 ? dg : 0.0f; e[3] += p == 3 ? dg : 0.0f;
+        }
+        return e;
+    };
 
-    // ---- blocked Cholesky, right-looking over block columns, blocks in registers
+    // ---- blocked Cholesky, LEFT-looking over block columns: column kb is assembled when its turn comes, takes the products of
+    // the finished panels X(i, j) X(kb, j)^T (j < kb), is factored, and becomes the panels X(i, kb).  Live at any time: the panels
+    // of the rows still to come and one block column — at most 16 blocks = 64 registers (the right-looking order keeps all 28
+    // blocks = 112 registers alive from the first update to the last).
     float g9[9];
+    floatx4 X[NBLK];              // X[fit_blk(i, j)], i > j
 #pragma unroll
     for (int kb = 0; kb < NBR; ++kb) {
+        floatx4 Cc[NBR];
+        {
+            const float4 ub4 = *reinterpret_cast<const float4 *>(s_u[4 * kb + g]);
+            const float4 nb = *reinterpret_cast<const float4 *>(s_n[4 * kb + g]);
+#pragma unroll
+            for (int i = kb; i < NBR; ++i) Cc[i] = assemble(i, ub4, nb, i == kb);
+        }
+        FIT_T(1);
+#pragma unroll
+        for (int j = 0; j < kb; ++j) {
+            const floatx4 nx = -X[fit_blk(kb, j)];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = kb; i < NBR; ++i)
+                    Cc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(nx[s], i == kb ? -nx[s] : X[fit_blk(i, j)][s], Cc[i], 0, 0, 0);
+        }
+        FIT_T(3);
         // the diagonal block -> one row per lane
-        *reinterpret_cast<floatx4 *>(&S[rr * FIT_LD + 4 * g]) = C[fit_blk(kb, kb)];
+        *reinterpret_cast<floatx4 *>(&S[rr * FIT_LD + 4 * g]) = Cc[kb];
         __syncthreads();
         float row[FIT_B];
         if (g == 0) {
@@ -271,22 +281,13 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
         for (int r = 0; r < 4; ++r) li[r] = S[(4 * g + r) * FIT_LD + rr];
         __syncthreads();
         FIT_T(2);
-        // panel: X(i) = C(i, kb) L^-T, in place
-        floatx4 X[NBR];
+        // panels: X(i, kb) = C(i, kb) L^-T
 #pragma unroll
-        for (int i = kb + 1; i < NBR; ++i) X[i] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = kb + 1; i < NBR; ++i) X[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(li[s], C[fit_blk(i, kb)][s], X[i], 0, 0, 0);
-        // trailing updates: C(i, j) -= X(i) X(j)^T
+        for (int i = kb + 1; i < NBR; ++i) X[fit_blk(i, kb)] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = kb + 1; i < NBR; ++i)
-#pragma unroll
-                for (int j = kb + 1; j <= i; ++j)
-                    C[fit_blk(i, j)] = __builtin_amdgcn_mfma_f32_16x16x4f32(-X[j][s], X[i][s], C[fit_blk(i, j)], 0, 0, 0);
+            for (int i = kb + 1; i < NBR; ++i) X[fit_blk(i, kb)] = __builtin_amdgcn_mfma_f32_16x16x4f32(li[s], Cc[i][s], X[fit_blk(i, kb)], 0, 0, 0);
         FIT_T(3);
     }
 

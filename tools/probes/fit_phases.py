@@ -25,7 +25,7 @@ lib.hrbf_probe_fit_phases(buf.ctypes.data_as(C.c_void_p), 0)
 fitted = g.get_image("FIT_CURV1")[..., 3].ravel() != 1000.0
 n = int(fitted.sum())
 out = buf[fitted].astype(np.float64).sum(0)
-names = ["gather + zero", "assemble", "column sweeps + panel products (7 block columns)", "trailing updates on the matrix core (7)", "(unused)", "read-out"]
+names = ["gather", "assemble (registers)", "diagonal block: LDS round trip + column sweep (7)", "panel solves + trailing updates on the matrix core (6)", "read-out", "(unused)"]
 tot = sum(out[i] for i in range(6))
 print("%.2f ms, %d systems; cycles per wave (s_memtime ticks = 100 MHz on gfx9: x core/100MHz):" % (ms, n))
 for i, nm in enumerate(names):
