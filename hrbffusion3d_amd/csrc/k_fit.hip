@@ -55,40 +55,44 @@ __device__ __forceinline__ void fit_wendland(float r, float &phi, float &F, floa
     G = 560.0f * t4;
 }
 
-// Columns 0..NCOL-1 of the diagonal block and of the identity block beside it: a lane owns one ROW (16 registers); lanes 0..15
-// hold the rows of the diagonal block, lanes 16..31 the rows of an identity.  Column j of every row is the same recurrence
-// s = a_ij - sum_{t<j} l_it l_jt, so the identity rows come out as W = L^-T beside the factor.  Four columns advance together: the
-// factor's finished columns stand in LDS (T[t][i] = l_it) and l_{j0..j0+3, t} arrives as ONE broadcast 16-byte read per t (the
-// first version took every l_jt through v_readlane_b32 + an SGPR: 844 broadcasts and as many hazard nops per system); inside the
-// group of four the six l_jt come by v_readlane_b32.  v_rsq_f32 (1 ulp) instead of the IEEE sqrt + division: this operator is held
-// to a tolerance against a float64 statement, not to bits.
+// Columns 0..NCOL-1 of the diagonal block and of the identity block beside it: a lane owns one ROW (16 registers, as eight
+// pairs); lanes 0..15 hold the rows of the diagonal block, lanes 16..31 the rows of an identity (lanes 32..63 repeat lanes 0..31).
+// Column j of every row is the same recurrence s = a_ij - sum_{t<j} l_it l_jt, so the identity rows come out as W = L^-T beside
+// the factor.  Four columns advance together: the factor's finished rows stand in LDS (Tr[j][t] = l_jt, written 16 bytes at a
+// time) and l_{j, t..t+3} arrives as ONE broadcast 16-byte read; the sum runs over PAIRS of t on v_pk_fma_f32 — (row[t], row[t+1])
+// and (l_jt, l_jt+1) are natural register pairs, the two partial sums are added at the end.  (The first version took every l_jt
+// through v_readlane_b32 + an SGPR: 844 broadcasts and as many hazard nops per system.)  Inside the group of four the six l_jt
+// come by v_readlane_b32.  v_rsq_f32 (1 ulp) instead of the IEEE sqrt + division: this operator is held to a tolerance against a
+// float64 statement, not to bits.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 template <int NCOL>
-__device__ __forceinline__ void fit_columns(float (&row)[FIT_B], int lane, float *T)
+__device__ __forceinline__ void fit_columns(floatx2 (&row)[FIT_B / 2], int lane, float *Tr)
 {
 #pragma unroll
     for (int j0 = 0; j0 < NCOL; j0 += 4) {
-        float s[4] = {row[j0], row[j0 + 1], row[j0 + 2], row[j0 + 3]};
+        floatx2 acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-        for (int t = 0; t < j0; ++t) {
-            const floatx4 l = *reinterpret_cast<const floatx4 *>(&T[t * FIT_B + j0]);
+        for (int t = 0; t < j0; t += 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (j0 + q < NCOL) s[q] = fmaf(-row[t], l[q], s[q]);
+            for (int q = 0; q < 4; ++q) {
+                if (j0 + q >= NCOL) break;
+                const floatx4 l = *reinterpret_cast<const floatx4 *>(&Tr[(j0 + q) * FIT_B + t]);
+                acc[q] = __builtin_elementwise_fma(row[t / 2], floatx2{l[0], l[1]}, acc[q]);
+                acc[q] = __builtin_elementwise_fma(row[t / 2 + 1], floatx2{l[2], l[3]}, acc[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (j0 + q >= NCOL) break;
             const int j = j0 + q;
+            float s = row[j / 2][j & 1] - (acc[q][0] + acc[q][1]);
 #pragma unroll
-            for (int t = j0; t < j; ++t) s[q] = fmaf(-row[t], fit_readlane(row[t], j), s[q]);
-            row[j] = s[q] * __builtin_amdgcn_rsqf(fit_readlane(s[q], j));     // lane j: pivot / sqrt(pivot) = l_jj; the rows above
+            for (int t = j0; t < j; ++t) s = fmaf(-row[t / 2][t & 1], fit_readlane(row[t / 2][t & 1], j), s);
+            row[j / 2][j & 1] = s * __builtin_amdgcn_rsqf(fit_readlane(s, j));     // lane j: pivot / sqrt(pivot) = l_jj; the rows above
             // the diagonal (lanes < j) take a value nobody reads: their later columns are above the diagonal too
         }
         if (j0 + 4 < NCOL) {
-            if (lane < FIT_B) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) T[(j0 + q) * FIT_B + lane] = row[j0 + q];
-            }
+            if (lane < FIT_B) *reinterpret_cast<floatx4 *>(&Tr[lane * FIT_B + j0]) = floatx4{row[j0 / 2][0], row[j0 / 2][1], row[j0 / 2 + 1][0], row[j0 / 2 + 1][1]};
             __syncthreads();
         }
     }
@@ -123,8 +127,8 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
     constexpr int LC = RB - FIT_B * (NBR - 1);            // local row / column of the b row in the last block row (= 4)
     __shared__ __attribute__((aligned(16))) float s_u[4 * NBR][4];      // centre: u.xyz; slots >= k hold zeros
     __shared__ __attribute__((aligned(16))) float s_n[4 * NBR][4];      // its normal
-    __shared__ __attribute__((aligned(16))) float S[FIT_B * FIT_LD];    // the diagonal block on its way to / from the row sweep
-    __shared__ __attribute__((aligned(16))) float T[FIT_B * FIT_B];     // the factor's finished columns, T[t][i] = l_it
+    __shared__ __attribute__((aligned(16))) float S[2 * FIT_B * FIT_LD];    // rows 0..15: the diagonal block on its way to / from the row sweep; rows 16..31: an identity
+    __shared__ __attribute__((aligned(16))) float T[FIT_B * FIT_B];         // the factor's finished rows, T[j][t] = l_jt
     const int lane = threadIdx.x, pi = blockIdx.x;
     const int W = cam.W, H = cam.H;
     const int px = pi % W, py = pi / W;
@@ -166,6 +170,11 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
     if (ok) {
         *reinterpret_cast<float4 *>(s_u[slot]) = make_float4(dx / rho, dy / rho, dz / rho, 0.0f);
         *reinterpret_cast<float4 *>(s_n[slot]) = make_float4(nn.x, nn.y, nn.z, 0.0f);
+    }
+    if (lane < FIT_B) {
+#pragma unroll
+        for (int c = 0; c < FIT_B; c += 4)
+            *reinterpret_cast<floatx4 *>(&S[(FIT_B + lane) * FIT_LD + c]) = floatx4{c == lane ? 1.0f : 0.0f, c + 1 == lane ? 1.0f : 0.0f, c + 2 == lane ? 1.0f : 0.0f, c + 3 == lane ? 1.0f : 0.0f};
     }
     if (lane >= k && lane < 4 * NBR) {   // padding: centres far from everything (and from each other) with no normal — their
         // sub-blocks with every other centre vanish (compact support), their own is diag(1, 56/3, 56/3, 56/3): an inert tail
@@ -251,29 +260,24 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
         // the diagonal block -> one row per lane
         *reinterpret_cast<floatx4 *>(&S[rr * FIT_LD + 4 * g]) = Cc[kb];
         __syncthreads();
-        float row[FIT_B];
-        if (g == 0) {
+        floatx2 row[FIT_B / 2];
 #pragma unroll
-            for (int c = 0; c < FIT_B; c += 4) {
-                const floatx4 t = *reinterpret_cast<const floatx4 *>(&S[rr * FIT_LD + c]);
-                row[c] = t[0]; row[c + 1] = t[1]; row[c + 2] = t[2]; row[c + 3] = t[3];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < FIT_B; ++c) row[c] = c == rr ? 1.0f : 0.0f;
+        for (int c = 0; c < FIT_B; c += 4) {
+            const floatx4 t = *reinterpret_cast<const floatx4 *>(&S[(lane & 31) * FIT_LD + c]);
+            row[c / 2] = floatx2{t[0], t[1]}; row[c / 2 + 1] = floatx2{t[2], t[3]};
         }
         __syncthreads();
         if (kb == NBR - 1) {      // the last block: columns 0 .. LC are all that is read
             fit_columns<LC + 1>(row, lane, T);
-            const float piv = fit_readlane(row[LC], LC);
+            const float piv = fit_readlane(row[LC / 2][LC & 1], LC);
 #pragma unroll
-            for (int m = 0; m < 9; ++m) g9[m] = -fit_readlane(row[LC], LC + 1 + m) * piv;
+            for (int m = 0; m < 9; ++m) g9[m] = -fit_readlane(row[LC / 2][LC & 1], LC + 1 + m) * piv;
             break;
         }
         fit_columns<FIT_B>(row, lane, T);
         if (g == 1) {
 #pragma unroll
-            for (int c = 0; c < FIT_B; c += 4) *reinterpret_cast<floatx4 *>(&S[rr * FIT_LD + c]) = floatx4{row[c], row[c + 1], row[c + 2], row[c + 3]};
+            for (int c = 0; c < FIT_B; c += 4) *reinterpret_cast<floatx4 *>(&S[rr * FIT_LD + c]) = floatx4{row[c / 2][0], row[c / 2][1], row[c / 2 + 1][0], row[c / 2 + 1][1]};
         }
         __syncthreads();
         floatx4 li;               // L(kb, kb)^-1 in the block layout: Linv[rr][4g + r] = W[4g + r][rr]
@@ -295,26 +299,28 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
     FIT_T(4);
     if (lane != 0) return;
     const float *gq = g9, *h = g9 + 3;
-    const float gn = sqrtf((gq[0] * gq[0] + gq[1] * gq[1]) + gq[2] * gq[2]);
-    if (!(gn > 0.0f) || !isfinite(gn)) {
+    const float g2 = (gq[0] * gq[0] + gq[1] * gq[1]) + gq[2] * gq[2];
+    const float ign = __builtin_amdgcn_rsqf(g2), gn = g2 * ign;
+    if (!(g2 > 0.0f) || !isfinite(gn)) {
         out_c1[pi] = make_float4(0, 0, 0, FIT_SENTINEL); out_c2[pi] = make_float4(0, 0, 0, FIT_SENTINEL); out_n[pi] = make_float4(0, 0, 0, 0);
         return;
     }
-    const f3 n = mk3(gq[0] / gn, gq[1] / gn, gq[2] / gn);
+    const f3 n = mk3(gq[0] * ign, gq[1] * ign, gq[2] * ign);
     const f3 ax = fabsf(n.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0);
-    const f3 t1 = normalize3(cross3(n, ax)), t2 = cross3(n, t1);
-    const float sc = 1.0f / (rho * gn);       // H_x = H_u / rho; shape operator = tangential H_x / |grad|
+    const f3 c1 = cross3(n, ax);
+    const f3 t1 = scale3(c1, __builtin_amdgcn_rsqf(dot3(c1, c1))), t2 = cross3(n, t1);
+    const float sc = __builtin_amdgcn_rcpf(rho * gn);       // H_x = H_u / rho; shape operator = tangential H_x / |grad|
     auto Hv = [&](f3 x) { return mk3((h[0] * x.x + h[1] * x.y) + h[2] * x.z, (h[1] * x.x + h[3] * x.y) + h[4] * x.z, (h[2] * x.x + h[4] * x.y) + h[5] * x.z); };
     const f3 H1 = Hv(t1), H2 = Hv(t2);
     const float m00 = dot3(t1, H1) * sc, m01 = dot3(t1, H2) * sc, m11 = dot3(t2, H2) * sc;
-    const float mean = 0.5f * (m00 + m11), diff = 0.5f * (m00 - m11), rad = sqrtf(diff * diff + m01 * m01);
+    const float mean = 0.5f * (m00 + m11), diff = 0.5f * (m00 - m11), rad = __builtin_amdgcn_sqrtf(diff * diff + m01 * m01);
     const float kmax = mean + rad, kmin = mean - rad;
     float vx, vy;       // eigenvector of kmax in the (t1, t2) basis
     if (fabsf(m01) > 1.0e-12f * (fabsf(m00) + fabsf(m11) + 1.0e-30f)) { vx = m01; vy = kmax - m00; }
     else if (diff >= 0.0f) { vx = 1.0f; vy = 0.0f; }
     else { vx = 0.0f; vy = 1.0f; }
-    const float vl = sqrtf(vx * vx + vy * vy);
-    vx /= vl; vy /= vl;
+    const float ivl = __builtin_amdgcn_rsqf(vx * vx + vy * vy);
+    vx *= ivl; vy *= ivl;
     const f3 dmax = add3(scale3(t1, vx), scale3(t2, vy)), dmin = add3(scale3(t1, -vy), scale3(t2, vx));
     out_c1[pi] = make_float4(dmax.x, dmax.y, dmax.z, kmax);
     out_c2[pi] = make_float4(dmin.x, dmin.y, dmin.z, kmin);
