@@ -796,16 +796,18 @@ def main():
             ms_fit = float(np.mean(ts))
             n_sys = 100                      # 25 centres x 4 unknowns (+ the right-hand-side row; padded to 7 x 7 blocks of 16)
             flops_alg = fitted * (n_sys ** 3 / 3.0 + 2.0 * n_sys ** 2)      # Cholesky + two triangular solves of the 100 x 100 system
-            flops_mfma = fitted * 56 * 2.0 * 16 ** 3                        # what the matrix core executes: 56 block products of 16 x 16 x 16
-            fit = {"what": "EXTENSION, no reference counterpart: Hermite-RBF fit (5x5 window, 100x100 SPD system per pixel, blocked Cholesky, "
-                           "trailing updates on v_mfma_f32_16x16x4_f32) over the %dx%d live frame; never part of processFrame or of `value`" % (W, H),
+            flops_mfma = fitted * 77 * 2.0 * 16 ** 3                        # what the matrix core executes: 56 update + 21 panel products of 16 x 16 x 16
+            fit = {"what": "EXTENSION, no reference counterpart: Hermite-RBF fit (5x5 window, 100x100 SPD system per pixel, blocked left-looking Cholesky "
+                           "with the whole system in registers, panel solves and trailing updates on v_mfma_f32_16x16x4_f32) over the %dx%d live frame; "
+                           "never part of `value`" % (W, H),
                    "ms_per_call": ms_fit, "pixels_fitted": fitted, "systems_per_s": fitted / (ms_fit * 1e-3),
                    "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": flops_alg / (ms_fit * 1e-3) / 1e12,
                                 "frac": flops_alg / (ms_fit * 1e-3) / 1e12 / 157.3,
                                 "achieved_executed_mfma": flops_mfma / (ms_fit * 1e-3) / 1e12,
-                                "note": "f32-input MFMA peak (= the f32 vector peak); `achieved` counts the algorithm's flops (n^3/3 + 2n^2, n = 100), "
-                                        "`achieved_executed_mfma` the padded 16-blocks the matrix core really multiplies; the kernel is bound by the "
-                                        "sequential column recurrences of the factorisation (one wave per system), not by the matrix core"}}
+                                "note": "f32-input MFMA peak at 2.4 GHz (= the packed-f32 vector peak); `achieved` counts the algorithm's flops (n^3/3 + 2n^2, "
+                                        "n = 100), `achieved_executed_mfma` the padded 16-blocks the matrix core really multiplies. On this part f32 MFMA "
+                                        "and VALU instructions do not overlap (tools/probes/mfma_valu_overlap.hip: their times add) and the matrix core "
+                                        "runs at ~1.8 GHz under this load: the kernel is its 308 MFMAs (1.7 ms) plus its vector work (1.1 ms)"}}
         except Exception as e:
             fit = {"error": repr(e)}
 

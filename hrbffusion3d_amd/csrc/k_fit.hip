@@ -30,6 +30,11 @@
 #include "kernels.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+#ifdef FIT_NO_MFMA   // measurement only (wrong results): what the kernel costs without its matrix-core instructions
+#define FIT_MFMA(a, b, c) (c)
+#else
+#define FIT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
 
 #define FIT_B 16                        // block edge (v_mfma_f32_16x16x4_f32)
 #define FIT_LD 20                       // floats per row of the diagonal block's LDS tile (16-byte aligned rows, conflict-free transposed reads)
@@ -254,7 +259,7 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = kb; i < NBR; ++i)
-                    Cc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(nx[s], i == kb ? -nx[s] : X[fit_blk(i, j)][s], Cc[i], 0, 0, 0);
+                    Cc[i] = FIT_MFMA(nx[s], i == kb ? -nx[s] : X[fit_blk(i, j)][s], Cc[i]);
         }
         FIT_T(3);
         // the diagonal block -> one row per lane
@@ -291,7 +296,7 @@ void k_hrbf_fit(Cam cam, const float4 *__restrict__ vertex, const float4 *__rest
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = kb + 1; i < NBR; ++i) X[fit_blk(i, kb)] = __builtin_amdgcn_mfma_f32_16x16x4f32(li[s], Cc[i][s], X[fit_blk(i, kb)], 0, 0, 0);
+            for (int i = kb + 1; i < NBR; ++i) X[fit_blk(i, kb)] = FIT_MFMA(li[s], Cc[i][s], X[fit_blk(i, kb)]);
         FIT_T(3);
     }
 
