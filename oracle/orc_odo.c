@@ -157,7 +157,11 @@ static void pyrdown_gauss_f(const float *src, int srows, int scols, float *dst)
                         count += (int)g;
                     }
                 }
+#if ORC_MUTANT == 20     /* the depth pyramid by plain subsampling instead of the NaN-aware 5 x 5 binomial */
+            dst[y * dcols + x] = src[(2 * y) * scols + 2 * x];
+#else
             dst[y * dcols + x] = sum / (float)count;
+#endif
         }
 }
 /* pyrDownKernelIntensityGauss :818-848 */
@@ -184,16 +188,27 @@ static void pyrdown_gauss_u8(const uint8_t *src, int srows, int scols, uint8_t *
 /* bgr2IntensityKernel :896-911 — channel x = R as uploaded (HRBFFusion.cpp:1010) */
 static inline uint8_t intensity(int r, int g, int b)
 {
+#if ORC_MUTANT == 25     /* a different but CONSISTENT image: the textbook luma 0.299 R + 0.587 G + 0.114 B */
+    float v = (float)r * 0.299f;
+    v = v + (float)g * 0.587f;
+    v = v + (float)b * 0.114f;
+#else
     float v = (float)r * 0.114f;
     v = v + (float)g * 0.299f;
     v = v + (float)b * 0.587f;
+#endif
     return (uint8_t)(int)v;
 }
 /* applyKernel (Sobel) :927-954 incl. the running kernelIndex quirk at borders */
 static void sobel(const uint8_t *src, int rows, int cols, int16_t *dx, int16_t *dy)
 {
+#if ORC_MUTANT == 26     /* the two Sobel kernels swapped: dIdx holds the vertical derivative */
+    static const float gy[9] = {1, 0, -1, 2, 0, -2, 1, 0, -1};
+    static const float gx[9] = {1, 2, 1, 0, 0, 0, -1, -2, -1};
+#else
     static const float gx[9] = {1, 0, -1, 2, 0, -2, 1, 0, -1};
     static const float gy[9] = {1, 2, 1, 0, 0, 0, -1, -2, -1};
+#endif
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
             float dxv = 0.0f, dyv = 0.0f;
@@ -369,11 +384,19 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
     float ck1 = PL(*k1c, 3, y, x), ck2 = PL(*k2c, 3, y, x);
     if (hd_isnanf(vcur.x) || hd_isnanf(ncur.x) || hd_isnanf(ck1) || hd_isnanf(ck2)) return;
     f3 vg_ = add3(m33_mul(Rcurr, vcur), tcurr);
+#if ORC_MUTANT == 15     /* the live vertex projected as if the previous camera stood at the origin of the tracker's frame */
+    f3 vcp = vg_;
+#else
     f3 vcp = m33_mul(Rpi, sub3(vg_, tprev));
+#endif
     float fu = vcp.x * fx / vcp.z + cx, fv = vcp.y * fy / vcp.z + cy;
     if (hd_isnanf(fu) || hd_isnanf(fv)) return;
     if (!(fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f)) return;
+#if ORC_MUTANT == 14     /* the associated texel by truncation instead of __float2int_rn */
+    int ux = (int)fu, uy = (int)fv;
+#else
     int ux = (int)rintf(fu), uy = (int)rintf(fv);
+#endif
     if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcp.z < 0.0f) return;
     f3 ncur_g = m33_mul(Rcurr, ncur);
     const int R = use_search ? radius : 0;
@@ -441,7 +464,11 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
        uninitialised locals and icpWeight[-1][-1]; the products are all zero here (bv = bn = 0), the weight is defined 0 */
     if (use_weight) { float w = bx < 0 ? 0.0f : icpw[by * cols + bx]; weight = hd_isnanf(w) ? 0.0f : w; }
     float row[7];
+#if ORC_MUTANT == 13     /* the rotational columns of the ICP row as n x s instead of s x n */
+    f3 cr = cross3(n_cp, s_cp);
+#else
     f3 cr = cross3(s_cp, n_cp);
+#endif
     row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z; row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
 #if ORC_MUTANT == 2      /* residual n . (d - s) instead of n . (s - d) */
     row[6] = dot3(n_cp, sub3(d_cp, s_cp));
@@ -610,7 +637,11 @@ static void rgb_residual_core(int rows, int cols, const int16_t *dIdx, const int
 #endif
             if (!(u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows)) continue;
             float d0 = lastDepth[v0 * cols + u0];
+#if ORC_MUTANT == 16     /* the depth gate on the live pixel's own depth instead of its depth in the model camera */
+            if (d0 > 0.0f && fabsf(d1 - d0) <= maxDepthDelta && lastImage[v0 * cols + u0] != 0) {
+#else
             if (d0 > 0.0f && fabsf(td1 - d0) <= maxDepthDelta && lastImage[v0 * cols + u0] != 0) {
+#endif
                 float diff = (float)nextImage[y * cols + x] - (float)lastImage[v0 * cols + u0];
                 co[0] = (int16_t)u0; co[1] = (int16_t)v0; co[2] = (int16_t)x; co[3] = (int16_t)y; co[4] = 1;
                 corres_diff[k] = diff;
@@ -647,7 +678,11 @@ static void rgb_step_core(int rows, int cols, const int16_t *corres, const float
             const int16_t *co = &corres[(size_t)k * 6];
             if (!co[4]) continue;
             float diff = corres_diff[k];
+#if ORC_MUTANT == 19     /* the photometric weight 1 / sigma: no down-weighting of large residuals */
+            float w = sigma;
+#else
             float w = sigma + fabsf(diff);
+#endif
             w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
             if (sigma == -1.0f) w = 1.0f;
             float row[7];
@@ -662,7 +697,11 @@ static void rgb_step_core(int rows, int cols, const int16_t *corres, const float
             float dIy = w * sobelScale * (float)dIdyl[co[3] * cols + co[2]];
 #endif
             float v0 = dIx * fx * invz, v1 = dIy * fy * invz;
+#if ORC_MUTANT == 18     /* the depth column of the photometric row without its second division by z */
+            float v2 = -(v0 * cp.x + v1 * cp.y);
+#else
             float v2 = -(v0 * cp.x + v1 * cp.y) * invz;
+#endif
             row[0] = v0; row[1] = v1; row[2] = v2;
 #if ORC_MUTANT == 3      /* the rotational columns of the photometric row with the cross product the other way round */
             row[3] = cp.z * v1 - cp.y * v2;
@@ -851,7 +890,12 @@ void orc_odo_track(orc_ctx *c)
         double lastResultR[9]; memcpy(lastResultR, resultR, sizeof(resultR));
         for (int it = 0; it < 10; ++it) {
             double KR[9], Hm[9];
+#if ORC_MUTANT == 24     /* the SO3 homography with the rotation transposed: K R^T K^-1 */
+            { double Rtr[9]; for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Rtr[r * 3 + k] = resultR[k * 3 + r]; mul3d(K, Rtr, KR); }
+            mul3d(KR, Kinv, Hm);
+#else
             mul3d(K, resultR, KR); mul3d(KR, Kinv, Hm);
+#endif
             float basis[9], kinvf[9], krlr[9];
             for (int k = 0; k < 9; ++k) { basis[k] = (float)Hm[k]; kinvf[k] = (float)Kinv[k]; krlr[k] = (float)KR[k]; }
             double s[11];
@@ -891,6 +935,9 @@ void orc_odo_track(orc_ctx *c)
     iterations[0] = c->prm.fast_odom ? 3 : 10;
     iterations[1] = c->prm.pyramid ? 5 : 0;
     iterations[2] = c->prm.pyramid ? 4 : 0;
+#if ORC_MUTANT == 21     /* the schedule 10 / 5 / 4 given to the levels the other way round (most iterations on the coarsest) */
+    if (c->prm.pyramid) { iterations[0] = 4; iterations[2] = c->prm.fast_odom ? 3 : 10; }
+#endif
 
     float Rprev_inv[9];
     {   /* Eigen 3x3 float inverse -> cofactor inverse */
@@ -936,6 +983,9 @@ void orc_odo_track(orc_ctx *c)
             inv3d(L, Li);
             for (int r = 0; r < 3; ++r)
                 ti[r] = -((Li[r * 3] * Rt[3] + Li[r * 3 + 1] * Rt[7]) + Li[r * 3 + 2] * Rt[11]);
+#if ORC_MUTANT == 17     /* the photometric warp built from resultRt itself instead of its inverse (RGBDOdometry.cpp:981) */
+            memcpy(Li, L, sizeof(L)); ti[0] = Rt[3]; ti[1] = Rt[7]; ti[2] = Rt[11];
+#endif
             double KR[9], KRK[9];
             mul3d(K, Li, KR); mul3d(KR, Kinv, KRK);
             float krk[9]; for (int k = 0; k < 9; ++k) krk[k] = (float)KRK[k];
@@ -945,7 +995,11 @@ void orc_odo_track(orc_ctx *c)
 
             int64_t sigma = 0, rgbSize = 0, sigma_unwrapped = 0;
             if (rgb) {
+#if ORC_MUTANT == 23     /* the gradient threshold compared unsquared with the squared magnitude */
+                float minScale = (float)((double)minGrad[i] / sobelScale);
+#else
                 float minScale = (float)(((double)minGrad[i] * (double)minGrad[i]) / (sobelScale * sobelScale));
+#endif
                 rgb_residual(c, i, minScale, krk, kt, &rgbSize, &sigma);
                 /* `int sigma` (RGBDOdometry.cpp:994) summed in int2 on the device (reduce.cu:985-1046): wraps beyond 2^31 */
                 sigma_unwrapped = sigma;
@@ -1017,7 +1071,11 @@ void orc_odo_track(orc_ctx *c)
             for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) U[r * 4 + k] = Ru[r * 3 + k]; U[r * 4 + 3] = result[r]; }
             U[12] = U[13] = U[14] = 0; U[15] = 1;
             for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k)
+#if ORC_MUTANT == 22     /* the increment composed on the right: resultRt * update instead of update * resultRt (OdometryProvider.h:91) */
+                N[r * 4 + k] = ((Rt[r * 4] * U[k] + Rt[r * 4 + 1] * U[4 + k]) + Rt[r * 4 + 2] * U[8 + k]) + Rt[r * 4 + 3] * U[12 + k];
+#else
                 N[r * 4 + k] = ((U[r * 4] * Rt[k] + U[r * 4 + 1] * Rt[4 + k]) + U[r * 4 + 2] * Rt[8 + k]) + U[r * 4 + 3] * Rt[12 + k];
+#endif
             memcpy(Rt, N, sizeof(N));
             float oR[9], ot[3];
             for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) oR[r * 3 + k] = (float)Rt[r * 4 + k]; ot[r] = (float)Rt[r * 4 + 3]; }

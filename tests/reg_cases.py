@@ -34,14 +34,17 @@ def make_engine(kind, p):
     return HRBFFusion(p)       # raises without the HIP library / a gfx950 device: there is no fallback
 
 
-def two_frames(kind, W, H, TA, TB, scene=rs.ROOM, wavelength=None, units=5000.0, T0=None, trace=False, **params):
+def two_frames(kind, W, H, TA, TB, scene=rs.ROOM, wavelength=None, units=5000.0, T0=None, trace=False, contrast=1.0, edit_b=None, **params):
     """frame A seeds an empty map (pose T0 or identity), frame B is registered against it.
+    `edit_b(rgb, depth) -> (rgb, depth)` changes frame B before it is handed over (holes, ...).
     -> dict(E: estimated pose of B, G: true relative pose, z: depth of B, K, trace, bits: raw pose)"""
     K = intrinsics(W, H)
     p = default_params(W, H, *K, max_surfels=1 << 20, **params)
     wl = wavelength if wavelength is not None else 160.0 / W      # 7-13 cm at 640x480: 20-35 px at level 0, 5-9 px at level 2
-    a = rs.render(TA, W, H, K, scene, units=units, wavelength=wl)
-    b = rs.render(TB, W, H, K, scene, units=units, wavelength=wl)
+    a = rs.render(TA, W, H, K, scene, units=units, wavelength=wl, contrast=contrast)
+    b = rs.render(TB, W, H, K, scene, units=units, wavelength=wl, contrast=contrast)
+    if edit_b is not None:
+        b = edit_b(b[0], b[1]) + tuple(b[2:])
     e = make_engine(kind, p)
     try:
         if T0 is not None:
@@ -52,7 +55,7 @@ def two_frames(kind, W, H, TA, TB, scene=rs.ROOM, wavelength=None, units=5000.0,
         tr = e.odo_trace() if (trace and kind == "oracle") else None
     finally:
         e.close()
-    return {"E": P.astype(np.float64), "G": np.linalg.inv(TA) @ TB, "z": b[2], "K": K, "trace": tr,
+    return {"E": P.astype(np.float64), "G": np.linalg.inv(TA) @ TB, "z": b[2], "za": a[2], "K": K, "trace": tr,
             "bits": np.ascontiguousarray(P, np.float32).view(np.uint32).copy()}
 
 

@@ -22,6 +22,15 @@ code states, written down before looking at any output of the oracle, on analyti
  (vii) ICP term alone on the three-wall corner recovers the motion to a fraction of the photometric bound.
  (viii) the residual's sum of squares is a 32-bit int that wraps, like the reference's.
  (ix)  time reversal and photometric / joint agreement on the reference's own GPUTest frames (the only real data there is).
+ (x)   a frame registered against itself does not move (nearest-texel association and look-up: every pixel meets itself).
+ (xi)  the photometric depth gate (0.07 m, reduce.cu:1033) compares the pixel's depth IN THE MODEL CAMERA with the model's depth: after
+       an 8.5 cm move along the optical axis the gate is shut at the start and opens as the estimate approaches the motion.
+ (xii) the depth pyramid is NaN-aware (cudafuncs.cu:493-524 counts valid taps only): a live frame with a hole at every even pixel still
+       has photometric correspondences on levels 1 and 2.
+ (xiii) the loop itself, read from the trace: 4 / 5 / 10 iterations on levels 2 / 1 / 0 (RGBDOdometry.cpp:897-903) and every increment
+       acts on the LEFT of the running transform, with the raw translation (OdometryProvider.h:73-93).
+ (xiv) a texture whose analytic gradient stays below minimumGradientMagnitudes[0] = 5 grey levels per pixel contributes nothing on level 0.
+ (xv)  the photometric weight depends on sigma + |diff| only (reduce.cu:733-735): two residual images with the same sum give the same matrix.
 
 GPU twins (-m gpu): the HIP library on the same frames meets the same bounds and returns the oracle's pose bit for bit.
 DESIGN.md §8 ("The drift ...") rests on (i): the photometric term works to its half-pixel bound, and no better."""
@@ -164,6 +173,114 @@ def test_icp_term_alone_recovers_the_motion_in_the_corner(oracle_lib_built):
     assert np.linalg.norm(e[:3, 3]) < 1.0e-3 and rs.rot_angle_deg(e[:3, :3]) < 0.05
 
 
+# ------------------------------------------------------------------------------------------------------------------ (x)
+@pytest.mark.parametrize("mode", [dict(), dict(icp_weight=100.0), dict(rgb_only=1)], ids=["joint", "icp_only", "rgb_only"])
+def test_a_frame_registered_against_itself_does_not_move(oracle_lib_built, mode):
+    scene, TA = rc.VIEWS["room"]
+    r = rc.two_frames("oracle", *QVGA, TA, TA, scene=scene, so3=0, **mode)
+    # the model is the prediction from the one-frame map (fused, ray cast), not the frame itself: "does not move" is to a hundredth
+    # of a pixel, not to the last bit
+    assert rs.reprojection_px(r["E"], np.eye(4), r["z"], r["K"]) < 0.02
+    assert np.linalg.norm(r["E"][:3, 3]) < 2.0e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xi)
+def test_the_photometric_depth_gate_is_on_the_depth_in_the_model_camera(oracle_lib_built):
+    TA = rs.pose(-0.15, 0.25, 0.0)              # the far wall nearly frontal (a move along the axis changes its depth by the move), two more walls at the rim
+    r = rc.two_frames("oracle", *VGA, TA, TA @ rs.pose(t=(0.0, 0.0, 0.085)), scene=rs.ROOM, trace=True, so3=0)
+    # the premise, from the analytic frames alone: at the same pixel the two depth images differ by more than the gate nearly everywhere
+    both = (r["z"] > 0) & (r["za"] > 0)
+    assert (np.abs(r["z"] - r["za"])[both] > 0.07).mean() > 0.75
+    rows = [t for t in r["trace"] if int(t[0]) >= 0]
+    first, last = rows[0], rows[-1]
+    assert int(first[0]) == 2 and int(last[0]) == 0
+    # shut at the start (the estimate is the previous pose: the depth in the model camera is the pixel's own depth) ...
+    assert first[93] < 0.25 * (VGA[0] // 4) * (VGA[1] // 4), first[93]
+    # ... open at the end: the estimate carries the pixel into the model camera, where its depth agrees with the model's
+    assert last[93] > 100000, last[93]
+    assert rs.reprojection_px(r["E"], r["G"], r["z"], r["K"]) <= 0.5
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xii)
+def test_the_depth_pyramid_averages_over_the_valid_taps_only(oracle_lib_built):
+    scene, TA = rc.VIEWS["room"]
+
+    def holes(rgb, depth):
+        d = depth.copy(); d[0::2, 0::2] = 0          # every texel plain subsampling would pick
+        return rgb, d
+    r = rc.two_frames("oracle", *VGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, trace=True, rgb_only=1, so3=0, edit_b=holes)
+    for lvl in (2, 1):
+        n = [t[93] for t in _level_rows(r["trace"], lvl)]
+        assert len(n) > 0 and min(n) > 0.25 * (VGA[0] >> lvl) * (VGA[1] >> lvl), (lvl, n)
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xiii)
+def test_the_loop_runs_4_5_10_iterations_and_every_increment_acts_on_the_left(oracle_lib_built):
+    from scipy.spatial.transform import Rotation
+    scene, TA = rc.VIEWS["room"]
+    r = rc.two_frames("oracle", *QVGA, TA, TA @ rs.pose(0.02, -0.03, 0.01, (0.02, -0.015, 0.01)), scene=scene, trace=True, so3=0)
+    rows = [t for t in r["trace"] if int(t[0]) >= 0]
+    assert [int(t[0]) for t in rows] == [2] * 4 + [1] * 5 + [0] * 10
+    worst_left = worst_right = 0.0
+    for a, b in zip(rows[:-1], rows[1:]):
+        Rt0, Rt1 = a[96:112].reshape(4, 4), b[96:112].reshape(4, 4)
+        U = np.eye(4)
+        U[:3, :3] = Rotation.from_rotvec(a[89:92]).as_matrix()
+        U[:3, 3] = a[86:89]                                       # the raw translation: no V(omega) in computeUpdateSE3
+        worst_left = max(worst_left, np.abs(U @ Rt0 - Rt1).max())
+        worst_right = max(worst_right, np.abs(Rt0 @ U - Rt1).max())
+    assert worst_left < 1.0e-9, worst_left
+    assert worst_right > 1.0e-6, worst_right                      # the motion is large enough for the side to matter
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xiv)
+def test_a_texture_below_the_gradient_threshold_contributes_nothing_on_level_0(oracle_lib_built):
+    scene, TA = rc.VIEWS["room"]
+    W, H = VGA
+    K = rc.intrinsics(W, H)
+    # the premise, from the rendered frame alone (grey: any luma formula whose weights sum to one leaves it as it is): at a tenth of
+    # the contrast the image gradient stays below 4 grey levels per pixel on all but the most oblique stretches of wall
+    img = rs.render(TA @ rc.MOTIONS["2px"], W, H, K, scene, wavelength=160.0 / W, contrast=0.1)[0][..., 0].astype(np.float64)
+    gy, gx = np.gradient(img)
+    steep = (np.hypot(gx, gy) >= 4.0).mean()
+    assert steep < 0.01, steep
+    r = rc.two_frames("oracle", W, H, TA, TA @ rc.MOTIONS["2px"], scene=scene, trace=True, so3=0, contrast=0.1)
+    lvl0 = _level_rows(r["trace"], 0)
+    assert len(lvl0) == 10 and all(t[93] <= 0.01 * W * H for t in lvl0), [t[93] for t in lvl0]
+    # the same frames do carry texture for a lower threshold: level 2 (1 grey level per level-2 pixel = a quarter per level-0 pixel) sees it
+    assert min(t[93] for t in _level_rows(r["trace"], 2)) > 0.2 * (W // 4) * (H // 4)
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xv)
+def test_the_photometric_weight_depends_on_sigma_plus_the_residual_only(oracle_lib_built):
+    import ctypes as C
+    import oracle_lib
+    lib = oracle_lib.load()
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)
+    H, W = 24, 32
+    rng = np.random.default_rng(5)
+    ys, xs = np.mgrid[0:H, 0:W]
+    co = np.zeros((H * W, 6), np.int16)
+    co[:, 0] = xs.ravel(); co[:, 1] = ys.ravel(); co[:, 2] = xs.ravel(); co[:, 3] = ys.ravel(); co[:, 4] = 1
+    z = 1.0 + rng.random((H, W))
+    cloud = np.ascontiguousarray(np.stack([(xs - 16.0) * z / 30.0, (ys - 12.0) * z / 30.0, z], -1).astype(np.float32))
+    dIdx = rng.integers(-300, 300, (H, W)).astype(np.int16); dIdy = rng.integers(-300, 300, (H, W)).astype(np.int16)
+
+    def step(sigma, diff):
+        df = np.full(H * W, diff, np.float32)
+        A = np.zeros(36); b = np.zeros(6); res = np.zeros(2)
+        lib.orc_rgb_step(_p(co), _p(df), float(sigma), _p(cloud), 30.0, 30.0, _p(dIdx), _p(dIdy), 0, H, W, _p(A), _p(b), _p(res))
+        return A, b
+    A1, b1 = step(3.0, 5.0)
+    A2, b2 = step(6.0, 2.0)                 # the same sigma + |diff|
+    A3, b3 = step(6.0, -2.0)
+    np.testing.assert_allclose(A2, A1, rtol=1e-5)
+    np.testing.assert_allclose(b2 * (5.0 / 2.0), b1, rtol=1e-5)
+    np.testing.assert_allclose(A3, A2, rtol=1e-6); np.testing.assert_allclose(b3, -b2, rtol=1e-6)
+    A4, _ = step(3.0, 13.0)                 # sigma + |diff| doubled: the rows halve, the matrix quarters
+    np.testing.assert_allclose(A4 * 4.0, A1, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------------------------ (viii)
 def _inverted_pair(kind, **mode):
     """the same view twice: frame A almost white, frame B dark with the texture's gradients: |diff| ~ 190 on ~140 k correspondences"""
@@ -272,6 +389,33 @@ def test_hip_meets_the_same_bounds_and_equals_the_oracle(gpu_available, oracle_l
     g = rc.two_frames("hip", *size, TA, TB, scene=scene, **mode)
     assert rs.reprojection_px(g["E"], g["G"], g["z"], g["K"]) <= bound
     o = rc.two_frames("oracle", *size, TA, TB, scene=scene, **mode)
+    assert np.array_equal(g["bits"], o["bits"])
+
+
+def _holes_at_even_texels(rgb, depth):
+    d = depth.copy(); d[0::2, 0::2] = 0
+    return rgb, d
+
+
+# the scenarios of (x) - (xiv) on the HIP library: the same bound, and the oracle's pose bit for bit (so the counts the CPU tests read from
+# the oracle's trace are the library's too)
+GPU_SCENARIOS = [
+    ("itself_joint", QVGA, rc.CORNER_VIEW, rs.pose(), dict(so3=0), dict(), 0.02),
+    ("itself_rgb_only", QVGA, rc.CORNER_VIEW, rs.pose(), dict(so3=0, rgb_only=1), dict(), 0.02),
+    ("axial_8.5cm_depth_gate", VGA, rs.pose(-0.15, 0.25, 0.0), rs.pose(t=(0.0, 0.0, 0.085)), dict(so3=0), dict(), 0.5),
+    ("holes_at_even_texels", VGA, rc.CORNER_VIEW, rc.MOTIONS["2px"], dict(so3=0, rgb_only=1), dict(edit_b=_holes_at_even_texels), 0.5),
+    ("large_motion_19_iterations", QVGA, rc.CORNER_VIEW, rs.pose(0.02, -0.03, 0.01, (0.02, -0.015, 0.01)), dict(so3=0), dict(), 0.5),
+    ("tenth_of_the_contrast", VGA, rc.CORNER_VIEW, rc.MOTIONS["2px"], dict(so3=0), dict(contrast=0.1), 1.0),      # level 0 sees no texture: the coarser levels and the ICP term carry it
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_SCENARIOS, ids=[c[0] for c in GPU_SCENARIOS])
+def test_hip_on_the_scenarios_of_x_to_xiv(gpu_available, oracle_lib_built, case):
+    _, size, TA, motion, mode, extra, bound = case
+    g = rc.two_frames("hip", *size, TA, TA @ motion, scene=rs.ROOM, **mode, **extra)
+    assert rs.reprojection_px(g["E"], g["G"], g["z"], g["K"]) <= bound
+    o = rc.two_frames("oracle", *size, TA, TA @ motion, scene=rs.ROOM, **mode, **extra)
     assert np.array_equal(g["bits"], o["bits"])
 
 
