@@ -154,7 +154,7 @@ struct hrbf_context {
     RecPlanes rec; int32_t *d_rec_flag; uint32_t *d_rec_best;
     uint32_t *d_init_flags, *d_init_offs;
     uint32_t max_tiles;
-    float4 *d_clean_tex;        // packed index-map texels + update mask for the clean test (k_resolve)
+    float4 *d_clean_tex;        // packed index-map texels for the clean test (k_resolve)
     float clean_thr; int clean_time;   // the threshold and time baked into them
     DevPose *d_pose;
     int index_submap;           // submap id stamped on new surfels (HRBFFusion::indexSubmap)
@@ -807,14 +807,18 @@ static void st_init(hrbf_context *c)
     launch_odo_first_rgb(c->stream, c->odo, c->d_rgb);
 }
 // what: which outputs of the projection the next consumer reads (k_resolve); the stage API asks for everything
-static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
+// classes: the projection also leaves pass A's first decision per surfel in the keep-byte plane (k_project) — only the frame
+// path asks for it, where the clean pass follows at once on the same map and pose (st_clean(c, true))
+static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7, bool classes = false)
 {
     const float maxd = c->prm.max_depth_processed;
+    const float cthr = c->prm.confidence_threshold;
+#define CLS(k) (classes ? c->sh[k].d_keep_flags : nullptr), cthr
     float4 *ctex = for_clean ? c->d_clean_tex : nullptr;
     if (for_clean && (what & 4)) { c->clean_thr = c->prm.confidence_threshold; c->clean_time = c->tick; }
     if (c->G == 1 && !c->shard_real) {
         launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[0].map, shard_ref(c, 0), c->sh[0].count_ub, c->d_zbuf,
-                       c->d_submap_active, c->n_submap_active);
+                       c->d_submap_active, c->n_submap_active, CLS(0));
         launch_resolve(c->stream, c->cam, c->d_pose, c->sh[0].map, shard_ref(c, 0), c->d_zbuf, c->d_idx, c->d_im_vertconf,
                        c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctex, what, 1,
                        c->clean_thr, c->clean_time);
@@ -826,13 +830,14 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
     for (int k = 0; k < c->nsh; ++k) {
         if (c->hash_mode) {   // two-level z-test: private {depth, local index}, then {depth, gid} into the buffer that is reduced
             launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[k].map, shard_ref(c, k), c->sh[k].count_ub, c->sh[k].d_zpriv,
-                           c->d_submap_active, c->n_submap_active);
+                           c->d_submap_active, c->n_submap_active, CLS(k));
             launch_keys_global(c->stream, c->sh[k].d_zpriv, c->sh[k].d_gid, c->d_zbuf, c->P, k > 0 ? 1 : 0);
             continue;
         }
         unsigned long long *zb = k == 0 ? c->d_zbuf : c->x.zbuf;
         launch_project(c->stream, c->cam, c->d_pose, maxd, c->sh[k].map, shard_ref(c, k), c->sh[k].count_ub, zb,
-                       c->d_submap_active, c->n_submap_active);
+                       c->d_submap_active, c->n_submap_active, CLS(k));
+#undef CLS
         if (k > 0) launch_zbuf_min_merge(c->stream, c->d_zbuf, c->x.zbuf, c->P);
     }
     if (c->shard_real && c->comm.comm) rccl_allreduce_min_u64(c->comm.comm, c->d_zbuf, (size_t)c->P, c->stream);
@@ -849,7 +854,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
                            k == c->nsh - 1 ? 1 : 0, c->clean_thr, c->clean_time, k > 0 ? cnt : nullptr,
                            k > 0 ? c->x.send_idx : nullptr, c->x.send_f, cap, k == 0 ? 1 : 0, c->sh[k].d_zpriv);
             if (k > 0)
-                launch_winner_unpack(c->stream, c->P, cnt, 0, cap, c->x.send_idx, c->x.send_f, cap, what, c->d_im_vertconf,
+                launch_winner_unpack(c->stream, c->P, c->cam.W, cnt, 0, cap, c->x.send_idx, c->x.send_f, cap, what, c->d_im_vertconf,
                                      c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
         }
         return;
@@ -867,7 +872,6 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
                                c->clean_thr, c->clean_time, c->sh[0].d_zpriv);
         if (peer_meet(c)) return;                                           // every owner has written into every rank's images
         launch_zbuf_reset(c->stream, c->d_zbuf, c->P);                       // re-arm the private z-buffer: nobody reads it any more
-        if (for_clean && (what & 4)) launch_clean_bits_decode(c->stream, c->d_clean_tex, c->P);
         return;
     }
     // one shard per rank
@@ -903,7 +907,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7)
     }
     g_rccl.GroupEnd();
     if (off) {
-        launch_winner_unpack(c->stream, c->P, nullptr, 0, off, c->x.recv_idx, c->x.recv_f, cap, what,
+        launch_winner_unpack(c->stream, c->P, c->cam.W, nullptr, 0, off, c->x.recv_idx, c->x.recv_f, cap, what,
                              c->d_im_vertconf, c->d_im_colortime, c->d_im_normrad, c->d_im_curvmax, c->d_im_curvmin, ctx_clean);
     }
 }
@@ -1026,11 +1030,11 @@ static int hash_renumber(hrbf_context *c)
     ++c->hash_renumbered;
     return HRBF_OK;
 }
-static int st_clean(hrbf_context *c)
+static int st_clean(hrbf_context *c, bool have_class = false)
 {
     // the clean texels carry the confidence threshold and the time they were resolved with; a caller that changed
     // either since (stage API / named operators) gets a fresh projection instead of a stale test
-    if (c->clean_thr != c->prm.confidence_threshold || c->clean_time != c->tick) st_indices(c, true, 7);
+    if (c->clean_thr != c->prm.confidence_threshold || c->clean_time != c->tick) { st_indices(c, true, 7); have_class = false; }
     if (c->hash_mode && c->g_next > c->g_renumber_at) {
         // ids must never run past g_renumber_at: a pass that cannot renumber does not run (the map stays as the merge left it), the
         // condition is sticky (HRBF_STATUS_ID_SPACE) and every later frame fails at once instead of retrying a host-synchronous,
@@ -1055,7 +1059,7 @@ static int st_clean(hrbf_context *c)
                      ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
                      last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0,
                      ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr, sh.d_merged_part,
-                     c->hash_mode ? sh.d_gid : nullptr, c->g_next, c->G, gk, c->hash_inv_cell);
+                     c->hash_mode ? sh.d_gid : nullptr, c->g_next, c->G, gk, c->hash_inv_cell, have_class ? 1 : 0);
         sh.tile_dirty[cur] = dirty[0]; sh.tile_dirty[1 - cur] = dirty[1]; sh.tile_par = 1 - cur;
         if (last) {
             const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
@@ -1150,9 +1154,9 @@ static int process_frame_resident(hrbf_context *c, float wmul)
             TIMER(3);
             st_fuse(c);
             TIMER(4);
-            st_indices(c, true, 4);      // the clean test reads the packed texels only
+            st_indices(c, true, 4, true);      // the clean test reads the packed texels only; + pass A's classes
             TIMER(5);
-            frame_rc = st_clean(c);
+            frame_rc = st_clean(c, true);   // nothing between the projection and the pass: the classes describe this map and pose
             if (frame_rc) snprintf(frame_err, sizeof(frame_err), "%s", hrbf_last_error());   // later stages (peer barriers) may set their own text
             TIMER(6);
         } else { TIMER(3); TIMER(4); TIMER(5); TIMER(6); }

@@ -150,11 +150,19 @@ __device__ __forceinline__ uint32_t shard_offset(const ShardRef &sh)
     return o;
 }
 
+// What the projection in front of the clean pass leaves per surfel for pass A (k_clean_flags), in the keep-byte plane pass A is
+// about to overwrite: a STABLE surfel outside the frustum is kept whatever else it holds (copy_unstable.vert:62-166 tests nothing
+// on it), so pass A reads one byte for it instead of its 16-byte position — on a map that is mostly out of view the position
+// stream of pass A shrinks to the surfels that need a test.  The projection has the position in a register anyway.
+#define CLEAN_CLASS_OUT_STABLE 0
+#define CLEAN_CLASS_OUT_UNSTABLE 1
+#define CLEAN_CLASS_IN_VIEW 2
 __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restrict__ dp, float maxDepth, const float4 *__restrict__ pos,
                                                  ShardRef sh,
                                                  unsigned long long *__restrict__ zbuf,
                                                  const float4 *__restrict__ color_time /* read only with a mask */,
-                                                 const uint8_t *__restrict__ submap_active /* nullable */, int n_active)
+                                                 const uint8_t *__restrict__ submap_active /* nullable */, int n_active,
+                                                 uint8_t *__restrict__ item_class /* nullable: see CLEAN_CLASS_* */, float confThr)
 {
     // ids in the keys are GLOBAL for contiguous ranges; LOCAL in the private z-buffer of a hash-owned shard (kernels.h)
     const uint32_t n = sh.counts[sh.k], off = sh.gid ? 0u : shard_offset(sh);
@@ -177,14 +185,18 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
             const uint32_t s = s0 + (uint32_t)k * stride;
             if (s >= n) continue;
             const float4 p = pk[k];
+            f3 h = xform(tinv, xyz(p));
+            float u = ((cam.fx * h.x) / h.z) + cam.cx;
+            float v = ((cam.fy * h.y) / h.z) + cam.cy;
+            if (item_class) {   // the projection in front of the clean pass: this lane holds what pass A's first decision needs
+                const bool inv = h.z < maxDepth && h.z > 0.0f && u > 0.0f && v > 0.0f && u < (float)cam.W && v < (float)cam.H;   // = in_view()
+                item_class[s] = inv ? CLEAN_CLASS_IN_VIEW : (p.w < confThr ? CLEAN_CLASS_OUT_UNSTABLE : CLEAN_CLASS_OUT_STABLE);
+            }
             if (submap_active) {   // index_map.vert:41-45: surfels of inactive submaps are not drawn
                 const uint32_t sm = (uint32_t)color_time[s].y;
                 if (sm >= (uint32_t)n_active || submap_active[sm] == 0) continue;
             }
-            f3 h = xform(tinv, xyz(p));
             if (h.z > maxDepth || h.z < 0.0f) continue;
-            float u = ((cam.fx * h.x) / h.z) + cam.cx;
-            float v = ((cam.fy * h.y) / h.z) + cam.cy;
             // viewport transform + snap to the 1/256-pixel grid, as the GL rasteriser places the point (hrbf_detmath.h)
             int clip_u, clip_v;
             u = hd_gl_point_window_coord(u, (float)cam.W, &clip_u);
@@ -248,17 +260,31 @@ __device__ __forceinline__ PixelWinner pixel_winner(const ShardRef &sh, unsigned
 // The clean test's view of the index map (pass A of the fuse): ONE 16-byte texel per pixel {winner position in the
 // camera frame, winner's init time} — zero when there is no winner, when it is surfel 0 (the reference's
 // `current > 0U` gate, copy_unstable.vert:111) or when its confidence is not above the threshold (both predicates of
-// the test need it) — followed by one bit per pixel: "the winner was updated this frame".  A zero texel has z = 0 and
-// fails every `vcf.z > lp.z` of the test, so validity costs no extra flag.  4.9 MB + 38 KB at VGA instead of the
-// 9.8 MB of two float4 per pixel: it stays in L2 and the window needs 9 + 3 loads instead of 18.
-__host__ __device__ inline size_t clean_tex_float4s(int P) { return (size_t)P + (size_t)P / 128 + 4; }   // texels + bit words (+ slack)
-__device__ __forceinline__ const uint32_t *clean_bits(const float4 *clean_tex, int P)
+// the test need it).  A zero texel has z = 0 and fails every `vcf.z > lp.z` of the test, so validity costs no extra
+// flag; and a winner's z is never negative (the projection culls h.z < 0), so the SIGN of z carries the test's third
+// input, "the winner was updated this frame" (it was a separate 1-bit-per-pixel mask: two 4-byte gathers per window row).
+// Texels are stored in 4 x 2 blocks — eight texels = one 128-byte line — so the 2..3 x 2..3 distinct texels of a window
+// lie in 1..4 lines instead of 2..3 rows x 1..2 lines (W % 4 == 0, H % 2 == 0: both are multiples of 8).
+__host__ __device__ inline size_t clean_tex_float4s(int P) { return (size_t)P + 8; }
+__device__ __forceinline__ uint32_t clean_tex_slot(int x, int y, int W)
 {
-    return reinterpret_cast<const uint32_t *>(clean_tex + P);
+    return ((((uint32_t)y >> 1) * ((uint32_t)W >> 2) + ((uint32_t)x >> 2)) << 3) + (((uint32_t)y & 1u) << 2) + ((uint32_t)x & 3u);
+}
+__device__ __forceinline__ uint32_t clean_tex_slot_of_pixel(uint32_t i, int W) { return clean_tex_slot((int)(i % (uint32_t)W), (int)(i / (uint32_t)W), W); }
+__device__ __forceinline__ float4 clean_texel_pack(float4 t, bool updated)
+{
+    if (updated) t.z = hd_u2f(hd_f2u(t.z) | 0x80000000u);
+    return t;
+}
+__device__ __forceinline__ bool clean_texel_unpack(float4 &t)   // returns `updated`, leaves the plain texel
+{
+    const uint32_t zb = hd_f2u(t.z);
+    t.z = hd_u2f(zb & 0x7FFFFFFFu);
+    return (zb >> 31) != 0u;
 }
 
 // Sharded map: instead of reducing dense images between the ranks, a rank packs ONE record per pixel whose
-// winner it owns — the pixel index (bit 31: "updated this frame", for the clean mask) and the winner's attributes the
+// winner it owns — the pixel index and the winner's attributes the
 // next consumer reads — into compact arrays that are exchanged (all-gather-v) and scattered by k_winner_unpack.
 // rec.f holds six planes of `cap` float4: 0 vertconf, 1 normrad, 2 colortime, 3 curvmax, 4 curvmin, 5 clean texel.
 struct WinnerRecords { uint32_t *count; uint32_t *idx; float4 *f; uint32_t cap; };
@@ -322,11 +348,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
     if (dense && live) {
         if (what & RESOLVE_GEOM) { vertconf[i] = o_vc; normrad[i] = o_nr; }
         if (what & RESOLVE_ATTR) { colortime[i] = o_ct; curvmax[i] = o_c1; curvmin[i] = o_c2; }
-        if (what & RESOLVE_CLEAN) {
-            clean_tex[i] = o_clean;
-            const unsigned long long bal = __ballot(updated);   // a wave = 64 consecutive pixels = one 8-byte word of the mask
-            if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(clean_tex + P)[i >> 6] = bal;
-        }
+        if (what & RESOLVE_CLEAN) clean_tex[clean_tex_slot_of_pixel((uint32_t)i, cam.W)] = clean_texel_pack(o_clean, updated);
     }
     if (rec.idx) {   // pack the owned winners: one position per workgroup from a single atomic (same-address atomics serialise)
         __shared__ uint32_t s_n[4], s_base;
@@ -340,11 +362,11 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
             uint32_t pos = s_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             for (int w = 0; w < wid; ++w) pos += s_n[w];
             if (pos < rec.cap) {
-                rec.idx[pos] = (uint32_t)i | (updated ? 0x80000000u : 0u);
+                rec.idx[pos] = (uint32_t)i;
                 const size_t cap = rec.cap;
                 if (what & RESOLVE_GEOM) { rec.f[pos] = o_vc; rec.f[cap + pos] = o_nr; }
                 if (what & RESOLVE_ATTR) { rec.f[2 * cap + pos] = o_ct; rec.f[3 * cap + pos] = o_c1; rec.f[4 * cap + pos] = o_c2; }
-                if (what & RESOLVE_CLEAN) rec.f[5 * cap + pos] = o_clean;
+                if (what & RESOLVE_CLEAN) rec.f[5 * cap + pos] = clean_texel_pack(o_clean, updated);
             }
         }
     }
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(256) void k_resolve(Cam cam, const DevPose *__restr
 
 // scatter the winner records of other shards into the dense images (the pixels they cover were written as zeros by this
 // rank's own k_resolve: one owner per pixel)
-__global__ __launch_bounds__(256) void k_winner_unpack(int P, const uint32_t *__restrict__ count /* nullable */, uint32_t n_fixed, uint32_t first, const uint32_t *__restrict__ ridx,
+__global__ __launch_bounds__(256) void k_winner_unpack(int P, int W, const uint32_t *__restrict__ count /* nullable */, uint32_t n_fixed, uint32_t first, const uint32_t *__restrict__ ridx,
                                                        const float4 *__restrict__ rf, uint32_t cap, int what,
                                                        float4 *__restrict__ vertconf, float4 *__restrict__ colortime,
                                                        float4 *__restrict__ normrad, float4 *__restrict__ curvmax,
@@ -361,16 +383,12 @@ __global__ __launch_bounds__(256) void k_winner_unpack(int P, const uint32_t *__
     const uint32_t n = count ? *count : n_fixed;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const uint32_t pos = first + r;
-        const uint32_t w = ridx[pos];
-        const uint32_t i = w & 0x7FFFFFFFu;
+        const uint32_t i = ridx[pos];
         if (i >= (uint32_t)P) continue;
         const size_t c = cap;
         if (what & RESOLVE_GEOM) { vertconf[i] = rf[pos]; normrad[i] = rf[c + pos]; }
         if (what & RESOLVE_ATTR) { colortime[i] = rf[2 * c + pos]; curvmax[i] = rf[3 * c + pos]; curvmin[i] = rf[4 * c + pos]; }
-        if (what & RESOLVE_CLEAN) {
-            clean_tex[i] = rf[5 * c + pos];
-            if (w & 0x80000000u) atomicOr(reinterpret_cast<uint32_t *>(clean_tex + P) + (i >> 5), 1u << (i & 31u));
-        }
+        if (what & RESOLVE_CLEAN) clean_tex[clean_tex_slot_of_pixel(i, W)] = rf[5 * c + pos];   // packed by the owner (clean_texel_pack)
     }
 }
 
@@ -711,8 +729,6 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
     const bool nz_ok = hd_fabsf(ln.z) > 0.85f && own_active;
     const float rad14 = vn.w * 1.4f;
     const float ftime = (float)cp.time;
-    const int P = cam.W * cam.H;
-    const uint32_t *bits = clean_bits(clean_tex, P);
     (void)ftime;
     if (cp.nw == 4) {
         // the 4 samples of an axis — 5 where the fp32-accumulated coordinate ends an ulp below the bound (hd_halfpixel_walk) — are
@@ -735,31 +751,25 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
         if (sx0 < 0 || sy0 < 0) return true;   // an empty walk (cannot happen for a surfel in view)
         const int sxk[1] = {sx0}, syk[1] = {sy0};
         float4 ta[9];
-        uint32_t upd[3];   // bit jx of upd[jy]: the winner at (sx0 + jx, sy0 + jy) was updated this frame
 #pragma unroll
-        for (int jy = 0; jy < 3; ++jy) {
-            upd[jy] = 0u;
-            if (my[jy] > 0) {   // rows outside the visit pattern may lie outside the image: not read
-                const uint32_t bi = (uint32_t)((syk[0] + jy) * cam.W + sxk[0]);
-                const uint32_t lo = bits[bi >> 5], hi = bits[(bi >> 5) + 1];   // one word of slack behind the mask
-                upd[jy] = (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (bi & 31u)) & 7u;
-            }
+        for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
-            for (int jx = 0; jx < 3; ++jx) {
+            for (int jx = 0; jx < 3; ++jx) {   // texels outside the visit pattern may lie outside the image: not read
                 ta[jx * 3 + jy] = make_float4(0, 0, 0, 0);
-                if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = clean_tex[(syk[0] + jy) * cam.W + (sxk[0] + jx)];
+                if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = clean_tex[clean_tex_slot(sxk[0] + jx, syk[0] + jy, cam.W)];
             }
-        }
 #pragma unroll
         for (int jx = 0; jx < 3; ++jx)
 #pragma unroll
             for (int jy = 0; jy < 3; ++jy) {
                 const int wgt = mx[jx] * my[jy];
-                const float4 vcf = ta[jx * 3 + jy];   // {winner xyz, winner init time}; all zero = no usable winner
+                float4 vcf = ta[jx * 3 + jy];   // {winner xyz, winner init time}, sign of z = updated this frame; all zero = no usable winner
+                const bool upd = clean_texel_unpack(vcf);
+                ta[jx * 3 + jy] = vcf;
                 if (wgt > 0 && vcf.z > lp.z) {
                     float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
                     if (vcf.w < init_time && vcf.z - lp.z < 0.01f && hd_sqrtf(dx * dx + dy * dy) < rad14) count += wgt;
-                    if (((upd[jy] >> jx) & 1u) && vcf.z - lp.z > 0.01f && nz_ok) zCount += wgt;
+                    if (upd && vcf.z - lp.z > 0.01f && nz_ok) zCount += wgt;
                 }
             }
 #ifdef CLEAN_DIAG
@@ -785,12 +795,12 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
                 const int sy = hd_window_texel(fj, cam.H);
                 if (sy != prev_sy) {
                     prev_sy = sy; c1 = 0; z1 = 0;
-                    const int si = sy * cam.W + sx;
-                    const float4 vcf = clean_tex[si];
+                    float4 vcf = clean_tex[clean_tex_slot(sx, sy, cam.W)];
+                    const bool upd = clean_texel_unpack(vcf);
                     if (vcf.z > lp.z) {
                         float dx = vcf.x - lp.x, dy = vcf.y - lp.y;
                         if (vcf.w < init_time && vcf.z - lp.z < 0.01f && hd_sqrtf(dx * dx + dy * dy) < rad14) c1 = 1;
-                        if (((bits[si >> 5] >> (si & 31)) & 1u) && vcf.z - lp.z > 0.01f && nz_ok) z1 = 1;
+                        if (upd && vcf.z - lp.z > 0.01f && nz_ok) z1 = 1;
                     }
                 }
                 colc += c1; colz += z1;
@@ -813,7 +823,9 @@ __device__ __forceinline__ bool in_view(const CleanParams &cp, const Rigid &tinv
 // the clean test of one item: surfel `idx` of the map or association record `idx`
 __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &tinv, float ftime, const MapPlanes &m,
                                            const RecPlanes &rec, bool is_surf, uint32_t idx,
-                                           const float4 *__restrict__ clean_tex, const float4 vp /* pos_conf of the item */)
+                                           const float4 *__restrict__ clean_tex, const float4 vp /* pos_conf of the item */,
+                                           const bool pre = false /* the caller knew the item's class and requested its planes together */,
+                                           const float4 pre_vc = {0, 0, 0, 0}, const float4 pre_vn = {0, 0, 0, 0})
 {
     bool keep = true;
     f3 lp; float x, y;
@@ -822,9 +834,9 @@ __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &t
     // test) and for records; a stable surfel outside the frustum is decided by pos_conf alone (16 B)
     const bool need_ct = inv || !is_surf || vp.w < cp.confThr || cp.full_check;
     float4 vc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (need_ct) vc = is_surf ? m.p1[idx] : rec.p1[idx];
+    if (need_ct) vc = pre ? pre_vc : (is_surf ? m.p1[idx] : rec.p1[idx]);
     if (inv) {
-        const float4 vn = is_surf ? m.p2[idx] : rec.p2[idx];
+        const float4 vn = pre ? pre_vn : (is_surf ? m.p2[idx] : rec.p2[idx]);
         keep = clean_window(cp, tinv, lp, x, y, vc.z, vc.y, vn, clean_tex);
     }
     if (!is_surf || cp.full_check || (need_ct && vc.w == ftime)) {
@@ -853,7 +865,8 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
                                                      const uint32_t *__restrict__ count_in,
                                                      const float4 *__restrict__ clean_tex,
                                                      uint8_t *__restrict__ keep_flags,
-                                                     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ stats)
+                                                     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ stats,
+                                                     int have_class /* keep_flags[0..N) holds k_project's CLEAN_CLASS_* of this very map and pose */)
 {
     const uint32_t N = *count_in;
     const Rigid tinv = cp.dp->tinv;
@@ -909,17 +922,31 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
 #endif
     const uint32_t stride = sgrid * blockDim.x;
     for (uint32_t it0 = sb * blockDim.x + threadIdx.x; it0 < N64; it0 += CLEAN_UNROLL * stride) {
-        float4 vp[CLEAN_UNROLL];
+        float4 vp[CLEAN_UNROLL], vc[CLEAN_UNROLL], vn[CLEAN_UNROLL];
+        bool settled[CLEAN_UNROLL];   // a stable surfel outside the frustum, classified by the projection: kept, nothing read
+        const bool cls = have_class && !cp.full_check;
 #pragma unroll
         for (int k = 0; k < CLEAN_UNROLL; ++k) {
             const uint32_t it = it0 + (uint32_t)k * stride;
-            vp[k] = it < N ? m.p0[it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            vc[k] = z4; vn[k] = z4;
+            if (cls) {   // one byte decides what the item needs, and what it needs is requested in ONE round (position -> colour/time,
+                         // normal/radius are two dependent rounds without the class)
+                const uint32_t cl = it < N ? keep_flags[it] : CLEAN_CLASS_OUT_STABLE;
+                settled[k] = cl == CLEAN_CLASS_OUT_STABLE;
+                vp[k] = settled[k] ? z4 : m.p0[it];
+                if (!settled[k]) vc[k] = m.p1[it];
+                if (cl == CLEAN_CLASS_IN_VIEW) vn[k] = m.p2[it];
+            } else {
+                settled[k] = false;
+                vp[k] = it < N ? m.p0[it] : z4;
+            }
         }
 #pragma unroll
         for (int k = 0; k < CLEAN_UNROLL; ++k) {
             const uint32_t it = it0 + (uint32_t)k * stride;
             if (it >= N64) break;          // wave-uniform: N64 and the strides are multiples of 64
-            const bool keep = it < N && clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k]);
+            const bool keep = it < N && (settled[k] || clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k], cls, vc[k], vn[k]));
 #ifndef CLEAN_NO_STORE
             if (it < N) keep_flags[it] = keep ? 1 : 0;
 #endif
@@ -1228,9 +1255,7 @@ void launch_iota_u32(hipStream_t s, uint32_t *p, uint32_t n, uint32_t base)
 // ---- sharded map over peer-mapped images (SURVEY §8e sharding 2): the OWNER of a pixel's winner writes the
 // winner's attributes straight into every rank's index-map images (hipIpcMemHandle-mapped; xGMI peers on one node) — no
 // packing, no count exchange, no host read-back.  A pixel has exactly one owner, so the writes never collide; a pixel nobody
-// hit is zeroed by every rank locally.  The clean pass's "winner updated this frame" bit travels in the sign of the clean
-// texel's w (the winner's init time, >= 0): w < 0 encodes updated with init time -w - 1; k_clean_bits_decode restores the texel
-// and builds the local 1-bit-per-pixel mask after the ranks have met.
+// hit is zeroed by every rank locally.  The clean texel is written as every other path writes it (clean_texel_pack, 4 x 2 blocks).
 __global__ __launch_bounds__(256) void k_zbuf_min_peers(PeerImages pi, unsigned long long *__restrict__ zred, int P)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1255,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_resolve_scatter(Cam cam, const DevPose 
         const int g = pi.me;
         if (what & RESOLVE_GEOM) { pi.vertconf[g][i] = z4; pi.normrad[g][i] = z4; }
         if (what & RESOLVE_ATTR) { pi.colortime[g][i] = z4; pi.curvmax[g][i] = z4; pi.curvmin[g][i] = z4; }
-        if (what & RESOLVE_CLEAN) pi.clean[g][i] = z4;
+        if (what & RESOLVE_CLEAN) pi.clean[g][clean_tex_slot_of_pixel((uint32_t)i, cam.W)] = z4;
         return;
     }
     const PixelWinner w = pixel_winner(sh, key, zpriv, i);
@@ -1264,24 +1289,13 @@ __global__ __launch_bounds__(256) void k_resolve_scatter(Cam cam, const DevPose 
     if (!w.owned) return;   // another rank owns the winner and writes this pixel
     WinnerTexels o;
     const bool updated = resolve_winner(m, s, sg, dp->tinv, what, clean_conf_thr, clean_time, o);
-    if (updated) o.clean.w = -(o.clean.w + 1.0f);
+    o.clean = clean_texel_pack(o.clean, updated);
+    const uint32_t ci = clean_tex_slot_of_pixel((uint32_t)i, cam.W);
     for (int g = 0; g < pi.world; ++g) {
         if (what & RESOLVE_GEOM) { pi.vertconf[g][i] = o.vc; pi.normrad[g][i] = o.nr; }
         if (what & RESOLVE_ATTR) { pi.colortime[g][i] = o.ct; pi.curvmax[g][i] = o.c1; pi.curvmin[g][i] = o.c2; }
-        if (what & RESOLVE_CLEAN) pi.clean[g][i] = o.clean;
+        if (what & RESOLVE_CLEAN) pi.clean[g][ci] = o.clean;
     }
-}
-__global__ __launch_bounds__(256) void k_clean_bits_decode(float4 *__restrict__ clean_tex, int P)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // P is a multiple of 64: whole waves
-    bool updated = false;
-    if (i < P) {
-        float4 t = clean_tex[i];
-        updated = t.w < 0.0f;
-        if (updated) { t.w = -t.w - 1.0f; clean_tex[i] = t; }
-    }
-    const unsigned long long bal = __ballot(updated);
-    if (i < P && (threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(clean_tex + P)[i >> 6] = bal;
 }
 void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long long *zred, int P)
 {
@@ -1295,19 +1309,16 @@ void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, Ma
     if (!for_clean) what &= ~RESOLVE_CLEAN;
     hipLaunchKernelGGL(k_resolve_scatter, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, zred, idx, pi, what, clean_conf_thr, clean_time, zpriv);
 }
-void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P)
-{
-    hipLaunchKernelGGL(k_clean_bits_decode, dim3((P + 255) / 256), dim3(256), 0, s, clean_tex, P);
-}
 
 void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
-                    uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active, int n_active)
+                    uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active, int n_active,
+                    uint8_t *item_class, float confThr)
 {
     uint32_t blocks = (count_ub + 255) / 256;   // zbuf is ZB_EMPTY on entry: launch_zbuf_reset once, k_resolve afterwards
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride the rest
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, sh, zbuf, m.p1, submap_active,
-                       n_active);
+                       n_active, item_class, confThr);
 }
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
@@ -1320,7 +1331,7 @@ void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes 
     hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, cam, dp, m, sh, rearm, zbuf, idx, vertconf,
                        colortime, normrad, curvmax, curvmin, clean_tex, what, clean_conf_thr, clean_time, rec, dense, zpriv);
 }
-void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
+void launch_winner_unpack(hipStream_t s, int P, int W, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
                           const float4 *rf, uint32_t cap, int what, float4 *vertconf, float4 *colortime, float4 *normrad,
                           float4 *curvmax, float4 *curvmin, float4 *clean_tex)
 {
@@ -1328,7 +1339,7 @@ void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t 
     uint32_t blocks = (n_ub + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_winner_unpack, dim3(blocks), dim3(256), 0, s, P, count, n_ub, first, ridx, rf, cap, what, vertconf, colortime,
+    hipLaunchKernelGGL(k_winner_unpack, dim3(blocks), dim3(256), 0, s, P, W, count, n_ub, first, ridx, rf, cap, what, vertconf, colortime,
                        normrad, curvmax, curvmin, clean_tex);
 }
 
@@ -1371,7 +1382,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   uint32_t *tile_dirty /* [2]: entries this / the other buffer may hold */, uint32_t *tile_done, uint32_t epoch,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
                   int n_records, int zero_records, uint32_t *stats_ring_slot, const uint32_t *merged_part,
-                  uint32_t *gid, uint32_t g_base, int hash_G, int hash_me, float hash_inv_cell)
+                  uint32_t *gid, uint32_t g_base, int hash_G, int hash_me, float hash_inv_cell, int have_class)
 {
     const int Qfull = (cam.W / 2) * (cam.H / 2);
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
@@ -1389,7 +1400,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     if (fblocks == 0) fblocks = 1;
     if (Q > 0) fblocks += quarter_tile_blocks(cam.W, cam.H);   // ... behind the record workgroups
     hipLaunchKernelGGL(k_clean_flags, dim3(fblocks), dim3(256), 0, s, cp, m, rec, rec_flag, Q, count_in, clean_tex,
-                       keep_flags, tile_count, stats);
+                       keep_flags, tile_count, stats, have_class);
     // any grid size is safe (ticketed tiles); one FUSE_THREADS-thread workgroup per CU, one item per lane (more loads in
     // flight per lane cost bandwidth on this part)
     uint32_t blocks = tiles < 256u * FUSE_WG_PER_CU ? tiles : 256u * FUSE_WG_PER_CU;

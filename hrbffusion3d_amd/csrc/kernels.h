@@ -93,10 +93,12 @@ void launch_gid_rank(hipStream_t s, const uint32_t *const *ptrs, const uint32_t 
 // (launch_winner_unpack); `rearm` lets the last local shard leave the z-buffer empty for the next pass.
 void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
                     uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active /* nullable: KeyFrameIDMap */,
-                    int n_active);
+                    int n_active,
+                    uint8_t *item_class = nullptr /* nullable: one byte per surfel for pass A of the clean pass (k_project) */,
+                    float confThr = 0.0f);
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
-                    float4 *clean_tex /* nullable: packed texels + update mask for the clean test (clean_tex_elems) */,
+                    float4 *clean_tex /* nullable: packed texels for the clean test (clean_tex_elems) */,
                     int what /* 1 geometry images | 2 attribute images | 4 clean texels */, int rearm,
                     float clean_conf_thr, int clean_time /* baked into the clean texels */,
                     uint32_t *rec_count = nullptr, uint32_t *rec_idx = nullptr /* nullable: pack the owned winners */,
@@ -105,10 +107,10 @@ void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes 
                     unsigned long long *zpriv = nullptr /* hash ownership: this shard's private z-buffer {depth, local index}; zbuf then holds the reduced {depth, gid} keys */);
 void launch_keys_global(hipStream_t s, const unsigned long long *zpriv, const uint32_t *gid, unsigned long long *out, int P, int merge);
 // sharded map: scatter `*count` (or, with count == null, n_ub) winner records, starting at record `first`, into the dense images
-void launch_winner_unpack(hipStream_t s, int P, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
+void launch_winner_unpack(hipStream_t s, int P, int W, const uint32_t *count, uint32_t first, uint32_t n_ub, const uint32_t *ridx,
                           const float4 *rf, uint32_t cap, int what, float4 *vertconf, float4 *colortime, float4 *normrad,
                           float4 *curvmax, float4 *curvmin, float4 *clean_tex);
-size_t clean_tex_elems(int P);   // float4 elements of the clean-texel buffer (texels + one bit per pixel)
+size_t clean_tex_elems(int P);   // float4 elements of the clean-texel buffer (4 x 2 blocked, sign of z = updated)
 void launch_zbuf_min_merge(hipStream_t s, unsigned long long *dst, unsigned long long *src_reset, int P);   // local stand-in for allReduce(min)
 // sharded map over peer-mapped images: the index-map images (and the private z-buffer) of every rank of the node, as mapped
 // into this process (hipIpcOpenMemHandle; entry `me` = the local buffers)
@@ -124,7 +126,6 @@ void launch_zbuf_min_peers(hipStream_t s, const PeerImages &pi, unsigned long lo
 void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, const unsigned long long *zred,
                             uint32_t *idx, const PeerImages &pi, int what, bool for_clean, float clean_conf_thr, int clean_time,
                             unsigned long long *zpriv = nullptr);
-void launch_clean_bits_decode(hipStream_t s, float4 *clean_tex, int P);
 // what data.vert recomputes a new point's normal and radius from (data.vert:83-96)
 struct RecNormalSrc { const float *depth_metric_f; float radius_mult; int use_pca; };
 void launch_fuse(hipStream_t s, const Cam &cam, const DevPose *dp, int tick, float maxDepth, int index_submap,
@@ -150,7 +151,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   const uint32_t *merged_part /* as launch_fuse: summed into word 1 of the ring slot */,
                   uint32_t *gid /* nullable; hash ownership: the shard's global-order ids, moved along with the planes */,
                   uint32_t g_base /* id of record 0 if it is appended (record q gets g_base + q) */,
-                  int hash_G, int hash_me, float hash_inv_cell /* only records whose cell hashes to hash_me are appended */);
+                  int hash_G, int hash_me, float hash_inv_cell /* only records whose cell hashes to hash_me are appended */,
+                  int have_class = 0 /* keep_flags[0..count) holds the classes launch_project(item_class) wrote for THIS map and pose */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
