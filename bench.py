@@ -251,13 +251,16 @@ def fuse_real_bytes(n_in, n_view, n_unst_out, merged, appended, moved, Q, P, ful
     """MODELLED HBM/L2 bytes the three fuse kernels touch per frame (the measured figure is the PMC one in profiles/):
     F2 k_apply_merges: every record lane reads its 80-B record + flag + best (8 B); a winning record reads and rewrites
        its surfel (160 B) and its slot word;
-    pass A k_clean_flags: 16 B per surfel (+16 colour/time if in view or unstable, +16 normal/radius if in view, +32
-       curvature if merged or full_check), 80 B + 4 B per record, the 16-B clean texel image once (L2-resident
+    pass A k_clean_flags: 1 class byte per surfel (left by the projection in front of the pass), 32 B position +
+       colour/time if in view or unstable, +16 normal/radius if in view, +32 curvature if merged; with full_check (after a
+       map upload) 16 B per surfel and no class; 80 B + 4 B per record, the 16-B clean texel image once (L2-resident
        afterwards), 1 keep byte per item;
     pass B k_fuse_stream: 1 keep byte per item of the moving tiles, 160 B per surfel that changes slot, 160 B per
        appended record."""
     f2 = Q * (80 + 8) + merged * (160 + 8)
-    a = n_in * 16 + (n_view + n_unst_out) * 16 + n_view * 16 + (n_in * 32 if full_check else merged * 32) + Q * 84 + P * 16 + (n_in + Q)
+    a_surf = (n_in * 16 + (n_view + n_unst_out) * 16 + n_view * 16 + n_in * 32) if full_check else \
+             (n_in * 1 + (n_view + n_unst_out) * 32 + n_view * 16 + merged * 32)
+    a = a_surf + Q * 84 + P * 16 + (n_in + Q)
     b = (moved + Q) * 1 + moved * 160 + appended * 160
     return float(f2 + a + b)
 
