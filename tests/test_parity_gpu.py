@@ -479,6 +479,46 @@ def test_stale_surfel_purge_matches_oracle(pair):
     assert st8[0][6] > 0.9 * n and g.status() == 0
 
 
+def test_clean_pass_classes_on_a_map_that_is_mostly_elsewhere(pair):
+    """Pass A of the clean pass takes its first decision per surfel from a class byte the projection in front of it leaves
+    (stable and outside the frustum: kept unread; unstable and outside: position + colour/time; in view: + normal/radius, all
+    in one round — DESIGN 5 item 2).  A map whose surfels are mostly NOT where the camera looks — behind it, beyond the depth
+    limit, far to the side, stable and unstable, fresh and stale, interleaved with a seeded room so that every wave holds all
+    three classes — through tracked noisy frames: frame 1 runs the full check after the upload (no classes), the later ones
+    the classified path.  Images, map (content and order), statistics and pose bit for bit against the oracle."""
+    W, H = 320, 240
+    K = synth.intrinsics(W, H)
+    room = synth.seed_map(60_000, width=W)
+    rng = np.random.default_rng(17)
+    n_x = 90_000
+    extra = room[rng.integers(0, len(room), n_x)].copy()
+    extra[:, 0:3] = rng.uniform(-12.0, 12.0, (n_x, 3)).astype(np.float32)          # anywhere in a 24 m box around the room
+    extra[:, 3] = np.where(rng.random(n_x) < 0.4, 1.0, rng.uniform(5.0, 20.0, n_x)).astype(np.float32)   # 40 % unstable
+    extra[:, 7] = rng.choice(np.array([1.0, 50.0, 250.0], np.float32), n_x)        # last seen: stale (tick 300) or not
+    extra[:, 6] = 1.0
+    seed = np.concatenate([room, extra])
+    seed = seed[rng.permutation(len(seed))]
+    n = len(seed)
+    p = default_params(W, H, *K, max_surfels=n + 200_000)
+    o, g = pair(p)
+    rgb, d, T = synth.frame(0, W, H, noise=True)
+    for x in (o, g):
+        x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d); x.set_tick(300)
+    removed = 0
+    for k in range(1, 6):
+        rgb, d, T = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "classes frame %d" % k)
+        assert np.array_equal(o.fuse_stats(), g.fuse_stats())
+        st = g.fuse_stats().astype(np.int64)
+        removed += int(st[0] + st[2] - st[3])
+    assert removed > 0.2 * n_x * 0.4 and g.status() == 0      # the stale unstable surfels outside the frustum went
+    # the stage API's clean pass (position first, no classes) on the same state gives the same map as the frame path did
+    for x in (o, g):
+        x.run_stage("PREDICT_INDICES"); x.run_stage("CLEAN")
+    assert_same_state(o, g, "stage-API clean after the classified frames", images=[])
+
+
 def test_upload_of_a_larger_map_after_frames_ran(pair):
     """a count read-back armed by earlier frames must not survive hrbf_upload_map / initialise — it
     describes the OLD map, and folding it into the host bound later would size the next fuse pass (LDS tile counts,
