@@ -1061,6 +1061,14 @@ __global__ __launch_bounds__(RB) void k_so3_persistent(OdoLevel L, OdoState *st,
 }
 
 // ------------------------------------------------------------------------------------------ O3 + O4 fused launch
+// The Gauss-Newton kernels are chains of memory round trips (VALU busy 11-12 %): what hipcc does with `load; if (field) return;
+// use the rest` is to fetch the tested field alone and the rest behind the branch — one more dependent round trip per early exit
+// (the ICP pixel took five: c0.w, c0.xyz, m1.w, the other nine floats, m0.w; two are needed).  hold2 / hold4 pin whole texels
+// that were requested together in registers before the first test: same values, same arithmetic, fewer round trips.
+__device__ __forceinline__ void hold2(float4 &a, float4 &b)
+{
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
 struct IcpArgs {
     const float *vmap_c, *nmap_c, *ck1_c, *ck2_c, *vmap_g, *nmap_g, *ck1_g, *ck2_g, *icpw;
     const float4 *cur_tex, *model_tex;   // packed operands (pack_icp_texels); null in the icpStep seam
@@ -1108,9 +1116,9 @@ __device__ __forceinline__ bool icp_pixel_packed_rows(const IcpArgs &A, const fl
                                                       int x, int y, float (&row)[7], float &weight)
 {
     const int rows = A.rows, cols = A.cols;
-    const float4 c0 = A.cur_tex[2 * (y * cols + x)];
+    float4 c0 = A.cur_tex[2 * (y * cols + x)], c1 = A.cur_tex[2 * (y * cols + x) + 1];
+    hold2(c0, c1);
     if (c0.w == 0.0f) return false;
-    const float4 c1 = A.cur_tex[2 * (y * cols + x) + 1];
     const f3 vcur = mk3(c0.x, c0.y, c0.z), ncur = mk3(c1.x, c1.y, c1.z);
     f3 vg_ = add3(m33_mul(Rcurr, vcur), tcurr);
     f3 vcp = m33_mul(Rpi, sub3(vg_, tprev));
@@ -1120,7 +1128,8 @@ __device__ __forceinline__ bool icp_pixel_packed_rows(const IcpArgs &A, const fl
     int ux = (int)hd_rintf(fu), uy = (int)hd_rintf(fv);
     if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcp.z < 0.0f) return false;
     f3 ncur_g = m33_mul(Rcurr, ncur);
-    const float4 m0 = A.model_tex[2 * (uy * cols + ux)], m1 = A.model_tex[2 * (uy * cols + ux) + 1];
+    float4 m0 = A.model_tex[2 * (uy * cols + ux)], m1 = A.model_tex[2 * (uy * cols + ux) + 1];
+    hold2(m0, m1);
     if (m1.w == 0.0f) return false;
     const f3 bv = mk3(m0.x, m0.y, m0.z), bn = mk3(m1.x, m1.y, m1.z);
     float dist = len3(sub3(bv, vg_)), sine = len3(cross3(ncur_g, bn));
@@ -1264,10 +1273,15 @@ __device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S
     RgbCorr r; r.c0 = r.c1 = r.c2 = r.c3 = r.c4 = 0; r.diff = 0.0f;
     // the window / gradient / depth part of the test does not depend on the pose: k_odo_prepare evaluates it once per
     // frame (rgb_mask), the iterations read one byte instead of 16 + 2 + 1 values; the seam kernels pass no mask
-    const bool pre = L.rgb_mask ? L.rgb_mask[k] != 0 : rgb_residual_static_test(L, minScale, k);
+    // the pixel's own three values are requested together, and so are the two of the model pixel further down (five dependent
+    // round trips otherwise: mask, depth, model depth, model intensity, own intensity)
+    float d1 = L.next_depth[k];
+    int own_i = (int)L.next_image[k];
+    int mask_b = L.rgb_mask ? (int)L.rgb_mask[k] : 1;
+    asm volatile("" : "+v"(d1), "+v"(own_i), "+v"(mask_b));
+    const bool pre = L.rgb_mask ? mask_b != 0 : rgb_residual_static_test(L, minScale, k);
     if (!pre) return r;
     const int y = i, x = j0;
-    const float d1 = L.next_depth[y * cols + x];
     const float *krk = st->krk;
     float td1 = d1 * ((krk[6] * (float)x + krk[7] * (float)y) + krk[8]) + st->kt[2];
     float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + st->kt[0]) / td1;
@@ -1276,8 +1290,10 @@ __device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S
         int u0 = (int)hd_rintf(fu), v0 = (int)hd_rintf(fv);
         if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
             float d0 = L.last_depth[v0 * cols + u0];
-            if (d0 > 0.0f && hd_fabsf(td1 - d0) <= 0.07f && L.last_image[v0 * cols + u0] != 0) {
-                float diff = (float)L.next_image[y * cols + x] - (float)L.last_image[v0 * cols + u0];
+            int model_i = (int)L.last_image[v0 * cols + u0];
+            asm volatile("" : "+v"(d0), "+v"(model_i));
+            if (d0 > 0.0f && hd_fabsf(td1 - d0) <= 0.07f && model_i != 0) {
+                float diff = (float)own_i - (float)model_i;
                 r.c0 = (int16_t)u0; r.c1 = (int16_t)v0; r.c2 = (int16_t)x; r.c3 = (int16_t)y; r.c4 = 1;
                 r.diff = diff;
                 cnt += 1;
@@ -1555,23 +1571,33 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
     __shared__ float s_sigma;
     __shared__ int s_break;
     __shared__ long long s_res[2];
+    // The pixel's record and gradients, then the model point it names, are requested BEFORE the residual slots are folded (they
+    // do not depend on sigma): the fold's own round trip and its two barriers then run under the gather instead of in front of the
+    // record (residual slots -> record -> point were three dependent round trips).  A record left by an earlier iteration (the
+    // loop has stopped: `brk`) names a pixel of this level; it is read and not used.
+    const int k = p0 + blockIdx.x * RB + threadIdx.x;
+    int2 rec = make_int2(-1, 0);
+    int g = 0;
+    if (k < p1) {
+        rec = reinterpret_cast<const int2 *>(corres)[k];
+        g = L.dIxy[k];
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(g));
+    }
+    // an unconditional load (texel 0 stands in where there is no point to fetch): a load under a branch is waited for where the
+    // branch ends, in front of the fold
+    const uint32_t u0 = (uint32_t)rec.x & 0xffffu, v0 = (uint32_t)rec.x >> 16;
+    const bool has_point = rec.x != -1 && u0 < (uint32_t)L.cols && v0 < (uint32_t)L.rows;
+    const float4 cp = L.cloud4[has_point ? (size_t)v0 * L.cols + u0 : (size_t)0];
     fold_residual<false>(res_part, st->gn_break, st->lastRGBError, rgb_only, &s_sigma, &s_break, s_res);
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[174] = s_res[0]; totals[175] = s_res[1]; }
     const float sigma = s_sigma;
     const int brk = s_break;
     float out[29], row[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rw = 0.0f;
     bool valid = false;
-    const int k = p0 + blockIdx.x * RB + threadIdx.x;
-    if (!brk && k < p1) {
-        const int2 rec = reinterpret_cast<const int2 *>(corres)[k];
-        if (rec.x != -1) {
-            const int u0 = rec.x & 0xffff, v0 = (int)((uint32_t)rec.x >> 16);
-            const float4 cp = L.cloud4[(size_t)v0 * L.cols + u0];
-            const int g = L.dIxy[k];
-            rgb_row_core(__int_as_float(rec.y), cp.x, cp.y, cp.z, (int)(int16_t)(g & 0xffff), (int)(int16_t)((uint32_t)g >> 16),
-                         sigma, fx, fy, use_grad, row, rw);
-            valid = true;
-        }
+    if (!brk && k < p1 && rec.x != -1) {
+        rgb_row_core(__int_as_float(rec.y), cp.x, cp.y, cp.z, (int)(int16_t)(g & 0xffff), (int)(int16_t)((uint32_t)g >> 16),
+                     sigma, fx, fy, use_grad, row, rw);
+        valid = true;
     }
     products29(row, rw, out);   // formed after the control flow has merged; a lane without a correspondence contributes zeros
     out[28] = valid ? 1.0f : 0.0f;
