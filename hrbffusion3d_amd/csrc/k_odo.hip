@@ -1100,6 +1100,8 @@ __device__ __forceinline__ void products29(const float (&row)[7], float weight, 
 
 __device__ __forceinline__ bool icp_pixel_packed_rows(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
                                                       int x, int y, float (&row)[7], float &weight);
+__device__ __forceinline__ bool icp_pixel_packed_rows_pre(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                                          const float4 c0, const float4 c1, float (&row)[7], float &weight);
 
 __device__ __forceinline__ bool icp_pixel_packed(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
                                                  int x, int y, float *out)
@@ -1115,9 +1117,16 @@ __device__ __forceinline__ bool icp_pixel_packed(const IcpArgs &A, const float *
 __device__ __forceinline__ bool icp_pixel_packed_rows(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
                                                       int x, int y, float (&row)[7], float &weight)
 {
-    const int rows = A.rows, cols = A.cols;
+    const int cols = A.cols;
     float4 c0 = A.cur_tex[2 * (y * cols + x)], c1 = A.cur_tex[2 * (y * cols + x) + 1];
     hold2(c0, c1);
+    return icp_pixel_packed_rows_pre(A, Rcurr, tcurr, Rpi, tprev, c0, c1, row, weight);
+}
+// ... with the pixel's two texels already in registers (the Gauss-Newton kernel requests them beside the registration state)
+__device__ __forceinline__ bool icp_pixel_packed_rows_pre(const IcpArgs &A, const float *Rcurr, f3 tcurr, const float *Rpi, f3 tprev,
+                                                          const float4 c0, const float4 c1, float (&row)[7], float &weight)
+{
+    const int rows = A.rows, cols = A.cols;
     if (c0.w == 0.0f) return false;
     const f3 vcur = mk3(c0.x, c0.y, c0.z), ncur = mk3(c1.x, c1.y, c1.z);
     f3 vg_ = add3(m33_mul(Rcurr, vcur), tcurr);
@@ -1360,15 +1369,32 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
         for (int k = 0; k < 29; ++k) out[k] = 0.0f;
         bool valid = false;
         const int i = p0 + blockIdx.x * RB + threadIdx.x;
-        if (do_icp && !st->gn_break && i < p1) {
+        // the usual case (packed operands, no windowed search): the pixel's two texels and the registration state are requested side
+        // by side, before the loop's stop flag is looked at — hipcc had them in a chain (flag, arguments, texels, state: four
+        // dependent round trips in front of the model gather)
+        const bool usual = !SPARSE && A.cur_tex && !A.use_search;
+        // (unconditional loads — the head of the registration state stands in where there is no texel to fetch: a load under a
+        //  branch is waited for where the branch ends, in front of the state)
+        const float4 *tex = (usual && do_icp && i < p1) ? A.cur_tex + 2 * (size_t)i : reinterpret_cast<const float4 *>(st);
+        float4 c0 = tex[0], c1 = tex[1];
+        float Rc[9], Rp[9], tc[3], tp[3];
+        int brk = st->gn_break;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Rc[k] = st->Rcurr[k]; Rp[k] = st->Rprev_inv[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tc[k] = st->tcurr[k]; tp[k] = st->tprev[k]; }
+        asm volatile("" : "+s"(brk), "+s"(Rc[0]), "+s"(Rc[1]), "+s"(Rc[2]), "+s"(Rc[3]), "+s"(Rc[4]), "+s"(Rc[5]), "+s"(Rc[6]), "+s"(Rc[7]),
+                          "+s"(Rc[8]), "+s"(tc[0]), "+s"(tc[1]), "+s"(tc[2]));
+        asm volatile("" : "+s"(Rp[0]), "+s"(Rp[1]), "+s"(Rp[2]), "+s"(Rp[3]), "+s"(Rp[4]), "+s"(Rp[5]), "+s"(Rp[6]), "+s"(Rp[7]), "+s"(Rp[8]),
+                          "+s"(tp[0]), "+s"(tp[1]), "+s"(tp[2]));
+        hold2(c0, c1);
+        if (do_icp && !brk && i < p1) {
             const int y = i / A.cols, x = i - y * A.cols;
             if (SPARSE)
-                valid = icp_pixel_sparse(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
-                                         mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
-            else if (A.cur_tex && !A.use_search) {   // the usual case: packed operands, products formed after the early exits
+                valid = icp_pixel_sparse(A, Rc, mk3(tc[0], tc[1], tc[2]), Rp, mk3(tp[0], tp[1], tp[2]), x, y, out);
+            else if (usual) {   // products formed after the early exits
                 float row[7], weight;
-                valid = icp_pixel_packed_rows(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
-                                              mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, row, weight);
+                valid = icp_pixel_packed_rows_pre(A, Rc, mk3(tc[0], tc[1], tc[2]), Rp, mk3(tp[0], tp[1], tp[2]), c0, c1, row, weight);
                 if (!valid) {
                     weight = 0.0f;
 #pragma unroll
@@ -1377,8 +1403,7 @@ __global__ __launch_bounds__(RB) void k_gn_icp_residual(OdoLevel L, IcpArgs A, c
                 products29(row, weight, out);          // a lane without a match contributes 0 * 0 * 0
                 out[28] = valid ? 1.0f : 0.0f;
             } else
-                valid = icp_pixel(A, st->Rcurr, mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]), st->Rprev_inv,
-                                  mk3(st->tprev[0], st->tprev[1], st->tprev[2]), x, y, out);
+                valid = icp_pixel(A, Rc, mk3(tc[0], tc[1], tc[2]), Rp, mk3(tp[0], tp[1], tp[2]), x, y, out);
         }
         // icp_part rows are indexed by blockIdx.x in [0, nb); every path leaves exact zeros in the lanes it rejects
         block_reduce_exact<29, true>(out, valid, icp_part);
