@@ -1286,15 +1286,21 @@ __device__ __forceinline__ RgbCorr rgb_residual_pixel(const OdoLevel &L, const S
     // round trips otherwise: mask, depth, model depth, model intensity, own intensity)
     float d1 = L.next_depth[k];
     int own_i = (int)L.next_image[k];
-    int mask_b = L.rgb_mask ? (int)L.rgb_mask[k] : 1;
+    int mask_b = (int)*(L.rgb_mask ? L.rgb_mask + k : L.next_image + k);   // (an unconditional load: no wait where a branch would end)
+    float krk[9], kt[3];   // the warp's operands travel beside the pixel's values, not behind them
+#pragma unroll
+    for (int q = 0; q < 9; ++q) krk[q] = st->krk[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) kt[q] = st->kt[q];
+    asm volatile("" : "+s"(krk[0]), "+s"(krk[1]), "+s"(krk[2]), "+s"(krk[3]), "+s"(krk[4]), "+s"(krk[5]), "+s"(krk[6]), "+s"(krk[7]),
+                      "+s"(krk[8]), "+s"(kt[0]), "+s"(kt[1]), "+s"(kt[2]));
     asm volatile("" : "+v"(d1), "+v"(own_i), "+v"(mask_b));
-    const bool pre = L.rgb_mask ? mask_b != 0 : rgb_residual_static_test(L, minScale, k);
+    const bool pre = L.rgb_mask ? mask_b != 0 : rgb_residual_static_test(L, minScale, k);   // (no mask: the seam kernels)
     if (!pre) return r;
     const int y = i, x = j0;
-    const float *krk = st->krk;
-    float td1 = d1 * ((krk[6] * (float)x + krk[7] * (float)y) + krk[8]) + st->kt[2];
-    float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + st->kt[0]) / td1;
-    float fv = (d1 * ((krk[3] * (float)x + krk[4] * (float)y) + krk[5]) + st->kt[1]) / td1;
+    float td1 = d1 * ((krk[6] * (float)x + krk[7] * (float)y) + krk[8]) + kt[2];
+    float fu = (d1 * ((krk[0] * (float)x + krk[1] * (float)y) + krk[2]) + kt[0]) / td1;
+    float fv = (d1 * ((krk[3] * (float)x + krk[4] * (float)y) + krk[5]) + kt[1]) / td1;
     if (fu > -1.0e9f && fu < 1.0e9f && fv > -1.0e9f && fv < 1.0e9f) {
         int u0 = (int)hd_rintf(fu), v0 = (int)hd_rintf(fv);
         if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
@@ -1601,6 +1607,9 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
     // record (residual slots -> record -> point were three dependent round trips).  A record left by an earlier iteration (the
     // loop has stopped: `brk`) names a pixel of this level; it is read and not used.
     const int k = p0 + blockIdx.x * RB + threadIdx.x;
+    int brk0 = st->gn_break;
+    float last_err = st->lastRGBError;
+    asm volatile("" : "+s"(brk0), "+s"(last_err));   // (thread 0 read them behind the fold's first barrier)
     int2 rec = make_int2(-1, 0);
     int g = 0;
     if (k < p1) {
@@ -1613,7 +1622,7 @@ __global__ __launch_bounds__(RB) void k_gn_rgb_step(OdoLevel L, const OdoState *
     const uint32_t u0 = (uint32_t)rec.x & 0xffffu, v0 = (uint32_t)rec.x >> 16;
     const bool has_point = rec.x != -1 && u0 < (uint32_t)L.cols && v0 < (uint32_t)L.rows;
     const float4 cp = L.cloud4[has_point ? (size_t)v0 * L.cols + u0 : (size_t)0];
-    fold_residual<false>(res_part, st->gn_break, st->lastRGBError, rgb_only, &s_sigma, &s_break, s_res);
+    fold_residual<false>(res_part, brk0, last_err, rgb_only, &s_sigma, &s_break, s_res);
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[174] = s_res[0]; totals[175] = s_res[1]; }
     const float sigma = s_sigma;
     const int brk = s_break;
