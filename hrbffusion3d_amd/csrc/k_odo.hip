@@ -354,17 +354,43 @@ __device__ __forceinline__ void pyrdown_taps(const T *__restrict__ src, int srow
     const int ty = 2 * y + 3 < srows - 1 ? 2 * y + 3 : srows - 1;
     const int lx = 2 * x - 2 > 0 ? 2 * x - 2 : 0, ly = 2 * y - 2 > 0 ? 2 * y - 2 : 0;
     sum = 0.0f; count = 0;
+    // All 25 taps are requested before the first is used: a tap the border cuts off reads the clamped texel and is not used.  (With
+    // the loads under `if (cy < ly) continue` a lane waited for every tap where its branch ended — 25 dependent round trips, which
+    // made the four pyramid tasks the slowest of the 13 this kernel runs side by side.)
+    T tap[25];
 #pragma unroll
     for (int kr = 4; kr >= 0; --kr) {
         const int cy = ty - 1 - kr;
-        if (cy < ly) continue;
 #pragma unroll
         for (int kc = 4; kc >= 0; --kc) {
             const int cx = tx - 1 - kc;
-            if (cx < lx) continue;
+            tap[kr * 5 + kc] = src[(cy < ly ? ly : cy) * scols + (cx < lx ? lx : cx)];
+        }
+    }
+    {   // pinned: hipcc otherwise sinks every load into the block that uses it, and the chain is back
+        uint32_t raw[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            if constexpr (sizeof(T) == 4) raw[t] = __builtin_bit_cast(uint32_t, tap[t]); else raw[t] = (uint32_t)tap[t];
+        }
+        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
+                          "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]));
+        asm volatile("" : "+v"(raw[13]), "+v"(raw[14]), "+v"(raw[15]), "+v"(raw[16]), "+v"(raw[17]), "+v"(raw[18]), "+v"(raw[19]),
+                          "+v"(raw[20]), "+v"(raw[21]), "+v"(raw[22]), "+v"(raw[23]), "+v"(raw[24]));
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            if constexpr (sizeof(T) == 4) tap[t] = __builtin_bit_cast(T, raw[t]); else tap[t] = (T)raw[t];
+        }
+    }
+#pragma unroll
+    for (int kr = 4; kr >= 0; --kr) {
+        const int cy = ty - 1 - kr;
+#pragma unroll
+        for (int kc = 4; kc >= 0; --kc) {
+            const int cx = tx - 1 - kc;
             constexpr int w[5] = {1, 4, 6, 4, 1};
-            const T s = src[cy * scols + cx];
-            if (valid(s)) { sum += (float)s * (float)(w[kr] * w[kc]); count += w[kr] * w[kc]; }
+            const T s = tap[kr * 5 + kc];
+            if (cy >= ly && cx >= lx && valid(s)) { sum += (float)s * (float)(w[kr] * w[kc]); count += w[kr] * w[kc]; }
         }
     }
 }
