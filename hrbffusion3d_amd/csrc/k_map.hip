@@ -455,9 +455,22 @@ __global__ __launch_bounds__(256) void k_associate(Cam cam, const DevPose *__res
                           (hd_uv_attribute(ppx, cam.W) != hd_uv_fragment(ppx, cam.W) || hd_uv_attribute(ppy, cam.H) != hd_uv_fragment(ppy, cam.H));
         if (__ballot(need) != 0ull) {
             float *t = s_zf[threadIdx.x >> 6];
-            for (int e = lane; e < RT * RT; e += 64) {
-                const int gx = clampi(bx0 + e % RT, 0, cam.W - 1), gy = clampi(by0 + e / RT, 0, cam.H - 1);
-                t[e] = rn.depth_metric_f[gy * cam.W + gx];
+            // the lane's eight texels are requested together (as a loop this was load, wait, LDS store eight times over: eight
+            // dependent round trips at the head of a kernel that runs one wave per SIMD)
+            constexpr int NST = (RT * RT + 63) / 64;
+            float zv[NST];
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {
+                const int e = lane + r * 64, ee = e < RT * RT ? e : RT * RT - 1;
+                const int gx = clampi(bx0 + ee % RT, 0, cam.W - 1), gy = clampi(by0 + ee / RT, 0, cam.H - 1);
+                zv[r] = rn.depth_metric_f[gy * cam.W + gx];
+            }
+            static_assert(NST == 8, "the pin below lists eight values");
+            asm volatile("" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(zv[4]), "+v"(zv[5]), "+v"(zv[6]), "+v"(zv[7]));
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {
+                const int e = lane + r * 64;
+                if (e < RT * RT) t[e] = zv[r];
             }
         }
     }
