@@ -79,6 +79,14 @@ def parse():
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the one-sequence sharded leg (child processes)")
     ap.add_argument("--sharded-leg-timeout", type=float, default=420.0, help="seconds the sharded leg's child processes may take")
     ap.add_argument("--one-sequence-child", action="store_true", help=argparse.SUPPRESS)   # set by the parent for the sharded leg
+    ap.add_argument("--dataset", default=None,
+                    help="run a RECORDED sequence instead of the synthetic stream: a directory in the TUM RGB-D layout (rgb/, depth/, "
+                         "rgb.txt + depth.txt or associations.txt, groundtruth.txt) or the ICL-NUIM TUM-compatible PNG package, or a root "
+                         "that holds `rgbd_dataset_freiburg1_desk/` / `living_room_traj2_frei_png/` (see --sequence); BASELINE configs "
+                         "2 / 3, with the reference's GUI settings (hrbffusion3d_amd/datasets.py); same line shape, data: \"real\"")
+    ap.add_argument("--sequence", choices=["icl_nuim_lr_kt2", "tum_fr1_desk"], default=None, help="with --dataset ROOT: which sequence")
+    ap.add_argument("--dataset-kind", choices=["tum", "icl"], default=None, help="with --dataset DIR: override the layout detection")
+    ap.add_argument("--dataset-label", default=None, help=argparse.SUPPRESS)    # tests: say what the files really are
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: start the ranks (gloo), run the barrier / max-over-ranks / rank-count plumbing and the child-leg "
                          "launch, print the line's skeleton (tests/test_multigpu_gloo.py)")
@@ -557,8 +565,136 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def dataset_leg(args):
+    """BASELINE configs 2 / 3: a recorded sequence from its own files through the same timed loop (inputs decoded and resident in HBM
+    before timing, W untimed + exactly K timed frames of the whole processFrame, one synchronise either side), started from an empty
+    map like the reference's caller does, with the reference's GUI settings; ATE against the dataset's ground truth by the benchmark's
+    rule; roofline of the fuse pass from the event ring; the oracle on the first frames as cpu_baseline and bit-parity witness."""
+    import tempfile
+    import torch
+    from hrbffusion3d_amd import datasets as ds
+    from hrbffusion3d_amd.api import HRBFFusion
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.gpus != 1:
+        raise SystemExit("bench.py --dataset: one recorded sequence is one dependent chain of frames; run it with --gpus 1")
+    seq, name = args.dataset, args.sequence
+    if name is None:
+        for cand in ds.SEQUENCES:
+            if ds.find_sequence(args.dataset, cand):
+                name = cand
+                break
+    if name is not None and ds.find_sequence(args.dataset, name):
+        seq = ds.find_sequence(args.dataset, name)
+    if not (os.path.isdir(os.path.join(seq, "rgb")) and os.path.isdir(os.path.join(seq, "depth"))):
+        raise SystemExit("bench.py --dataset %s: no rgb/ and depth/ directories there (nor a known sequence below it)" % args.dataset)
+    kind = args.dataset_kind or (ds.SEQUENCES[name][0] if name else
+                                 ("icl" if any(os.path.isfile(os.path.join(seq, n)) for n in ds.GT_NAMES["icl"][:3]) else "tum"))
+    K, Wm = args.steps, args.warmup
+    work = tempfile.mkdtemp(prefix="hrbf_bench_dataset_")
+    info = ds.prepare(seq, work, kind, max_frames=Wm + K)
+    if info["frames"] < Wm + K:
+        raise SystemExit("bench.py --dataset: the sequence has %d associated frames, --warmup %d + --steps %d need %d" % (info["frames"], Wm, K, Wm + K))
+    t_dec = time.perf_counter()
+    frames = list(ds.read_frames(info, Wm + K))
+    t_dec = time.perf_counter() - t_dec
+    cam = info["camera"]
+    W, H = cam["width"], cam["height"]
+    cap = 4 * 1024 * 1024 + (W // 2) * (H // 2) * 8
+    prm = ds.params_for(info, max_surfels=cap)
+    torch.cuda.set_device(0)
+    fus = HRBFFusion(prm, device=0)
+    d_rgb = [torch.from_numpy(f[1]).cuda() for f in frames]
+    d_dep = [torch.from_numpy(f[2].view(np.int16)).cuda() for f in frames]
+    torch.cuda.synchronize()
+    for k in range(Wm):
+        fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), frames[k][0])
+    fus.synchronize()
+    count0 = fus.surfel_count()
+    fus.enable_timing(2)
+    fus.set_fuse_ring_stride(max(1, args.ring_stride))
+    fus.reset_fuse_ring()
+    torch.cuda.synchronize(); fus.synchronize()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        fus.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), frames[k][0])
+    t_enq = time.perf_counter() - t0
+    fus.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mm, ms2, st = fus.fuse_ring_parts(K)
+    ms = mm + ms2
+    ok = (mm >= 0) & (ms2 > 0)
+    B = 80.0 * (st[:, 0].astype(np.float64) + st[:, 3] + st[:, 1] + st[:, 2])
+    gbps = float((B[ok] / (ms[ok] * 1e-3)).mean() / 1e9) if ok.any() else 0.0
+    fuse_ms = float(ms[ok].mean()) if ok.any() else 0.0
+    merge_ms = float(mm[ok].mean()) if ok.any() else 0.0
+    count1 = fus.surfel_count()
+    traj = fus.pose_log(0, Wm + K)
+    status = fus.status()
+    fus.enable_timing(False)
+    ate = None
+    stamps = info["stamps_s"][:len(traj)]
+    if info["groundtruth"]:
+        gs, gp = ds.load_groundtruth(info["groundtruth"])
+        est = [np.asarray(T, np.float64).copy() for T in traj]
+        if info["icl_nuim"]:       # what the reference's writer does before anybody compares (TrajectoryManager.cpp:329)
+            for T in est:
+                T[1, 3] = -T[1, 3]
+        ate = ds.evaluate_ate(stamps, est, gs, gp)
+        ate_timed = ds.evaluate_ate(stamps[Wm:], est[Wm:], gs, gp)
+    # the oracle on the first frames of the same files: cpu_baseline (bounded sample) and the bit-parity witness
+    cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "skipped (--cpu-frames 0)"}
+    if args.cpu_frames > 0:
+        try:
+            from oracle_lib import Oracle
+            n = min(args.cpu_frames, Wm + K)
+            cores = min(len(os.sched_getaffinity(0)), 32)
+            os.environ["OMP_NUM_THREADS"] = str(cores)
+            o = Oracle(prm, omp=True)
+            t1 = time.perf_counter()
+            otraj = []
+            for k in range(n):
+                o.process_frame(frames[k][1], frames[k][2], frames[k][0])
+                otraj.append(o.get_pose())
+            t1 = time.perf_counter() - t1
+            o.close()
+            same = all(np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32)) for a, b in zip(otraj, traj[:n]))
+            e = np.asarray([a[:3, 3] for a in otraj], np.float64) - np.asarray([b[:3, 3] for b in traj[:n]], np.float64)
+            cpu = {"value": n / t1, "unit": "frames/s", "cores": cores, "kind": "port", "host_cores": len(os.sched_getaffinity(0)),
+                   "sample": "the first %d frames of the same sequence from an empty map (oracle, OpenMP, %d threads)" % (n, cores),
+                   "ate_vs_oracle_mm": float(1000.0 * np.sqrt((e ** 2).sum(1).mean())), "ate_vs_oracle_frames": n, "poses_bit_identical": bool(same)}
+        except Exception as e:
+            cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    label = args.dataset_label or {"icl_nuim_lr_kt2": "ICL-NUIM living-room kt2", "tum_fr1_desk": "TUM fr1/desk"}.get(name, os.path.basename(os.path.normpath(seq)))
+    out = {
+        "metric": "frames/sec at 640x480, 1M-surfel map, 1 MI355X; ATE vs reference",
+        "value": K / dt, "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "real" if not args.dataset_label else "synthetic",
+        "config": {"workload": "%s, %dx%d, %s layout read from %s, the reference's GUI settings with the sparse back-end off, from an empty map, "
+                               "full processFrame per step" % (label, W, H, "TUM RGB-D" if kind == "tum" else "ICL-NUIM (TUM-compatible PNG)", seq),
+                   "parallelism": "single GPU", "surfels_start": int(count0), "surfels_end": int(count1),
+                   "ate_rmse_mm": None if not ate or ate["rmse_m"] is None else 1000.0 * ate["rmse_m"], "ate_frames": None if not ate else ate["pairs"],
+                   "ate_timed_frames_rmse_mm": None if not ate or ate_timed["rmse_m"] is None else 1000.0 * ate_timed["rmse_m"],
+                   "ate_against": "the dataset's ground truth (%s): stamps associated within 20 ms, Horn alignment, translation RMSE" % info["groundtruth"],
+                   "ate_vs_oracle_mm": cpu.get("ate_vs_oracle_mm"),
+                   "intrinsics": [cam["fx"], cam["fy"], cam["cx"], cam["cy"]], "depth_factor": cam["factor"],
+                   "host_submit_ms_per_frame": 1e3 * t_enq / K, "png_decode_s_before_timing": t_dec},
+        "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
+                     "kernel": "k_apply_merges + k_clean_flags + k_fuse_stream (F2 + F3, every kernel of the pass)",
+                     "avg_kernel_ms": fuse_ms, "merge_ms": merge_ms, "clean_compact_ms": fuse_ms - merge_ms, "launches_timed": int(ok.sum()),
+                     "timed_every_nth_frame": max(1, args.ring_stride), "bytes_per_launch": float(B[ok].mean()) if ok.any() else 0.0,
+                     "note": "a map grown from one sequence (well under 1 M surfels) is cache-resident: three dependent launches of latency, "
+                             "not an HBM measurement — the HBM-bound leg is the default run's roofline_worst_case", "status": status},
+        "cpu_baseline": cpu,
+    }
+    fus.close()
+    print(json.dumps(out)); sys.stdout.flush()
+
+
 def main():
     args = parse()
+    if args.dataset:
+        return dataset_leg(args)
     if args.only_worst:
         print(json.dumps({"roofline_worst_case": worst_case_leg(args, int(os.environ.get("LOCAL_RANK", "0")))}))
         return

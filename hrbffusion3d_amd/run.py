@@ -115,7 +115,8 @@ def frame_source(args):
         for td, fd, tr, fr in hio.load_associations(os.path.join(args.tum, getattr(args, "assoc_name", "associations.txt"))):
             depth = np.asarray(Image.open(os.path.join(args.tum, fd)), np.uint16)
             rgb = np.asarray(Image.open(os.path.join(args.tum, fr)).convert("RGB"), np.uint8)
-            yield int(round(td * 1e6)), np.ascontiguousarray(rgb), np.ascontiguousarray(depth), None
+            # int64_t(t * 1000000.0): truncated, not rounded (GUI/src/Tools/RawImageReader.cpp:93)
+            yield int(np.float64(td) * np.float64(1000000.0)), np.ascontiguousarray(rgb), np.ascontiguousarray(depth), None
     else:
         for k in range(args.synthetic):
             rgb, depth, T = synth.frame(k, args.width, args.height, noise=args.noise, depth_units=args.depth_factor)

@@ -433,7 +433,7 @@ public:
     void read(size_t i, Frame &out) const
     {
         const Entry &e = entries_.at(i);
-        out.timestamp = (int64_t)std::llround(e.td * 1e6);
+        out.timestamp = (int64_t)(e.td * 1000000.0);   // truncated, not rounded: GUI/src/Tools/RawImageReader.cpp:93
         loadDepthPng(base_ + e.depth, W_, H_, out.depth);
         loadRgbPng(base_ + e.rgb, W_, H_, out.rgb);
     }

@@ -1,0 +1,185 @@
+"""BASELINE configs 2 / 3 end to end (GPU): ICL-NUIM living-room kt2 and TUM fr1/desk through the reference's caller loop
+(tools/hrbf_run.cpp: GlobalStateParam.txt with the reference's GUI settings + camera YAML + association file -> processFrame per
+frame -> trajectory in TrajectoryManager.cpp:313-344's format) -> ATE against the dataset's ground truth by the benchmark's rule
+(stamp association, Horn alignment), AND the HIP library == the CPU oracle bit for bit (every image, the map incl. order, the
+pose) on the first frames of the same files.
+
+The datasets are not in the image.  Point HRBF_DATASET_ROOT at a directory that holds `living_room_traj2_frei_png/` (+ the
+publisher's `livingRoom2.gt.freiburg`, inside or beside it) and / or `rgbd_dataset_freiburg1_desk/` and the two `real` tests
+run; unset, they skip with that reason.  Their synthetic-layout twins run always: the synthetic stream written to disk in each
+dataset's native layout (hrbffusion3d_amd/datasets.py), so that real data adds pixels, not code paths."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hrbffusion3d_amd import datasets as ds
+from hrbffusion3d_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA_ROOT = os.environ.get("HRBF_DATASET_ROOT", "")
+REPORT = os.path.join(ROOT, "gpurun_out", "r06_datasets_report.jsonl")
+
+
+def _report(rec):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+def _run_sequence(name, info, tmp, oracle_lib, parity_frames, max_surfels):
+    """the three legs every sequence takes; returns the ATE record"""
+    from test_cpp_io import _build
+    from test_parity_gpu import assert_same_state, bits
+    from hrbffusion3d_amd.api import HRBFFusion
+    assert info["groundtruth"], "no ground-truth file found for %s (looked for %s)" % (name, ", ".join(ds.GT_NAMES[info["kind"]]))
+    exe = _build(str(tmp))
+    traj = os.path.join(str(tmp), "hrbf_trajectory.freiburg")
+    # (1) the reference's caller loop in C++, the whole sequence
+    out = subprocess.run([exe, "--config", info["config"], "--out", traj, "--max-surfels", str(max_surfels)],
+                         capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    assert j["frames"] == info["frames"] and j["poses"] == info["frames"] and j["surfels"] > 0
+    # the file is in the reference's format: TUM prints seconds with six decimals, ICL-NUIM the integer microsecond stamp and -ty
+    first = open(traj).readline().split()
+    assert len(first) == 8
+    if info["icl_nuim"]:
+        assert first[0] == str(ds.reference_frame_stamp(info["stamps_s"][0]))
+    else:
+        assert first[0] == "%.6f" % (ds.reference_frame_stamp(info["stamps_s"][0]) / 1e6)
+    s, p = ds.load_saved_trajectory(traj, icl_nuim=info["icl_nuim"])
+    assert len(p) == info["frames"] and np.allclose(s, info["stamps_s"], atol=2e-6)
+    gs, gp = ds.load_groundtruth(info["groundtruth"])
+    ate = ds.evaluate_ate(s, p, gs, gp)
+    assert ate["rmse_m"] is not None and ate["pairs"] >= min(info["frames"], len(gs)) - 2, ate
+    # (2) HIP == oracle, bit for bit, on the first frames of the same files (same parameters as the runner derives)
+    prm = ds.params_for(info, max_surfels=max_surfels)
+    g = HRBFFusion(prm); o = oracle_lib.Oracle(prm, omp=True)
+    poses = []
+    try:
+        for ts, rgb, depth in ds.read_frames(info, parity_frames):
+            g.process_frame(rgb, depth, ts); o.process_frame(rgb, depth, ts)
+            a, b = o.get_pose(), g.get_pose()
+            assert np.array_equal(bits(a), bits(b)), "%s: pose differs at frame %d" % (name, len(poses))
+            poses.append(b)
+        assert_same_state(o, g, name)
+        count = g.surfel_count()
+    finally:
+        g.close(); o.close()
+    # (3) the C++ runner and the Python class saw the same frames: the file's first poses are those poses (%g: six digits)
+    for k, T in enumerate(poses):
+        t = np.asarray(T, np.float64)[:3, 3].copy()
+        if info["icl_nuim"]:
+            t[1] = -t[1]
+        assert np.allclose(np.asarray(p[k])[:3, 3], t, rtol=2e-6, atol=2e-6), (name, k)
+    _run_sequence.last_file_positions = np.asarray([np.asarray(x)[:3, 3] for x in p], np.float64)
+    rec = dict(sequence=name, data_dir=os.path.dirname(info["groundtruth"]), frames=info["frames"], ate=ate, surfels=j["surfels"],
+               fps_including_io=j["fps_including_io"], parity_frames=len(poses), parity_surfels=count, hip_equals_oracle=True)
+    _report(rec)
+    return rec
+
+
+def _twin(kind, tmp, n):
+    """the synthetic stream, noisy, 640x480, with the dataset's own intrinsics, in the dataset's own layout"""
+    if kind == "tum":
+        frames = [synth.frame(k, 640, 480, noise=True, K=synth.TUM_FR1) for k in range(n)]
+        seq = os.path.join(str(tmp), "data", "rgbd_dataset_freiburg1_desk")
+        ds.write_tum_layout(seq, frames)
+        name = "tum_fr1_desk"
+    else:
+        frames = [synth.frame(k, 640, 480, noise=True, K=synth.ICL_NUIM_NEG) for k in range(n)]     # the publisher's camera: fy < 0
+        seq = os.path.join(str(tmp), "data", "living_room_traj2_frei_png")
+        ds.write_icl_layout(seq, frames)
+        name = "icl_nuim_lr_kt2"
+    found = ds.find_sequence(os.path.join(str(tmp), "data"), name)
+    assert found == seq
+    return name, ds.prepare(found, os.path.join(str(tmp), "work"), kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tum", "icl"])
+def test_synthetic_stream_in_the_datasets_native_layout(tmp_path, gpu_available, oracle_lib_built, kind):
+    name, info = _twin(kind, tmp_path, 20)
+    rec = _run_sequence(name + " (synthetic twin)", info, tmp_path, oracle_lib_built, parity_frames=12, max_surfels=1 << 21)
+    # 20 noisy frames from an EMPTY map with the reference's settings: the young-map drift of DESIGN.md §8 (3.5 mm / 11 mm after the
+    # rigid alignment; tests/test_tracking_accuracy.py says where it comes from), the same number the oracle gives on the CPU
+    assert rec["ate"]["rmse_m"] < 0.02, rec
+    assert rec["ate"]["pairs"] == (19 if kind == "icl" else 20)
+    if kind == "icl":
+        # the mirrored-y convention without the help of an alignment: the tracker starts at the identity in a world whose y axis
+        # is flipped, the writer negates ty, so the file holds the motion relative to frame 0 in the TRUE world.  The camera
+        # climbs 5 cm in these 20 frames: with the wrong sign the last position is 10 cm off, with the right one a drift's worth
+        T0i = np.linalg.inv(synth.camera_pose(0))
+        rel = np.asarray([(T0i @ synth.camera_pose(k))[:3, 3] for k in range(20)])
+        est = _run_sequence.last_file_positions
+        assert abs(rel[19, 1]) > 0.04
+        assert np.linalg.norm(est[19] - rel[19]) < 0.03 and np.linalg.norm(est[19] * [1, -1, 1] - rel[19]) > 0.07
+
+
+def _real(name):
+    if not DATA_ROOT:
+        pytest.skip("HRBF_DATASET_ROOT is not set: the datasets are not in the image (README.md, 'Real datasets')")
+    seq = ds.find_sequence(DATA_ROOT, name)
+    if seq is None:
+        pytest.skip("no %s under HRBF_DATASET_ROOT=%s (directory names tried: %s)" % (name, DATA_ROOT, ", ".join(ds.SEQUENCES[name][1])))
+    return seq
+
+
+@pytest.mark.gpu
+def test_icl_nuim_living_room_kt2_real(tmp_path, gpu_available, oracle_lib_built):
+    """BASELINE config 2.  Sanity bound only: the reference publishes no ATE; the number goes to the report"""
+    seq = _real("icl_nuim_lr_kt2")
+    info = ds.prepare(seq, str(tmp_path / "work"), "icl")
+    rec = _run_sequence("icl_nuim_lr_kt2", info, tmp_path, oracle_lib_built, parity_frames=30, max_surfels=6 * 1024 * 1024)
+    assert rec["ate"]["rmse_m"] < 0.10, rec
+
+
+@pytest.mark.gpu
+def test_tum_fr1_desk_real(tmp_path, gpu_available, oracle_lib_built):
+    """BASELINE config 3 (front-end only, loop closure off)"""
+    seq = _real("tum_fr1_desk")
+    info = ds.prepare(seq, str(tmp_path / "work"), "tum")
+    rec = _run_sequence("tum_fr1_desk", info, tmp_path, oracle_lib_built, parity_frames=30, max_surfels=6 * 1024 * 1024)
+    assert rec["ate"]["rmse_m"] < 0.15, rec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tum", "icl"])
+def test_bench_dataset_leg_on_the_synthetic_twins(tmp_path, gpu_available, oracle_lib_built, kind):
+    """`bench.py --dataset DIR`: the same line shape as the default run, the layout detected from the directory, ATE against the
+    directory's ground truth, the oracle's poses of the first frames equal to the HIP path's bit for bit"""
+    import sys
+    name, info = _twin(kind, tmp_path, 18)
+    seq = os.path.join(str(tmp_path), "data")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dataset", seq, "--steps", "12", "--warmup", "4", "--cpu-frames", "6",
+                          "--dataset-label", "synthetic stream in the %s layout" % kind], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().split("\n")[-1])
+    assert j["metric"] == "frames/sec at 640x480, 1M-surfel map, 1 MI355X; ATE vs reference" and j["unit"] == "frames/s"
+    assert j["steps"] == 12 and j["warmup"] == 4 and j["n_gpus"] == 1 and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert abs(j["value"] - 1000.0 / j["ms_per_step"]) < 1e-6 * j["value"] and j["value"] > 30.0
+    c = j["config"]
+    assert ("ICL-NUIM" if kind == "icl" else "TUM RGB-D") in c["workload"] and c["surfels_end"] > c["surfels_start"] > 0
+    assert c["ate_frames"] == (15 if kind == "icl" else 16) and 0.0 < c["ate_rmse_mm"] < 20.0
+    assert c["intrinsics"][1] == (480.0 if kind == "icl" else 516.5)
+    b = j["cpu_baseline"]
+    assert b["poses_bit_identical"] is True and b["ate_vs_oracle_mm"] == 0.0 and b["ate_vs_oracle_frames"] == 6 and b["value"] > 0 and b["kind"] == "port"
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["launches_timed"] > 0 and 0.0 < r["frac"] < 1.0 and r["status"] == 0
+    _report(dict(bench_dataset_leg=kind, value=j["value"], ate_rmse_mm=c["ate_rmse_mm"], cpu=b["value"]))
+
+
+def test_bench_dataset_leg_refuses_what_it_cannot_run(tmp_path):
+    """no GPU needed: a directory without rgb/ and depth/ is refused before anything starts; so is a multi-GPU request"""
+    import sys
+    for extra, msg in (([], "no rgb/ and depth/"), (["--gpus", "2"], None)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dataset", str(tmp_path)] + extra, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert out.returncode != 0
+        if msg and "no HIP device" not in out.stderr:
+            assert msg in out.stderr
