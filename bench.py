@@ -778,6 +778,7 @@ def main():
     fus.enable_timing(2)     # only the events around the fuse pass (roofline); region events stay off
     fus.set_fuse_ring_stride(max(1, args.ring_stride))
     fus.reset_fuse_ring()
+    fus.comm_stats(reset=True)      # the library's collective counters cover exactly the timed frames
 
     barrier(); torch.cuda.synchronize(); fus.synchronize()
     t0 = time.perf_counter()
@@ -787,6 +788,7 @@ def main():
     fus.synchronize(); torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
 
+    comm_timed = fus.comm_stats()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -950,6 +952,28 @@ def main():
         except Exception as e:
             fit = {"error": repr(e)}
 
+    # the LIBRARY's own account of its communicator and of what it issued over the timed frames (hrbf_comm_stats): what RCCL itself
+    # reports as world size and rank for the library's communicator, and the exchange steps per frame (DESIGN.md §7's model)
+    lib_comm = None
+    if one_sequence or args.virtual_shards > 1:
+        cs = comm_timed
+        keys = ("world", "rank", "frames", "limb_allreduce", "limb_allreduce_bytes", "key_min_reduce", "key_min_reduce_bytes", "allgather",
+                "allgather_bytes", "word_allreduce", "send", "send_bytes", "recv", "recv_bytes", "host_barriers")
+        rows = [[cs[k] for k in keys]]
+        if dist is not None:
+            mine_cs = torch.tensor(rows[0], dtype=torch.int64, device="cuda")
+            all_cs = [torch.zeros_like(mine_cs) for _ in range(world)]
+            dist.all_gather(all_cs, mine_cs)
+            rows = [[int(v) for v in a.tolist()] for a in all_cs]
+        fr = max(1, rows[0][2])
+        lib_comm = {"transport": cs["transport"], "per_rank": [dict(zip(keys, r)) for r in rows],
+                    "world_sizes_reported_by_the_library": sorted(set(r[0] for r in rows)),
+                    "ranks_reported_by_the_library": sorted(r[1] for r in rows),
+                    "per_frame_rank0": {"limb_allreduce": rows[0][3] / fr, "key_min_reduce": rows[0][5] / fr, "allgather": rows[0][7] / fr,
+                                        "word_allreduce": rows[0][9] / fr, "send": rows[0][10] / fr, "recv": rows[0][12] / fr},
+                    "model": "per frame: 3 key min-reduces (one per projection), 1 counts all-gather (+ 1 first-id all-gather under hash "
+                             "ownership), 10 + 2 x 19 limb all-reduces when the registration is row-sharded, 1 one-word all-reduce per "
+                             "projection with peer-mapped images (or the packed records over send / recv)"}
     per_rank_fuse_ms = None
     coll = None
     if dist is not None:
@@ -972,7 +996,7 @@ def main():
         sharded = sharded_leg(args, rank, world, barrier, any_rank)
         if sharded is not None and "error" not in sharded:      # keep what the leg is for; the rest of the child's line repeats this one's
             sharded = {k: sharded.get(k) for k in ("workload", "value", "unit", "ms_per_step", "scaling", "n_gpus", "ranks_observed", "steps", "warmup",
-                                                   "per_rank_fuse_ms", "collectives", "wall_s_incl_setup")} | {
+                                                   "per_rank_fuse_ms", "collectives", "library_comm", "wall_s_incl_setup")} | {
                 "parallelism": sharded.get("config", {}).get("parallelism"), "surfels_end_rank0": sharded.get("config", {}).get("surfels_end"),
                 "final_translation_error_mm": sharded.get("config", {}).get("final_translation_error_mm"),
                 "status": sharded.get("roofline", {}).get("status")}
@@ -1022,6 +1046,7 @@ def main():
             "ranks_observed": ranks_observed,
             "per_rank_fuse_ms": per_rank_fuse_ms,      # [fuse pass ms, of which merge ms, live surfels] per rank
             "collectives": coll,
+            "library_comm": lib_comm,
             "sharded_one_sequence": sharded,
         }
         if args.cpu_frames > 0 and world == 1:

@@ -27,7 +27,7 @@ EXPORTS = [
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
     "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_peer_release_id", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts", "hrbf_hash_owner", "hrbf_hash_renumber_count", "hrbf_gn_graph_captures", "hrbf_fit_curvature", "hrbf_set_hrbf_fit", "hrbf_shard_exchange_mode",
-    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding",
+    "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding", "hrbf_comm_stats",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_dense_enough", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
     "hrbf_probe_single_workgroup_iteration", "hrbf_probe_sqrt_rounding", "hrbf_probe_exp_scaling", "hrbf_probe_division", "hrbf_set_fuse_ring_stride",
@@ -36,6 +36,17 @@ EXPORTS = [
 
 class HrbfError(RuntimeError):
     pass
+
+
+class CommCounters(C.Structure):
+    """mirror of hrbf_comm_counters (include/hrbf_mi355.h)"""
+    _fields_ = [("transport", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32), ("frames", C.c_int32)] + \
+               [(n, C.c_uint64) for n in ("limb_allreduce", "limb_allreduce_bytes", "key_min_reduce", "key_min_reduce_bytes", "allgather",
+                                          "allgather_bytes", "word_allreduce", "word_allreduce_bytes", "send", "send_bytes", "recv",
+                                          "recv_bytes", "host_barriers")]
+
+
+TRANSPORTS = {0: "none", 1: "rccl", 2: "shm", 3: "virtual"}
 
 
 def load_library():
@@ -97,6 +108,7 @@ def load_library():
     lib.hrbf_download_gids.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_shard_counts.argtypes = [vp, vp]
     lib.hrbf_hash_owner.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i32]; lib.hrbf_hash_renumber_count.argtypes = [vp]; lib.hrbf_gn_graph_captures.argtypes = [vp]; lib.hrbf_fit_curvature.argtypes = [vp, i32, f32, f32, f32, vp]; lib.hrbf_set_hrbf_fit.argtypes = [vp, i32]; lib.hrbf_shard_exchange_mode.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
+    lib.hrbf_comm_stats.argtypes = [vp, C.c_void_p, i32]
     lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
     lib.hrbf_dense_enough.argtypes = [vp, vp]
     lib.hrbf_predict_indices.argtypes = [vp, vp, i32, f32, i32]; lib.hrbf_fuse.argtypes = [vp, vp, i32, f32, i32]
@@ -260,6 +272,15 @@ class HRBFFusion:
         partition: "ranges" = contiguous ranges of the global order, "hash" = ownership by spatial hash of the surfel's cell"""
         mode = 0 if not enable else (2 if partition == "hash" else 1)
         self._check(self.lib.hrbf_map_shard_init(self.h, mode))
+
+    def comm_stats(self, reset=False):
+        """what the library's own communicator is and what the sharded paths have issued since the last reset (hrbf_comm_stats):
+        a dict of the hrbf_comm_counters fields, `transport` as a name"""
+        o = CommCounters()
+        self._check(self.lib.hrbf_comm_stats(self.h, C.byref(o), 1 if reset else 0))
+        d = {n: int(getattr(o, n)) for n, _ in CommCounters._fields_}
+        d["transport"] = TRANSPORTS.get(d["transport"], str(d["transport"]))
+        return d
 
     def shard_counts(self):
         """(partition, counts): partition 0 one map | 1 contiguous ranges | 2 spatial hash; live surfel counts of the G shards"""

@@ -56,6 +56,7 @@ struct MapShard {
     int tile_par;               // buffer the next pass accumulates into
     uint32_t *d_tile_done; uint32_t epoch;   // tile_done holds the epoch (pass counter) of the pass that raised it
     uint8_t *d_keep_flags;      // one byte per surfel + record: result of the clean test (pass A)
+    uint32_t *d_class_word;     // CLEAN_CLASS_WORD builds: {class, first window texel} per surfel from the projection in front of pass A
     uint32_t *d_merged_part;    // the merged count of the last fuse, one word per workgroup of k_apply_merges
     // ownership by spatial hash (kernels.h, ShardRef): allocated by hrbf_map_shard_init(c, 2)
     uint32_t *d_gid;            // cap words: the surfel's place in the global order, moved along with the planes
@@ -161,6 +162,9 @@ struct hrbf_context {
     uint8_t *d_submap_active; int n_submap_active;   // KeyFrameIDMap (null = all active)
     float *d_delta; int delta_cap;                   // updateModel matrices
     OdoComm comm;               // row-sharded registration (null comm + virtual_world <= 1: single GPU)
+    hrbf_comm_counters cstats;  // hrbf_comm_stats: what the sharded paths issued since the last reset
+    unsigned long long ar_count[2];   // limb all-reduces {calls, bytes}, bumped by launch_odometry through comm.ar_count
+    int ar_failed;              // launch_odometry: an all-reduce returned non-zero -> HRBF_STATUS_COLLECTIVE
     int fill_flag_fresh;        // DevPose::should_fill_in was computed by the last k_fillin (nothing touched the prediction since)
     OdoBuffers odo;
     // timing
@@ -214,6 +218,9 @@ static int alloc_shard(hrbf_context *c, MapShard &sh)
     sh.tile_dirty[0] = sh.tile_dirty[1] = 0; sh.tile_par = 0; sh.epoch = 0;
     if (!r) r = dalloc(&sh.d_tile_done, c->max_tiles);
     if (!r) r = dalloc(&sh.d_keep_flags, (size_t)c->cap + (size_t)c->Q + 64);
+#ifdef CLEAN_CLASS_WORD
+    if (!r) r = dalloc(&sh.d_class_word, (size_t)c->cap + 64);
+#endif
     if (!r) r = dalloc(&sh.d_merged_part, (size_t)merge_workgroups(c->Q));
     sh.count_ub = 0;
     return r;
@@ -221,9 +228,9 @@ static int alloc_shard(hrbf_context *c, MapShard &sh)
 static void free_shard(MapShard &sh)
 {
     free_planes(sh.map);
-    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count[0], sh.d_tile_count[1], sh.d_tile_done, sh.d_keep_flags, sh.d_merged_part};
+    void *q[] = {sh.d_slot, sh.d_stats, sh.d_tile_count[0], sh.d_tile_count[1], sh.d_tile_done, sh.d_keep_flags, sh.d_merged_part, sh.d_class_word};
     for (void *p : q) if (p) hipFree(p);
-    sh.d_slot = sh.d_stats = sh.d_tile_count[0] = sh.d_tile_count[1] = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr;
+    sh.d_slot = sh.d_stats = sh.d_tile_count[0] = sh.d_tile_count[1] = sh.d_tile_done = nullptr; sh.d_keep_flags = nullptr; sh.d_class_word = nullptr;
     sh.d_merged_part = nullptr;
     void *hq[] = {sh.d_gid, sh.d_own_local, sh.d_rec_lbest, sh.d_zpriv};
     for (void *p : hq) if (p) hipFree(p);
@@ -375,8 +382,10 @@ struct RcclApi {
     int (*Recv)(void *recv, size_t count, int dtype, int peer, void *comm, hipStream_t s);
     int (*GroupStart)();
     int (*GroupEnd)();
+    int (*CommCount)(void *comm, int *count);        // optional (hrbf_comm_stats)
+    int (*CommUserRank)(void *comm, int *rank);      // optional
 };
-RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 // ncclDataType_t / ncclRedOp_t values (rccl.h)
 const int kNcclUint32 = 3, kNcclInt64 = 4, kNcclUint64 = 5, kNcclSum = 0, kNcclMin = 3;
 
@@ -396,6 +405,8 @@ int rccl_load()
     g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(lib, "ncclRecv");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(lib, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(lib, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather ||
         !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         hrbf_set_error("librccl.so lacks an expected entry point"); dlclose(lib); return HRBF_ERR_COMM;
@@ -422,6 +433,8 @@ int rccl_allgather_u32(void *comm, const uint32_t *own, uint32_t *row, size_t co
     return g_rccl.AllGather(own, row, count_each, kNcclUint32, comm, s);
 }
 }   // namespace
+// hrbf_comm_stats: one exchange step of kind `what` issued, `bytes` contributed by this rank
+#define COMM_COUNT(c, what, bytes) do { (c)->cstats.what += 1; (c)->cstats.what##_bytes += (uint64_t)(bytes); } while (0)
 
 extern "C" void hrbf_destroy(hrbf_handle c)
 {
@@ -537,6 +550,16 @@ static void st_conf(hrbf_context *c)
     launch_confidence(c->stream, c->cam, c->d_gradmag, c->d_confidence, &c->d_pose->weighting, c->prm.use_conf_eval,
                       c->prm.conf_eval_epsilon);
 }
+// a test hook's environment variable names THIS rank: a complete non-negative decimal number equal to it (atoi would read "",
+// "abc" and "0x1" as rank 0)
+static bool env_names_rank(const char *name, int rank)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return false;
+    char *end = nullptr;
+    const long n = strtol(v, &end, 10);
+    return end != v && *end == 0 && n >= 0 && n == (long)rank;
+}
 // ---- peer link -----------------------------------------------------------------------------------------------------------
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -549,6 +572,7 @@ static int peer_barrier_host(hrbf_context *c)
     // rank leaves this barrier with the same verdict instead of the healthy ones spinning for a minute (round-3 advice)
     const bool bad = hipStreamSynchronize(c->stream) != hipSuccess;
     if (bad) { pl.shm->failed = 1u; __sync_synchronize(); }
+    c->cstats.host_barriers += 1;
     const uint32_t target = ++pl.gen * (uint32_t)pl.world;
     __sync_fetch_and_add(&pl.shm->arrived, 1u);
     struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -574,9 +598,9 @@ static int shm_allreduce_i64(void *ctx, long long *buf, size_t n, hipStream_t s)
     hrbf_context *c = (hrbf_context *)ctx;
     PeerLink &pl = c->peer;
     if (!pl.shm_mode || n > PEER_RED_WORDS) return -1;
-    long long mine[PEER_RED_WORDS];
+    long long mine[PEER_RED_WORDS] = {0};
     hipMemcpyAsync(mine, buf, sizeof(long long) * n, hipMemcpyDeviceToHost, s);
-    (void)hipStreamSynchronize(s);              // an error here is reported by the barrier below, which this rank still reaches
+    if (hipStreamSynchronize(s) != hipSuccess) { pl.shm->failed = 1u; __sync_synchronize(); }   // `mine` may be stale: every rank leaves the barrier below with the failure
     const int slot = (int)((pl.gen + 1u) & 1u);
     for (size_t i = 0; i < n; ++i) pl.shm->red[slot][pl.rank][i] = mine[i];
     __sync_synchronize();
@@ -592,6 +616,7 @@ static int shm_allreduce_i64(void *ctx, long long *buf, size_t n, hipStream_t s)
 // the point after which every rank's writes into this rank's images are complete
 static int peer_meet(hrbf_context *c)
 {
+    COMM_COUNT(c, word_allreduce, 4);
     if (c->peer.shm_mode) return peer_barrier_host(c);
     return rccl_allreduce_sum_u32(c->comm.comm, c->peer.d_token, 1, c->stream) == 0 ? HRBF_OK : HRBF_ERR_COMM;
 }
@@ -633,6 +658,7 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
     uint32_t *d = nullptr;   // RCCL transport: device staging of the handle bytes (448 B per rank) + the agreement word
     const size_t words = sizeof(all[0]) / 4;
     if (pl.shm_mode) {
+        COMM_COUNT(c, allgather, sizeof(all[me]));
         memcpy((void *)pl.shm->handles[me], all[me], sizeof(all[me]));
         if (fail) pl.shm->map_failed = 1u;
         __sync_synchronize();
@@ -644,6 +670,7 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
         int e = 0;
         if (d) {
             hipMemcpyAsync(d + (size_t)me * words, all[me], sizeof(all[me]), hipMemcpyHostToDevice, c->stream);
+            COMM_COUNT(c, allgather, words * 4);
             e = rccl_allgather_u32(c->comm.comm, d + (size_t)me * words, d, words, c->stream);
             hipMemcpyAsync(all, d, sizeof(all[0]) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
         }
@@ -664,11 +691,12 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
         pi.zbuf[g] = (unsigned long long *)q[0]; pi.vertconf[g] = (float4 *)q[1]; pi.normrad[g] = (float4 *)q[2];
         pi.colortime[g] = (float4 *)q[3]; pi.curvmax[g] = (float4 *)q[4]; pi.curvmin[g] = (float4 *)q[5]; pi.clean[g] = (float4 *)q[6]; pi.gid[g] = (uint32_t *)q[7];
     }
-    const char *forced = getenv("HRBF_TEST_FAIL_PEER_MAP");   // tests: this rank pretends its mapping failed ("all" or a rank number)
-    if (forced && (!strcmp(forced, "all") || atoi(forced) == me)) fail = 1;
+    const char *forced = getenv("HRBF_TEST_FAIL_PEER_MAP");   // tests: this rank pretends its mapping failed ("all" or a complete rank number)
+    if (forced && (!strcmp(forced, "all") || env_names_rank("HRBF_TEST_FAIL_PEER_MAP", me))) fail = 1;
     uint32_t failed_ranks = 0;
     if (pl.shm_mode) {
         if (fail) { pl.shm->map_failed = 1u; __sync_synchronize(); }
+        COMM_COUNT(c, word_allreduce, 4);
         const int r = peer_barrier_host(c);    // nobody touches a peer's memory before everybody has mapped it — or has said it cannot
         if (r) return r;
         failed_ranks = pl.shm->map_failed;
@@ -676,6 +704,7 @@ static int peer_map_images(hrbf_context *c, int *all_mapped)
         const uint32_t f = (uint32_t)fail;
         uint32_t *w = d + COMM_SCRATCH_VOTE;
         hipMemcpyAsync(w, &f, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        COMM_COUNT(c, word_allreduce, 4);
         const int e = rccl_allreduce_sum_u32(c->comm.comm, w, 1, c->stream);
         hipMemcpyAsync(&failed_ranks, w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         const hipError_t se = hipStreamSynchronize(c->stream);
@@ -723,7 +752,9 @@ static void request_count(hrbf_context *c)
 // single-process test mode reduces the private outputs of the virtual shards with local kernels instead (st_indices).
 static void shard_allgather_counts(hrbf_context *c, uint32_t *row)
 {
+    if (c->nsh > 1) COMM_COUNT(c, allgather, 4);      // one process playing all shards: the row is already whole
     if (!c->shard_real) return;
+    COMM_COUNT(c, allgather, 4);
     if (c->peer.shm_mode) {   // through the rendezvous segment (double buffered by barrier generation)
         PeerLink &pl = c->peer;
         uint32_t mine = 0;
@@ -749,7 +780,9 @@ static void hash_refresh_gfirst(hrbf_context *c, const uint32_t *counts_row)
     const uint32_t *gids[HRBF_MAX_SHARDS];
     for (int k = 0; k < c->nsh; ++k) gids[k] = c->sh[k].d_gid;
     launch_gfirst(c->stream, counts_row, c->shard_first, c->nsh, gids, c->d_gfirst, 0);
+    if (c->nsh > 1) COMM_COUNT(c, allgather, 4);
     if (!c->shard_real) return;
+    COMM_COUNT(c, allgather, 4);
     uint32_t mine = HRBF_NO_SURFEL, all[HRBF_PEER_MAX];
     if (c->peer.shm_mode) {   // through the rendezvous segment, like the counts
         PeerLink &pl = c->peer;
@@ -813,7 +846,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7, boo
 {
     const float maxd = c->prm.max_depth_processed;
     const float cthr = c->prm.confidence_threshold;
-#define CLS(k) (classes ? c->sh[k].d_keep_flags : nullptr), cthr
+#define CLS(k) (classes ? c->sh[k].d_keep_flags : nullptr), cthr, c->sh[k].d_class_word, c->prm.clean_window_multiplier
     float4 *ctex = for_clean ? c->d_clean_tex : nullptr;
     if (for_clean && (what & 4)) { c->clean_thr = c->prm.confidence_threshold; c->clean_time = c->tick; }
     if (c->G == 1 && !c->shard_real) {
@@ -840,6 +873,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7, boo
 #undef CLS
         if (k > 0) launch_zbuf_min_merge(c->stream, c->d_zbuf, c->x.zbuf, c->P);
     }
+    if (c->shard_real || c->nsh > 1) COMM_COUNT(c, key_min_reduce, 8 * (size_t)c->P);   // RCCL below; shm: barrier + launch_zbuf_min_peers; virtual: launch_zbuf_min_merge / launch_keys_global above
     if (c->shard_real && c->comm.comm) rccl_allreduce_min_u64(c->comm.comm, c->d_zbuf, (size_t)c->P, c->stream);
     const uint32_t cap = (uint32_t)c->P;
     float4 *ctx_clean = for_clean ? c->d_clean_tex : nullptr;
@@ -883,6 +917,7 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7, boo
                    c->clean_time, cnt, c->x.send_idx, c->x.send_f, cap, 1, c->sh[0].d_zpriv);
     if (!c->comm.comm || G == 1) return;
     // sizes of the variable-length exchange: all-gather of the record counts, read back (the one host round trip of the pass)
+    COMM_COUNT(c, allgather, 4);
     rccl_allgather_u32(c->comm.comm, cnt, c->x.rec_count, 1, c->stream);
     hipMemcpyAsync(c->x.h_counts, c->x.rec_count, sizeof(uint32_t) * (size_t)G, hipMemcpyDeviceToHost, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return;
@@ -897,11 +932,11 @@ static void st_indices(hrbf_context *c, bool for_clean = true, int what = 7, boo
         if (p == me) continue;
         const uint32_t n_p = c->x.h_counts[p];
         if (off + n_p > cap) break;   // cannot happen: a pixel has one owner, so the counts of all ranks add up to <= P
-        if (n_me) g_rccl.Send(c->x.send_idx, n_me, kNcclUint32, p, c->comm.comm, c->stream);
-        if (n_p) g_rccl.Recv(c->x.recv_idx + off, n_p, kNcclUint32, p, c->comm.comm, c->stream);
+        if (n_me) { COMM_COUNT(c, send, 4 * (size_t)n_me); g_rccl.Send(c->x.send_idx, n_me, kNcclUint32, p, c->comm.comm, c->stream); }
+        if (n_p) { COMM_COUNT(c, recv, 4 * (size_t)n_p); g_rccl.Recv(c->x.recv_idx + off, n_p, kNcclUint32, p, c->comm.comm, c->stream); }
         for (int t = 0; t < np; ++t) {
-            if (n_me) g_rccl.Send(c->x.send_f + (size_t)planes[t] * cap, (size_t)n_me * 4, kNcclUint32, p, c->comm.comm, c->stream);
-            if (n_p) g_rccl.Recv(c->x.recv_f + (size_t)planes[t] * cap + off, (size_t)n_p * 4, kNcclUint32, p, c->comm.comm, c->stream);
+            if (n_me) { COMM_COUNT(c, send, 16 * (size_t)n_me); g_rccl.Send(c->x.send_f + (size_t)planes[t] * cap, (size_t)n_me * 4, kNcclUint32, p, c->comm.comm, c->stream); }
+            if (n_p) { COMM_COUNT(c, recv, 16 * (size_t)n_p); g_rccl.Recv(c->x.recv_f + (size_t)planes[t] * cap + off, (size_t)n_p * 4, kNcclUint32, p, c->comm.comm, c->stream); }
         }
         off += n_p;
     }
@@ -942,6 +977,7 @@ static int read_counts(hrbf_context *c, uint32_t out[HRBF_MAX_SHARDS]);
 static int peer_vote(hrbf_context *c, int fail)
 {
     if (!c->shard_real) return fail ? 1 : 0;
+    COMM_COUNT(c, word_allreduce, 4);
     if (c->peer.shm_mode) {
         if (fail) { c->peer.shm->failed = 1u; __sync_synchronize(); }
         return peer_barrier_host(c) != HRBF_OK ? 1 : 0;
@@ -965,8 +1001,9 @@ static int hash_renumber(hrbf_context *c)
 {
     uint32_t cnt[HRBF_MAX_SHARDS] = {0};
     int rc = HRBF_OK;
-    const char *inject = getenv("HRBF_TEST_FAIL_RENUMBER");      // tests: this rank pretends an allocation failed
-    if (inject && atoi(inject) == c->comm.rank) { hrbf_set_error("hash ownership: id renumbering: injected failure"); rc = HRBF_ERR_DEVICE; }
+    // tests: this rank pretends an allocation failed.  The value must be a complete decimal rank number and the map one shard
+    // per rank: "" / "yes" / "0x1" inject nothing, and a single process (whose rank is always 0) is never hit by a stray "0"
+    if (c->shard_real && env_names_rank("HRBF_TEST_FAIL_RENUMBER", c->comm.rank)) { hrbf_set_error("hash ownership: id renumbering: injected failure"); rc = HRBF_ERR_DEVICE; }
     if (rc == HRBF_OK && read_counts(c, cnt)) { hrbf_set_error("hash ownership: id renumbering: the counts could not be read"); rc = HRBF_ERR_DEVICE; }
     uint64_t total = 0;
     for (int g = 0; g < c->G; ++g) total += cnt[g];
@@ -1001,6 +1038,7 @@ static int hash_renumber(hrbf_context *c)
     // ---- phase B
     if (records) {
         hipMemcpyAsync(gathered + (size_t)c->comm.rank * maxc, c->sh[0].d_gid, sizeof(uint32_t) * (size_t)maxc, hipMemcpyDeviceToDevice, c->stream);
+        COMM_COUNT(c, allgather, 4 * (size_t)maxc);
         if (rccl_allgather_u32(c->comm.comm, gathered + (size_t)c->comm.rank * maxc, gathered, maxc, c->stream) != 0) rc = HRBF_ERR_COMM;
         for (int g = 0; g < c->G; ++g) ptrs[g] = gathered + (size_t)g * maxc;
     }
@@ -1059,7 +1097,7 @@ static int st_clean(hrbf_context *c, bool have_class = false)
                      ring ? c->ring_e1[c->ring_head % HRBF_RING] : nullptr, c->d_submap_active, c->n_submap_active,
                      last ? c->Q : 0, (c->shard_real || k == c->nsh - 1) ? 1 : 0,
                      ring ? c->d_stats_ring + (size_t)(c->ring_head % HRBF_RING) * 8 : nullptr, sh.d_merged_part,
-                     c->hash_mode ? sh.d_gid : nullptr, c->g_next, c->G, gk, c->hash_inv_cell, have_class ? 1 : 0);
+                     c->hash_mode ? sh.d_gid : nullptr, c->g_next, c->G, gk, c->hash_inv_cell, have_class ? 1 : 0, sh.d_class_word);
         sh.tile_dirty[cur] = dirty[0]; sh.tile_dirty[1 - cur] = dirty[1]; sh.tile_par = 1 - cur;
         if (last) {
             const uint64_t ub = (uint64_t)sh.count_ub + (uint64_t)c->Q;
@@ -1122,6 +1160,7 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
     OdoConfig cfg = make_cfg(c);
     const bool sharded = (c->comm.allreduce_i64 != nullptr || c->comm.virtual_world > 1) && !c->rows_replicated;
     launch_odometry(c->stream, c->odo, src, cfg, c->d_pose, sharded ? &c->comm : nullptr, weight_multiplier, c->level0_done);
+    if (c->ar_failed) { c->status |= HRBF_STATUS_COLLECTIVE; c->ar_failed = 0; }   // either transport: the solve ran on unreduced sums
     c->level0_done = 0;
 }
 
@@ -1130,6 +1169,7 @@ static void st_odometry(hrbf_context *c, float weight_multiplier = -1.0f)
 static int process_frame_resident(hrbf_context *c, float wmul)
 {
     hipSetDevice(c->device);
+    c->cstats.frames += 1;
     if (c->renumber_failed) { hrbf_set_error("hash ownership: the id space is exhausted and renumbering failed (HRBF_STATUS_ID_SPACE)%s", c->shard_real ? "; final for a map shared by ranks" : "; clear the status to retry"); return HRBF_ERR_DEVICE; }
     int frame_rc = HRBF_OK;
     char frame_err[200] = "";
@@ -1395,6 +1435,26 @@ __global__ void k_map_from_aos(MapPlanes m, uint32_t n, const float4 *__restrict
 
 // The local shards in global order: the whole map for a single-GPU context and in the single-process sharded mode;
 // a rank of a sharded map returns its own range (its size: hrbf_local_surfel_count).
+extern "C" int hrbf_comm_stats(hrbf_handle c, hrbf_comm_counters *out, int reset)
+{
+    if (!c || !out) return HRBF_ERR_INVALID;
+    *out = c->cstats;
+    out->limb_allreduce = c->ar_count[0]; out->limb_allreduce_bytes = c->ar_count[1];
+    out->transport = HRBF_TRANSPORT_NONE; out->world = 1; out->rank = 0;
+    if (c->comm.comm) {
+        // the library's own communicator, asked directly: what RCCL says, not what hrbf_comm_init was told
+        out->transport = HRBF_TRANSPORT_RCCL; out->world = -1; out->rank = -1;
+        int n = 0, r = 0;
+        if (g_rccl.CommCount && g_rccl.CommCount(c->comm.comm, &n) == 0) out->world = n;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm.comm, &r) == 0) out->rank = r;
+    } else if (c->peer.shm_mode) {
+        out->transport = HRBF_TRANSPORT_SHM; out->world = c->peer.world; out->rank = c->peer.rank;
+    } else if (c->comm.virtual_world > 1 || c->nsh > 1) {
+        out->transport = HRBF_TRANSPORT_VIRTUAL; out->world = c->comm.virtual_world > 1 ? c->comm.virtual_world : c->nsh; out->rank = 0;
+    }
+    if (reset) { memset(&c->cstats, 0, sizeof(c->cstats)); c->ar_count[0] = c->ar_count[1] = 0; }
+    return HRBF_OK;
+}
 extern "C" uint32_t hrbf_local_surfel_count(hrbf_handle c)
 {
     if (!c) return 0;
@@ -2046,7 +2106,8 @@ extern "C" int hrbf_comm_init(hrbf_handle c, int rank, int world, const uint8_t 
     if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
     if (c->d_comm_scratch) { hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; }
     peer_close(c); peer_shm_release(c);
-    c->comm.rank = 0; c->comm.world = 1; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
+    c->comm.rank = 0; c->comm.world = 1; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr; c->comm.ar_count = c->ar_count; c->comm.ar_failed = &c->ar_failed;
+    memset(&c->cstats, 0, sizeof(c->cstats)); c->ar_count[0] = c->ar_count[1] = 0;
     if (rank < 0) { c->comm.virtual_world = world > 1 ? world : 0; return HRBF_OK; }
     if (rank >= world || !id128) return HRBF_ERR_INVALID;
     int r = rccl_load();
@@ -2095,7 +2156,8 @@ extern "C" int hrbf_comm_init_peer(hrbf_handle c, int rank, int world, const uin
     if (c->comm.comm) { g_rccl.CommDestroy(c->comm.comm); c->comm.comm = nullptr; }
     if (c->d_comm_scratch) { hipFree(c->d_comm_scratch); c->d_comm_scratch = nullptr; }
     peer_close(c); peer_shm_release(c);
-    c->comm.rank = rank; c->comm.world = world; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr;
+    c->comm.rank = rank; c->comm.world = world; c->comm.virtual_world = 0; c->comm.allreduce_i64 = nullptr; c->comm.ar_count = c->ar_count; c->comm.ar_failed = &c->ar_failed;
+    memset(&c->cstats, 0, sizeof(c->cstats)); c->ar_count[0] = c->ar_count[1] = 0;
     PeerLink &pl = c->peer;
     memcpy(pl.shm_name, id128, 63); pl.shm_name[63] = 0;
     const int fd = shm_open(pl.shm_name, O_RDWR, 0600);
@@ -2282,8 +2344,8 @@ extern "C" int hrbf_map_rebalance(hrbf_handle c)
             float4 *sp = src_local ? map_plane(c->sh[a - first].map, pl) + so : nullptr;
             float4 *dp = dst_local ? map_plane(tmp[b - first], pl) + d_o : nullptr;
             if (src_local && dst_local) hipMemcpyAsync(dp, sp, sizeof(float4) * len, hipMemcpyDeviceToDevice, c->stream);
-            else if (src_local) g_rccl.Send(sp, len * 4, kNcclUint32, b, c->comm.comm, c->stream);
-            else if (dst_local) g_rccl.Recv(dp, len * 4, kNcclUint32, a, c->comm.comm, c->stream);
+            else if (src_local) { COMM_COUNT(c, send, 16 * len); g_rccl.Send(sp, len * 4, kNcclUint32, b, c->comm.comm, c->stream); }
+            else if (dst_local) { COMM_COUNT(c, recv, 16 * len); g_rccl.Recv(dp, len * 4, kNcclUint32, a, c->comm.comm, c->stream); }
         }
     }
     if (c->shard_real) g_rccl.GroupEnd();

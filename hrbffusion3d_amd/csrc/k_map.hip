@@ -154,6 +154,14 @@ __device__ __forceinline__ uint32_t shard_offset(const ShardRef &sh)
 // about to overwrite: a STABLE surfel outside the frustum is kept whatever else it holds (copy_unstable.vert:62-166 tests nothing
 // on it), so pass A reads one byte for it instead of its 16-byte position — on a map that is mostly out of view the position
 // stream of pass A shrinks to the surfels that need a test.  The projection has the position in a register anyway.
+// ONE statement of "the surfel projects into the frustum" (copy_unstable.vert:77-83), used by the projection's class and by the
+// clean test itself: the class is trusted by pass A, so the two must never drift apart (round-5 advice)
+__device__ __forceinline__ bool project_in_view(const Cam &cam, f3 h, float maxDepth, float &u, float &v)
+{
+    u = ((cam.fx * h.x) / h.z) + cam.cx;
+    v = ((cam.fy * h.y) / h.z) + cam.cy;
+    return h.z < maxDepth && h.z > 0.0f && u > 0.0f && v > 0.0f && u < (float)cam.W && v < (float)cam.H;
+}
 #define CLEAN_CLASS_OUT_STABLE 0
 #define CLEAN_CLASS_OUT_UNSTABLE 1
 #define CLEAN_CLASS_IN_VIEW 2
@@ -162,7 +170,11 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
                                                  unsigned long long *__restrict__ zbuf,
                                                  const float4 *__restrict__ color_time /* read only with a mask */,
                                                  const uint8_t *__restrict__ submap_active /* nullable */, int n_active,
-                                                 uint8_t *__restrict__ item_class /* nullable: see CLEAN_CLASS_* */, float confThr)
+                                                 uint8_t *__restrict__ item_class /* nullable: see CLEAN_CLASS_* */, float confThr
+#ifdef CLEAN_CLASS_WORD
+                                                 , uint32_t *__restrict__ item_word /* nullable: class | first window texel, see below */, float wm
+#endif
+                                                 )
 {
     // ids in the keys are GLOBAL for contiguous ranges; LOCAL in the private z-buffer of a hash-owned shard (kernels.h)
     const uint32_t n = sh.counts[sh.k], off = sh.gid ? 0u : shard_offset(sh);
@@ -186,11 +198,24 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
             if (s >= n) continue;
             const float4 p = pk[k];
             f3 h = xform(tinv, xyz(p));
-            float u = ((cam.fx * h.x) / h.z) + cam.cx;
-            float v = ((cam.fy * h.y) / h.z) + cam.cy;
+            float u, v;
+            const bool inv = project_in_view(cam, h, maxDepth, u, v);
             if (item_class) {   // the projection in front of the clean pass: this lane holds what pass A's first decision needs
-                const bool inv = h.z < maxDepth && h.z > 0.0f && u > 0.0f && v > 0.0f && u < (float)cam.W && v < (float)cam.H;   // = in_view()
-                item_class[s] = inv ? CLEAN_CLASS_IN_VIEW : (p.w < confThr ? CLEAN_CLASS_OUT_UNSTABLE : CLEAN_CLASS_OUT_STABLE);
+                const uint32_t cl = inv ? CLEAN_CLASS_IN_VIEW : (p.w < confThr ? CLEAN_CLASS_OUT_UNSTABLE : CLEAN_CLASS_OUT_STABLE);
+#ifdef CLEAN_CLASS_WORD
+                // ... and where its window starts: the first texel of the half-pixel walk of either axis (the walk visits that texel and
+                // the next two, hd_halfpixel_walk), so pass A can request the window's texels TOGETHER with the item's planes instead of
+                // behind the projected position it would first have to compute from them (the last dependent round trip of the pass)
+                if (item_word) {
+                    uint32_t word = cl;
+                    if (inv) {
+                        const hd_walk wx = hd_halfpixel_walk(u, cam.W, wm), wy = hd_halfpixel_walk(v, cam.H, wm);
+                        word |= ((uint32_t)hd_window_texel(wx.lo, cam.W) << 2) | ((uint32_t)hd_window_texel(wy.lo, cam.H) << 15);
+                    }
+                    item_word[s] = word;
+                } else
+#endif
+                item_class[s] = (uint8_t)cl;
             }
             if (submap_active) {   // index_map.vert:41-45: surfels of inactive submaps are not drawn
                 const uint32_t sm = (uint32_t)color_time[s].y;
@@ -710,6 +735,7 @@ struct CleanParams {
     const uint8_t *submap_active;   // nullable: KeyFrameIDMap (copy_unstable.vert:98-101)
     int n_active;
     int hash_G, hash_me; float hash_inv_cell;   // hash ownership (hash_G > 1): a shard appends the new surfels whose cell is its own
+    const uint32_t *class_word;     // CLEAN_CLASS_WORD builds: k_project's {class, first window texel} per surfel (with have_class)
 };
 
 #ifdef CLEAN_DIAG
@@ -729,7 +755,9 @@ extern "C" int hrbf_probe_clean_diag(unsigned long long out[4], int reset)
 // written by k_resolve) and its two predicates are counted with the multiplicity of the visit pattern.
 __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid &tinv, f3 lp, float x, float y,
                                              float init_time, float submap, float4 vn,
-                                             const float4 *__restrict__ clean_tex)
+                                             const float4 *__restrict__ clean_tex,
+                                             const float4 *pre_tex = nullptr /* 9 texels requested ahead from (pre_sx0, pre_sy0), [jx * 3 + jy] */,
+                                             int pre_sx0 = -1, int pre_sy0 = -1)
 {
     const Cam &cam = cp.cam;
     int count = 0, zCount = 0;
@@ -769,7 +797,8 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
 #pragma unroll
             for (int jx = 0; jx < 3; ++jx) {   // texels outside the visit pattern may lie outside the image: not read
                 ta[jx * 3 + jy] = make_float4(0, 0, 0, 0);
-                if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = clean_tex[clean_tex_slot(sxk[0] + jx, syk[0] + jy, cam.W)];
+                if (pre_tex && pre_sx0 == sx0 && pre_sy0 == sy0) { if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = pre_tex[jx * 3 + jy]; }   // the same texels, requested a round earlier
+                else if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = clean_tex[clean_tex_slot(sxk[0] + jx, syk[0] + jy, cam.W)];
             }
 #pragma unroll
         for (int jx = 0; jx < 3; ++jx)
@@ -828,9 +857,7 @@ __device__ __forceinline__ bool in_view(const CleanParams &cp, const Rigid &tinv
 {
     const Cam &cam = cp.cam;
     lp = xform(tinv, xyz(vp));
-    x = ((cam.fx * lp.x) / lp.z) + cam.cx;
-    y = ((cam.fy * lp.y) / lp.z) + cam.cy;
-    return lp.z < cp.maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)cam.W && y < (float)cam.H;
+    return project_in_view(cam, lp, cp.maxDepth, x, y);
 }
 
 // the clean test of one item: surfel `idx` of the map or association record `idx`
@@ -838,7 +865,8 @@ __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &t
                                            const RecPlanes &rec, bool is_surf, uint32_t idx,
                                            const float4 *__restrict__ clean_tex, const float4 vp /* pos_conf of the item */,
                                            const bool pre = false /* the caller knew the item's class and requested its planes together */,
-                                           const float4 pre_vc = {0, 0, 0, 0}, const float4 pre_vn = {0, 0, 0, 0})
+                                           const float4 pre_vc = {0, 0, 0, 0}, const float4 pre_vn = {0, 0, 0, 0},
+                                           const float4 *pre_tex = nullptr, int pre_sx0 = -1, int pre_sy0 = -1)
 {
     bool keep = true;
     f3 lp; float x, y;
@@ -850,7 +878,7 @@ __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &t
     if (need_ct) vc = pre ? pre_vc : (is_surf ? m.p1[idx] : rec.p1[idx]);
     if (inv) {
         const float4 vn = pre ? pre_vn : (is_surf ? m.p2[idx] : rec.p2[idx]);
-        keep = clean_window(cp, tinv, lp, x, y, vc.z, vc.y, vn, clean_tex);
+        keep = clean_window(cp, tinv, lp, x, y, vc.z, vc.y, vn, clean_tex, pre_tex, pre_sx0, pre_sy0);
     }
     if (!is_surf || cp.full_check || (need_ct && vc.w == ftime)) {
         const float k1 = is_surf ? m.p3[idx].w : rec.p3[idx].w;
@@ -936,6 +964,9 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     const uint32_t stride = sgrid * blockDim.x;
     for (uint32_t it0 = sb * blockDim.x + threadIdx.x; it0 < N64; it0 += CLEAN_UNROLL * stride) {
         float4 vp[CLEAN_UNROLL], vc[CLEAN_UNROLL], vn[CLEAN_UNROLL];
+#ifdef CLEAN_CLASS_WORD
+        float4 tex[CLEAN_UNROLL][9]; int psx[CLEAN_UNROLL], psy[CLEAN_UNROLL];
+#endif
         bool settled[CLEAN_UNROLL];   // a stable surfel outside the frustum, classified by the projection: kept, nothing read
         const bool cls = have_class && !cp.full_check;
 #pragma unroll
@@ -943,6 +974,29 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
             const uint32_t it = it0 + (uint32_t)k * stride;
             const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             vc[k] = z4; vn[k] = z4;
+#ifdef CLEAN_CLASS_WORD
+            if (cls && cp.class_word) {   // one word: the class AND where the window starts — planes and window texels in ONE round
+                const uint32_t wd = it < N ? cp.class_word[it] : CLEAN_CLASS_OUT_STABLE;
+                const uint32_t cl = wd & 3u;
+                settled[k] = cl == CLEAN_CLASS_OUT_STABLE;
+                vp[k] = settled[k] ? z4 : m.p0[it];
+                if (!settled[k]) vc[k] = m.p1[it];
+                psx[k] = psy[k] = -1;
+                if (cl == CLEAN_CLASS_IN_VIEW) {
+                    vn[k] = m.p2[it];
+                    if (cp.nw == 4) {
+                        psx[k] = (int)((wd >> 2) & 0x1FFFu); psy[k] = (int)(wd >> 15);
+#pragma unroll
+                        for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+                            for (int jy = 0; jy < 3; ++jy) {   // the walk visits texels first .. first + 2 at most; clamped: an address inside the image
+                                const int tx = psx[k] + jx < cp.cam.W ? psx[k] + jx : cp.cam.W - 1, ty = psy[k] + jy < cp.cam.H ? psy[k] + jy : cp.cam.H - 1;
+                                tex[k][jx * 3 + jy] = clean_tex[clean_tex_slot(tx, ty, cp.cam.W)];
+                            }
+                    }
+                }
+            } else
+#endif
             if (cls) {   // one byte decides what the item needs, and what it needs is requested in ONE round (position -> colour/time,
                          // normal/radius are two dependent rounds without the class)
                 const uint32_t cl = it < N ? keep_flags[it] : CLEAN_CLASS_OUT_STABLE;
@@ -959,7 +1013,13 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
         for (int k = 0; k < CLEAN_UNROLL; ++k) {
             const uint32_t it = it0 + (uint32_t)k * stride;
             if (it >= N64) break;          // wave-uniform: N64 and the strides are multiples of 64
+#ifdef CLEAN_CLASS_WORD
+            const bool havew = cls && cp.class_word;
+            const bool keep = it < N && (settled[k] || clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k], cls, vc[k], vn[k],
+                                                                  havew && psx[k] >= 0 ? tex[k] : nullptr, havew ? psx[k] : -1, havew ? psy[k] : -1));
+#else
             const bool keep = it < N && (settled[k] || clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k], cls, vc[k], vn[k]));
+#endif
 #ifndef CLEAN_NO_STORE
             if (it < N) keep_flags[it] = keep ? 1 : 0;
 #endif
@@ -1325,13 +1385,19 @@ void launch_resolve_scatter(hipStream_t s, const Cam &cam, const DevPose *dp, Ma
 
 void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDepth, MapPlanes m, ShardRef sh,
                     uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active, int n_active,
-                    uint8_t *item_class, float confThr)
+                    uint8_t *item_class, float confThr, uint32_t *item_word, float wm)
 {
     uint32_t blocks = (count_ub + 255) / 256;   // zbuf is ZB_EMPTY on entry: launch_zbuf_reset once, k_resolve afterwards
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride the rest
     if (blocks == 0) blocks = 1;
+#ifdef CLEAN_CLASS_WORD
+    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, sh, zbuf, m.p1, submap_active,
+                       n_active, item_class, confThr, item_class ? item_word : nullptr, wm);
+#else
+    (void)item_word; (void)wm;
     hipLaunchKernelGGL(k_project, dim3(blocks), dim3(256), 0, s, cam, dp, maxDepth, m.p0, sh, zbuf, m.p1, submap_active,
                        n_active, item_class, confThr);
+#endif
 }
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
@@ -1395,7 +1461,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   uint32_t *tile_dirty /* [2]: entries this / the other buffer may hold */, uint32_t *tile_done, uint32_t epoch,
                   uint32_t max_tiles, hipEvent_t e0, hipEvent_t e1, const uint8_t *submap_active, int n_active,
                   int n_records, int zero_records, uint32_t *stats_ring_slot, const uint32_t *merged_part,
-                  uint32_t *gid, uint32_t g_base, int hash_G, int hash_me, float hash_inv_cell, int have_class)
+                  uint32_t *gid, uint32_t g_base, int hash_G, int hash_me, float hash_inv_cell, int have_class, const uint32_t *class_word)
 {
     const int Qfull = (cam.W / 2) * (cam.H / 2);
     const int Q = n_records;   // records are appended by one shard only (the end of the global order)
@@ -1404,6 +1470,7 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
     cp.nw = (int)ceilf(2.0f * clean_window_multiplier); cp.w0 = clean_window_multiplier * 0.5f; cp.wm = clean_window_multiplier; cp.full_check = full_check;
     cp.submap_active = submap_active; cp.n_active = n_active;
     cp.hash_G = gid ? hash_G : 1; cp.hash_me = hash_me; cp.hash_inv_cell = hash_inv_cell;
+    cp.class_word = have_class ? class_word : nullptr;
     const uint32_t items_ub = count_ub + (uint32_t)Q;
     uint32_t tiles = (items_ub + FUSE_TILE - 1) / FUSE_TILE;
     if (tiles > max_tiles) tiles = max_tiles;

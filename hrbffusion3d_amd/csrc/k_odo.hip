@@ -1829,7 +1829,8 @@ void launch_odometry(hipStream_t s, OdoBuffers &ob, const OdoSources &src, const
         p1 = (int)((long long)L.rows * (r + 1) / vworld) * L.cols;
     };
     auto allreduce = [&](long long *buf, size_t n) {
-        if (sharded && oc->allreduce_i64) oc->allreduce_i64(oc->ar_ctx, buf, n, s);
+        if (sharded && oc->ar_count) { oc->ar_count[0] += 1; oc->ar_count[1] += sizeof(long long) * n; }
+        if (sharded && oc->allreduce_i64 && oc->allreduce_i64(oc->ar_ctx, buf, n, s) != 0 && oc->ar_failed) *oc->ar_failed = 1;
     };
     const int rgb = cfg.rgb_only || cfg.icp_weight < 100.0f;
     const int icp = !cfg.rgb_only && cfg.icp_weight > 0.0f;

@@ -95,7 +95,9 @@ void launch_project(hipStream_t s, const Cam &cam, const DevPose *dp, float maxD
                     uint32_t count_ub, unsigned long long *zbuf, const uint8_t *submap_active /* nullable: KeyFrameIDMap */,
                     int n_active,
                     uint8_t *item_class = nullptr /* nullable: one byte per surfel for pass A of the clean pass (k_project) */,
-                    float confThr = 0.0f);
+                    float confThr = 0.0f,
+                    uint32_t *item_word = nullptr /* CLEAN_CLASS_WORD builds: {class, first window texel} per surfel instead of the byte */,
+                    float clean_window_multiplier = 0.0f);
 void launch_resolve(hipStream_t s, const Cam &cam, const DevPose *dp, MapPlanes m, ShardRef sh, unsigned long long *zbuf,
                     uint32_t *idx, float4 *vertconf, float4 *colortime, float4 *normrad, float4 *curvmax, float4 *curvmin,
                     float4 *clean_tex /* nullable: packed texels for the clean test (clean_tex_elems) */,
@@ -152,7 +154,8 @@ void launch_clean(hipStream_t s, const Cam &cam, const DevPose *dp, float maxDep
                   uint32_t *gid /* nullable; hash ownership: the shard's global-order ids, moved along with the planes */,
                   uint32_t g_base /* id of record 0 if it is appended (record q gets g_base + q) */,
                   int hash_G, int hash_me, float hash_inv_cell /* only records whose cell hashes to hash_me are appended */,
-                  int have_class = 0 /* keep_flags[0..count) holds the classes launch_project(item_class) wrote for THIS map and pose */);
+                  int have_class = 0 /* keep_flags[0..count) holds the classes launch_project(item_class) wrote for THIS map and pose */,
+                  const uint32_t *class_word = nullptr /* CLEAN_CLASS_WORD builds: what launch_project(item_word) wrote */);
 void launch_update_model(hipStream_t s, MapPlanes m, const uint32_t *count, uint32_t count_ub, const float *delta16, int n);
 void launch_fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 void launch_zbuf_reset(hipStream_t s, unsigned long long *zbuf, int P);
@@ -337,6 +340,9 @@ struct OdoComm {
     int virtual_world;
     int (*allreduce_i64)(void *ar_ctx, long long *buf, size_t count, hipStream_t s);   // in place, on the stream (or synchronously)
     void *ar_ctx;       // its first argument: the RCCL communicator, or the context itself on the shared-memory transport
+    int *ar_failed;                 // nullable: set to 1 when an all-reduce returns non-zero (the frame cannot stop half way: the caller raises a status bit)
+    unsigned long long *ar_count;   // nullable: {calls, bytes} of the limb all-reduces the sharded path ISSUES (counted whether a wire
+                                    // carries them or one process plays the ranks) — hrbf_comm_stats
 };
 // weight_multiplier >= 0: the velocity weighting of the frame epilogue is computed by the last solve as well.
 // level0_done: launch_curvature_level0 has written level 0 of the pyramids for this frame already (1), and the packed

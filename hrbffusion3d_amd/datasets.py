@@ -171,8 +171,11 @@ def load_saved_trajectory(path, icl_nuim=False, frame_stamps_s=None):
     s, p = hio.load_trajectory_tum(path)
     if icl_nuim:
         s = s / 1e6
+    # the reference pushes a pose for EVERY frame but a stamp only from the second frame on (HRBFFusion.cpp:1060 against
+    # :1131-1132), so its file pairs pose i with the stamp of frame i + 1 and the last pose with whatever follows the vector;
+    # include/HRBFFusion.h keeps that.  Whoever evaluates such a file has to re-pair it: pose i belongs to frame i
     if frame_stamps_s is not None and len(frame_stamps_s) == len(s):
-        s = np.asarray(frame_stamps_s, np.float64)      # the file prints %.6f of a truncated stamp: use the source's
+        s = np.asarray(frame_stamps_s, np.float64)
     return s, p
 
 

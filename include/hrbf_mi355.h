@@ -253,6 +253,8 @@ int hrbf_set_load_trajectory(hrbf_handle h, int v);
 #define HRBF_STATUS_FUSE_TIMEOUT 8u    /* the in-place compaction ran into its (bounded) tile wait: the map of that frame is not trustworthy */
 #define HRBF_STATUS_ID_SPACE 16u       /* hash-owned map: the 32-bit order ids were about to run out and renumbering failed: that frame's clean
                                           pass did not run, hrbf_process_frame returned the error and keeps failing until this is cleared */
+#define HRBF_STATUS_COLLECTIVE 32u     /* row-sharded registration: an all-reduce of the limb sums failed (either transport): that frame's
+                                          pose was solved from unreduced sums and is not to be trusted */
 int hrbf_get_status(hrbf_handle h, uint32_t *flags, int clear);
 int hrbf_shard_exchange_mode(hrbf_handle h);   /* see "How the ranks exchange the index map" below */
 /* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
@@ -417,6 +419,27 @@ int hrbf_set_row_sharding(hrbf_handle h, int enable);   /* 0: keep the communica
 int hrbf_map_rebalance(hrbf_handle h);
 int hrbf_rebalance_plan(const uint32_t *counts, int n_shards, uint32_t *new_counts, uint32_t *moves5, int *n_moves);
 uint32_t hrbf_local_surfel_count(hrbf_handle h);
+
+/* What the library's OWN communicator is and what it has issued since the last reset — so that a multi-GPU bench line can
+ * prove from the library's side that N ranks took part, and a test can hold the per-frame collective count to the model of
+ * SURVEY.md §8e ("ncclAllReduce(sum) per GN iteration; ncclAllReduce(min, P x u64) per projection; ncclAllGather of ...").
+ * Operations are counted where the sharded path ISSUES them, by meaning, whichever transport carries them: RCCL on the
+ * context's stream, the shared-memory segment (a host barrier + a kernel over the peers' buffers), or — one process playing
+ * all shards / ranks in turn — a local kernel (transport 3: nothing crosses a wire, the count is that of the exchange steps). */
+enum { HRBF_TRANSPORT_NONE = 0, HRBF_TRANSPORT_RCCL = 1, HRBF_TRANSPORT_SHM = 2, HRBF_TRANSPORT_VIRTUAL = 3 };
+typedef struct hrbf_comm_counters {
+    int32_t transport;              /* HRBF_TRANSPORT_* */
+    int32_t world, rank;            /* RCCL: what ncclCommCount / ncclCommUserRank report for the library's communicator (-1 if the entry
+                                       points are missing); shm: the segment's; virtual: the number of shards / ranks played, rank 0 */
+    int32_t frames;                 /* hrbf_process_frame* calls since the last reset */
+    uint64_t limb_allreduce, limb_allreduce_bytes;       /* registration: all-reduce(sum, int64) of the exact limb sums */
+    uint64_t key_min_reduce, key_min_reduce_bytes;       /* projection: all-reduce(min, u64) over the W*H z-buffer keys */
+    uint64_t allgather, allgather_bytes;                 /* all-gather(u32): live counts, first ids, record counts, handles, id planes (bytes contributed per rank) */
+    uint64_t word_allreduce, word_allreduce_bytes;       /* one-word all-reduce(sum, u32): agreement votes, "every owner has written" */
+    uint64_t send, send_bytes, recv, recv_bytes;         /* ncclSend / ncclRecv: packed-record exchange, hrbf_map_rebalance */
+    uint64_t host_barriers;                              /* shm transport: barriers through the segment */
+} hrbf_comm_counters;
+int hrbf_comm_stats(hrbf_handle h, hrbf_comm_counters *out, int reset);
 
 #ifdef __cplusplus
 }

@@ -174,6 +174,13 @@ int orc_icp_step_sparse(const float Rcurr[9], const float tcurr[3], const float 
                         const float *ck1_g_prev, const float *ck2_g_prev, const float *icp_weight_prev, int rows,
                         int cols, float dist_thresh, float angle_thresh, int use_weight, const float *lambda_map,
                         float *z_map_out, int32_t *corres_out, double A_out[36], double b_out[6], double residual_out[2]);
+/* the windowed correspondence search (reduce.cu:357-430) with its choice per pixel returned (tests only) */
+int orc_icp_step_search(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                        const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9], const float tprev[3],
+                        float fx, float fy, float cx, float cy, const float *vmap_g_prev, const float *nmap_g_prev,
+                        const float *ck1_g_prev, const float *ck2_g_prev, const float *icp_weight_prev, int rows,
+                        int cols, float dist_thresh, float angle_thresh, int use_weight, int use_search, int radius,
+                        int32_t *corres_out, double A_out[36], double b_out[6], double residual_out[2]);
 int orc_update_lambda_map(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float Rprev_inv[9],
                           const float tprev[3], const float *vmap_g_prev, const int32_t *corres, const float *z_map,
                           float *lambda_map, int rows, int cols);

@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+/* ORC_MUTANT: see orc_odo.c (deliberate misreadings for tools/mutation_report.py; 0 = the oracle) */
+#ifndef ORC_MUTANT
+#define ORC_MUTANT 0
+#endif
 #include "oracle.h"
 #include "orc_vec.h"
 
@@ -180,11 +184,21 @@ int orc_process_frame(orc_ctx *c, const uint8_t *rgb, const uint16_t *depth, int
         float Rm[9];
         for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Rm[r * 3 + k] = M4(diff, r, k);
         float a = len3(dt), b = len3(rodrigues2(Rm));
+#if ORC_MUTANT == 44     /* the translation alone: no max with the rotation angle (HRBFFusion.cpp:1116) */
+        float weighting = a; (void)b;
+#else
         float weighting = a > b ? a : b;
+#endif
         const float largest = 0.01f, minWeight = 0.5f;
         if (weighting > largest) weighting = largest;
         float wv = 1.0f - (weighting / largest);
+#if ORC_MUTANT == 45     /* no lower clamp at minWeight (HRBFFusion.cpp:1124) */
+        c->weighting = wv * wmul;
+#elif ORC_MUTANT == 46   /* weightMultiplier inside the clamp: max((1 - w / largest) * wMul, minWeight) */
+        c->weighting = (wv * wmul > minWeight ? wv * wmul : minWeight);
+#else
         c->weighting = (wv > minWeight ? wv : minWeight) * wmul;
+#endif
         orc_confidence(c);
         if (!c->prm.rgb_only) {
             orc_predict_indices(c);

@@ -40,7 +40,11 @@ static void copy_maps(const f4 *vsrc, const f4 *nsrc, orc_planar *vd, orc_planar
         for (int x = 0; x < cols; ++x) {
             f4 v = vsrc[y * cols + x], n = nsrc[y * cols + x];
             f4 vo = v4(qn, qn, qn, qn), no = vo;
+#if ORC_MUTANT == 32     /* copyMaps validity on the vertex alone: `nsrc.w > 0` dropped (cudafuncs.cu:366) */
+            if (!(v.z == 0.0f)) { vo = v; no = n; }
+#else
             if (!(v.z == 0.0f) && n.w > 0.0f) { vo = v; no = n; }
+#endif
             PL(*vd, 0, y, x) = vo.x; PL(*vd, 1, y, x) = vo.y; PL(*vd, 2, y, x) = vo.z; PL(*vd, 3, y, x) = vo.w;
             PL(*nd, 0, y, x) = no.x; PL(*nd, 1, y, x) = no.y; PL(*nd, 2, y, x) = no.z; PL(*nd, 3, y, x) = no.w;
         }
@@ -53,7 +57,11 @@ static void copy_curv(const f4 *src, orc_planar *d, float thr)
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
             f4 s = src[y * cols + x], o = v4(qn, qn, qn, qn);
+#if ORC_MUTANT == 33     /* curvature kept when kappa < threshold, without `> -threshold` (cudafuncs.cu:420) */
+            if (s.w < thr && !hd_isnanf(s.w)) o = s;
+#else
             if (s.w < thr && s.w > -thr && !hd_isnanf(s.w)) o = s;
+#endif
             PL(*d, 0, y, x) = o.x; PL(*d, 1, y, x) = o.y; PL(*d, 2, y, x) = o.z; PL(*d, 3, y, x) = o.w;
         }
 }
@@ -68,6 +76,22 @@ static void resize_map(const orc_planar *in, orc_planar *out, int normalize)
             int xs = x * 2, ys = y * 2;
             float x00 = PL(*in, 0, ys, xs), x01 = PL(*in, 0, ys, xs + 1), x10 = PL(*in, 0, ys + 1, xs),
                   x11 = PL(*in, 0, ys + 1, xs + 1);
+#if ORC_MUTANT == 30     /* 2 x 2 resize averaging the VALID taps (like the depth pyramid) instead of "NaN if any tap is NaN" (cudafuncs.cu:549-556) */
+            {
+                const float t4[4] = {x00, x01, x10, x11};
+                int nv = 0; float r4[4] = {0, 0, 0, 0};
+                for (int q = 0; q < 4; ++q) if (!hd_isnanf(t4[q])) {
+                    ++nv;
+                    for (int k = 0; k < 4; ++k) r4[k] += PL(*in, k, ys + (q >> 1), xs + (q & 1));
+                }
+                if (nv > 0 && nv < 4) {
+                    for (int k = 0; k < 4; ++k) r4[k] /= (float)nv;
+                    if (normalize) { float inv = 1.0f / sqrtf((r4[0] * r4[0] + r4[1] * r4[1]) + r4[2] * r4[2]); r4[0] *= inv; r4[1] *= inv; r4[2] *= inv; }
+                    for (int k = 0; k < 4; ++k) PL(*out, k, y, x) = r4[k];
+                    continue;
+                }
+            }
+#endif
             if (hd_isnanf(x00) || hd_isnanf(x01) || hd_isnanf(x10) || hd_isnanf(x11)) {
                 PL(*out, 0, y, x) = qn; PL(*out, 1, y, x) = qn; PL(*out, 2, y, x) = qn; PL(*out, 3, y, x) = qn;
                 continue;
@@ -76,6 +100,9 @@ static void resize_map(const orc_planar *in, orc_planar *out, int normalize)
             for (int k = 0; k < 4; ++k)
                 r[k] = (((PL(*in, k, ys, xs) + PL(*in, k, ys, xs + 1)) + PL(*in, k, ys + 1, xs)) +
                         PL(*in, k, ys + 1, xs + 1)) / 4.0f;
+#if ORC_MUTANT == 31     /* the resized normal left as the plain average: no renormalisation (cudafuncs.cu:573-581) */
+            normalize = 0;
+#endif
             if (normalize) {
                 float inv = 1.0f / sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
                 r[0] *= inv; r[1] *= inv; r[2] *= inv;
@@ -118,7 +145,11 @@ static void transform_map(orc_planar *m, const float *R, f3 t, int add_t)
 static void copy_icpw(const float *src, float *dst, int n)
 {
     const float qn = hd_nanf();
+#if ORC_MUTANT == 34     /* icp weight kept when >= 0 instead of > 0 (cudafuncs.cu:462) */
+    for (int i = 0; i < n; ++i) dst[i] = src[i] >= 0.0f ? src[i] : qn;
+#else
     for (int i = 0; i < n; ++i) dst[i] = src[i] > 0.0f ? src[i] : qn;
+#endif
 }
 static void resize_icpw(const float *in, int irows, int icols, float *out)
 {
@@ -237,7 +268,8 @@ void orc_odo_init_model(orc_ctx *c, const f4 *vtex, const f4 *ntex, const uint8_
         resize_map(&c->vmap_g[i - 1], &c->vmap_g[i], 0);
         resize_map(&c->nmap_g[i - 1], &c->nmap_g[i], 1);
     }
-    for (int i = 0; i < ORC_NUM_PYRS; ++i) { transform_map(&c->vmap_g[i], R, t, 1); transform_map(&c->nmap_g[i], R, t, 0); }
+    /* ORC_MUTANT 27: the model normals moved like points (R n + t); 28: the model vertices rotated only (R v) — cudafuncs.cu:230,246 */
+    for (int i = 0; i < ORC_NUM_PYRS; ++i) { transform_map(&c->vmap_g[i], R, t, ORC_MUTANT != 28); transform_map(&c->nmap_g[i], R, t, ORC_MUTANT == 27); }
     /* initRGBModel :689-693 -> populateRGBDData :660-687 */
     vertices_to_depth(vtex, c->last_depth[0], c->P, 6.0f);
     for (int i = 0; i + 1 < ORC_NUM_PYRS; ++i) pyrdown_gauss_f(c->last_depth[i], c->H >> i, c->W >> i, c->last_depth[i + 1]);
@@ -247,7 +279,9 @@ void orc_odo_init_model(orc_ctx *c, const f4 *vtex, const f4 *ntex, const uint8_
     copy_curv(k1tex, &c->ck1_g[0], c->prm.curv_valid_threshold);
     copy_curv(k2tex, &c->ck2_g[0], c->prm.curv_valid_threshold);
     for (int i = 1; i < ORC_NUM_PYRS; ++i) { resize_cmap(&c->ck1_g[i - 1], &c->ck1_g[i]); resize_cmap(&c->ck2_g[i - 1], &c->ck2_g[i]); }
+#if ORC_MUTANT != 29     /* 29: the model's principal directions left in the camera frame (transformCurvMaps skipped, cudafuncs.cu:279-322) */
     for (int i = 0; i < ORC_NUM_PYRS; ++i) { transform_map(&c->ck1_g[i], R, t, 0); transform_map(&c->ck2_g[i], R, t, 0); }
+#endif
     /* initICPweight :759-775 */
     copy_icpw(icpw_tex, c->icpw[0], c->P);
     for (int i = 1; i < ORC_NUM_PYRS; ++i) resize_icpw(c->icpw[i - 1], c->H >> (i - 1), c->W >> (i - 1), c->icpw[i]);
@@ -366,15 +400,31 @@ typedef struct { hd_acc128 a[29]; } acc29;
 /* side images of the sparse (ADMM) variant, one level: multiplier lambdaMap, shrunk residual z_thrinkMap, corresICP */
 typedef struct { f3 *lambda, *z; int32_t *corres; int64_t *shrunk; } orc_sparse;
 
+/* the rejection rule of reduce.cu:383: `sine > angleThres || dist > distThres`, and three misreadings of it */
+#if ORC_MUTANT == 35     /* the distance threshold met by the SQUARED distance */
+#define ICP_REJECT(sine, dist, nc, np, vp, vg) ((sine) > angleThres || (dist) * (dist) > distThres)
+#elif ORC_MUTANT == 36   /* the angle threshold met by 1 - cosine instead of the sine */
+#define ICP_REJECT(sine, dist, nc, np, vp, vg) (1.0f - dot3(nc, np) > angleThres || (dist) > distThres)
+#elif ORC_MUTANT == 37   /* the distance threshold on the depth difference instead of the Euclidean distance */
+#define ICP_REJECT(sine, dist, nc, np, vp, vg) ((sine) > angleThres || fabsf((vp).z - (vg).z) > distThres)
+#else
+#define ICP_REJECT(sine, dist, nc, np, vp, vg) ((sine) > angleThres || (dist) > distThres)
+#endif
+#if ORC_MUTANT == 47     /* the shrink operator of the l1 norm (soft threshold 1 / mu) instead of l_p, p = 0.5 (reduce.cu:302-315, :652) */
+static inline float orc_shrink(float hnorm) { return hnorm <= 1.0f / HD_SPARSE_MU ? 0.0f : 1.0f - (1.0f / HD_SPARSE_MU) / hnorm; }
+#else
+static inline float orc_shrink(float hnorm) { return hd_sparse_shrink_factor(hnorm); }
+#endif
 static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const orc_planar *nc,
                       const orc_planar *k1c, const orc_planar *k2c, const float *Rpi, f3 tprev,
                       float fx, float fy, float cx, float cy, const orc_planar *vg, const orc_planar *ng,
                       const orc_planar *k1g, const orc_planar *k2g, const float *icpw, float distThres,
-                      float angleThres, int use_search, int radius, int use_weight, const orc_sparse *sp, int x, int y,
-                      float out[29])
+                      float angleThres, int use_search, int radius, int use_weight, const orc_sparse *sp, int32_t *probe,
+                      int x, int y, float out[29])
 {
     int rows = vc->rows, cols = vc->cols;
     for (int i = 0; i < 29; ++i) out[i] = 0.0f;
+    if (probe) { probe[2 * (y * cols + x)] = -1; probe[2 * (y * cols + x) + 1] = -1; }   /* corresICP of the plain variant (reduce.cu:444-456) */
     if (sp) {   /* getProducts writes both side outputs for every pixel before the found test (reduce.cu:455-471) */
         sp->z[y * cols + x] = v3(0, 0, 0);
         sp->corres[2 * (y * cols + x)] = -1; sp->corres[2 * (y * cols + x) + 1] = -1;
@@ -413,7 +463,7 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
             float c1 = PL(*k1g, 3, cy_, cx_), c2 = PL(*k2g, 3, cy_, cx_);
             if (hd_isnanf(vp.x) || hd_isnanf(np.x) || hd_isnanf(c1) || hd_isnanf(c2)) continue;
             float dist = len3(sub3(vp, vg_)), sine = len3(cross3(ncur_g, np));
-            if (sine > angleThres || dist > distThres) continue;
+            if (ICP_REJECT(sine, dist, ncur_g, np, vp, vg_)) continue;
             if (dist > DpR) DpR = dist;
         }
     for (int cy_ = uy - R; cy_ < uy + R + 1; ++cy_)
@@ -424,20 +474,29 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
             float c1 = PL(*k1g, 3, cy_, cx_), c2 = PL(*k2g, 3, cy_, cx_);
             if (hd_isnanf(vp.x) || hd_isnanf(np.x) || hd_isnanf(c1) || hd_isnanf(c2)) continue;
             float dist = len3(sub3(vp, vg_)), sine = len3(cross3(ncur_g, np));
-            if (sine > angleThres || dist > distThres) continue;
+            if (ICP_REJECT(sine, dist, ncur_g, np, vp, vg_)) continue;
             float p = 1.0f;
             if (use_search) {
                 float a1 = fabsf(c1), a2 = fabsf(c2);
                 float ckmax = a1 > a2 ? a1 : a2;
+#if ORC_MUTANT == 39     /* D_p normalised by the distance threshold instead of the window's largest accepted distance (reduce.cu:421) */
+                float D_p = dist / distThres;
+#else
                 float D_p = dist / DpR;
+#endif
                 float D_n = 1.0f - dot3(np, ncur_g);
                 float D_c = 1.0f - hd_expf(-fabsf(c1 - ck1) / ckmax) * hd_expf(-fabsf(c2 - ck2) / ckmax);
                 p = (0.333f * D_p + 0.333f * D_n) + 0.333f * D_c;
             }
+#if ORC_MUTANT == 38     /* ties go to the LAST candidate in raster order (`<=` for the reference's `<`, reduce.cu:429) */
+            if (p <= p_smallest) { bx = cx_; by = cy_; bv = vp; bn = np; p_smallest = p; }
+#else
             if (p < p_smallest) { bx = cx_; by = cy_; bv = vp; bn = np; p_smallest = p; }
+#endif
             found = 1;
         }
     if (!found) return;
+    if (probe) { probe[2 * (y * cols + x)] = bx; probe[2 * (y * cols + x) + 1] = by; }
     f3 s_cp = m33_mul(Rpi, sub3(vg_, tprev));
     f3 d_cp = m33_mul(Rpi, sub3(bv, tprev));
 #if ORC_MUTANT == 1      /* the matched normal left in the tracker's world frame */
@@ -449,14 +508,22 @@ static void icp_pixel(const float *Rcurr, f3 tcurr, const orc_planar *vc, const 
         const int k = y * cols + x;
         sp->corres[2 * k] = bx; sp->corres[2 * k + 1] = by;
         f3 lm = v3(sp->lambda[k].x / HD_SPARSE_MU, sp->lambda[k].y / HD_SPARSE_MU, sp->lambda[k].z / HD_SPARSE_MU);
+#if ORC_MUTANT == 40     /* h = s - d - lambda / mu (the multiplier with the opposite sign, reduce.cu:482) */
+        f3 h = sub3(sub3(s_cp, d_cp), lm);
+#else
         f3 h = add3(sub3(s_cp, d_cp), lm);
-        float beta = hd_sparse_shrink_factor(len3(h));
+#endif
+        float beta = orc_shrink(len3(h));
         if (beta != 0.0f && sp->shrunk) {   /* test evidence only: how often the non-trivial branch ran */
 #pragma omp atomic
             ++*sp->shrunk;
         }
         f3 z = v3(beta * h.x, beta * h.y, beta * h.z);
+#if ORC_MUTANT == 41     /* the target moved by z + lambda / mu instead of z - lambda / mu (reduce.cu:485) */
+        d_cp = add3(add3(d_cp, z), lm);
+#else
         d_cp = sub3(add3(d_cp, z), lm);
+#endif
         sp->z[k] = z;
     }
     float weight = 1.0f;
@@ -495,7 +562,8 @@ static void icp_step(const float *Rcurr, f3 tcurr, const orc_planar *vc, const o
                      const orc_planar *k1c, const orc_planar *k2c, const float *Rpi, f3 tprev,
                      float fx, float fy, float cx, float cy, const orc_planar *vg, const orc_planar *ng,
                      const orc_planar *k1g, const orc_planar *k2g, const float *icpw, float distThres,
-                     float angleThres, int use_search, int radius, int use_weight, const orc_sparse *sp, double sums[29])
+                     float angleThres, int use_search, int radius, int use_weight, const orc_sparse *sp, int32_t *probe,
+                     double sums[29])
 {
     acc29 tot; for (int i = 0; i < 29; ++i) hd_acc_zero(&tot.a[i]);
 #pragma omp parallel
@@ -506,7 +574,7 @@ static void icp_step(const float *Rcurr, f3 tcurr, const orc_planar *vc, const o
             for (int x = 0; x < vc->cols; ++x) {
                 float o[29];
                 icp_pixel(Rcurr, tcurr, vc, nc, k1c, k2c, Rpi, tprev, fx, fy, cx, cy, vg, ng, k1g, k2g, icpw,
-                          distThres, angleThres, use_search, radius, use_weight, sp, x, y, o);
+                          distThres, angleThres, use_search, radius, use_weight, sp, probe, x, y, o);
                 if (o[28] != 0.0f) for (int i = 0; i < 29; ++i) hd_acc_add_f32(&loc.a[i], o[i]);
             }
 #pragma omp critical
@@ -530,11 +598,15 @@ static void sparse_update_lambda(const float *Rcurr, f3 tcurr, const orc_planar 
             f3 vlp = m33_mul(Rpi, sub3(add3(m33_mul(Rcurr, vcur), tcurr), tprev));
             f3 vp = m33_mul(Rpi, sub3(v3(PL(*vg, 0, uy, ux), PL(*vg, 1, uy, ux), PL(*vg, 2, uy, ux)), tprev));
             f3 d = sub3(sub3(vlp, vp), sp->z[k]);
+#if ORC_MUTANT == 42     /* lambda - mu * Delta (cudafuncs.cu:1066-1067 with the opposite sign) */
+            sp->lambda[k] = sub3(sp->lambda[k], v3(HD_SPARSE_MU * d.x, HD_SPARSE_MU * d.y, HD_SPARSE_MU * d.z));
+#else
             sp->lambda[k] = add3(sp->lambda[k], v3(HD_SPARSE_MU * d.x, HD_SPARSE_MU * d.y, HD_SPARSE_MU * d.z));
+#endif
         }
 }
 
-float orc_sparse_shrink_factor(float hnorm) { return hd_sparse_shrink_factor(hnorm); }
+float orc_sparse_shrink_factor(float hnorm) { return orc_shrink(hnorm); }
 int64_t orc_sparse_shrunk_count(const orc_ctx *c) { return c->sp_shrunk; }
 
 int orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
@@ -551,7 +623,34 @@ int orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_c
     double s[29];
     icp_step(Rcurr, v3(tcurr[0], tcurr[1], tcurr[2]), &vc, &nc, &k1c, &k2c, Rprev_inv,
              v3(tprev[0], tprev[1], tprev[2]), fx, fy, cx, cy, &vg, &ng, &k1g, &k2g, icp_weight_prev,
-             dist_thresh, angle_thresh, 0, 0, use_weight, NULL, s);
+             dist_thresh, angle_thresh, 0, 0, use_weight, NULL, NULL, s);
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            double v = s[shift++];
+            if (j == 6) b_out[i] = v; else A_out[j * 6 + i] = A_out[i * 6 + j] = v;
+        }
+    residual_out[0] = s[27]; residual_out[1] = s[28];
+    return 0;
+}
+
+/* icpStep with icp_if_use_coorespondence_search = true (reduce.cu:357-430) as a stand-alone operator that also returns corresICP
+   (2 int32 per pixel, (-1, -1) = none): the windowed search's choice is an observable of its own */
+int orc_icp_step_search(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                        const float *ck1_curr, const float *ck2_curr, const float Rprev_inv[9], const float tprev[3],
+                        float fx, float fy, float cx, float cy, const float *vmap_g_prev, const float *nmap_g_prev,
+                        const float *ck1_g_prev, const float *ck2_g_prev, const float *icp_weight_prev, int rows,
+                        int cols, float dist_thresh, float angle_thresh, int use_weight, int use_search, int radius,
+                        int32_t *corres_out, double A_out[36], double b_out[6], double residual_out[2])
+{
+    orc_planar vc = {rows, cols, (float *)vmap_curr}, nc = {rows, cols, (float *)nmap_curr};
+    orc_planar k1c = {rows, cols, (float *)ck1_curr}, k2c = {rows, cols, (float *)ck2_curr};
+    orc_planar vg = {rows, cols, (float *)vmap_g_prev}, ng = {rows, cols, (float *)nmap_g_prev};
+    orc_planar k1g = {rows, cols, (float *)ck1_g_prev}, k2g = {rows, cols, (float *)ck2_g_prev};
+    double s[29];
+    icp_step(Rcurr, v3(tcurr[0], tcurr[1], tcurr[2]), &vc, &nc, &k1c, &k2c, Rprev_inv,
+             v3(tprev[0], tprev[1], tprev[2]), fx, fy, cx, cy, &vg, &ng, &k1g, &k2g, icp_weight_prev,
+             dist_thresh, angle_thresh, use_search, radius, use_weight, NULL, corres_out, s);
     int shift = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 7; ++j) {
@@ -579,7 +678,7 @@ int orc_icp_step_sparse(const float Rcurr[9], const float tcurr[3], const float 
     double s[29];
     icp_step(Rcurr, v3(tcurr[0], tcurr[1], tcurr[2]), &vc, &nc, &k1c, &k2c, Rprev_inv,
              v3(tprev[0], tprev[1], tprev[2]), fx, fy, cx, cy, &vg, &ng, &k1g, &k2g, icp_weight_prev,
-             dist_thresh, angle_thresh, 0, 0, use_weight, &sp, s);
+             dist_thresh, angle_thresh, 0, 0, use_weight, &sp, NULL, s);
     int shift = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 7; ++j) {
@@ -1024,7 +1123,7 @@ void orc_odo_track(orc_ctx *c)
                 icp_step(Rcurr, tcurr, &c->vmap_c[i], &c->nmap_c[i], &c->ck1_c[i], &c->ck2_c[i], Rprev_inv, tprev,
                          fxl, fyl, cxl, cyl, &c->vmap_g[i], &c->nmap_g[i], &c->ck1_g[i], &c->ck2_g[i], c->icpw[i],
                          distThres, angleThres, c->prm.icp_use_corr_search, c->prm.icp_search_radius,
-                         c->prm.icp_use_weighted, sparse ? &sp : NULL, s);
+                         c->prm.icp_use_weighted, sparse ? &sp : NULL, NULL, s);
                 unpack27(s, A_icp, b_icp);
                 res_icp[0] = (float)s[27]; res_icp[1] = (float)s[28];
             }
@@ -1097,7 +1196,9 @@ void orc_odo_track(orc_ctx *c)
     }
     if (rgb) {
         f3 d = sub3(tcurr, tprev);
+#if ORC_MUTANT != 43     /* 43: no 0.3 m guard (RGBDOdometry.cpp:1232-1236) */
         if (len3(d) > 0.3f) { memcpy(Rcurr, Rprev, sizeof(Rprev)); tcurr = tprev; }
+#endif
     }
     if (c->prm.so3)
         for (int i = 0; i < ORC_NUM_PYRS; ++i) { uint8_t *t = c->last_next_image[i]; c->last_next_image[i] = c->next_image[i]; c->next_image[i] = t; }

@@ -79,6 +79,8 @@ def load(omp=False):
     lib.orc_icp_step_sparse.argtypes = [C.c_void_p] * 6 + [C.c_void_p] * 2 + [C.c_float] * 4 + [C.c_void_p] * 5 + \
         [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 6
     lib.orc_update_lambda_map.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int]
+    lib.orc_icp_step_search.argtypes = [C.c_void_p] * 6 + [C.c_void_p] * 2 + [C.c_float] * 4 + [C.c_void_p] * 5 + \
+        [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.orc_sparse_shrink_factor.restype = C.c_float; lib.orc_sparse_shrink_factor.argtypes = [C.c_float]
     lib.orc_sparse_shrunk_count.restype = C.c_int64; lib.orc_sparse_shrunk_count.argtypes = [C.c_void_p]
     lib.orc_icp_step.argtypes = [C.c_void_p] * 6 + [C.c_void_p] * 2 + [C.c_float] * 4 + [C.c_void_p] * 5 + \

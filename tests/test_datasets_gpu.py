@@ -46,15 +46,17 @@ def _run_sequence(name, info, tmp, oracle_lib, parity_frames, max_surfels):
     assert out.returncode == 0, out.stdout + out.stderr
     j = json.loads(out.stdout.strip().split("\n")[-1])
     assert j["frames"] == info["frames"] and j["poses"] == info["frames"] and j["surfels"] > 0
-    # the file is in the reference's format: TUM prints seconds with six decimals, ICL-NUIM the integer microsecond stamp and -ty
-    first = open(traj).readline().split()
-    assert len(first) == 8
-    if info["icl_nuim"]:
-        assert first[0] == str(ds.reference_frame_stamp(info["stamps_s"][0]))
-    else:
-        assert first[0] == "%.6f" % (ds.reference_frame_stamp(info["stamps_s"][0]) / 1e6)
-    s, p = ds.load_saved_trajectory(traj, icl_nuim=info["icl_nuim"])
-    assert len(p) == info["frames"] and np.allclose(s, info["stamps_s"], atol=2e-6)
+    # the file is in the reference's format: TUM prints seconds with six decimals, ICL-NUIM the integer microsecond stamp and -ty.
+    # And it keeps the reference's pairing: `poses` gets an entry for every frame, `timstamp` none for the first one
+    # (HRBFFusion.cpp:1060 against :1131-1132), so line i carries the stamp of frame i + 1 (the last line has none to carry)
+    lines = open(traj).read().splitlines()
+    us = [ds.reference_frame_stamp(t) for t in info["stamps_s"]]
+    shown = (lambda k: str(us[k])) if info["icl_nuim"] else (lambda k: "%.6f" % (us[k] / 1000000.0))
+    assert len(lines) == info["frames"] and all(len(l.split()) == 8 for l in lines)
+    assert [l.split()[0] for l in lines[:-1]] == [shown(k + 1) for k in range(info["frames"] - 1)]
+    # the evaluation pairs pose i with the stamp of frame i (what a user of the benchmark's tools has to do with that file)
+    s, p = ds.load_saved_trajectory(traj, icl_nuim=info["icl_nuim"], frame_stamps_s=info["stamps_s"])
+    assert len(p) == info["frames"]
     gs, gp = ds.load_groundtruth(info["groundtruth"])
     ate = ds.evaluate_ate(s, p, gs, gp)
     assert ate["rmse_m"] is not None and ate["pairs"] >= min(info["frames"], len(gs)) - 2, ate

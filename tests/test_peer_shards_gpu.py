@@ -73,11 +73,32 @@ def _run(rank, world, uid, cfg, out):
             res["gids"] = g.download_gids()
             res["renumbered"] = g.hash_renumber_count()
         res["status"] = g.status()
+        res["comm"] = g.comm_stats()            # hrbf_comm_stats: the library's own account of its transport and exchange steps
+        res["tracked"] = frames - 1             # frames behind the first (seeding or bootstrap): registration + fuse path
         g.close()
         out.put((rank, res))
     except Exception as e:   # surface the failure in the parent instead of a hang
         import traceback
         out.put((rank, {"error": "%r\n%s" % (e, traceback.format_exc())}))
+
+
+def _check_comm(two, cfg):
+    """two real processes over the shared-memory rendezvous: the per-frame exchange steps of DESIGN.md section 7's model, counted by
+    the library on each rank (the same numbers tests/test_comm_stats_gpu.py asserts for one process playing the shards)"""
+    W, H = cfg[0], cfg[1]
+    partition = cfg[5] if len(cfg) > 5 else "ranges"
+    rows = bool(cfg[7]) if len(cfg) > 7 else False
+    assert sorted(two[r]["comm"]["rank"] for r in (0, 1)) == [0, 1]
+    for r in (0, 1):
+        c, n = two[r]["comm"], two[r]["tracked"]
+        assert c["transport"] == "shm" and c["world"] == 2 and c["frames"] >= n, c
+        assert c["limb_allreduce"] == ((10 + 2 * 19) * n if rows else 0), c
+        if partition:
+            assert c["key_min_reduce"] >= 3 * n and c["key_min_reduce_bytes"] == c["key_min_reduce"] * 8 * W * H, c
+            assert c["allgather"] >= (2 if partition == "hash" else 1) * n and c["word_allreduce"] >= 3 * n, c
+        else:
+            assert c["key_min_reduce"] == 0 and c["allgather"] == 0, c
+        assert c["send"] == 0 and c["recv"] == 0 and c["host_barriers"] > 0, c      # this transport: barriers through the segment, no RCCL call
 
 
 def _launch(world, cfg):
@@ -105,7 +126,7 @@ def test_two_processes_share_one_sharded_map_bit_identical_to_a_single_map(gpu_a
     two = _launch(2, cfg)
     assert two[0]["status"] == 0 and two[1]["status"] == 0
     for k, v in single.items():
-        if k in ("map", "local_count", "status"):
+        if k in ("map", "local_count", "status", "comm", "tracked"):
             continue
         if k.startswith("stats"):   # {in, merged, appended, out} are per rank: they add up to the single map's
             assert np.array_equal(two[0][k].astype(np.int64) + two[1][k], v), k
@@ -119,6 +140,7 @@ def test_two_processes_share_one_sharded_map_bit_identical_to_a_single_map(gpu_a
     assert np.array_equal(joined, single["map"].reshape(-1, 20))
     if cfg[2]:
         assert min(two[0]["local_count"], two[1]["local_count"]) > 10_000   # both ranks really own part of the view
+    _check_comm(two, cfg)
 
 
 @pytest.mark.parametrize("cfg", [(160, 120, 0, 7, 0, "hash"), (320, 240, 150_000, 6, 1, "hash"), (160, 120, 0, 8, 0, "hash", 20000)],
@@ -131,7 +153,7 @@ def test_two_processes_share_one_hash_owned_map_bit_identical_to_a_single_map(gp
     two = _launch(2, cfg)
     assert two[0]["status"] == 0 and two[1]["status"] == 0
     for k, v in single.items():
-        if k in ("map", "local_count", "status"):
+        if k in ("map", "local_count", "status", "comm", "tracked"):
             continue
         if k.startswith("stats"):
             assert np.array_equal(two[0][k].astype(np.int64) + two[1][k], v), k
@@ -151,6 +173,7 @@ def test_two_processes_share_one_hash_owned_map_bit_identical_to_a_single_map(gp
     assert len(np.unique(ids)) == n and (np.diff(two[0]["gids"].astype(np.int64)) > 0).all() and (np.diff(two[1]["gids"].astype(np.int64)) > 0).all()
     joined = np.concatenate([two[0]["map"].reshape(-1, 20), two[1]["map"].reshape(-1, 20)])[np.argsort(ids, kind="stable")]
     assert np.array_equal(joined, single["map"].reshape(-1, 20))
+    _check_comm(two, cfg)
 
 
 ROW_CASES = [(160, 120, 0, 6, 0, None, 0, 1), (320, 240, 150_000, 5, 1, None, 0, 1), (320, 240, 150_000, 5, 1, "hash", 0, 1),
@@ -169,7 +192,7 @@ def test_two_processes_row_shard_the_registration_bit_identical_to_one(gpu_avail
     assert two[0]["status"] == 0 and two[1]["status"] == 0
     part = cfg[5]
     for k, v in single.items():
-        if k in ("map", "local_count", "status", "gids", "renumbered"):
+        if k in ("map", "local_count", "status", "gids", "renumbered", "comm", "tracked"):
             continue
         if k.startswith("stats") and part:
             assert np.array_equal(two[0][k].astype(np.int64) + two[1][k], v), k
@@ -189,6 +212,7 @@ def test_two_processes_row_shard_the_registration_bit_identical_to_one(gpu_avail
         ids = np.concatenate([two[0]["gids"], two[1]["gids"]])
         joined = np.concatenate([two[0]["map"].reshape(-1, 20), two[1]["map"].reshape(-1, 20)])[np.argsort(ids, kind="stable")]
         assert np.array_equal(joined, single["map"].reshape(-1, 20))
+    _check_comm(two, cfg)
 
 
 def _run_failing_map(rank, world, uid, out):

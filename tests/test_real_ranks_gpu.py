@@ -86,6 +86,8 @@ def _run(rank, world, uid, cfg, out):
             res["renumbered"] = g.hash_renumber_count()
         res["exchange_mode"] = g.shard_exchange_mode()
         res["status"] = g.status()
+        res["comm"] = g.comm_stats()            # the library's own account: what ITS communicator says, what it issued (hrbf_comm_stats)
+        res["tracked"] = frames - first - (0 if seed is not None else 1)      # frames that ran the registration + fuse path
         g.close()
         out.put((rank, res))
     except Exception as e:   # surface the failure in the parent instead of a hang
@@ -116,6 +118,30 @@ def _launch(world, cfg):
     return got
 
 
+def _check_comm(many, G, cfg):
+    """every rank's library-side record: RCCL's own world size and rank for the library's communicator, and the per-frame exchange
+    steps of DESIGN.md section 7's model (tests/test_comm_stats_gpu.py asserts the same numbers on one device)"""
+    W, H, nseed, frames, sparse, partition, rows, exchange, renumber_at = cfg
+    assert sorted(many[r]["comm"]["rank"] for r in range(G)) == list(range(G))
+    for r in range(G):
+        c, n = many[r]["comm"], many[r]["tracked"]
+        assert c["transport"] == "rccl" and c["world"] == G and c["rank"] == r, c
+        if rows:
+            assert c["limb_allreduce"] == (10 + 2 * 19) * n, c
+        else:
+            assert c["limb_allreduce"] == 0, c
+        if partition:
+            assert c["key_min_reduce"] >= 3 * n and c["key_min_reduce_bytes"] == c["key_min_reduce"] * 8 * W * H, c
+            assert c["allgather"] >= (2 if partition == "hash" else 1) * n, c
+            if exchange == "records":
+                assert c["send"] > 0 and c["recv"] > 0 and c["send_bytes"] > 0, c
+            else:
+                assert c["word_allreduce"] >= 3 * n and c["send"] == 0, c
+        else:
+            assert c["key_min_reduce"] == 0 and c["send"] == 0, c
+        assert c["host_barriers"] == 0
+
+
 def _world():
     return min(_device_count(), int(os.environ.get("HRBF_REAL_RANKS", "2")))
 
@@ -134,9 +160,10 @@ def test_row_sharded_registration_over_rccl_is_bit_identical(gpu_available, cfg)
     for r, res in many.items():
         assert res["status"] == 0
         for k, v in single.items():
-            if k in ("status", "exchange_mode"):
+            if k in ("status", "exchange_mode", "comm", "tracked"):
                 continue
             assert np.array_equal(res[k], v), "rank %d differs in %s" % (r, k)
+    _check_comm(many, _world(), cfg)
 
 
 RANGES = [(160, 120, 0, 6, 0, "ranges", True, None, 0), (320, 240, 150_000, 5, 1, "ranges", True, None, 0),
@@ -150,7 +177,7 @@ def test_range_owned_map_over_rccl_is_bit_identical(gpu_available, cfg):
     G = _world()
     many = _launch(G, cfg)
     for k, v in single.items():
-        if k in ("map", "local_count", "status", "exchange_mode"):
+        if k in ("map", "local_count", "status", "exchange_mode", "comm", "tracked"):
             continue
         if k.startswith("stats"):
             assert np.array_equal(sum(many[r][k].astype(np.int64) for r in range(G)), v), k
@@ -162,6 +189,7 @@ def test_range_owned_map_over_rccl_is_bit_identical(gpu_available, cfg):
         assert all(many[r]["exchange_mode"] == 2 for r in range(G))
     joined = np.concatenate([many[r]["map"].reshape(-1, 20) for r in range(G)])
     assert np.array_equal(joined, single["map"].reshape(-1, 20))
+    _check_comm(many, G, cfg)
 
 
 HASH = [(160, 120, 0, 7, 0, "hash", True, None, 0), (320, 240, 150_000, 5, 1, "hash", True, None, 0),
@@ -180,7 +208,7 @@ def test_hash_owned_map_over_rccl_is_bit_identical(gpu_available, cfg):
     many = _launch(G, cfg)
     assert all(many[r]["status"] == 0 for r in range(G))
     for k, v in single.items():
-        if k in ("map", "local_count", "status", "exchange_mode"):
+        if k in ("map", "local_count", "status", "exchange_mode", "comm", "tracked"):
             continue
         if k.startswith("stats"):
             assert np.array_equal(sum(many[r][k].astype(np.int64) for r in range(G)), v), k
@@ -199,3 +227,4 @@ def test_hash_owned_map_over_rccl_is_bit_identical(gpu_available, cfg):
     assert len(np.unique(ids)) == n
     joined = np.concatenate([many[r]["map"].reshape(-1, 20) for r in range(G)])[np.argsort(ids, kind="stable")]
     assert np.array_equal(joined, single["map"].reshape(-1, 20))
+    _check_comm(many, G, cfg)

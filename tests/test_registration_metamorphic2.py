@@ -1,0 +1,551 @@
+"""Second family of known-answer / metamorphic tests on the registration (VERDICT r05 "next" #2): the CUDA rows round 5's suite
+did not touch.  As in tests/test_registration_metamorphic.py every expected answer is a consequence of what the reference's code
+STATES (file:line below), on analytic scenes or planted inputs — never an output of the oracle written down afterwards.
+
+ (xvi)   the model maps live in the tracker's world frame: vertices R v + t, normals and principal directions R n WITHOUT t, curvature
+         values untouched (cudafuncs.cu:213-322): with a far-away start pose every model vertex lies on a wall of the analytic room,
+         normals are unit wall normals, principal directions stay tangent.
+ (xvii)  2 x 2 resize: "NaN if ANY tap is NaN", plain mean of the four taps, normals renormalised (cudafuncs.cu:526-587): the levels
+         above a planted hole are predicted texel for texel from level 0.
+ (xviii) copy validity: `z == 0 || n.w <= 0` (cudafuncs.cu:344-383), `-300 < kappa < 300 && !NaN` (:405-431): k planted pixels on the
+         wrong side of a rule cost exactly k inliers, on the right side none.
+ (xix)   icp weights: `w > 0` else NaN (cudafuncs.cu:452-470), NaN if any tap NaN one level up (:694-726), NaN weight -> weight 0
+         (reduce.cu:494-500): zero weights at every even texel silence levels 1 and 2 completely and leave the inlier count alone.
+ (xx)    ICP rejection `dist > 0.1` on the Euclidean distance (reduce.cu:383, RGBDOdometry.h:65): backing off a frontal wall by 9 cm
+         leaves exactly the pixels whose ray is shorter than 0.1 / 0.09 — a disc — and the step is recovered; 11 cm leaves none.
+ (xxi)   ICP rejection `sine > sin 20 deg` (reduce.cu:383): live normals turned by 19 degrees all pass, by 21 degrees none.
+ (xxii)  windowed correspondence search (reduce.cu:357-430): ties go to the first candidate in raster order; the candidate that agrees
+         in position, normal and curvature wins wherever it sits; a candidate beyond the thresholds neither wins nor enters the
+         distance normalisation; D_p is normalised by the window's largest ACCEPTED distance.
+ (xxiii) sparse ICP (reduce.cu:302-315,479-492; cudafuncs.cu:1030-1080): with lambda = 0 and |s - d| below the threshold the system
+         is the plain one; lambda <- lambda + mu (s - d - z); one multiplier update on a standing offset DOUBLES the right-hand
+         side; matches in column 0 never update (`corresp.x > 0`, kept); z is the minimiser of |z|^p + mu/2 |z - h|^2.
+ (xxiv)  the 0.3 m guard (RGBDOdometry.cpp:1232-1236): an estimate beyond 0.3 m is thrown away — the pose is the previous pose to the bit.
+ (xxv)   velocity weighting (HRBFFusion.cpp:1112-1123): max(1 - min(max(|dt|, |dtheta|), 0.01) / 0.01, 0.5) * weightMultiplier.
+
+Every test here fails on at least one of the deliberate misreadings 27-47 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
+profiles/r06_mutation_report.txt).  GPU twins (-m gpu): the HIP library on the same scenarios returns the oracle's pose / weighting
+bits and meets the same outcome bounds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import reg_cases as rc
+import reg_scenes as rs
+import reg_staged as st
+from hrbffusion3d_amd.params import default_params
+
+QVGA = (320, 240)
+I4 = np.eye(4)
+ICP_ONLY = dict(icp_weight=100.0, so3=0, icp_use_weighted=0)       # `rgb = rgbOnly || icpWeight < 100` (RGBDOdometry.cpp:807)
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xvi)
+def _model_pyramids(e):
+    return {n: [e.pyramid(n, l) for l in range(3)] for n in ("vmap_g", "nmap_g", "ck1_g", "ck2_g")}
+
+
+def test_the_model_maps_live_in_the_trackers_world_frame(oracle_lib_built):
+    scene, TA = rc.VIEWS["room"]
+    T0 = rs.pose(0.3, -0.5, 0.2, (5.0, -3.0, 2.0))                 # far from the origin, turned by ~35 degrees
+    r = st.staged("oracle", *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, T0=T0, keep=_model_pyramids, so3=0)
+    r1 = st.staged("oracle", *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, keep=_model_pyramids, so3=0)     # the same from the identity
+    Wm = T0 @ np.linalg.inv(TA)                                     # scene frame -> tracker's world frame
+    Rw, tw = Wm[:3, :3], Wm[:3, 3]
+    for l in range(3):
+        v, n, k1, k2 = (r["extra"][m][l].astype(np.float64) for m in ("vmap_g", "nmap_g", "ck1_g", "ck2_g"))
+        ok = ~np.isnan(v[..., 0]) & ~np.isnan(n[..., 0])
+        assert ok.mean() > 0.95
+        P, N = v[ok][:, :3], n[ok][:, :3]
+        best = np.full(len(P), np.inf); wall = np.zeros((len(P), 3))
+        for pn, d in scene:
+            pn = np.asarray(pn, np.float64); d = d / np.linalg.norm(pn); pn = pn / np.linalg.norm(pn)
+            nw = Rw @ pn
+            dist = np.abs(P @ nw - (d + nw @ tw))
+            upd = dist < best
+            best = np.where(upd, dist, best); wall[upd] = nw
+        assert best.max() < 0.03 and np.percentile(best, 99) < 0.012, (l, best.max())         # on a wall (bilateral-rounded creases: 1.5 cm)
+        assert np.abs(np.linalg.norm(N, axis=1) - 1.0).max() < 1e-5, l                          # R n: still unit (R n + t would not be)
+        assert np.percentile(np.abs((N * wall).sum(1)), 5) > 0.9, l                             # and it is that wall's normal
+        for k in (k1, k2):
+            kk = ok & ~np.isnan(k[..., 0])
+            d = k[kk][:, :3]; ln = np.linalg.norm(d, axis=1)
+            good = ln > 0.5                                         # averaged directions of a flat wall may cancel on the upper levels
+            assert np.percentile(np.abs((d[good] * n[kk][:, :3][good]).sum(1)) / ln[good], 95) < 0.02, l   # tangent in the WORLD frame
+            # the curvature VALUE is carried over as it is: the same image from either start pose
+            same = kk & ~np.isnan(r1["extra"]["ck1_g" if k is k1 else "ck2_g"][l][..., 0])
+            a = k[same][:, 3]; b = r1["extra"]["ck1_g" if k is k1 else "ck2_g"][l].astype(np.float64)[same][:, 3]
+            assert np.median(np.abs(a - b)) < 1e-3 and np.percentile(np.abs(a - b), 99) < 0.5, l
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xvii)
+def _live_pyramids(e):
+    return {n: [e.pyramid(n, l) for l in range(3)] for n in ("vmap_c", "nmap_c")}
+
+
+def _holes(e):
+    a = e.get_image("VERTEX_FILTERED").copy()
+    a[101, 143, :] = 0; a[50:53, 200:203, :] = 0                   # one texel; a 3 x 3 block straddling 2 x 2 cells
+    e.set_image("VERTEX_FILTERED", a)
+
+
+def test_resize_is_nan_if_any_tap_is_nan_and_renormalises_normals(oracle_lib_built):
+    scene, TA = rc.VIEWS["room"]
+    r = st.staged("oracle", *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, keep=_live_pyramids, edit=_holes, so3=0)
+    quad = lambda a: (a[0::2, 0::2], a[0::2, 1::2], a[1::2, 0::2], a[1::2, 1::2])
+    for name in ("vmap_c", "nmap_c"):
+        lv = r["extra"][name]
+        for l in (1, 2):
+            below = ~np.isnan(lv[l - 1][..., 0])
+            q = quad(below)
+            assert np.array_equal(~np.isnan(lv[l][..., 0]), q[0] & q[1] & q[2] & q[3]), (name, l)
+        # the premise: the rule bites (a NaN-aware mean would keep every cell that has ONE valid tap)
+        q = quad(~np.isnan(lv[0][..., 0]))
+        assert (~(q[0] & q[1] & q[2] & q[3])).sum() >= 5 and (~(q[0] | q[1] | q[2] | q[3])).sum() <= 1
+    v, n = r["extra"]["vmap_c"], r["extra"]["nmap_c"]
+    for l in (1, 2):
+        ok = ~np.isnan(v[l][..., 0])
+        qv = quad(v[l - 1][..., :3].astype(np.float64)); qn = quad(n[l - 1][..., :3].astype(np.float64))
+        mv = (qv[0] + qv[1] + qv[2] + qv[3]) / 4.0; mn = (qn[0] + qn[1] + qn[2] + qn[3]) / 4.0
+        assert np.abs(v[l][ok][:, :3] - mv[ok]).max() < 1e-6, l                                   # plain mean of the four taps
+        ln = np.linalg.norm(mn, axis=-1)
+        assert np.abs(n[l][ok][:, :3] - (mn / ln[..., None])[ok]).max() < 1e-6, l                 # ... renormalised for normals
+        assert np.abs(np.linalg.norm(n[l][ok][:, :3], axis=1) - 1.0).max() < 1e-6
+        if l == 1:
+            assert ln[ok].min() < 0.99                              # the premise: across a crease the plain mean is visibly short
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xviii)
+_PLANT_AT = None
+
+
+def _plant(img, chan, val, n=100):
+    def edit(e):
+        global _PLANT_AT
+        rng = np.random.default_rng(3)
+        ys = rng.integers(60, 180, n * 3); xs = rng.integers(80, 240, n * 3)
+        pts = list(dict.fromkeys(zip(ys.tolist(), xs.tolist())))[:n]
+        a = e.get_image(img).copy()
+        for y, x in pts:
+            a[y, x, chan] = val
+        e.set_image(img, a)
+    return edit
+
+
+VALIDITY_CASES = [("NORMAL", 3, 0.0, 100), ("NORMAL", 3, -1.0, 100), ("NORMAL", 3, 1e-6, 0), ("VERTEX_FILTERED", 2, 0.0, 100),
+                  ("CURV1", 3, 301.0, 100), ("CURV1", 3, -301.0, 100), ("CURV1", 3, 299.0, 0), ("CURV1", 3, -299.0, 0),
+                  ("CURV2", 3, -301.0, 100), ("CURV2", 3, 299.0, 0), ("CURV1", 3, float("nan"), 100)]
+
+
+def _validity_run(kind, case=None):
+    scene, TA = rc.VIEWS["plane"]
+    edit = _plant(*case[:3]) if case else None
+    return st.staged(kind, *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, edit=edit, pyramid=0, **ICP_ONLY)
+
+
+@pytest.mark.parametrize("case", VALIDITY_CASES, ids=["%s.%d=%g" % c[:3] for c in VALIDITY_CASES])
+def test_copy_validity_rules_cost_exactly_the_planted_pixels(oracle_lib_built, case):
+    n0 = st.inliers(_validity_run("oracle")["trace"])
+    assert n0 == QVGA[0] * QVGA[1]                                  # the analytic plane: every pixel is an inlier before planting
+    assert n0 - st.inliers(_validity_run("oracle", case)["trace"]) == case[3], case
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xix)
+def _zero_weight_at_even_texels(e):
+    for name in ("PRED_ICPWEIGHT", "FILL_ICPWEIGHT"):
+        w = np.ones_like(e.get_image(name)); w[0::2, 0::2] = 0.0
+        e.set_image(name, w)
+
+
+def test_zero_icp_weights_are_invalid_and_silence_the_levels_above(oracle_lib_built):
+    scene, TA = rc.VIEWS["room"]
+    r = st.staged("oracle", *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, edit=_zero_weight_at_even_texels, icp_weight=100.0, so3=0, icp_use_weighted=1)
+    for lvl in (2, 1):
+        rows = st.gn_rows(r["trace"], lvl)
+        assert len(rows) == (4 if lvl == 2 else 5)
+        for row in rows:
+            assert not row[2:38].any() and not row[38:44].any()     # every 2 x 2 cell holds a zero -> NaN -> weight 0: A = 0, b = 0 ...
+            assert row[92] > 0.9 * (QVGA[0] >> lvl) * (QVGA[1] >> lvl)   # ... while every pixel is still counted as an inlier
+    rows0 = st.gn_rows(r["trace"], 0)
+    assert np.abs(rows0[0][2:38]).max() > 1000.0 and rows0[0][92] > 0.9 * QVGA[0] * QVGA[1]
+    # three quarters of the level-0 pixels carry weight 1: the matrix is 3/4 of the unweighted one
+    u = st.staged("oracle", *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, icp_weight=100.0, so3=0, icp_use_weighted=0, pyramid=0)
+    A_w, A_u = rows0[0][2:38].reshape(6, 6), st.gn_rows(u["trace"], 0)[0][2:38].reshape(6, 6)
+    assert np.abs(A_w - 0.75 * A_u).max() < 0.02 * np.abs(A_u).max()
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xx)
+def _back_off(kind, d, **kw):
+    return st.staged(kind, *QVGA, I4, rs.pose(t=(0.0, 0.0, -d)), scene=st.frontal_plane(1.5), pyramid=0, **ICP_ONLY, **kw)
+
+
+def test_distance_rejection_is_euclidean_at_ten_centimetres(oracle_lib_built):
+    W, H = QVGA
+    fx, fy, cx, cy = rc.intrinsics(W, H)
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    ray = np.sqrt(1.0 + ((u - cx) / fx) ** 2 + ((v - cy) / fy) ** 2)
+    near = _back_off("oracle", 0.09)
+    # the live point sits d * |ray| from the model point on the same ray: inside 10 cm on a disc round the principal point
+    expect = int((0.09 * ray <= 0.1).sum())
+    assert 0.5 * W * H < expect < 0.8 * W * H
+    assert abs(st.inliers(near["trace"]) - expect) <= 0.01 * expect, (st.inliers(near["trace"]), expect)
+    e = np.linalg.inv(near["G"]) @ near["E"]
+    assert abs(near["E"][2, 3] + 0.09) < 0.002 and abs(e[2, 3]) < 0.002          # ... and the step along the normal is recovered
+    assert st.inliers(near["trace"], it=9) > 0.85 * W * H                          # once aligned (nearly) every pixel is within reach
+    far = _back_off("oracle", 0.11)
+    assert all(int(row[92]) == 0 for row in st.gn_rows(far["trace"]))              # 11 cm: nothing, on any iteration
+    assert np.array_equal(far["E"], far["P0"])                                     # an empty system leaves the pose where it was
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxi)
+def _turn_normals(deg):
+    def edit(e):
+        n = e.get_image("NORMAL").copy()
+        n[..., :3] = n[..., :3] @ rs.rot(np.radians(deg), 0.0, 0.0).astype(np.float32).T
+        e.set_image("NORMAL", n)
+    return edit
+
+
+@pytest.mark.parametrize("deg", [19.0, -19.0, 21.0, -21.0])
+def test_angle_rejection_is_the_sine_of_twenty_degrees(oracle_lib_built, deg):
+    r = st.staged("oracle", *QVGA, I4, I4, scene=st.frontal_plane(1.5), edit=_turn_normals(deg), pyramid=0, **ICP_ONLY)
+    n = st.inliers(r["trace"])
+    assert n == (QVGA[0] * QVGA[1] if abs(deg) < 20.0 else 0), (deg, n)
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxii)
+class _Window:
+    """one live pixel against a hand-made 5 x 5 neighbourhood of model texels (everything else NaN), through the oracle's search seam"""
+    ROWS, COLS = 24, 32
+    K = (30.0, 30.0, 16.0, 12.0)
+    X0, Y0, Z = 15, 11, 1.5
+
+    def __init__(self, lib):
+        self.lib = lib
+        r, c = self.ROWS, self.COLS
+        self.v = np.full((4, r, c), np.nan, np.float32); self.n = np.full((4, r, c), np.nan, np.float32)
+        self.k1 = np.full((4, r, c), np.nan, np.float32); self.k2 = np.full((4, r, c), np.nan, np.float32)
+        fx, fy, cx, cy = self.K
+        self.p = np.array([(self.X0 - cx) / fx * self.Z, (self.Y0 - cy) / fy * self.Z, self.Z])
+        self.lv = np.full((4, r, c), np.nan, np.float32); self.ln = np.full((4, r, c), np.nan, np.float32)
+        self.lk1 = np.full((4, r, c), np.nan, np.float32); self.lk2 = np.full((4, r, c), np.nan, np.float32)
+        self.live(2.0, 2.0)
+
+    def live(self, k1, k2, normal=(0.0, 0.0, 1.0)):
+        y, x = self.Y0, self.X0
+        self.lv[:, y, x] = [*self.p, 1.0]; self.ln[:, y, x] = [*normal, 1.0]
+        self.lk1[:, y, x] = [1, 0, 0, k1]; self.lk2[:, y, x] = [0, 1, 0, k2]
+
+    def put(self, dx, dy, offset=(0.0, 0.0, 0.01), tilt_deg=0.0, k1=2.0, k2=2.0):
+        y, x = self.Y0 + dy, self.X0 + dx
+        self.v[:, y, x] = [*(self.p + np.asarray(offset)), 1.0]
+        t = np.radians(tilt_deg)
+        self.n[:, y, x] = [np.sin(t), 0.0, np.cos(t), 1.0]
+        self.k1[:, y, x] = [1, 0, 0, k1]; self.k2[:, y, x] = [0, 1, 0, k2]
+
+    def search(self, use_search=1, radius=2):
+        pp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        I3 = np.eye(3, dtype=np.float32); t0 = np.zeros(3, np.float32)
+        w = np.ones((self.ROWS, self.COLS), np.float32)
+        co = np.full((self.ROWS, self.COLS, 2), 7, np.int32)
+        A = np.zeros(36); b = np.zeros(6); res = np.zeros(2)
+        keep = [np.ascontiguousarray(a) for a in (self.lv, self.ln, self.lk1, self.lk2, self.v, self.n, self.k1, self.k2)]
+        self.lib.orc_icp_step_search(pp(I3), pp(t0), pp(keep[0]), pp(keep[1]), pp(keep[2]), pp(keep[3]), pp(I3), pp(t0), *self.K,
+                                     pp(keep[4]), pp(keep[5]), pp(keep[6]), pp(keep[7]), pp(w), self.ROWS, self.COLS, 0.1, 0.3420201433, 0,
+                                     int(use_search), int(radius), pp(co), pp(A), pp(b), pp(res))
+        got = tuple(int(q) for q in co[self.Y0, self.X0])
+        others = co.copy(); others[self.Y0, self.X0] = -1
+        assert (others == -1).all()                                 # no other live pixel is valid: no other match
+        return (got[0] - self.X0, got[1] - self.Y0) if got != (-1, -1) else None, int(res[1])
+
+
+@pytest.fixture()
+def window(oracle_lib_built):
+    return _Window(oracle_lib_built.load())
+
+
+def test_search_ties_go_to_the_first_candidate_in_raster_order(window):
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            window.put(dx, dy)                                      # 25 identical candidates, 1 cm behind the live point
+    assert window.search() == ((-2, -2), 1)
+    assert window.search(radius=1) == ((-1, -1), 1)                # `icp_radius` is the half width of the window
+    assert window.search(use_search=0) == ((0, 0), 1)              # without the search only the projected texel is looked at
+
+
+@pytest.mark.parametrize("at", [(-2, -2), (2, -1), (0, 0), (-1, 2), (2, 2)])
+def test_search_picks_the_candidate_that_agrees_wherever_it_sits(window, at):
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            window.put(dx, dy, offset=(0.03, 0.0, 0.04), tilt_deg=15.0, k1=5.0, k2=-4.0)     # 5 cm off, 15 degrees off, other curvature
+    window.put(*at, offset=(0.0, 0.0, 0.001), tilt_deg=0.0, k1=2.0, k2=2.0)
+    assert window.search() == (at, 1)
+
+
+def test_search_ignores_candidates_beyond_the_thresholds_also_in_the_normalisation(window):
+    # A: 1 cm, curvature mismatch worth D_c = 0.3; B: 2 cm, same curvature as the live point (2.3567: exp(-0.3567) = 0.7)
+    window.live(2.3567, 2.3567)
+    window.put(-1, 0, offset=(0.0, 0.0, 0.01), k1=2.0, k2=2.0)
+    window.put(1, 0, offset=(0.0, 0.0, 0.02), k1=2.3567, k2=2.3567)
+    # D_p = dist / (largest ACCEPTED distance = 2 cm): cost A = .333 (0.5 + 0 + 0.3) < cost B = .333 (1 + 0 + 0)
+    assert window.search() == ((-1, 0), 1)
+    # a perfect-looking candidate 12 cm away and one tilted by 25 degrees: rejected outright; and they do NOT stretch the
+    # normalisation (with D_p = dist / 12 cm the costs would be .333 (.083 + .3) against .333 (.167): B would win)
+    window.put(0, -2, offset=(0.0, 0.0, 0.12), k1=2.3567, k2=2.3567)
+    window.put(0, 2, offset=(0.0, 0.0, 0.0005), tilt_deg=25.0, k1=2.3567, k2=2.3567)
+    assert window.search() == ((-1, 0), 1)
+    # a candidate outside the 5 x 5 window does not exist for the search
+    window.put(3, 0, offset=(0.0, 0.0, 0.0001), k1=2.3567, k2=2.3567)
+    assert window.search() == ((-1, 0), 1)
+
+
+def test_search_cost_is_the_stated_sum_on_random_windows(window):
+    """argmin of .333 dist / D_p_R + .333 (1 - n.n') + .333 (1 - exp(-|dk1| / kmax) exp(-|dk2| / kmax)) (reduce.cu:419-428), float64,
+    on windows whose best and second-best cost are clearly apart"""
+    rng = np.random.default_rng(11)
+    checked = 0
+    for trial in range(60):
+        w = _Window(window.lib)
+        lk = rng.uniform(-3, 3, 2); w.live(*lk)
+        cand = {}
+        for dy in range(-2, 3):
+            for dx in range(-2, 3):
+                if rng.random() < 0.3:
+                    continue
+                off = rng.uniform(-0.05, 0.05, 3); tilt = rng.uniform(-25, 25); k = rng.uniform(-3, 3, 2)
+                w.put(dx, dy, offset=off, tilt_deg=tilt, k1=k[0], k2=k[1])
+                cand[(dx, dy)] = (np.linalg.norm(off.astype(np.float32)), tilt, k)
+        ok = {c: v for c, v in cand.items() if v[0] <= 0.1 and abs(np.sin(np.radians(v[1]))) <= 0.3420201433}
+        if len(ok) < 2 or min(abs(abs(np.sin(np.radians(v[1]))) - 0.342) for v in cand.values()) < 0.004:
+            continue
+        dmax = max(v[0] for v in ok.values())
+        cost = {c: 0.333 * v[0] / dmax + 0.333 * (1 - np.cos(np.radians(v[1]))) +
+                   0.333 * (1 - np.exp(-abs(v[2][0] - lk[0]) / max(abs(v[2]))) * np.exp(-abs(v[2][1] - lk[1]) / max(abs(v[2])))) for c, v in ok.items()}
+        order = sorted(cost, key=cost.get)
+        if cost[order[1]] - cost[order[0]] < 1e-3:
+            continue
+        assert w.search() == (order[0], 1), (trial, order[:2])
+        checked += 1
+    assert checked >= 25
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxiii)
+class _Offset:
+    """a frontal wall at 1.5 m seen twice, the live copy `e` metres behind the model, through the sparse-ICP seams"""
+    ROWS, COLS = 24, 32
+    K = (30.0, 30.0, 16.0, 12.0)
+
+    def __init__(self, lib, e=(0.0, 0.0, 0.01)):
+        self.lib = lib
+        r, c = self.ROWS, self.COLS
+        fx, fy, cx, cy = self.K
+        u, v = np.meshgrid(np.arange(c, dtype=np.float64), np.arange(r, dtype=np.float64))
+        P = np.stack([(u - cx) / fx * 1.5, (v - cy) / fy * 1.5, np.full_like(u, 1.5)])
+        one = np.ones((1, r, c))
+        self.model = np.ascontiguousarray(np.concatenate([P, one]).astype(np.float32))
+        self.live = np.ascontiguousarray(np.concatenate([P + np.asarray(e, np.float64)[:, None, None], one]).astype(np.float32))
+        self.nrm = np.ascontiguousarray(np.concatenate([np.zeros((2, r, c)), one, one]).astype(np.float32))
+        self.kk = np.zeros((4, r, c), np.float32); self.kk[3] = 0.5
+        self.w = np.ones((r, c), np.float32)
+        self.e = np.asarray(e, np.float64)
+
+    def step(self, lam, plain=False, live=None):
+        pp = lambda a: a.ctypes.data_as(C.c_void_p)
+        I3 = np.eye(3, dtype=np.float32); t0 = np.zeros(3, np.float32)
+        live = self.live if live is None else live
+        A = np.zeros(36); b = np.zeros(6); res = np.zeros(2)
+        if plain:
+            self.lib.orc_icp_step(pp(I3), pp(t0), pp(live), pp(self.nrm), pp(self.kk), pp(self.kk), pp(I3), pp(t0), *self.K, pp(self.model),
+                                  pp(self.nrm), pp(self.kk), pp(self.kk), pp(self.w), self.ROWS, self.COLS, 0.1, 0.3420201433, 0, pp(A), pp(b), pp(res))
+            return A, b, res
+        z = np.full((self.ROWS, self.COLS, 3), 7.0, np.float32); co = np.full((self.ROWS, self.COLS, 2), 5, np.int32)
+        lam = np.ascontiguousarray(lam, np.float32)
+        self.lib.orc_icp_step_sparse(pp(I3), pp(t0), pp(live), pp(self.nrm), pp(self.kk), pp(self.kk), pp(I3), pp(t0), *self.K, pp(self.model),
+                                     pp(self.nrm), pp(self.kk), pp(self.kk), pp(self.w), self.ROWS, self.COLS, 0.1, 0.3420201433, 0,
+                                     pp(lam), pp(z), pp(co), pp(A), pp(b), pp(res))
+        return A, b, res, z, co
+
+    def update(self, lam, z, co):
+        pp = lambda a: a.ctypes.data_as(C.c_void_p)
+        I3 = np.eye(3, dtype=np.float32); t0 = np.zeros(3, np.float32)
+        lam = np.ascontiguousarray(lam, np.float32).copy()
+        self.lib.orc_update_lambda_map(pp(I3), pp(t0), pp(self.live), pp(I3), pp(t0), pp(self.model), pp(co), pp(z), pp(lam), self.ROWS, self.COLS)
+        return lam
+
+
+def test_sparse_icp_multiplier_update_doubles_a_standing_offset(oracle_lib_built):
+    o = _Offset(oracle_lib_built.load())
+    zero = np.zeros((o.ROWS, o.COLS, 3), np.float32)
+    A_p, b_p, r_p = o.step(None, plain=True)
+    A0, b0, r0, z0, co = o.step(zero)
+    # 1 cm is far below the shrink threshold (0.32 m): z = 0, and with lambda = 0 the sparse system IS the plain one
+    assert not z0.any() and np.array_equal(A0, A_p) and np.array_equal(b0, b_p) and np.array_equal(r0, r_p)
+    matched = co[..., 0] >= 0
+    assert matched.sum() == int(r0[1]) > 0.8 * o.ROWS * o.COLS
+    # lambda <- lambda + mu (s - d - z) with mu = 10, where a correspondence was found — tested as corresp.x > 0 (cudafuncs.cu:1048)
+    lam1 = o.update(zero, z0, co)
+    upd = co[..., 0] > 0
+    assert np.allclose(lam1[upd], 10.0 * o.e, rtol=1e-4, atol=1e-7) and not lam1[~upd].any()
+    assert (matched & ~upd).sum() >= o.ROWS - 4                     # the matches in column 0: found, never updated
+    # the next step sees h = (s - d) + lambda / mu = 2 e (still z = 0) and a target moved by -lambda / mu: residual n.(s - d) doubles
+    A1, b1, r1, z1, co1 = o.step(lam1)
+    assert not z1.any() and np.array_equal(co1, co)
+    np.testing.assert_allclose(A1, A0, rtol=1e-6)
+    col0 = o.live.copy(); col0[0, :, 1:] = np.nan                  # the same system restricted to column 0 (its residual does not double)
+    _, b_c0, _ = o.step(None, plain=True, live=col0)
+    np.testing.assert_allclose(b1, 2.0 * b0 - b_c0, rtol=2e-5, atol=1e-7)
+    assert np.abs(b1 - b0).max() > 0.5 * np.abs(b0).max()
+
+
+def test_sparse_icp_shrunk_residual_points_along_h(oracle_lib_built):
+    """beyond the threshold z = beta h with 0 < beta < 1 and h = s - d + lambda / mu (reduce.cu:482-483): z is PARALLEL to h"""
+    o = _Offset(oracle_lib_built.load())
+    lam = np.zeros((o.ROWS, o.COLS, 3), np.float32); lam[..., 2] = 4.0        # lambda / mu = 0.4 m along the offset
+    _, _, _, z, co = o.step(lam)
+    m = co[..., 0] >= 0
+    h = o.e + np.array([0.0, 0.0, 0.4])
+    beta = float(oracle_lib_built.load().orc_sparse_shrink_factor(C.c_float(float(np.linalg.norm(h)))))
+    assert 0.5 < beta < 1.0
+    np.testing.assert_allclose(z[m], np.broadcast_to(beta * h, z[m].shape), rtol=1e-4, atol=1e-6)
+
+
+def test_shrink_operator_minimises_the_lp_proximal_objective(oracle_lib_built):
+    """z = thrink(h) (reduce.cu:302-315, p = 0.5, mu = 10, three sweeps) is the shrinkage step of sparse ICP: the minimiser over
+    z = beta h of |z|^p + mu / 2 |z - h|^2.  Dense search over beta in float64, no formula from the code"""
+    lib = oracle_lib_built.load()
+    betas = np.linspace(0.0, 1.0, 200001)
+    p, mu = 0.5, 10.0
+    for hn in (0.05, 0.2, 0.30, 0.315, 0.33, 0.35, 0.4, 0.6, 1.0, 3.0):
+        obj = (betas * hn) ** p + 0.5 * mu * (hn * (1.0 - betas)) ** 2
+        star = betas[np.argmin(obj)]
+        got = float(lib.orc_sparse_shrink_factor(C.c_float(hn)))
+        if star == 0.0:
+            assert got == 0.0, (hn, got)
+        else:
+            assert abs(got - star) < 4e-3, (hn, got, star)          # three fixed-point sweeps: 3e-3 at the threshold, 1e-6 beyond 0.4
+    # the threshold itself: the objective at the best interior beta equals the objective at z = 0 where the operator switches on
+    lo, hi = 0.30, 0.35
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if float(lib.orc_sparse_shrink_factor(C.c_float(mid))) == 0.0 else (lo, mid)
+    obj = (betas * lo) ** p + 0.5 * mu * (lo * (1.0 - betas)) ** 2
+    interior = obj[betas > 0.3].min()
+    assert abs(interior - obj[0]) < 2e-3 * obj[0], (lo, interior, obj[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxiv)
+def _sidestep(kind, d, trace=True):
+    # a wall 5.5 m away at 160 x 120: 1 px = 4.2 cm, so 0.24-0.36 m of sideways motion is 6-9 px (1.5-2 px on level 2); joint mode:
+    # the ICP term (blind to motion along the wall) pins tz, rx, ry, the photometric term finds the sidestep
+    return rc.two_frames(kind, 160, 120, I4, rs.pose(t=(d, 0.0, 0.0)), scene=st.frontal_plane(5.5), so3=0, wavelength=3.0, trace=trace, depth_cutoff=6.0)
+
+
+def test_an_estimate_beyond_thirty_centimetres_is_thrown_away(oracle_lib_built):
+    near = _sidestep("oracle", 0.24)
+    assert abs(near["E"][0, 3] - 0.24) < 0.03 and np.linalg.norm(near["E"][:3, 3]) < 0.3          # below the guard: kept
+    far = _sidestep("oracle", 0.36)
+    last = rc.trace_pose(st.gn_rows(far["trace"])[-1])
+    assert np.linalg.norm(last[:3, 3]) > 0.3                        # the premise: the loop did arrive beyond 0.3 m ...
+    assert np.array_equal(far["E"], np.eye(4))                      # ... and the frame keeps the previous pose, rotation included, to the bit
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxv)
+WEIGHTING = {   # name: (relative motion, weightMultiplier, expected weighting from HRBFFusion.cpp:1112-1123 at the TRUE motion, tolerance)
+    "static": (I4, 1.0, 1.0, 0.0),
+    "3mm": (rs.pose(t=(0.003, 0.0, 0.0)), 1.0, 0.7, 0.06),          # ICP alone is good to a third of a millimetre here
+    "2cm": (rs.pose(t=(0.012, -0.012, 0.010)), 1.0, 0.5, 0.0),      # beyond `largest`: the floor minWeight
+    "2cm_x3": (rs.pose(t=(0.012, -0.012, 0.010)), 3.0, 1.5, 0.0),   # the multiplier acts OUTSIDE the clamp
+    "turn_0.012": (rs.pose(0.0, 0.012, 0.0), 1.0, 0.5, 0.0),        # a pure rotation counts through its angle (radians against metres)
+    "turn_0.004": (rs.pose(0.0, 0.004, 0.0), 1.0, 0.6, 0.08),
+}
+
+
+def _weighting_run(kind, name):
+    M, wmul, _, _ = WEIGHTING[name]
+    W, H = QVGA
+    K = rc.intrinsics(W, H)
+    scene, TA = rc.VIEWS["room"]
+    a = rs.render(TA, W, H, K, scene, wavelength=160.0 / W); b = rs.render(TA @ M, W, H, K, scene, wavelength=160.0 / W)
+    e = rc.make_engine(kind, default_params(W, H, *K, max_surfels=1 << 20, icp_weight=100.0, icp_use_weighted=0))
+    try:
+        e.process_frame(a[0], a[1])
+        w1 = e.get_weighting()
+        e.process_frame(b[0], b[1], 0, wmul)
+        return w1, e.get_weighting(), np.ascontiguousarray(e.get_pose(), np.float32).view(np.uint32).copy()
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("name", list(WEIGHTING))
+def test_velocity_weighting_follows_the_stated_clamp(oracle_lib_built, name):
+    w1, w2, _ = _weighting_run("oracle", name)
+    _, wmul, expect, tol = WEIGHTING[name]
+    assert w1 == 1.0                                                # the first frame is fused with the initial weighting
+    assert abs(w2 - expect) <= tol * wmul + 1e-6, (name, w2, expect)
+    if name == "3mm":                                               # the multiplier is a plain factor on the same estimate
+        saved = WEIGHTING["3mm"]
+        try:
+            WEIGHTING["3mm"] = (saved[0], 3.0, saved[2], saved[3])
+            assert abs(_weighting_run("oracle", "3mm")[1] - 3.0 * w2) < 1e-6
+        finally:
+            WEIGHTING["3mm"] = saved
+
+
+# ================================================================================================================== GPU twins
+def _same_bits(a, b):
+    return np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["world_frame", "holes", "zero_weights", "back_off_9cm", "back_off_11cm", "normals_19", "normals_21",
+                                  "plant_normal_w", "plant_kappa", "corr_search", "sparse_search"])
+def test_hip_on_the_staged_scenarios(gpu_available, oracle_lib_built, case):
+    """the HIP library through the same stage / image seams: the oracle's pose bit for bit, and the outcome each scenario is about"""
+    scene, TA = rc.VIEWS["room"]
+    TB = TA @ rc.MOTIONS["2px"]
+    runs = {
+        "world_frame": lambda k: st.staged(k, *QVGA, TA, TB, scene=scene, T0=rs.pose(0.3, -0.5, 0.2, (5.0, -3.0, 2.0)), so3=0),
+        "holes": lambda k: st.staged(k, *QVGA, TA, TB, scene=scene, edit=_holes, so3=0),
+        "zero_weights": lambda k: st.staged(k, *QVGA, TA, TB, scene=scene, edit=_zero_weight_at_even_texels, icp_weight=100.0, so3=0, icp_use_weighted=1),
+        "back_off_9cm": lambda k: _back_off(k, 0.09, keep=lambda e: e.last_icp()),
+        "back_off_11cm": lambda k: _back_off(k, 0.11, keep=lambda e: e.last_icp()),
+        "normals_19": lambda k: st.staged(k, *QVGA, I4, I4, scene=st.frontal_plane(1.5), edit=_turn_normals(19.0), pyramid=0, keep=lambda e: e.last_icp(), **ICP_ONLY),
+        "normals_21": lambda k: st.staged(k, *QVGA, I4, I4, scene=st.frontal_plane(1.5), edit=_turn_normals(21.0), pyramid=0, keep=lambda e: e.last_icp(), **ICP_ONLY),
+        "plant_normal_w": lambda k: st.staged(k, *QVGA, *[rc.VIEWS["plane"][1], rc.VIEWS["plane"][1] @ rc.MOTIONS["2px"]], scene=rc.VIEWS["plane"][0],
+                                              edit=_plant("NORMAL", 3, 0.0), pyramid=0, keep=lambda e: e.last_icp(), **ICP_ONLY),
+        "plant_kappa": lambda k: st.staged(k, *QVGA, *[rc.VIEWS["plane"][1], rc.VIEWS["plane"][1] @ rc.MOTIONS["2px"]], scene=rc.VIEWS["plane"][0],
+                                           edit=_plant("CURV1", 3, -301.0), pyramid=0, keep=lambda e: e.last_icp(), **ICP_ONLY),
+        "corr_search": lambda k: st.staged(k, *QVGA, TA, TA @ rc.MOTIONS["5px"], scene=scene, icp_use_corr_search=1, icp_search_radius=2, so3=0),
+        "sparse_search": lambda k: st.staged(k, *QVGA, TA, TA @ rc.MOTIONS["5px"], scene=scene, icp_use_corr_search=1, use_sparse_icp=1, so3=0),
+    }
+    o, g = runs[case]("oracle"), runs[case]("hip")
+    assert _same_bits(o["bits"], g["bits"]), case
+    if case == "back_off_9cm":
+        assert abs(g["E"][2, 3] + 0.09) < 0.002 and g["extra"][1] == o["extra"][1] > 0.85 * QVGA[0] * QVGA[1]
+    if case in ("back_off_11cm", "normals_21"):
+        assert np.array_equal(g["E"], g["P0"]) and g["extra"][1] == 0.0
+    if case == "normals_19":
+        assert g["extra"][1] == QVGA[0] * QVGA[1]
+    if case in ("plant_normal_w", "plant_kappa"):
+        assert g["extra"][1] == o["extra"][1] and g["extra"][1] <= QVGA[0] * QVGA[1] - 100
+    if case in ("corr_search", "sparse_search", "world_frame", "holes"):
+        assert rs.reprojection_px(np.linalg.inv(g["P0"]) @ g["E"], g["G"], g["z"], g["K"]) < 0.6
+
+
+@pytest.mark.gpu
+def test_hip_keeps_the_thirty_centimetre_guard(gpu_available, oracle_lib_built):
+    for d in (0.24, 0.36):
+        o, g = _sidestep("oracle", d), _sidestep("hip", d, trace=False)
+        assert _same_bits(o["bits"], g["bits"]), d
+    assert np.array_equal(g["E"], np.eye(4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(WEIGHTING))
+def test_hip_velocity_weighting(gpu_available, oracle_lib_built, name):
+    ow1, ow2, ob = _weighting_run("oracle", name)
+    gw1, gw2, gb = _weighting_run("hip", name)
+    assert _same_bits(ob, gb) and np.float32(ow2).tobytes() == np.float32(gw2).tobytes() and gw1 == 1.0
+    _, wmul, expect, tol = WEIGHTING[name]
+    assert abs(gw2 - expect) <= tol * wmul + 1e-6

@@ -1,8 +1,8 @@
 """Do the metamorphic tests of tests/test_registration_metamorphic.py have teeth?  Runs them against 26 deliberately MISREAD
-builds of the oracle's registration (oracle/orc_odo.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
+builds of the oracle's registration — 47 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
 fail on which misreading.  A misreading no test fails on is a blind spot of the suite — it is listed as such.
 
-    python tools/mutation_report.py > profiles/r05_metamorphic_mutation_report.txt        (build container or any CPU host; ~20 minutes)
+    python tools/mutation_report.py [k ...] > profiles/r06_mutation_report.txt        (build container or any CPU host; ~40 minutes)
 """
 import os
 import re
@@ -37,10 +37,33 @@ MUTANTS = {
     24: "SO3 homography with the rotation transposed, K R^T K^-1 (RGBDOdometry.cpp:832)",
     25: "a different but CONSISTENT intensity image: textbook luma instead of the reference's 0.114 R + 0.299 G + 0.587 B (cudafuncs.cu:896-911)",
     26: "Sobel kernels swapped: dIdx holds the vertical derivative (cudafuncs.cu:927-954)",
+    # round 6: the CUDA rows round 5's misreadings did not touch (map building, rejection, search, sparse ICP, guard, weighting)
+    27: "model normals moved like points: R n + t (tranformMapsKernel, cudafuncs.cu:246)",
+    28: "model vertices rotated only: R v without t (cudafuncs.cu:230)",
+    29: "the model's principal directions left in the camera frame (transformCurvMaps skipped, cudafuncs.cu:279-322)",
+    30: "2x2 resize as a NaN-aware mean of the valid taps instead of 'NaN if any tap is NaN' (cudafuncs.cu:549-556)",
+    31: "resized normals not renormalised (cudafuncs.cu:573-581)",
+    32: "copyMaps validity on the vertex alone: `nsrc.w > 0` dropped (cudafuncs.cu:366)",
+    33: "curvature validity `kappa < thr` without `> -thr` (cudafuncs.cu:420)",
+    34: "icp weight kept when >= 0 instead of > 0 (cudafuncs.cu:462)",
+    35: "ICP distance threshold met by the squared distance (reduce.cu:383)",
+    36: "ICP angle threshold met by 1 - cosine instead of the sine (reduce.cu:383)",
+    37: "ICP distance threshold on the depth difference instead of the Euclidean distance (reduce.cu:381-383)",
+    38: "search ties go to the LAST candidate: `<=` for `<` (reduce.cu:429)",
+    39: "search cost: D_p normalised by the distance threshold instead of the window's largest accepted distance (reduce.cu:397-398,421)",
+    40: "sparse ICP: h = s - d - lambda / mu (reduce.cu:482)",
+    41: "sparse ICP: target moved by z + lambda / mu instead of z - lambda / mu (reduce.cu:485)",
+    42: "updateLambdaMap: lambda - mu * Delta (cudafuncs.cu:1066-1067)",
+    43: "no 0.3 m guard (RGBDOdometry.cpp:1232-1236)",
+    44: "velocity weighting from the translation alone: no max with the rotation angle (HRBFFusion.cpp:1116)",
+    45: "velocity weighting without the lower clamp minWeight (HRBFFusion.cpp:1124)",
+    46: "velocity weighting with weightMultiplier inside the clamp (HRBFFusion.cpp:1124)",
+    47: "sparse ICP: the l1 soft threshold instead of the l_p (p = 0.5) shrink operator (reduce.cu:302-315,652)",
 }
+MODULES = ["tests/test_registration_metamorphic.py", "tests/test_registration_metamorphic2.py"]
 
 
-def run(mutant, module="tests/test_registration_metamorphic.py"):
+def run(mutant, module):
     env = dict(os.environ)
     if mutant:
         env["HRBF_ORACLE_MUTANT"] = str(mutant)
@@ -61,22 +84,29 @@ def mutant_needs_second_look(failed):
 
 def main():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "mutants"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    failed, passed = run(0)
-    print("# tools/mutation_report.py: the CPU tests of tests/test_registration_metamorphic.py against deliberate misreadings of the registration")
-    print("oracle as it is: %d passed, %d failed" % (passed, len(failed)))
-    assert not failed, failed
+    only = [int(a) for a in sys.argv[1:]] or list(MUTANTS)
+    print("# tools/mutation_report.py: the CPU tests of %s against deliberate misreadings of the registration" % " + ".join(MODULES))
+    for mod in MODULES:
+        failed, passed = run(0, mod)
+        print("oracle as it is, %s: %d passed, %d failed" % (mod, passed, len(failed)))
+        assert not failed, failed
     caught = 0
-    for k, what in MUTANTS.items():
-        failed, passed = run(k)
+    for k in only:
+        what = MUTANTS[k]
+        failed, passed = [], 0
+        for mod in MODULES:
+            f, p = run(k, mod)
+            failed += [os.path.basename(mod)[:-3].replace("test_registration_", "") + "::" + t for t in f]; passed += p
         caught += bool(failed)
         print("\nmutant %2d  %s\n  -> %d of %d tests fail%s" % (k, what, len(failed), len(failed) + passed, "" if failed else "   ** NOT CAUGHT: a blind spot of these tests **"))
         for f in failed:
             print("       " + f)
+        sys.stdout.flush()
         if mutant_needs_second_look(failed):
             for mod in RESTATEMENTS:
                 f2, p2 = run(k, mod)
                 print("     (%s: %d of %d fail)" % (mod, len(f2), len(f2) + p2))
-    print("\n%d of %d misreadings are caught by at least one test" % (caught, len(MUTANTS)))
+    print("\n%d of %d misreadings are caught by at least one test" % (caught, len(only)))
 
 
 if __name__ == "__main__":
