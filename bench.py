@@ -945,10 +945,12 @@ def main():
                    "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": flops_alg / (ms_fit * 1e-3) / 1e12,
                                 "frac": flops_alg / (ms_fit * 1e-3) / 1e12 / 157.3,
                                 "achieved_executed_mfma": flops_mfma / (ms_fit * 1e-3) / 1e12,
-                                "note": "f32-input MFMA peak at 2.4 GHz (= the packed-f32 vector peak); `achieved` counts the algorithm's flops (n^3/3 + 2n^2, "
-                                        "n = 100), `achieved_executed_mfma` the padded 16-blocks the matrix core really multiplies. On this part f32 MFMA "
-                                        "and VALU instructions do not overlap (tools/probes/mfma_valu_overlap.hip: their times add) and the matrix core "
-                                        "runs at ~1.8 GHz under this load: the kernel is its 308 MFMAs (1.7 ms) plus its vector work (1.1 ms)"}}
+                                "note": "f32-input MFMA peak at 2.4 GHz (= the packed-f32 vector peak; tools/probes/mfma_f32_rate.hip measures 151-155 TFLOP/s for "
+                                        "v_mfma_f32_16x16x4_f32 in runs long enough for the clock to settle, 2.39 GHz under the load: the guide's figure). `achieved` "
+                                        "counts the algorithm's flops (n^3/3 + 2n^2, n = 100), `achieved_executed_mfma` the padded 16-blocks the matrix core really "
+                                        "multiplies. On this part f32 MFMA and VALU instructions do not overlap, also not across the waves of a SIMD (their times "
+                                        "add, profiles/r06_mfma_f32_rate.txt): the kernel is its 308 MFMAs at the full rate (1.24 ms per 640x480 frame) plus its "
+                                        "vector work (1.1 ms) plus the MFMA -> VALU -> MFMA dependency stalls four waves per SIMD do not hide (~0.45 ms)"}}
         except Exception as e:
             fit = {"error": repr(e)}
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "hrbf_get_fuse_stats", "hrbf_upload_frame", "hrbf_run_stage", "hrbf_set_tick", "hrbf_set_weighting",
     "hrbf_set_index_submap", "hrbf_set_active_submaps", "hrbf_update_model",
     "hrbf_so3_step", "hrbf_rgb_residual", "hrbf_rgb_step",
-    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_peer_release_id", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts", "hrbf_hash_owner", "hrbf_hash_renumber_count", "hrbf_gn_graph_captures", "hrbf_fit_curvature", "hrbf_set_hrbf_fit", "hrbf_shard_exchange_mode",
+    "hrbf_icp_step", "hrbf_icp_step_sparse", "hrbf_update_lambda_map", "hrbf_comm_unique_id", "hrbf_comm_init", "hrbf_peer_unique_id", "hrbf_comm_init_peer", "hrbf_peer_release_id", "hrbf_map_shard_init", "hrbf_map_rebalance", "hrbf_download_gids", "hrbf_shard_counts", "hrbf_hash_owner", "hrbf_hash_renumber_count", "hrbf_gn_graph_captures", "hrbf_fit_curvature", "hrbf_set_hrbf_fit", "hrbf_set_hrbf_fit_params", "hrbf_get_hrbf_fit", "hrbf_shard_exchange_mode",
     "hrbf_rebalance_plan", "hrbf_local_surfel_count", "hrbf_set_row_sharding", "hrbf_comm_stats",
     "hrbf_initialise", "hrbf_predict_indices", "hrbf_fuse", "hrbf_clean", "hrbf_predict_hrbf", "hrbf_dense_enough", "hrbf_bootstrap", "hrbf_get_fuse_ring", "hrbf_reset_fuse_ring", "hrbf_set_load_trajectory",
     "hrbf_get_fuse_ring_parts", "hrbf_get_status", "hrbf_frames_enqueued", "hrbf_frames_completed", "hrbf_get_pose_log",
@@ -106,7 +106,7 @@ def load_library():
     lib.hrbf_peer_unique_id.argtypes = [vp]; lib.hrbf_comm_init_peer.argtypes = [vp, i32, i32, vp]; lib.hrbf_peer_release_id.argtypes = [vp]
     lib.hrbf_map_shard_init.argtypes = [vp, i32]; lib.hrbf_map_rebalance.argtypes = [vp]
     lib.hrbf_download_gids.argtypes = [vp, vp, C.c_size_t]; lib.hrbf_shard_counts.argtypes = [vp, vp]
-    lib.hrbf_hash_owner.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i32]; lib.hrbf_hash_renumber_count.argtypes = [vp]; lib.hrbf_gn_graph_captures.argtypes = [vp]; lib.hrbf_fit_curvature.argtypes = [vp, i32, f32, f32, f32, vp]; lib.hrbf_set_hrbf_fit.argtypes = [vp, i32]; lib.hrbf_shard_exchange_mode.argtypes = [vp]
+    lib.hrbf_hash_owner.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i32]; lib.hrbf_hash_renumber_count.argtypes = [vp]; lib.hrbf_gn_graph_captures.argtypes = [vp]; lib.hrbf_fit_curvature.argtypes = [vp, i32, f32, f32, f32, vp]; lib.hrbf_set_hrbf_fit.argtypes = [vp, i32]; lib.hrbf_set_hrbf_fit_params.argtypes = [vp, i32, f32, f32, f32]; lib.hrbf_get_hrbf_fit.argtypes = [vp] * 6; lib.hrbf_shard_exchange_mode.argtypes = [vp]
     lib.hrbf_set_row_sharding.argtypes = [vp, i32]
     lib.hrbf_comm_stats.argtypes = [vp, C.c_void_p, i32]
     lib.hrbf_initialise.argtypes = [vp, vp]; lib.hrbf_predict_hrbf.argtypes = [vp]
@@ -300,6 +300,16 @@ class HRBFFusion:
     def set_hrbf_fit(self, enable):
         """EXTENSION, off by default: process_frame takes the live frame's curvatures from the true Hermite-RBF fit (results are then not the reference's)"""
         self._check(self.lib.hrbf_set_hrbf_fit(self.h, int(bool(enable))))
+
+    def set_hrbf_fit_params(self, window=2, support=1.25, ridge=0.1, jump=3.0):
+        self._check(self.lib.hrbf_set_hrbf_fit_params(self.h, int(window), float(support), float(ridge), float(jump)))
+
+    def get_hrbf_fit(self):
+        """(enabled, window, support, ridge, jump) of the in-frame Hermite-RBF fit option (an extension: off by default)"""
+        e, w = C.c_int(0), C.c_int(0)
+        s_, r, j = C.c_float(0), C.c_float(0), C.c_float(0)
+        self._check(self.lib.hrbf_get_hrbf_fit(self.h, C.byref(e), C.byref(w), C.byref(s_), C.byref(r), C.byref(j)))
+        return bool(e.value), w.value, s_.value, r.value, j.value
 
     def gn_graph_captures(self):
         """how often the Gauss-Newton loop was captured into a hipGraph (2 in a steady run: one per image parity)"""

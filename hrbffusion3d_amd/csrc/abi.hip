@@ -115,6 +115,7 @@ struct hrbf_context {
     uint32_t *d_comm_scratch;
     float4 *d_fit_curv1, *d_fit_curv2, *d_fit_normal;   // extension (hrbf_fit_curvature): allocated on first use
     int fit_in_frame;           // extension (hrbf_set_hrbf_fit): processFrame takes the live frame's curvatures from the fitted interpolant
+    int fit_window; float fit_support, fit_ridge, fit_jump;   // ... with these parameters (hrbf_set_hrbf_fit_params; defaults 2, 1.25, 0.1, 3.0)
     int device;
     hipStream_t stream;
     Cam cam;
@@ -1178,7 +1179,10 @@ static int process_frame_resident(hrbf_context *c, float wmul)
     st_filter(c); st_vnr(c);
     st_curv(c, c->tick > 1 && !c->prm.load_trajectory && c->fill_flag_fresh && !c->fit_in_frame);
     if (c->fit_in_frame)   // EXTENSION, off by default (hrbf_set_hrbf_fit): PRINCIPAL_CURV1 / 2 of the live frame from the true Hermite-RBF fit
-        launch_hrbf_fit(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, 2, 1.25f, 0.1f, 3.0f, c->d_curv1, c->d_curv2, c->d_fit_normal);   // ridge 0.1: an exact interpolant of noisy normals amplifies the noise
+    {   // default ridge 0.1: an exact interpolant of noisy normals amplifies the noise.  The frame's results are then NOT the reference's: sticky status bit
+        launch_hrbf_fit(c->stream, c->cam, c->d_vertex_filtered, c->d_normal, c->fit_window, c->fit_support, c->fit_ridge, c->fit_jump, c->d_curv1, c->d_curv2, c->d_fit_normal);
+        c->status |= HRBF_STATUS_EXTENSION;
+    }
     TIMER(1);
     if (c->tick == 1) {
         st_init(c);
@@ -1555,6 +1559,23 @@ extern "C" int hrbf_set_hrbf_fit(hrbf_handle c, int enable)
     hipSetDevice(c->device);
     if (enable) { const int r = fit_alloc(c); if (r) return r; }
     c->fit_in_frame = enable ? 1 : 0;
+    if (c->fit_window == 0) { c->fit_window = 2; c->fit_support = 1.25f; c->fit_ridge = 0.1f; c->fit_jump = 3.0f; }
+    return HRBF_OK;
+}
+extern "C" int hrbf_set_hrbf_fit_params(hrbf_handle c, int window, float support, float ridge, float jump)
+{
+    if (!c || window < 1 || window > 2 || !(support > 1.0f) || !(ridge >= 0.0f) || !(jump > 0.0f)) { hrbf_set_error("hrbf_set_hrbf_fit_params: window 1..2, support > 1, ridge >= 0, jump > 0"); return HRBF_ERR_INVALID; }
+    c->fit_window = window; c->fit_support = support; c->fit_ridge = ridge; c->fit_jump = jump;
+    return HRBF_OK;
+}
+extern "C" int hrbf_get_hrbf_fit(hrbf_handle c, int *enabled, int *window, float *support, float *ridge, float *jump)
+{
+    if (!c) return HRBF_ERR_INVALID;
+    if (enabled) *enabled = c->fit_in_frame;
+    if (window) *window = c->fit_window ? c->fit_window : 2;
+    if (support) *support = c->fit_window ? c->fit_support : 1.25f;
+    if (ridge) *ridge = c->fit_window ? c->fit_ridge : 0.1f;
+    if (jump) *jump = c->fit_window ? c->fit_jump : 3.0f;
     return HRBF_OK;
 }
 extern "C" int hrbf_fit_curvature(hrbf_handle c, int window, float support, float ridge, float jump, float *ms)

@@ -749,6 +749,14 @@ extern "C" int hrbf_probe_clean_diag(unsigned long long out[4], int reset)
     return 0;
 }
 #endif
+// CLEAN_CLASS_WORD == 4: only the 2 x 2 texels every walk visits are requested ahead (the third row / column, visited by about half
+// of the walks per axis, stays a dependent load): 16 instead of 36 registers of texels in flight
+#if defined(CLEAN_CLASS_WORD) && (CLEAN_CLASS_WORD + 0) == 4
+#define CLEAN_PRE(jx, jy) ((jx) < 2 && (jy) < 2)
+#else
+#define CLEAN_PRE(jx, jy) true
+#endif
+struct Tex9 { float4 t[9]; };   // by value / reference with constant indices only: stays in registers (a nullable pointer to it went to scratch)
 // window part of the test; returns false when the surfel must be dropped.
 // The reference walks a 4x4 half-pixel grid (copy_unstable.vert:104-141) = 2..3 DISTINCT texels per axis,
 // some visited twice.  Each distinct texel is fetched once from the packed clean texture (2 x float4,
@@ -756,7 +764,7 @@ extern "C" int hrbf_probe_clean_diag(unsigned long long out[4], int reset)
 __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid &tinv, f3 lp, float x, float y,
                                              float init_time, float submap, float4 vn,
                                              const float4 *__restrict__ clean_tex,
-                                             const float4 *pre_tex = nullptr /* 9 texels requested ahead from (pre_sx0, pre_sy0), [jx * 3 + jy] */,
+                                             const Tex9 &pre_tex = Tex9() /* 9 texels requested ahead from (pre_sx0, pre_sy0), [jx * 3 + jy] */,
                                              int pre_sx0 = -1, int pre_sy0 = -1)
 {
     const Cam &cam = cp.cam;
@@ -797,7 +805,7 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
 #pragma unroll
             for (int jx = 0; jx < 3; ++jx) {   // texels outside the visit pattern may lie outside the image: not read
                 ta[jx * 3 + jy] = make_float4(0, 0, 0, 0);
-                if (pre_tex && pre_sx0 == sx0 && pre_sy0 == sy0) { if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = pre_tex[jx * 3 + jy]; }   // the same texels, requested a round earlier
+                if (CLEAN_PRE(jx, jy) && pre_sx0 == sx0 && pre_sy0 == sy0) { if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = pre_tex.t[jx * 3 + jy]; }   // the same texels, requested a round earlier
                 else if (mx[jx] * my[jy] > 0) ta[jx * 3 + jy] = clean_tex[clean_tex_slot(sxk[0] + jx, syk[0] + jy, cam.W)];
             }
 #pragma unroll
@@ -866,7 +874,7 @@ __device__ __forceinline__ bool clean_item(const CleanParams &cp, const Rigid &t
                                            const float4 *__restrict__ clean_tex, const float4 vp /* pos_conf of the item */,
                                            const bool pre = false /* the caller knew the item's class and requested its planes together */,
                                            const float4 pre_vc = {0, 0, 0, 0}, const float4 pre_vn = {0, 0, 0, 0},
-                                           const float4 *pre_tex = nullptr, int pre_sx0 = -1, int pre_sy0 = -1)
+                                           const Tex9 &pre_tex = Tex9(), int pre_sx0 = -1, int pre_sy0 = -1)
 {
     bool keep = true;
     f3 lp; float x, y;
@@ -965,7 +973,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
     for (uint32_t it0 = sb * blockDim.x + threadIdx.x; it0 < N64; it0 += CLEAN_UNROLL * stride) {
         float4 vp[CLEAN_UNROLL], vc[CLEAN_UNROLL], vn[CLEAN_UNROLL];
 #ifdef CLEAN_CLASS_WORD
-        float4 tex[CLEAN_UNROLL][9]; int psx[CLEAN_UNROLL], psy[CLEAN_UNROLL];
+        Tex9 tex[CLEAN_UNROLL]; int psx[CLEAN_UNROLL], psy[CLEAN_UNROLL];
 #endif
         bool settled[CLEAN_UNROLL];   // a stable surfel outside the frustum, classified by the projection: kept, nothing read
         const bool cls = have_class && !cp.full_check;
@@ -990,8 +998,9 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
                         for (int jx = 0; jx < 3; ++jx)
 #pragma unroll
                             for (int jy = 0; jy < 3; ++jy) {   // the walk visits texels first .. first + 2 at most; clamped: an address inside the image
+                                if (!CLEAN_PRE(jx, jy)) continue;
                                 const int tx = psx[k] + jx < cp.cam.W ? psx[k] + jx : cp.cam.W - 1, ty = psy[k] + jy < cp.cam.H ? psy[k] + jy : cp.cam.H - 1;
-                                tex[k][jx * 3 + jy] = clean_tex[clean_tex_slot(tx, ty, cp.cam.W)];
+                                tex[k].t[jx * 3 + jy] = clean_tex[clean_tex_slot(tx, ty, cp.cam.W)];
                             }
                     }
                 }
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanParams cp, MapPlanes m
 #ifdef CLEAN_CLASS_WORD
             const bool havew = cls && cp.class_word;
             const bool keep = it < N && (settled[k] || clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k], cls, vc[k], vn[k],
-                                                                  havew && psx[k] >= 0 ? tex[k] : nullptr, havew ? psx[k] : -1, havew ? psy[k] : -1));
+                                                                  tex[k], havew ? psx[k] : -1, havew ? psy[k] : -1));
 #else
             const bool keep = it < N && (settled[k] || clean_item(cp, tinv, ftime, m, rec, true, it, clean_tex, vp[k], cls, vc[k], vn[k]));
 #endif

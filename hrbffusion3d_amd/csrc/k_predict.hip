@@ -133,12 +133,27 @@ __device__ __forceinline__ v2f sqrt_pair_for_unit_complement(const v2f x)
 //     == value because the running sum is never -0 (it starts at +0 and x - x is +0);
 //   * a neighbour out of reach gets factor 0: v and 10 n are finite, so c is a zero again.
 // COUNT: the number of neighbours in reach is only consumed for the first sample of a ray (predict_hrbf.frag:139-141).
+#ifdef PREDICT_TRIP_STATS
+// measurement build: [0] (sample, centre) pairs evaluated, [1] of them with the centre's support reaching the
+// sample (hrbfbase.glsl:137-138), [2] samples, [3] samples no centre reaches, [4] list entries over all rays, [5] entries whose
+// support never reaches the ray's line at all, [6] entries whose support does not reach the marched stretch (+-10 cm of `closest`)
+__device__ unsigned long long g_support_stats[8];
+extern "C" int hrbf_probe_predict_support(unsigned long long out[8], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_support_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_support_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 template <bool SAFE, bool COUNT>
 __device__ __forceinline__ float hrbf_value(const float4 *__restrict__ tile, const uint16_t *__restrict__ list, int n,
                                             f3 p, int &nsup)
 {
     float value = 0.0f;
     int ns = 0;
+#ifdef PREDICT_TRIP_STATS
+    int ns_stat = 0;
+#endif
     const v2f pxy = {p.x, p.y};
     const uint32_t *pairs = reinterpret_cast<const uint32_t *>(list);
     uint32_t oo = pairs[0];
@@ -168,7 +183,14 @@ __device__ __forceinline__ float hrbf_value(const float4 *__restrict__ tile, con
             value = value - c.y;
         }
         if (COUNT) ns += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+#ifdef PREDICT_TRIP_STATS
+        ns_stat += (in0 ? 1 : 0) + ((k + 1 < n && !(a1.w < d2.y)) ? 1 : 0);
+#endif
     }
+#ifdef PREDICT_TRIP_STATS
+    atomicAdd(&g_support_stats[0], (unsigned long long)n); atomicAdd(&g_support_stats[1], (unsigned long long)ns_stat);
+    atomicAdd(&g_support_stats[2], 1ull); if (ns_stat == 0) atomicAdd(&g_support_stats[3], 1ull);
+#endif
     nsup = ns;
     return value;
 }
@@ -448,6 +470,22 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
     f3 p_temp = mk3(0, 0, 0);
     int trips;   // samples of the implicit this ray took (statistics builds only; dead otherwise)
 #ifdef PREDICT_TRIP_STATS
+    if (n > minn) {   // which list entries could a ray-parameter interval test discard for the WHOLE march?
+        const float rr = dot3(ray, ray), tc = dot3(closest, ray) / rr;
+        int never = 0, not_in_stretch = 0;
+        for (int k = 0; k < n; ++k) {
+            const float4 a = lds4(tile, list[list_slot(k)]);
+            const f3 c = mk3(a.x, a.y, a.z);
+            const float ta = dot3(c, ray) / rr;                       // parameter of the centre's foot point on the line
+            const float perp2 = dot3(c, c) - ta * ta * rr;            // squared distance of the centre from the line
+            if (perp2 > a.w) { ++never; ++not_in_stretch; continue; }
+            const float half = hd_sqrtf((a.w - perp2) / rr);          // the line is inside the support for ta - half .. ta + half
+            const float reach = 0.1f / hd_sqrtf(rr);                  // 25 coarse steps of 4 mm either way
+            if (ta + half < tc - reach || ta - half > tc + reach) ++not_in_stretch;
+        }
+        atomicAdd(&g_support_stats[4], (unsigned long long)n); atomicAdd(&g_support_stats[5], (unsigned long long)never);
+        atomicAdd(&g_support_stats[6], (unsigned long long)not_in_stretch);
+    }
     TripStats ts;
     const bool found = s_untame ? ray_march<true>(tile, list, n, minn, closest, ray, p_temp, trips, ts)
                                 : ray_march<false>(tile, list, n, minn, closest, ray, p_temp, trips, ts);

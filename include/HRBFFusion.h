@@ -353,6 +353,7 @@ public:
                       const float weightMultiplier = 1.f)
     {
         const int tick_before = hrbf_get_tick(h_);
+        icp_cached_ = false;            /* whatever happens below, the values of the previous frame are not this frame's */
         replayPose(tick_before);
         if (hrbf_process_frame(h_, rgb, depth, timestamp, weightMultiplier) != HRBF_OK)
             throw std::runtime_error(hrbf_last_error());
@@ -368,6 +369,7 @@ public:
     void processFrameDevice(const void *d_rgb, const void *d_depth, const int64_t &timestamp, const float weightMultiplier = 1.f)
     {
         const int tick_before = hrbf_get_tick(h_);
+        icp_cached_ = false;
         replayPose(tick_before);
         if (hrbf_process_frame_device(h_, d_rgb, d_depth, timestamp, weightMultiplier) != HRBF_OK)
             throw std::runtime_error(hrbf_last_error());
@@ -420,12 +422,16 @@ public:
     {
         const unsigned int now = hrbf_frames_enqueued(h_);
         if (!icp_cached_ || icp_cached_at_ != now) {
-            if (hrbf_last_icp(h_, &frame_to_model_.lastICPError, &frame_to_model_.lastICPCount) != HRBF_OK)
-                frame_to_model_.lastICPError = frame_to_model_.lastICPCount = std::numeric_limits<float>::quiet_NaN();
-            icp_cached_ = true; icp_cached_at_ = now;
+            /* a failed read is reported (NaN) but NOT cached: the next call asks again (round-5 advice) */
+            const bool ok = hrbf_last_icp(h_, &frame_to_model_.lastICPError, &frame_to_model_.lastICPCount) == HRBF_OK;
+            if (!ok) frame_to_model_.lastICPError = frame_to_model_.lastICPCount = std::numeric_limits<float>::quiet_NaN();
+            icp_cached_ = ok; icp_cached_at_ = now;
         }
         return frame_to_model_;
     }
+    /* a caller that runs a registration through the C-ABI's operator seams on handle() (hrbf_run_stage(ODOMETRY), hrbf_icp_step ...)
+       — calls that do not count as frames — drops the cached values with this before reading getFrameToModel() again */
+    void invalidateFrameToModel() { icp_cached_ = false; }
     float lastICPError() { return getFrameToModel().lastICPError; }
     float lastICPCount() { return getFrameToModel().lastICPCount; }
     /* setters applied every GUI frame (GUI/src/HRBF_fusion.cpp:448-456) */

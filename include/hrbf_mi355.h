@@ -255,6 +255,8 @@ int hrbf_set_load_trajectory(hrbf_handle h, int v);
                                           pass did not run, hrbf_process_frame returned the error and keeps failing until this is cleared */
 #define HRBF_STATUS_COLLECTIVE 32u     /* row-sharded registration: an all-reduce of the limb sums failed (either transport): that frame's
                                           pose was solved from unreduced sums and is not to be trusted */
+#define HRBF_STATUS_EXTENSION 64u      /* a frame was processed with an option that has no reference counterpart switched on (hrbf_set_hrbf_fit):
+                                          its results are not the reference's */
 int hrbf_get_status(hrbf_handle h, uint32_t *flags, int clear);
 int hrbf_shard_exchange_mode(hrbf_handle h);   /* see "How the ranks exchange the index map" below */
 /* number of surfels that entered / merged / appended / survived in the last frame's fuse pass */
@@ -409,6 +411,11 @@ int hrbf_fit_curvature(hrbf_handle h, int window, float support, float ridge, fl
  * weights, curvature validity, the records of the fusion) from the fitted interpolant, 5 x 5 window, ridge 0.1 (an exact interpolant
  * of noisy normals amplifies their noise), at ~7 ms per 640 x 480 frame */
 int hrbf_set_hrbf_fit(hrbf_handle h, int enable);
+/* the option's state and parameters, visible to the caller (round-5 advice: a context left in this mode fails parity with nothing
+ * to show for it): every frame processed with it raises the sticky HRBF_STATUS_EXTENSION.  Defaults: window 2 (5 x 5), support
+ * 1.25, ridge 0.1, jump 3.0 — the arguments of hrbf_fit_curvature */
+int hrbf_set_hrbf_fit_params(hrbf_handle h, int window, float support, float ridge, float jump);
+int hrbf_get_hrbf_fit(hrbf_handle h, int *enabled, int *window, float *support, float *ridge, float *jump);
 int hrbf_gn_graph_captures(hrbf_handle h);    /* times the Gauss-Newton loop was captured into a hipGraph: 2 in a steady run (one per image parity) whatever
                                                 weightMultiplier the caller passes per frame (GUI/src/HRBF_fusion.cpp:225); re-captured only when a setter changes the configuration */
 int hrbf_hash_renumber_count(hrbf_handle h);   /* hash ownership: times the 32-bit ids were renumbered to ranks (every ~55 000 VGA frames; order unchanged) */

@@ -18,6 +18,9 @@ implementation-defined at 640 x 480 and how the two executions differ there).
             pose of frame 2 from the oracle's own registration of the two crops (an input here: registration is CUDA)
   sphere  : an analytic scene (sphere on a slanted plane) under fx != fy and an off-centre principal point, second view
             from a different pose
+
+This script writes plain <scene>.npz files; what the tree keeps (and what travels to the GPU box) are their lossless re-codings
+<scene>.fxz: run `python tests/fixture_codec.py --encode` afterwards (it verifies the round trip bit for bit) and delete the .npz.
 """
 import os
 import sys

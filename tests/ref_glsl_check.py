@@ -19,7 +19,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_g
 
 
 def load(scene):
-    return dict(np.load(os.path.join(GOLD, scene + ".npz")))
+    """a scene's fixture arrays: `<scene>.fxz` (tests/fixture_codec.py: the same bits as the .npz make_ref_glsl.py wrote, CRC-checked,
+    at half the size) or the plain .npz where that is what the tree holds"""
+    import fixture_codec
+    return fixture_codec.load(scene)
 
 
 def ulp_diff(a, b):

@@ -181,13 +181,16 @@ def test_fit_as_an_option_inside_the_frame_path(gpu_available):
     p = default_params(W2, H2, *synth.intrinsics(W2, H2), max_surfels=1 << 19)
     g, ref = HRBFFusion(p), HRBFFusion(p)
     try:
+        assert g.get_hrbf_fit() == (False, 2, 1.25, 0.10000000149011612, 3.0)      # off by default; the parameters the option would use
         g.set_hrbf_fit(True)
+        assert g.get_hrbf_fit()[0] is True and ref.get_hrbf_fit()[0] is False
         for k in range(12):
             rgb, d, T = synth.frame(k, W2, H2, noise=True)
             if k == 0:
                 g.set_pose(T); ref.set_pose(T)
             g.process_frame(rgb, d); ref.process_frame(rgb, d)
-        assert g.status() == 0 and g.surfel_count() > 70_000
+        # the option leaves its mark: a context in this mode says so (HRBF_STATUS_EXTENSION = 64), the reference path does not
+        assert g.status() == 64 and ref.status() == 0 and g.surfel_count() > 70_000
         assert np.linalg.norm(g.get_pose()[:3, 3] - T[:3, 3]) < 0.05 and np.linalg.norm(ref.get_pose()[:3, 3] - T[:3, 3]) < 0.05
         c1, c1_ref = g.get_image("CURV1"), ref.get_image("CURV1")
         both = (c1[..., 3] != 1000.0) & (np.abs(c1_ref[..., 3]) < 300.0)

@@ -1,13 +1,15 @@
-"""The metamorphic tests must FAIL on a misread registration — otherwise they pin nothing.  oracle/orc_odo.c carries 26
+"""The metamorphic tests must FAIL on a misread registration — otherwise they pin nothing.  oracle/orc_odo.c and orc_ctx.c carry 47
 deliberate misreadings behind `#if ORC_MUTANT == k` (compiled only into oracle/_build/liboracle_mutant_<k>.so by `make mutants`);
-tools/mutation_report.py runs the whole metamorphic module against each (profiles/r05_metamorphic_mutation_report.txt).  Here, in
-the suite, one quick case per kind of misreading: a Jacobian sign, a frame, a weight, a composition."""
+tools/mutation_report.py runs both metamorphic modules against each (profiles/r06_mutation_report.txt).  Here, in the suite, one
+quick case per kind of misreading: a Jacobian sign, a frame, a weight, a composition — and, since round 6, a map transform, a resize
+rule, a validity rule, a rejection threshold, the search's tie order, the multiplier update, the 0.3 m guard, the weighting clamp."""
 import os
 import subprocess
 
 import pytest
 
 import test_registration_metamorphic as tm
+import test_registration_metamorphic2 as t2
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -30,6 +32,16 @@ CASES = [
     (22, "the increment composed on the right", lambda o: tm.test_the_loop_runs_4_5_10_iterations_and_every_increment_acts_on_the_left(o)),
     (23, "the gradient threshold unsquared", lambda o: tm.test_a_texture_below_the_gradient_threshold_contributes_nothing_on_level_0(o)),
     (19, "the photometric weight 1 / sigma", lambda o: tm.test_the_photometric_weight_depends_on_sigma_plus_the_residual_only(o)),
+    # round 6 (tests/test_registration_metamorphic2.py)
+    (28, "model vertices rotated without the translation", lambda o: t2.test_the_model_maps_live_in_the_trackers_world_frame(o)),
+    (30, "2 x 2 resize as a NaN-aware mean", lambda o: t2.test_resize_is_nan_if_any_tap_is_nan_and_renormalises_normals(o)),
+    (33, "curvature validity without the lower bound", lambda o: t2.test_copy_validity_rules_cost_exactly_the_planted_pixels(o, ("CURV1", 3, -301.0, 100))),
+    (35, "the distance threshold met by the squared distance", lambda o: t2.test_distance_rejection_is_euclidean_at_ten_centimetres(o)),
+    (36, "the angle threshold met by 1 - cosine", lambda o: t2.test_angle_rejection_is_the_sine_of_twenty_degrees(o, 21.0)),
+    (38, "search ties to the last candidate", lambda o: t2.test_search_ties_go_to_the_first_candidate_in_raster_order(t2._Window(o.load()))),
+    (41, "the sparse-ICP target moved by z + lambda / mu", lambda o: t2.test_sparse_icp_multiplier_update_doubles_a_standing_offset(o)),
+    (43, "no 0.3 m guard", lambda o: t2.test_an_estimate_beyond_thirty_centimetres_is_thrown_away(o)),
+    (45, "velocity weighting without its floor", lambda o: t2.test_velocity_weighting_follows_the_stated_clamp(o, "2cm")),
 ]
 
 
