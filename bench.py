@@ -809,6 +809,32 @@ def main():
     traj_all = fus.pose_log(0, Wm + K)
     ate_mm = 1000.0 * synth.ate_rmse(traj_all[Wm:Wm + K], poses[1 + Wm:1 + Wm + K]) if len(traj_all) == Wm + K else None
     m_timed = fus.download_map() if (world == 1 and args.virtual_shards <= 1) else None   # for the real-bytes model below
+    # A sharded run checks ITSELF (the claim of DESIGN.md §7 where the driver can see it, on whatever hardware this runs): every rank
+    # ends with the same pose bits, and rank 0 replays the same frames against the same map on ONE unsharded context — same pose
+    # bits, same global surfel count.  Outside the timed region; ~0.1 s.
+    self_check = None
+    if one_sequence or args.virtual_shards > 1:
+        pb = np.ascontiguousarray(P_end, np.float32).view(np.uint32).astype(np.int64).ravel()
+        same_on_all = True
+        if dist is not None:
+            mine_p = torch.from_numpy(pb).cuda()
+            all_p = [torch.zeros_like(mine_p) for _ in range(world)]
+            dist.all_gather(all_p, mine_p)
+            same_on_all = all(bool(torch.equal(a, mine_p)) for a in all_p)
+        if rank == 0:
+            try:
+                ref = HRBFFusion(p, device=local_rank)
+                ref.upload_map(seed); ref.set_pose(poses[0]); ref.bootstrap(frames[0][0], frames[0][1])
+                for k in range(1, 1 + Wm + K):
+                    ref.process_frame_device(d_rgb[k].data_ptr(), d_dep[k].data_ptr(), k)
+                ref.synchronize()
+                rb = np.ascontiguousarray(ref.get_pose(), np.float32).view(np.uint32).astype(np.int64).ravel()
+                self_check = {"pose_bits_equal_on_all_ranks": bool(same_on_all), "pose_bits_equal_one_unsharded_gpu": bool(np.array_equal(rb, pb)),
+                              "surfel_count_equal_one_unsharded_gpu": bool(ref.surfel_count() == count1), "frames_replayed": int(Wm + K),
+                              "status_unsharded": int(ref.status())}
+                ref.close()
+            except Exception as e:      # the check must never take the line down
+                self_check = {"error": repr(e), "pose_bits_equal_on_all_ranks": bool(same_on_all)}
     tm = np.zeros(8, np.float32)
     # PCIe-inclusive rate of the host-pointer entry point (never `value`): 1.5 MB upload + sync per frame
     pcie_fps = None
@@ -998,7 +1024,7 @@ def main():
         sharded = sharded_leg(args, rank, world, barrier, any_rank)
         if sharded is not None and "error" not in sharded:      # keep what the leg is for; the rest of the child's line repeats this one's
             sharded = {k: sharded.get(k) for k in ("workload", "value", "unit", "ms_per_step", "scaling", "n_gpus", "ranks_observed", "steps", "warmup",
-                                                   "per_rank_fuse_ms", "collectives", "library_comm", "wall_s_incl_setup")} | {
+                                                   "per_rank_fuse_ms", "collectives", "library_comm", "sharded_self_check", "wall_s_incl_setup")} | {
                 "parallelism": sharded.get("config", {}).get("parallelism"), "surfels_end_rank0": sharded.get("config", {}).get("surfels_end"),
                 "final_translation_error_mm": sharded.get("config", {}).get("final_translation_error_mm"),
                 "status": sharded.get("roofline", {}).get("status")}
@@ -1049,6 +1075,7 @@ def main():
             "per_rank_fuse_ms": per_rank_fuse_ms,      # [fuse pass ms, of which merge ms, live surfels] per rank
             "collectives": coll,
             "library_comm": lib_comm,
+            "sharded_self_check": self_check,
             "sharded_one_sequence": sharded,
         }
         if args.cpu_frames > 0 and world == 1:

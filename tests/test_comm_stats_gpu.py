@@ -107,3 +107,30 @@ def test_rccl_at_world_size_one_reports_what_the_communicator_says(gpu_available
     assert s["allgather"] == 2 * FRAMES and s["host_barriers"] == 0
     # a world of one has no peer to map: the packed-record path, whose exchange loop has nobody to send to
     assert s["send"] == 0 and s["recv"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["virtual_hash4", "rccl_world1_hash_rows"])
+def test_a_sharded_bench_line_carries_the_librarys_counters_and_checks_itself(gpu_available, mode):
+    """bench.py's one-sequence modes: `library_comm` (what the library's communicator reports and issued over the timed frames) and
+    `sharded_self_check` (all ranks end on the same pose bits; rank 0 replays the frames on one unsharded context: same pose bits,
+    same surfel count) — the two things a first run on a real node has to show, exercised on the shapes one device can run"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    extra = ["--virtual-shards", "4", "--partition", "hash"] if mode == "virtual_hash4" else ["--shard-map", "--partition", "hash", "--shard-odometry"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "3", "--surfels", "300000", "--width", "320", "--height", "240",
+                          "--cpu-frames", "0", "--worst-surfels", "0", "--big-surfels", "0", "--no-cpp-shim", "--no-traffic", "--no-fit-leg"] + extra,
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lc, sc = j["library_comm"], j["sharded_self_check"]
+    assert sc == {"pose_bits_equal_on_all_ranks": True, "pose_bits_equal_one_unsharded_gpu": True, "surfel_count_equal_one_unsharded_gpu": True,
+                  "frames_replayed": 11, "status_unsharded": 0}, sc
+    assert lc["transport"] == ("virtual" if mode == "virtual_hash4" else "rccl")
+    assert lc["world_sizes_reported_by_the_library"] == [4 if mode == "virtual_hash4" else 1] and lc["ranks_reported_by_the_library"] == [0]
+    pf = lc["per_frame_rank0"]
+    assert lc["per_rank"][0]["frames"] == 8 and pf["limb_allreduce"] == 48.0 and pf["key_min_reduce"] == 3.0 and pf["allgather"] == 2.0
+    assert j["scaling"] == ("weak" if mode == "virtual_hash4" else "strong") and j["roofline"]["status"] == 0
