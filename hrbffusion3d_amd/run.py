@@ -154,7 +154,7 @@ def main(argv=None):
         kw["fast_odom"] = 1
     p = default_params(args.width, args.height, args.fx, args.fy, args.cx, args.cy, **kw)
     fus = HRBFFusion(p, device=args.device)
-    poses, stamps, gts = [], [], []
+    poses, stamps, gts, file_stamps = [], [], [], []
     replay = None
     if getattr(args, "replay", None):
         replay = hio.load_trajectory_file(*args.replay)          # HRBFFusion.cpp:55-59: LoadFromFile, currPose = poses[0]
@@ -186,6 +186,8 @@ def main(argv=None):
             if fus.tick - 1 >= len(replay):
                 raise SystemExit("globalInputLoadTrajectory: the trajectory file has fewer poses than frames")
             fus.set_pose(replay[fus.tick - 1])                   # HRBFFusion.cpp:1105-1108
+        if fus.tick > 1 and replay is None:
+            file_stamps.append(ts)       # TrajectoryManager::timstamp: pushed from the second tick on (HRBFFusion.cpp:1131-1132), not at tick 1 (:1060)
         fus.process_frame(rgb, depth, ts, wm)
         poses.append(fus.get_pose()); stamps.append(ts); gts.append(T)
         n += 1
@@ -196,7 +198,11 @@ def main(argv=None):
     report = {"frames": n, "seconds": dt, "fps_including_io_and_pose_readback": n / dt if dt > 0 else 0.0,
               "surfels": fus.surfel_count()}
     if args.out:
-        hio.save_trajectory(args.out, poses, stamps_us=stamps, fmt="TUM", icl_nuim=args.icl_nuim)
+        # the reference's file: `poses` has an entry for every frame, `timstamp` none for a frame processed at tick 1 (HRBFFusion.cpp:1060
+        # against :1131-1132), so line i then carries the stamp of frame i + 1 and the last line what follows the vector (here: its
+        # index, like include/HRBFFusion.h).  The ATE below pairs pose i with frame i's own stamp.
+        hio.save_trajectory(args.out, poses, stamps_us=[file_stamps[i] if i < len(file_stamps) else i for i in range(len(poses))],
+                            fmt="TUM", icl_nuim=args.icl_nuim)
     if args.ply:
         report["ply_vertices"] = hio.save_ply(args.ply, fus.download_map(), conf_threshold=args.ply_confidence)
     if args.groundtruth:

@@ -279,6 +279,8 @@ def test_cpp_caller_loop_matches_the_python_runner(tmp_path, gpu_available, sens
     assert len(pa) == len(pb) == 12
     for a, b in zip(pa, pb):
         assert np.allclose(a, b, atol=2e-6)          # both files print %g: six significant digits of the same poses
+    # ... beside the same stamps: both keep the reference's pairing (line i carries frame i + 1's stamp, HRBFFusion.cpp:1060,1131)
+    assert [l.split()[0] for l in open(tmp_path / "cpp.freiburg")] == [l.split()[0] for l in open(tmp_path / "py.freiburg")]
     assert rep["surfels"] == j["surfels"]
     head = open(tmp_path / "cpp.ply", "rb").read(400).split(b"end_header")[0]
     assert b"element vertex" in head
