@@ -167,7 +167,11 @@ static void resize_icpw(const float *in, int irows, int icols, float *out)
 static void vertices_to_depth(const f4 *v, float *dst, int n, float cutoff)
 {
     const float qn = hd_nanf();
+#if ORC_MUTANT == 49     /* no far cut-off in verticesToDepth: only z <= 0 is invalid (cudafuncs.cu:881) */
+    for (int i = 0; i < n; ++i) { float z = v[i].z; (void)cutoff; dst[i] = (z <= 0.0f) ? qn : z; }
+#else
     for (int i = 0; i < n; ++i) { float z = v[i].z; dst[i] = (z > cutoff || z <= 0.0f) ? qn : z; }
+#endif
 }
 static const float GK[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
 /* pyrDownKernelGaussF :493-524 (including its border/index quirk) */
@@ -207,7 +211,11 @@ static void pyrdown_gauss_u8(const uint8_t *src, int srows, int scols, uint8_t *
             for (int cy = (2 * y - 2 > 0 ? 2 * y - 2 : 0); cy < ty; ++cy)
                 for (int cx = (2 * x - 2 > 0 ? 2 * x - 2 : 0); cx < tx; ++cx) {
                     uint8_t s = src[cy * scols + cx];
+#if ORC_MUTANT == 48     /* the intensity pyramid averaging EVERY tap: black (= no data) pixels darken their neighbourhood (cudafuncs.cu:836-841) */
+                    if (1) {
+#else
                     if (s > 0) {
+#endif
                         float g = GK[(ty - cy - 1) * 5 + (tx - cx - 1)];
                         sum += (float)s * g;
                         count += (int)g;

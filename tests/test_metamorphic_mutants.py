@@ -1,4 +1,4 @@
-"""The metamorphic tests must FAIL on a misread registration — otherwise they pin nothing.  oracle/orc_odo.c and orc_ctx.c carry 47
+"""The metamorphic tests must FAIL on a misread registration — otherwise they pin nothing.  oracle/orc_odo.c and orc_ctx.c carry 49
 deliberate misreadings behind `#if ORC_MUTANT == k` (compiled only into oracle/_build/liboracle_mutant_<k>.so by `make mutants`);
 tools/mutation_report.py runs both metamorphic modules against each (profiles/r06_mutation_report.txt).  Here, in the suite, one
 quick case per kind of misreading: a Jacobian sign, a frame, a weight, a composition — and, since round 6, a map transform, a resize
@@ -36,12 +36,14 @@ CASES = [
     (41, "the sparse-ICP target moved by z + lambda / mu", lambda o: t2.test_sparse_icp_multiplier_update_doubles_a_standing_offset(o)),
     (43, "no 0.3 m guard", lambda o: t2.test_an_estimate_beyond_thirty_centimetres_is_thrown_away(o)),
     (45, "velocity weighting without its floor", lambda o: t2.test_velocity_weighting_follows_the_stated_clamp(o, "2cm")),
+    (48, "the intensity pyramid counting black pixels", lambda o: t2.test_the_intensity_pyramid_skips_black_pixels(o)),
+    (49, "no far cut-off for the photometric depth", lambda o: t2.test_the_photometric_term_sees_nothing_beyond_six_metres(o, 6.2, False)),
 ]
 
 
 @pytest.fixture(scope="module")
 def mutants_built(oracle_lib_built):
-    # only the misread builds the cases below load (20 of 47), in parallel: a fresh tree compiles them in ~15 s
+    # only the misread builds the cases below load (22 of 49), in parallel: a fresh tree compiles them in ~15 s
     targets = ["_build/liboracle_mutant_%d.so" % k for k in sorted(set(c[0] for c in CASES))]
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle")] + targets, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return oracle_lib_built

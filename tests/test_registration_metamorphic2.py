@@ -22,8 +22,10 @@ STATES (file:line below), on analytic scenes or planted inputs — never an outp
          side; matches in column 0 never update (`corresp.x > 0`, kept); z is the minimiser of |z|^p + mu/2 |z - h|^2.
  (xxiv)  the 0.3 m guard (RGBDOdometry.cpp:1232-1236): an estimate beyond 0.3 m is thrown away — the pose is the previous pose to the bit.
  (xxv)   velocity weighting (HRBFFusion.cpp:1112-1123): max(1 - min(max(|dt|, |dtheta|), 0.01) / 0.01, 0.5) * weightMultiplier.
+ (xxvi)  the intensity pyramid counts a tap only if it is > 0 (cudafuncs.cu:836-841): black pixels do not darken the level above.
+ (xxvii) the photometric term's depth images end at maxDepthRGB = 6 m (RGBDOdometry.cpp:53,664; cudafuncs.cu:881).
 
-Every test here fails on at least one of the deliberate misreadings 27-47 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
+Every test here fails on at least one of the deliberate misreadings 27-49 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
 profiles/r06_mutation_report.txt).  GPU twins (-m gpu): the HIP library on the same scenarios returns the oracle's pose / weighting
 bits and meets the same outcome bounds."""
 import ctypes as C
@@ -492,6 +494,48 @@ def test_velocity_weighting_follows_the_stated_clamp(oracle_lib_built, name):
             WEIGHTING["3mm"] = saved
 
 
+# ------------------------------------------------------------------------------------------------------------------ (xxvi)
+def _black_at_even_texels(rgb, depth):
+    r = rgb.copy(); r[0::2, 0::2] = 0
+    return r, depth
+
+
+def test_the_intensity_pyramid_skips_black_pixels(oracle_lib_built):
+    """pyrDownKernelIntensityGauss counts a tap only if it is > 0 (cudafuncs.cu:836-841: "it stops incomplete model images from making
+    up colors"): a live image with a black pixel at every even texel keeps its brightness one level up — the mean over the taps that
+    hold data, not over all 25.  A uniform grey wall: level 1 of the holed image IS the grey; averaged with the zeros it would be a
+    quarter darker."""
+    W, H = QVGA
+    K = rc.intrinsics(W, H)
+    p = default_params(W, H, *K, max_surfels=1 << 20, so3=0)
+    a = rs.render(I4, W, H, K, st.frontal_plane(1.5), wavelength=1.0)
+    grey = np.full_like(a[0], 150)
+    e = rc.make_engine("oracle", p)
+    try:
+        e.process_frame(grey, a[1])
+        e.process_frame(*_black_at_even_texels(grey, a[1]))
+        l0, l1, l2 = (e.pyramid("next_image", l) for l in range(3))
+    finally:
+        e.close()
+    # (after the frame the SO3 branch is off: next_image holds the live frame's pyramid)
+    g0 = int(np.bincount(l0[1::2, 1::2].ravel()).argmax())            # the grey as the reference's luma makes it (its weights do not sum to one exactly)
+    assert (l0[0::2, 0::2] == 0).all() and abs(g0 - 150) <= 1
+    inner1, inner2 = l1[2:-2, 2:-2], l2[2:-2, 2:-2]
+    assert (np.abs(inner1.astype(int) - g0) <= 1).all() and (np.abs(inner2.astype(int) - g0) <= 1).all()
+    assert inner1.mean() > 0.98 * g0                                    # counting the black taps: 0.75 g0 (the 2 x-aligned zero lattice holds 9 of the 25 taps, weight 64 of 256)
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxvii)
+@pytest.mark.parametrize("depth, seen", [(5.8, True), (6.2, False)])
+def test_the_photometric_term_sees_nothing_beyond_six_metres(oracle_lib_built, depth, seen):
+    """populateRGBDData projects the vertices to a depth image with maxDepthRGB = 6 m (RGBDOdometry.cpp:53,664; cudafuncs.cu:881:
+    `z > cutOff || z <= 0` -> NaN): a textured wall at 5.8 m gives photometric correspondences, the same wall at 6.2 m none at all"""
+    r = rc.two_frames("oracle", 160, 120, I4, rs.pose(t=(0.02, 0.0, 0.0)), scene=st.frontal_plane(depth), rgb_only=1, so3=0, wavelength=3.0,
+                      trace=True, depth_cutoff=7.0)
+    n = [int(t[93]) for t in st.gn_rows(r["trace"])]
+    assert (min(n) > 500) if seen else (max(n) == 0), (depth, n)
+
+
 # ================================================================================================================== GPU twins
 def _same_bits(a, b):
     return np.array_equal(a, b)
@@ -549,3 +593,22 @@ def test_hip_velocity_weighting(gpu_available, oracle_lib_built, name):
     assert _same_bits(ob, gb) and np.float32(ow2).tobytes() == np.float32(gw2).tobytes() and gw1 == 1.0
     _, wmul, expect, tol = WEIGHTING[name]
     assert abs(gw2 - expect) <= tol * wmul + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["black_even_texels", "wall_5.8m", "wall_6.2m"])
+def test_hip_on_the_pyramid_validity_scenarios(gpu_available, oracle_lib_built, case):
+    """(xxvi) / (xxvii) through the HIP library: the oracle's pose bit for bit (the black-pixel frame registers like the plain one to a
+    tenth of a pixel; beyond 6 m the photometric-only estimate stays at the previous pose)"""
+    scene, TA = rc.VIEWS["room"]
+    if case == "black_even_texels":
+        run = lambda k: rc.two_frames(k, *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, so3=0, edit_b=_black_at_even_texels)
+    else:
+        d = float(case[5:8])
+        run = lambda k: rc.two_frames(k, 160, 120, I4, rs.pose(t=(0.02, 0.0, 0.0)), scene=st.frontal_plane(d), rgb_only=1, so3=0, wavelength=3.0, depth_cutoff=7.0)
+    o, g = run("oracle"), run("hip")
+    assert np.array_equal(o["bits"], g["bits"]), case
+    if case == "wall_6.2m":
+        assert np.array_equal(g["E"], np.eye(4))
+    if case == "black_even_texels":
+        assert rs.reprojection_px(g["E"], g["G"], g["z"], g["K"]) < 0.6

@@ -1,5 +1,5 @@
 """Do the metamorphic tests of tests/test_registration_metamorphic.py have teeth?  Runs them against 26 deliberately MISREAD
-builds of the oracle's registration — 47 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
+builds of the oracle's registration — 49 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
 fail on which misreading.  A misreading no test fails on is a blind spot of the suite — it is listed as such.
 
     python tools/mutation_report.py [k ...] > profiles/r06_mutation_report.txt        (build container or any CPU host; ~40 minutes)
@@ -59,6 +59,8 @@ MUTANTS = {
     45: "velocity weighting without the lower clamp minWeight (HRBFFusion.cpp:1124)",
     46: "velocity weighting with weightMultiplier inside the clamp (HRBFFusion.cpp:1124)",
     47: "sparse ICP: the l1 soft threshold instead of the l_p (p = 0.5) shrink operator (reduce.cu:302-315,652)",
+    48: "intensity pyramid averaging every tap, also the black (no data) pixels (pyrDownKernelIntensityGauss, cudafuncs.cu:836-841)",
+    49: "verticesToDepth without the far cut-off: only z <= 0 invalid (cudafuncs.cu:874-885, populateRGBDData's 6 m)",
 }
 MODULES = ["tests/test_registration_metamorphic.py", "tests/test_registration_metamorphic2.py"]
 
