@@ -721,11 +721,16 @@ static void rgb_residual_core(int rows, int cols, const int16_t *dIdx, const int
             int16_t *co = &corres[(size_t)k * 6];
             co[0] = co[1] = co[2] = co[3] = co[4] = co[5] = 0;
             corres_diff[k] = 0.0f;
+#if ORC_MUTANT != 52     /* 52: no border margin — every pixel of the image is a candidate (reduce.cu:999 drops the last 5 columns and the last row) */
             if (!(j0 < cols - 5 && i < rows - 1)) continue;
+#endif
             int valid = 1;
             for (int u = (i - 2 > 0 ? i - 2 : 0); u < (i + 2 < rows ? i + 2 : rows); ++u)
                 for (int v = (j0 - 2 > 0 ? j0 - 2 : 0); v < (j0 + 2 < cols ? j0 + 2 : cols); ++v)
                     valid = valid && (nextImage[u * cols + v] > 0);
+#if ORC_MUTANT == 50     /* the "not an isolated pixel" window dropped: black live pixels nearby do not matter (reduce.cu:1003-1010) */
+            valid = 1;
+#endif
             if (!valid) continue;
             int valx = dIdx[k], valy = dIdy[k];
             float mTwo = (float)((valx * valx) + (valy * valy));
@@ -747,7 +752,11 @@ static void rgb_residual_core(int rows, int cols, const int16_t *dIdx, const int
 #if ORC_MUTANT == 16     /* the depth gate on the live pixel's own depth instead of its depth in the model camera */
             if (d0 > 0.0f && fabsf(d1 - d0) <= maxDepthDelta && lastImage[v0 * cols + u0] != 0) {
 #else
+#if ORC_MUTANT == 51     /* a black model pixel accepted as a correspondence (`lastImage != 0` dropped, reduce.cu:1039) */
+            if (d0 > 0.0f && fabsf(td1 - d0) <= maxDepthDelta) {
+#else
             if (d0 > 0.0f && fabsf(td1 - d0) <= maxDepthDelta && lastImage[v0 * cols + u0] != 0) {
+#endif
 #endif
                 float diff = (float)nextImage[y * cols + x] - (float)lastImage[v0 * cols + u0];
                 co[0] = (int16_t)u0; co[1] = (int16_t)v0; co[2] = (int16_t)x; co[3] = (int16_t)y; co[4] = 1;
@@ -791,10 +800,16 @@ static void rgb_step_core(int rows, int cols, const int16_t *corres, const float
             float w = sigma + fabsf(diff);
 #endif
             w = w > 1.19209290e-07f ? 1.0f / w : 1.0f;
+#if ORC_MUTANT != 55     /* 55: the rgbOnly signal sigma == -1 not honoured: w stays 1 / (sigma + |diff|) (reduce.cu:737-740) */
             if (sigma == -1.0f) w = 1.0f;
+#endif
             float row[7];
             row[6] = -w * diff;
+#if ORC_MUTANT == 54     /* the row's 3-D point read at the LIVE pixel (`one`) instead of the model pixel (`zero`) (reduce.cu:744-746) */
+            f3 cp = cloud[co[3] * cols + co[2]];
+#else
             f3 cp = cloud[co[1] * cols + co[0]];
+#endif
             float invz = 1.0f / cp.z;
 #if ORC_MUTANT == 12     /* the gradient read at the model pixel (`zero`) instead of the live pixel (`one`) */
             float dIx = w * sobelScale * (float)dIdxl[co[1] * cols + co[0]];
@@ -823,7 +838,11 @@ static void rgb_step_core(int rows, int cols, const int16_t *corres, const float
             float rw = 1.0f;
             if (use_grad) {
                 float gm = sqrtf(dIx * dIx + dIy * dIy);
+#if ORC_MUTANT == 56     /* the gradient weight with the ratio upside down: exp(-0.5 (grad / 10)^2) (reduce.cu:757-758) */
+                rw = hd_expf(-0.5f * (gm / 10.0f) * (gm / 10.0f));
+#else
                 rw = hd_expf(-0.5f * (10.0f / gm) * (10.0f / gm));
+#endif
             }
             int q = 0;
             for (int i = 0; i < 6; ++i) for (int j = i; j < 7; ++j) hd_acc_add_f32(&loc.a[q++], rw * row[i] * row[j]);
@@ -868,7 +887,11 @@ static void so3_step(const uint8_t *lastImage, const uint8_t *nextImage, int row
             float gnx, gny, glx, gly;
             so3_grad(nextImage, cols, wx, wy, &gnx, &gny);
             so3_grad(lastImage, cols, x, y, &glx, &gly);
+#if ORC_MUTANT == 53     /* the SO3 row's image gradient from the warped live image alone, not the mean of both images' (reduce.cu:1224-1225) */
+            float gx = gnx, gy = gny; (void)glx; (void)gly;
+#else
             float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+#endif
             f3 point = m33_mul(kinv, un);
             float z2 = point.z * point.z;
             float a = krlr[0], b = krlr[1], cc = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6],

@@ -24,8 +24,13 @@ STATES (file:line below), on analytic scenes or planted inputs — never an outp
  (xxv)   velocity weighting (HRBFFusion.cpp:1112-1123): max(1 - min(max(|dt|, |dtheta|), 0.01) / 0.01, 0.5) * weightMultiplier.
  (xxvi)  the intensity pyramid counts a tap only if it is > 0 (cudafuncs.cu:836-841): black pixels do not darken the level above.
  (xxvii) the photometric term's depth images end at maxDepthRGB = 6 m (RGBDOdometry.cpp:53,664; cudafuncs.cu:881).
+ (xxviii) computeRgbResidual's validity rules (reduce.cu:985-1058): border margin, the live pixel's 4 x 4 window all > 0, model depth > 0,
+         model intensity != 0, the 7 cm depth gate, the gradient threshold — each planted violation removes exactly the pixels its rule names.
+ (xxix)  so3Step's row (reduce.cu:1156-1290): the image gradient is the mean of both images' central differences, inside a one-pixel border.
+ (xxx)   rgbStep (reduce.cu:697-896): the row's point is the MODEL pixel's, its gradient the LIVE pixel's; sigma == -1 means unit weights;
+         the optional gradient weight is exp(-0.5 (10 / |grad|)^2).
 
-Every test here fails on at least one of the deliberate misreadings 27-49 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
+Every test here fails on at least one of the deliberate misreadings 27-56 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
 profiles/r06_mutation_report.txt).  GPU twins (-m gpu): the HIP library on the same scenarios returns the oracle's pose / weighting
 bits and meets the same outcome bounds."""
 import ctypes as C
@@ -536,6 +541,182 @@ def test_the_photometric_term_sees_nothing_beyond_six_metres(oracle_lib_built, d
     assert (min(n) > 500) if seen else (max(n) == 0), (depth, n)
 
 
+# ------------------------------------------------------------------------------------------------------------------ (xxviii)
+class _ResidualSeam:
+    """computeRgbResidual (reduce.cu:985-1058) as an operator on hand-made images, identity warp (K R K^-1 = I, K t = 0): pixel (x, y)
+    of the live frame meets pixel (x, y) of the model; every pixel carries gradient and data, so WHICH pixels come back as
+    correspondences is decided by the kernel's validity rules alone"""
+    ROWS, COLS = 24, 40
+
+    def __init__(self, lib):
+        self.lib = lib
+        rng = np.random.default_rng(21)
+        r, c = self.ROWS, self.COLS
+        self.next_img = rng.integers(50, 200, (r, c)).astype(np.uint8); self.last_img = rng.integers(50, 200, (r, c)).astype(np.uint8)
+        self.next_d = np.full((r, c), 1.5, np.float32); self.last_d = np.full((r, c), 1.5, np.float32)
+        self.dIdx = np.full((r, c), 40, np.int16); self.dIdy = np.full((r, c), -30, np.int16)
+
+    def valid(self):
+        pp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        r, c = self.ROWS, self.COLS
+        krk = np.eye(3, dtype=np.float32).ravel(); kt = np.zeros(3, np.float32)
+        co = np.full((r * c, 6), 9, np.int16); df = np.full(r * c, 9.0, np.float32)
+        cnt, sig = C.c_longlong(), C.c_longlong()
+        keep = [np.ascontiguousarray(a) for a in (self.dIdx, self.dIdy, self.last_d, self.next_d, self.last_img, self.next_img)]
+        self.lib.orc_rgb_residual(C.c_float(25.0), *(pp(a) for a in keep), r, c, pp(kt), pp(krk), pp(co), pp(df), C.byref(cnt), C.byref(sig))
+        v = co[:, 4].reshape(r, c) == 1
+        assert cnt.value == v.sum()
+        # a correspondence is (x, y) -> (x, y) under the identity warp, its residual the difference of the two images, the sum the int of its square
+        ys, xs = np.nonzero(v)
+        assert np.array_equal(co[:, 0].reshape(r, c)[v], xs) and np.array_equal(co[:, 3].reshape(r, c)[v], ys)
+        d = self.next_img.astype(np.float32)[v] - self.last_img.astype(np.float32)[v]
+        assert np.array_equal(df.reshape(r, c)[v], d) and sig.value == int((d * d).astype(np.int64).sum())
+        return v
+
+
+def test_rgb_residual_validity_rules(oracle_lib_built):
+    """`j0 < cols - 5 && i < rows - 1` (reduce.cu:999), the live pixel's [i-2, i+2) x [j-2, j+2) window all > 0 (:1003-1010), a model
+    depth > 0, a model intensity != 0 (:1039): each planted violation removes exactly the pixels its rule names"""
+    lib = oracle_lib_built.load()
+    s = _ResidualSeam(lib)
+    r, c = s.ROWS, s.COLS
+    ys, xs = np.mgrid[0:r, 0:c]
+    margin = (xs < c - 5) & (ys < r - 1)
+    assert np.array_equal(s.valid(), margin) and margin.sum() == (c - 5) * (r - 1)
+    # one black LIVE pixel: the 16 pixels whose 4 x 4 window holds it
+    s.next_img[10, 17] = 0
+    hit = (ys >= 9) & (ys <= 12) & (xs >= 16) & (xs <= 19)
+    assert hit.sum() == 16 and np.array_equal(s.valid(), margin & ~hit)
+    s.next_img[10, 17] = 99
+    # one black MODEL pixel, a model pixel without depth (0 and NaN): that pixel alone
+    for plant in ("img", "zero", "nan"):
+        t = _ResidualSeam(lib)
+        if plant == "img":
+            t.last_img[7, 30] = 0
+        else:
+            t.last_d[7, 30] = 0.0 if plant == "zero" else np.nan
+        one = (ys == 7) & (xs == 30)
+        assert np.array_equal(t.valid(), margin & ~one), plant
+    # a live pixel without depth: itself; a depth difference beyond 7 cm: itself; a gradient below the threshold: itself
+    for plant in ("live_nan", "depth_gate", "gradient"):
+        t = _ResidualSeam(lib)
+        if plant == "live_nan":
+            t.next_d[5, 5] = np.nan
+        elif plant == "depth_gate":
+            t.last_d[5, 5] = 1.5 + 0.071
+        else:
+            t.dIdx[5, 5] = 3; t.dIdy[5, 5] = 3          # 18 < minScale = 25
+        one = (ys == 5) & (xs == 5)
+        assert np.array_equal(t.valid(), margin & ~one), plant
+    t = _ResidualSeam(lib)
+    t.last_d[5, 5] = 1.5 + 0.069                        # inside the gate
+    assert np.array_equal(t.valid(), margin)
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxix)
+def _so3_seam(lib, last, nxt):
+    pp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    r, c = last.shape
+    K = np.array([[30.0, 0, c / 2.0], [0, 30.0, r / 2.0], [0, 0, 1]])
+    I3 = np.eye(3, dtype=np.float32)
+    kinv = np.linalg.inv(K).astype(np.float32); krlr = K.astype(np.float32)       # K R_lr with R_lr = identity
+    A = np.zeros(9); b = np.zeros(3); res = np.zeros(2)
+    lib.orc_so3_step(pp(last), pp(nxt), r, c, pp(I3.ravel()), pp(kinv.ravel()), pp(krlr.ravel()), pp(A), pp(b), pp(res))
+    return A.reshape(3, 3), b, res
+
+
+def test_so3_rows_use_the_mean_gradient_of_both_images_inside_a_one_pixel_border(oracle_lib_built):
+    """so3Step (reduce.cu:1156-1290) at the identity: a pixel counts when it and its warped position keep one pixel from the border;
+    the row's image gradient is the MEAN of the two images' central differences (:1221-1225), so with ramps of slope s (model) and
+    3 s (live) the matrix is (2 s)^2 times the unit-slope matrix — 9 s^2 with the live gradient alone, s^2 with the model's"""
+    lib = oracle_lib_built.load()
+    r, c = 20, 28
+    xs = np.arange(c, dtype=np.float64)[None, :].repeat(r, 0)
+    ramp = lambda slope: np.clip(20.0 + slope * xs, 0, 255).astype(np.uint8)
+    A11, _, res = _so3_seam(lib, ramp(2.0), ramp(2.0))
+    assert res[1] == (r - 2) * (c - 2) and res[0] == 0.0 and np.abs(A11).max() > 0
+    A13, _, res13 = _so3_seam(lib, ramp(2.0), ramp(6.0))
+    assert res13[1] == (r - 2) * (c - 2)
+    np.testing.assert_allclose(A13, 4.0 * A11, rtol=1e-6)
+    A31, _, _ = _so3_seam(lib, ramp(6.0), ramp(2.0))
+    np.testing.assert_allclose(A31, 4.0 * A11, rtol=1e-6)          # symmetric in the two images
+    # and the right-hand side carries last - next: brightening the live image by 5 grey levels flips its sign against darkening it
+    _, b_up, r_up = _so3_seam(lib, ramp(2.0), (ramp(2.0).astype(int) + 5).astype(np.uint8))
+    _, b_dn, r_dn = _so3_seam(lib, ramp(2.0), (ramp(2.0).astype(int) - 5).astype(np.uint8))
+    np.testing.assert_allclose(b_up, -b_dn, rtol=1e-6)
+    assert r_up[0] == r_dn[0] == 25.0 * (r - 2) * (c - 2) and np.abs(b_up).max() > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxx)
+class _StepSeam:
+    """rgbStep (reduce.cu:697-896) on hand-made correspondences: live pixel `one` = (x, y) meets model pixel `zero` = (x + 3, y + 2)"""
+    H, W = 24, 32
+
+    def __init__(self, lib):
+        self.lib = lib
+        rng = np.random.default_rng(8)
+        H, W = self.H, self.W
+        ys, xs = np.mgrid[0:H, 0:W]
+        ok = (xs + 3 < W) & (ys + 2 < H)
+        self.co = np.zeros((H * W, 6), np.int16)
+        self.co[:, 0] = (xs + 3).ravel(); self.co[:, 1] = (ys + 2).ravel(); self.co[:, 2] = xs.ravel(); self.co[:, 3] = ys.ravel(); self.co[:, 4] = ok.ravel()
+        z = 1.0 + rng.random((H, W))
+        self.cloud = np.ascontiguousarray(np.stack([(xs - 16.0) * z / 30.0, (ys - 12.0) * z / 30.0, z], -1).astype(np.float32))
+        self.dIdx = rng.integers(-300, 300, (H, W)).astype(np.int16); self.dIdy = rng.integers(-300, 300, (H, W)).astype(np.int16)
+        self.zero_px = np.zeros((H, W), bool); self.zero_px[(ys + 2)[ok], (xs + 3)[ok]] = True        # pixels some correspondence reads as `zero`
+        self.n = int(ok.sum())
+
+    def step(self, sigma, diff, use_grad=0, cloud=None, dIdx=None, dIdy=None):
+        pp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        df = np.full(self.H * self.W, diff, np.float32) if np.isscalar(diff) else np.ascontiguousarray(diff, np.float32)
+        A = np.zeros(36); b = np.zeros(6); res = np.zeros(2)
+        keep = [np.ascontiguousarray(a) for a in (self.co, df, self.cloud if cloud is None else cloud, self.dIdx if dIdx is None else dIdx, self.dIdy if dIdy is None else dIdy)]
+        self.lib.orc_rgb_step(pp(keep[0]), pp(keep[1]), float(sigma), pp(keep[2]), 30.0, 30.0, pp(keep[3]), pp(keep[4]), int(use_grad), self.H, self.W, pp(A), pp(b), pp(res))
+        assert res[1] == self.n
+        return A.reshape(6, 6), b
+
+
+def test_rgb_step_reads_the_model_pixels_point_and_the_live_pixels_gradient(oracle_lib_built):
+    """reduce.cu:744-751: cloud at `zero`, Sobel gradients at `one`.  Two clouds that agree on every pixel some correspondence uses as
+    `zero` give the SAME system whatever they hold elsewhere; two that differ there give another.  Likewise gradients off the `one` pixels."""
+    s = _StepSeam(oracle_lib_built.load())
+    A0, b0 = s.step(3.0, 5.0)
+    other = s.cloud.copy(); other[~s.zero_px] += np.float32(0.37)               # changed only where no correspondence looks
+    A1, b1 = s.step(3.0, 5.0, cloud=other)
+    assert np.array_equal(A1, A0) and np.array_equal(b1, b0)
+    moved = s.cloud.copy(); moved[s.zero_px] += np.float32(0.37)
+    A2, _ = s.step(3.0, 5.0, cloud=moved)
+    assert np.abs(A2 - A0).max() > 1e-3 * np.abs(A0).max()
+    one_px = s.co[:, 4].reshape(s.H, s.W) == 1
+    gx = s.dIdx.copy(); gx[~one_px] = 0                                         # gradients of pixels that are nobody's `one`
+    A3, b3 = s.step(3.0, 5.0, dIdx=gx)
+    assert np.array_equal(A3, A0) and np.array_equal(b3, b0)
+
+
+def test_rgb_step_sigma_minus_one_means_unit_weights(oracle_lib_built):
+    """`if(sigma == -1) w = 1` (reduce.cu:737-740), the rgbOnly signal of RGBDOdometry.cpp:1019-1022: the matrix no longer depends on the
+    residuals, the right-hand side is linear in them"""
+    s = _StepSeam(oracle_lib_built.load())
+    A5, b5 = s.step(-1.0, 5.0)
+    A50, b50 = s.step(-1.0, 50.0)
+    assert np.array_equal(A5, A50)
+    np.testing.assert_allclose(b50, 10.0 * b5, rtol=1e-6)
+    Ar, _ = s.step(3.0, 5.0)                                                    # robust weights: w = 1 / 8, the matrix 64 times smaller
+    np.testing.assert_allclose(Ar * 64.0, A5, rtol=1e-5)
+
+
+def test_rgb_step_gradient_weight_is_exp_of_minus_half_ten_over_grad_squared(oracle_lib_built):
+    """registrationColorUseRGBGrad (reduce.cu:754-759): weight exp(-0.5 (10 / |grad|)^2) with grad = w * sobelScale * (dIdx, dIdy):
+    uniform gradients (160, 0) and unit weights give |grad| = 20 and the factor exp(-1/8) on every product; (80, 0) gives exp(-1/2)"""
+    s = _StepSeam(oracle_lib_built.load())
+    for d, factor in ((160, np.exp(-0.125)), (80, np.exp(-0.5)), (800, np.exp(-0.005))):
+        gx = np.full((s.H, s.W), d, np.int16); gy = np.zeros((s.H, s.W), np.int16)
+        Au, bu = s.step(-1.0, 5.0, use_grad=0, dIdx=gx, dIdy=gy)
+        Aw, bw = s.step(-1.0, 5.0, use_grad=1, dIdx=gx, dIdy=gy)
+        np.testing.assert_allclose(Aw, factor * Au, rtol=2e-5, atol=1e-9 * np.abs(Au).max())
+        np.testing.assert_allclose(bw, factor * bu, rtol=2e-5, atol=1e-9 * np.abs(bu).max())
+
+
 # ================================================================================================================== GPU twins
 def _same_bits(a, b):
     return np.array_equal(a, b)
@@ -612,3 +793,36 @@ def test_hip_on_the_pyramid_validity_scenarios(gpu_available, oracle_lib_built, 
         assert np.array_equal(g["E"], np.eye(4))
     if case == "black_even_texels":
         assert rs.reprojection_px(g["E"], g["G"], g["z"], g["K"]) < 0.6
+
+
+@pytest.mark.gpu
+def test_hip_rgb_residual_seam_keeps_the_validity_rules(gpu_available, oracle_lib_built):
+    """(xxviii) through hrbf_rgb_residual on device images: the same correspondences, residuals, count and sum as the oracle's seam,
+    for the plain images and for every planted violation"""
+    import torch
+    from hrbffusion3d_amd.api import HRBFFusion
+    lib = oracle_lib_built.load()
+    g = HRBFFusion(default_params(160, 120, *rc.intrinsics(160, 120), max_surfels=1024))
+    pp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    try:
+        for plant in ("none", "live_black", "model_black", "model_depth_nan", "depth_gate", "gradient"):
+            s = _ResidualSeam(lib)
+            if plant == "live_black": s.next_img[10, 17] = 0
+            if plant == "model_black": s.last_img[7, 30] = 0
+            if plant == "model_depth_nan": s.last_d[7, 30] = np.nan
+            if plant == "depth_gate": s.last_d[5, 5] = 1.571
+            if plant == "gradient": s.dIdx[5, 5] = 3; s.dIdy[5, 5] = 3
+            r, c = s.ROWS, s.COLS
+            krk = np.eye(3, dtype=np.float32).ravel(); kt = np.zeros(3, np.float32)
+            co0 = np.zeros((r * c, 6), np.int16); df0 = np.zeros(r * c, np.float32); c0, s0 = C.c_longlong(), C.c_longlong()
+            host = [np.ascontiguousarray(a) for a in (s.dIdx, s.dIdy, s.last_d, s.next_d, s.last_img, s.next_img)]
+            lib.orc_rgb_residual(C.c_float(25.0), *(pp(a) for a in host), r, c, pp(kt), pp(krk), pp(co0), pp(df0), C.byref(c0), C.byref(s0))
+            dev = [torch.from_numpy(a).cuda() for a in host]
+            d_co = torch.zeros((r * c, 6), dtype=torch.int16, device="cuda"); d_df = torch.zeros(r * c, dtype=torch.float32, device="cuda")
+            c1, s1 = C.c_longlong(), C.c_longlong()
+            assert g.lib.hrbf_rgb_residual(g.h, 25.0, *(dp(t) for t in dev), r, c, pp(kt), pp(krk), dp(d_co), dp(d_df), C.byref(c1), C.byref(s1)) == 0
+            assert (c0.value, s0.value) == (c1.value, s1.value), plant
+            assert np.array_equal(d_co.cpu().numpy(), co0) and np.array_equal(d_df.cpu().numpy().view(np.uint32), df0.view(np.uint32)), plant
+    finally:
+        g.close()

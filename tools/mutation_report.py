@@ -1,5 +1,5 @@
 """Do the metamorphic tests of tests/test_registration_metamorphic.py have teeth?  Runs them against 26 deliberately MISREAD
-builds of the oracle's registration — 49 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
+builds of the oracle's registration — 56 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
 fail on which misreading.  A misreading no test fails on is a blind spot of the suite — it is listed as such.
 
     python tools/mutation_report.py [k ...] > profiles/r06_mutation_report.txt        (build container or any CPU host; ~40 minutes)
@@ -61,6 +61,13 @@ MUTANTS = {
     47: "sparse ICP: the l1 soft threshold instead of the l_p (p = 0.5) shrink operator (reduce.cu:302-315,652)",
     48: "intensity pyramid averaging every tap, also the black (no data) pixels (pyrDownKernelIntensityGauss, cudafuncs.cu:836-841)",
     49: "verticesToDepth without the far cut-off: only z <= 0 invalid (cudafuncs.cu:874-885, populateRGBDData's 6 m)",
+    50: "RGB residual: the 'not an isolated pixel' window dropped (reduce.cu:1003-1010)",
+    51: "RGB residual: a black model pixel accepted (`lastImage != 0` dropped, reduce.cu:1039)",
+    52: "RGB residual: no border margin (`j0 < cols - 5 && i < rows - 1` dropped, reduce.cu:999)",
+    53: "SO3 row: image gradient from the warped live image alone instead of the mean of both images' (reduce.cu:1224-1225)",
+    54: "RGB step: the row's 3-D point read at the live pixel (`one`) instead of the model pixel (`zero`) (reduce.cu:744-746)",
+    55: "RGB step: the rgbOnly signal sigma == -1 not honoured (reduce.cu:737-740)",
+    56: "RGB step: gradient weight exp(-0.5 (grad / 10)^2) instead of exp(-0.5 (10 / grad)^2) (reduce.cu:757-758)",
 }
 MODULES = ["tests/test_registration_metamorphic.py", "tests/test_registration_metamorphic2.py"]
 
