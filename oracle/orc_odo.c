@@ -255,9 +255,16 @@ static void sobel(const uint8_t *src, int rows, int cols, int16_t *dx, int16_t *
             for (int j = (y - 1 > 0 ? y - 1 : 0); j <= (y + 1 < rows - 1 ? y + 1 : rows - 1); ++j)
                 for (int i = (x - 1 > 0 ? x - 1 : 0); i <= (x + 1 < cols - 1 ? x + 1 : cols - 1); ++i) {
                     float s = (float)src[j * cols + i];
+#if ORC_MUTANT == 57     /* the kernel entry that BELONGS to the tap (index from the tap's offset) instead of the reference's running index, which
+                            slips at the image border where the window is cut (cudafuncs.cu:937-946) */
+                    ki = 8 - ((j - (y - 1)) * 3 + (i - (x - 1)));
+                    dxv += s * gx[ki];
+                    dyv += s * gy[ki];
+#else
                     dxv += s * gx[ki];
                     dyv += s * gy[ki];
                     --ki;
+#endif
                 }
             dx[y * cols + x] = (int16_t)dxv;
             dy[y * cols + x] = (int16_t)dyv;

@@ -29,8 +29,10 @@ STATES (file:line below), on analytic scenes or planted inputs — never an outp
  (xxix)  so3Step's row (reduce.cu:1156-1290): the image gradient is the mean of both images' central differences, inside a one-pixel border.
  (xxx)   rgbStep (reduce.cu:697-896): the row's point is the MODEL pixel's, its gradient the LIVE pixel's; sigma == -1 means unit weights;
          the optional gradient weight is exp(-0.5 (10 / |grad|)^2).
+ (xxxi)  the Sobel images (cudafuncs.cu:927-954) by hand: interior of a ramp 8 x slope; a constant image's border carries the running
+         kernel index's slip: corners (-2 c, -4 c), edges (0, -4 c).
 
-Every test here fails on at least one of the deliberate misreadings 27-56 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
+Every test here fails on at least one of the deliberate misreadings 27-57 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
 profiles/r06_mutation_report.txt).  GPU twins (-m gpu): the HIP library on the same scenarios returns the oracle's pose / weighting
 bits and meets the same outcome bounds."""
 import ctypes as C
@@ -715,6 +717,39 @@ def test_rgb_step_gradient_weight_is_exp_of_minus_half_ten_over_grad_squared(ora
         Aw, bw = s.step(-1.0, 5.0, use_grad=1, dIdx=gx, dIdy=gy)
         np.testing.assert_allclose(Aw, factor * Au, rtol=2e-5, atol=1e-9 * np.abs(Au).max())
         np.testing.assert_allclose(bw, factor * bu, rtol=2e-5, atol=1e-9 * np.abs(bu).max())
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxxi)
+def test_sobel_images_by_hand_including_the_running_index_at_the_border(oracle_lib_built):
+    """applyKernel (cudafuncs.cu:927-954) walks the 3 x 3 window with ONE index running down from 8 over the taps that exist: in the
+    interior that is the Sobel pair {1 0 -1; 2 0 -2; 1 0 -1} / {1 2 1; 0 0 0; -1 -2 -1} read backwards (a ramp of slope s gives
+    dIdx = 8 s, dIdy = 0), at the border the window is cut and the index does NOT skip the missing taps — worked out by hand for a
+    constant image c: corners (-2 c, -4 c), every edge (0, -4 c), interior (0, 0)."""
+    W, H = QVGA
+    K = rc.intrinsics(W, H)
+    a = rs.render(I4, W, H, K, st.frontal_plane(1.5), wavelength=1.0)
+    e = rc.make_engine("oracle", default_params(W, H, *K, max_surfels=1 << 20, so3=0))
+    try:
+        grey = np.full_like(a[0], 100)
+        e.process_frame(grey, a[1]); e.process_frame(grey, a[1])
+        c = int(e.pyramid("next_image", 0)[5, 5])
+        dx, dy = e.pyramid("dIdx", 0).astype(int), e.pyramid("dIdy", 0).astype(int)
+        ramp = np.clip(20 + 2 * np.arange(W)[None, :, None].repeat(H, 0).repeat(3, 2) // 2 * 1, 0, 255).astype(np.uint8)   # grey = 20 + x
+        e.process_frame(ramp, a[1])
+        img = e.pyramid("next_image", 0).astype(int)
+        rdx, rdy = e.pyramid("dIdx", 0).astype(int), e.pyramid("dIdy", 0).astype(int)
+    finally:
+        e.close()
+    assert abs(c - 100) <= 1
+    assert (dx[1:-1, 1:-1] == 0).all() and (dy[1:-1, 1:-1] == 0).all()
+    for y, x in ((0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1)):
+        assert (dx[y, x], dy[y, x]) == (-2 * c, -4 * c), (y, x, dx[y, x], dy[y, x])
+    for sl in ((0, slice(1, -1)), (H - 1, slice(1, -1)), (slice(1, -1), 0), (slice(1, -1), W - 1)):
+        assert (dx[sl] == 0).all() and (dy[sl] == -4 * c).all(), sl
+    # interior of a ramp: 8 x the slope of the intensity image as the luma made it (20 + x up to rounding), no vertical part
+    slope = img[10, 2:-1] - img[10, 1:-2]
+    inner = rdx[10, 2:-2]
+    assert np.array_equal(inner, 4 * (img[10, 3:-1] - img[10, 1:-3])) and (rdy[5:-5, 5:-5] == 0).all() and abs(np.median(slope) - 1) == 0
 
 
 # ================================================================================================================== GPU twins
