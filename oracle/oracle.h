@@ -14,10 +14,10 @@
  *     (the shaders' exp / acos / division are llvmpipe's, not hrbf_detmath.h's).
  *   CUDA rows (O1-O6: pyramids, so3Step, residuals, icpStep, rgbStep, the Gauss-Newton loop): PARITY UNPINNED by execution
  *     (no nvcc; a hipify build would be a stand-in) — pinned only by analytic known-answer tests (tests/test_oracle_*.py),
- *     independent fp64 numpy evaluations, the intrinsics KATs (tests/kat_projection.py, tests/test_intrinsics_kat.py) and 82
+ *     independent fp64 numpy evaluations, the intrinsics KATs (tests/kat_projection.py, tests/test_intrinsics_kat.py) and 84
  *     metamorphic / analytic tests whose answers come from the mathematics the reference's code states
- *     (tests/test_registration_metamorphic*.py), themselves tested against 57 deliberately misread builds of this oracle
- *     (#if ORC_MUTANT in orc_odo.c / orc_ctx.c; tools/mutation_report.py: 57 of 57 caught).
+ *     (tests/test_registration_metamorphic*.py), themselves tested against 58 deliberately misread builds of this oracle
+ *     (#if ORC_MUTANT in orc_odo.c / orc_ctx.c; tools/mutation_report.py: 58 of 58 caught).
  *   tools/compare_reference_dump.py diffs against dump files the reference itself writes, should a reference run exist.
  *
  * Plain C99, scalar, single-thread (OpenMP over pixels/surfels when built with -fopenmp; results

@@ -126,6 +126,12 @@ static void resize_cmap(const orc_planar *in, orc_planar *out)
             for (int k = 0; k < 4; ++k)
                 PL(*out, k, y, x) = (((PL(*in, k, ys, xs) + PL(*in, k, ys, xs + 1)) + PL(*in, k, ys + 1, xs)) +
                                      PL(*in, k, ys + 1, xs + 1)) / 4.0f;
+#if ORC_MUTANT == 58     /* the resized principal direction renormalised like a normal (resizeCMapKernel takes the plain mean, cudafuncs.cu:618-674) */
+            {
+                float inv = 1.0f / sqrtf((PL(*out, 0, y, x) * PL(*out, 0, y, x) + PL(*out, 1, y, x) * PL(*out, 1, y, x)) + PL(*out, 2, y, x) * PL(*out, 2, y, x));
+                if (inv < 1.0e30f) { PL(*out, 0, y, x) *= inv; PL(*out, 1, y, x) *= inv; PL(*out, 2, y, x) *= inv; }
+            }
+#endif
         }
 }
 /* tranformMapsKernel cudafuncs.cu:213-257 (in place), tranformCurvMapsKernel :279-322 */

@@ -1,4 +1,4 @@
-"""The metamorphic tests must FAIL on a misread registration — otherwise they pin nothing.  oracle/orc_odo.c and orc_ctx.c carry 57
+"""The metamorphic tests must FAIL on a misread registration — otherwise they pin nothing.  oracle/orc_odo.c and orc_ctx.c carry 58
 deliberate misreadings behind `#if ORC_MUTANT == k` (compiled only into oracle/_build/liboracle_mutant_<k>.so by `make mutants`);
 tools/mutation_report.py runs both metamorphic modules against each (profiles/r06_mutation_report.txt).  Here, in the suite, one
 quick case per kind of misreading: a Jacobian sign, a frame, a weight, a composition — and, since round 6, a map transform, a resize
@@ -43,7 +43,7 @@ CASES = [
 
 @pytest.fixture(scope="module")
 def mutants_built(oracle_lib_built):
-    # only the misread builds the cases below load (22 of 57), in parallel: a fresh tree compiles them in ~15 s
+    # only the misread builds the cases below load (22 of 58), in parallel: a fresh tree compiles them in ~15 s
     targets = ["_build/liboracle_mutant_%d.so" % k for k in sorted(set(c[0] for c in CASES))]
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle")] + targets, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return oracle_lib_built

@@ -31,8 +31,10 @@ STATES (file:line below), on analytic scenes or planted inputs — never an outp
          the optional gradient weight is exp(-0.5 (10 / |grad|)^2).
  (xxxi)  the Sobel images (cudafuncs.cu:927-954) by hand: interior of a ramp 8 x slope; a constant image's border carries the running
          kernel index's slip: corners (-2 c, -4 c), edges (0, -4 c).
+ (xxxii) the intensity image is int(0.114 R + 0.299 G + 0.587 B) of the uploaded channels (cudafuncs.cu:896-911): 200 -> 22 / 59 / 117.
+ (xxxiii) curvature maps resize by the plain mean of all four planes, NaN if any tap's curvature is NaN (cudafuncs.cu:618-674).
 
-Every test here fails on at least one of the deliberate misreadings 27-57 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
+Every test here fails on at least one of the deliberate misreadings 27-58 of oracle/orc_odo.c / orc_ctx.c (tools/mutation_report.py,
 profiles/r06_mutation_report.txt).  GPU twins (-m gpu): the HIP library on the same scenarios returns the oracle's pose / weighting
 bits and meets the same outcome bounds."""
 import ctypes as C
@@ -750,6 +752,58 @@ def test_sobel_images_by_hand_including_the_running_index_at_the_border(oracle_l
     slope = img[10, 2:-1] - img[10, 1:-2]
     inner = rdx[10, 2:-2]
     assert np.array_equal(inner, 4 * (img[10, 3:-1] - img[10, 1:-3])) and (rdy[5:-5, 5:-5] == 0).all() and abs(np.median(slope) - 1) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxxii)
+def test_intensity_is_the_references_luma_of_the_uploaded_channels(oracle_lib_built):
+    """bgr2IntensityKernel (cudafuncs.cu:896-911): `int value = x * 0.114 + y * 0.299 + z * 0.587` on the texel AS UPLOADED — the frame's
+    R, G, B (HRBFFusion.cpp:1010 uploads GL_RGB) — truncated: the red channel carries the weight a textbook luma gives to blue.
+    Pure red / green / blue frames of 200: 22, 59, 117."""
+    W, H = QVGA
+    K = rc.intrinsics(W, H)
+    a = rs.render(I4, W, H, K, st.frontal_plane(1.5), wavelength=1.0)
+    e = rc.make_engine("oracle", default_params(W, H, *K, max_surfels=1 << 20, so3=0))
+    try:
+        e.process_frame(np.full_like(a[0], 100), a[1])
+        for ch, want in ((0, 22), (1, 59), (2, 117)):
+            img = np.zeros_like(a[0]); img[..., ch] = 200
+            e.process_frame(img, a[1])
+            got = e.pyramid("next_image", 0)
+            assert (got == want).all(), (ch, int(got[5, 5]))
+        mix = np.zeros_like(a[0]); mix[..., 0] = 10; mix[..., 1] = 100; mix[..., 2] = 250      # 1.14 + 29.9 + 146.75 = 177.79
+        e.process_frame(mix, a[1])
+        assert (e.pyramid("next_image", 0) == 177).all()
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------ (xxxiii)
+def test_curvature_maps_resize_by_the_plain_mean_without_renormalising(oracle_lib_built):
+    """resizeCMapKernel (cudafuncs.cu:618-674): NaN if any tap's curvature is NaN, otherwise the plain mean of all FOUR planes — the
+    principal direction is NOT renormalised (resizeMapKernel<true> does that for normals only)"""
+    scene, TA = rc.VIEWS["room"]
+
+    def keep(e):
+        return {n: [e.pyramid(n, l) for l in range(3)] for n in ("ck1_c", "ck2_c")}
+
+    def nan_kappa(e):
+        a = e.get_image("CURV1").copy(); a[101, 143, 3] = np.nan; e.set_image("CURV1", a)
+    r = st.staged("oracle", *QVGA, TA, TA @ rc.MOTIONS["2px"], scene=scene, keep=keep, edit=nan_kappa, so3=0)
+    quad = lambda a: (a[0::2, 0::2], a[0::2, 1::2], a[1::2, 0::2], a[1::2, 1::2])
+    shorter = 1.0
+    for name in ("ck1_c", "ck2_c"):
+        lv = r["extra"][name]
+        for l in (1, 2):
+            q = quad(~np.isnan(lv[l - 1][..., 3]))
+            ok = ~np.isnan(lv[l][..., 3])
+            assert np.array_equal(ok, q[0] & q[1] & q[2] & q[3]), (name, l)
+            qv = quad(lv[l - 1].astype(np.float64))
+            mean = (qv[0] + qv[1] + qv[2] + qv[3]) / 4.0
+            got, want = lv[l][ok].astype(np.float64), mean[ok]      # (a flat patch can carry a NaN direction beside a finite curvature: it propagates)
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.nanmax(np.abs(got - want)) < 1e-5, (name, l)
+            shorter = min(shorter, float(np.nanmin(np.linalg.norm(got[:, :3], axis=1))))
+    assert np.isnan(r["extra"]["ck1_c"][1][50, 71, 3]) and np.isnan(r["extra"]["ck1_c"][2][25, 35, 3])     # the planted NaN climbs the pyramid
+    assert shorter < 0.9                                           # the premise: somewhere the averaged direction is visibly short (it stays that way)
 
 
 # ================================================================================================================== GPU twins

@@ -1,5 +1,5 @@
 """Do the metamorphic tests of tests/test_registration_metamorphic.py have teeth?  Runs them against 26 deliberately MISREAD
-builds of the oracle's registration — 57 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
+builds of the oracle's registration — 58 since round 6 — (oracle/orc_odo.c, orc_ctx.c, `#if ORC_MUTANT == k`; `make -C oracle mutants`) and reports which tests
 fail on which misreading.  A misreading no test fails on is a blind spot of the suite — it is listed as such.
 
     python tools/mutation_report.py [k ...] > profiles/r06_mutation_report.txt        (build container or any CPU host; ~40 minutes)
@@ -69,6 +69,7 @@ MUTANTS = {
     55: "RGB step: the rgbOnly signal sigma == -1 not honoured (reduce.cu:737-740)",
     56: "RGB step: gradient weight exp(-0.5 (grad / 10)^2) instead of exp(-0.5 (10 / grad)^2) (reduce.cu:757-758)",
     57: "Sobel: the kernel entry taken from the tap's offset, without the running index that slips where the border cuts the window (cudafuncs.cu:937-946)",
+    58: "resizeCMap renormalising the averaged principal direction like a normal (cudafuncs.cu:618-674 takes the plain mean of all four planes)",
 }
 MODULES = ["tests/test_registration_metamorphic.py", "tests/test_registration_metamorphic2.py"]
 
