@@ -7,12 +7,21 @@ flow's association records equal the young flow's, vertices are the back-project
     derived : nothing — a numpy PREDICTOR rebuilds it from arrays decoded before it
     xor     : bits(array) XOR bits(prediction), byte planes separated, LZMA — small where the prediction is close (a rigid transform
               evaluated in numpy's op order instead of llvmpipe's: a few ulp)
-    raw     : byte planes separated, LZMA — what nothing here predicts (PCA normals, curvatures, ray-cast points, the seed map)
+    raw     : byte planes separated, LZMA — what nothing here predicts (integer inputs, index images, a few heads)
 
 and a CRC32 of every decoded array is kept: `decode` either returns the reference's bits or raises.  Predictors only decide the
-file's SIZE, never its content — a wrong predictor makes the file bigger, not different.  They are plain numpy (elementwise IEEE
-fp32, gathers, selects): no oracle, no library code.  `encode` runs in the build container (tests/golden/make_ref_glsl.py
---vga-fixture), `decode` wherever the tests run.
+file's SIZE, never its content — a wrong predictor makes the file bigger, not different.
+
+Two families of predictors.  Plain numpy (elementwise IEEE fp32, gathers, selects) for everything that is an exact function of
+other arrays.  And, since round 6 (the tree is pushed to a GPU box on every run: 29 MB -> 8 MB), the C ORACLE for the float-heavy
+passes that numpy does not restate — the bilateral filter, the PCA normals, the HRBF curvature pass, the ray-cast prediction —
+run stage by stage on the arrays decoded so far, the way tests/ref_glsl_check.run_vga feeds them: the oracle's output is within
+ulps of the shaders', so the XOR residual is mostly zero bits.  For the same reason frame 1's pre-processing images are now kept
+(helper arrays): the seed map's normals and curvature records are gathers from them.  This does NOT make the comparison circular:
+the residual restores the shaders' bits whatever the oracle computed and the CRC proves it; an oracle that drifts gives residuals
+that no longer decode, and `decode` raises instead of returning anything else.  The price: the file is tied to the oracle's
+arithmetic of those four stages — after a change there, re-run `make_ref_glsl.py --vga-fixture` in the build container (10 s).
+`encode` runs in the build container, `decode` wherever the tests run (tests/ may use the oracle; the product never does).
 """
 import json
 import lzma
@@ -61,14 +70,18 @@ def p_texcoord(fx):
     return np.stack([(xs.astype(f32) + f32(0.5)) / f32(W), (ys.astype(f32) + f32(0.5)) / f32(H)], -1).astype(f32)
 
 
-def p_metric(fx):
-    d = fx["f2_depth"]
+def _frame(fx, pre):
+    return (fx["f2_rgb"], fx["f2_depth"]) if pre == "f2_" else (_png("1c"), _png("1d"))
+
+
+def p_metric(fx, pre="f2_"):
+    d = _frame(fx, pre)[1]
     hi, lo = np.uint32(f32(3.5) / f32(DEPTH_SCALE)), np.uint32(f32(0.3) / f32(DEPTH_SCALE))
     return np.where((d > hi) | (d < lo), f32(0), d.astype(f32) * f32(DEPTH_SCALE)).astype(f32)
 
 
-def p_metric_filtered(fx):
-    v = fx["f2_DEPTH_FILTERED"]
+def p_metric_filtered(fx, pre="f2_"):
+    v = fx[pre + "DEPTH_FILTERED"]
     hi, lo = f32(3.5) / f32(DEPTH_SCALE), f32(0.3) / f32(DEPTH_SCALE)
     return np.where((v > hi) | (v < lo), f32(0), v * f32(DEPTH_SCALE)).astype(f32)
 
@@ -92,23 +105,23 @@ def _vertex(z, valid, w):
     return out
 
 
-def _valid(fx):
-    return (fx["f2_NORMAL_P3"][..., :3] != 0).any(-1)
+def _valid(fx, pre="f2_"):
+    return (fx[pre + "NORMAL_P3"][..., :3] != 0).any(-1)
 
 
 def p_vertex_raw(fx):
     return _vertex(fx["f2_DEPTH_METRIC"], _valid(fx), _radial_conf())
 
 
-def p_vertex_filtered(fx):
-    return _vertex(fx["f2_DEPTH_METRIC_FILTERED"], _valid(fx), f32(1))
+def p_vertex_filtered(fx, pre="f2_"):
+    return _vertex(fx[pre + "DEPTH_METRIC_FILTERED"], _valid(fx, pre), f32(1))
 
 
-def p_normal_p3(fx):
-    """xyz: nothing; w = radius_multiplier * getRadius(z_filtered, n.z) (surfels.glsl:19-33)"""
-    n = fx["f2_NORMAL_P3_xyz"]
+def p_normal_p3(fx, pre="f2_"):
+    """xyz: the oracle's PCA normal (o_normal_p3); w = radius_multiplier * getRadius(z_filtered, n.z) (surfels.glsl:19-33)"""
+    n = fx[pre + "NORMAL_P3_xyz"]
     out = np.zeros((H, W, 4), f32); out[..., :3] = n
-    z = fx["f2_DEPTH_METRIC_FILTERED"]
+    z = fx[pre + "DEPTH_METRIC_FILTERED"]
     camz, camw = f32(1.0 / FX), f32(1.0 / FY)
     mean_focal = ((f32(1) / abs(camz)) + (f32(1) / abs(camw))) / f32(2)
     rad = (z / mean_focal) * f32(1.41421356237)
@@ -118,8 +131,86 @@ def p_normal_p3(fx):
     return out
 
 
-def p_normal(fx):
-    out = np.zeros((H, W, 4), f32); out[..., :3] = fx["f2_NORMAL_xyz"]; out[..., 3] = fx["f2_NORMAL_P3"][..., 3]
+def p_normal(fx, pre="f2_"):
+    out = np.zeros((H, W, 4), f32); out[..., :3] = fx[pre + "NORMAL_xyz"]; out[..., 3] = fx[pre + "NORMAL_P3"][..., 3]
+    return out
+
+
+# ---- predictors that run the C oracle, one stage at a time, on the arrays decoded so far (see the header) ------------------------
+_ORC = {}
+
+
+def _oracle():
+    if "o" not in _ORC:
+        import sys
+        sys.path.insert(0, os.path.dirname(HERE))
+        import oracle_lib
+        from hrbffusion3d_amd.params import default_params
+        oracle_lib.build()
+        _ORC["o"] = oracle_lib.Oracle(default_params(max_surfels=1 << 20), omp=True)     # 640 x 480, K = (528, 528, 320, 240), 1 / 5000
+    return _ORC["o"]
+
+
+def _release_oracle():
+    o = _ORC.pop("o", None)
+    if o is not None:
+        o.close()
+    _ORC.clear()
+
+
+def o_depth_filtered(fx, pre):
+    """P1 filterDepth on the frame's raw images"""
+    o = _oracle()
+    o.upload_frame(*_frame(fx, pre)); o.run_stage("FILTER_DEPTH")
+    return o.get_image("DEPTH_FILTERED")
+
+
+def _o_p3(fx, pre):
+    """P3 on the shaders' metric depth images, at the texcoords the rasteriser interpolated (`tc`, the oracle's test hook)"""
+    o = _oracle()
+    o.upload_frame(*_frame(fx, pre)); o.set_fragment_texcoords(fx["tc"])
+    o.set_image("DEPTH_METRIC", fx[pre + "DEPTH_METRIC"]); o.set_image("DEPTH_METRIC_FILTERED", fx[pre + "DEPTH_METRIC_FILTERED"])
+    o.run_stage("VERTEX_NORMAL_RADIUS")
+    return o
+
+
+def o_normal_p3(fx, pre):
+    o = _o_p3(fx, pre)
+    n = np.ascontiguousarray(o.get_image("NORMAL")[..., :3])
+    o.set_fragment_texcoords(None)
+    return n
+
+
+def o_curvature(fx, pre, name):
+    """P4 / P5 on the shaders' PCA normals and filtered vertices: CURV1, CURV2, GRADIENT_MAG and the refined normal, one run"""
+    if ("curv", pre) not in _ORC:
+        o = _o_p3(fx, pre)
+        o.set_image("NORMAL", fx[pre + "NORMAL_P3"]); o.set_image("VERTEX_FILTERED", fx[pre + "VERTEX_FILTERED"])
+        o.run_stage("CURVATURE")
+        _ORC[("curv", pre)] = {"CURV1": o.get_image("CURV1"), "CURV2": o.get_image("CURV2"), "GRADIENT_MAG": o.get_image("GRADIENT_MAG"),
+                               "NORMAL_xyz": np.ascontiguousarray(o.get_image("NORMAL")[..., :3])}
+        o.set_fragment_texcoords(None)
+    return _ORC[("curv", pre)][name]
+
+
+def o_prediction(fx, name):
+    """H2 predictHRBF on the shaders' final map and index images at frame 2's pose"""
+    if "pred" not in _ORC:
+        o = _oracle()
+        o.upload_map(ref_final(fx, "x_")); o.set_pose(fx["f2_pose"]); o.set_tick(2)
+        for k in ("INDEX", "INDEX_VERTCONF", "INDEX_COLORTIME", "INDEX_NORMRAD", "INDEX_CURVMAX", "INDEX_CURVMIN"):
+            o.set_image(k, fx["x_p_" + k])
+        o.run_stage("PREDICT_HRBF")
+        _ORC["pred"] = {k: np.ascontiguousarray(o.get_image(k)[..., :3]) for k in ("PRED_VERTEX", "PRED_NORMAL")}
+    return _ORC["pred"][name]
+
+
+def p_f1_map_rest(fx):
+    """init_unstableTex.vert copies the row's pixel of frame 1's NORMAL (xyz + radius), CURV1 and CURV2 images"""
+    pix = fx["f1_pix"].astype(np.int64)
+    out = np.zeros((pix.size, 20), f32)
+    for c, k in ((8, "NORMAL"), (12, "CURV1"), (16, "CURV2")):
+        out[:, c:c + 4] = fx["f1_" + k].reshape(-1, 4)[pix]
     return out
 
 
@@ -400,15 +491,21 @@ def plan():
     add = lambda k, fn=None: P.append((k, fn))
     add("f2_pose"); add("f2_weighting"); add("tc", p_texcoord)
     add("f2_rgb", lambda fx: _png("2c")); add("f2_depth", lambda fx: _png("2d"))
-    add("f2_DEPTH_FILTERED")
-    add("f2_DEPTH_METRIC", p_metric); add("f2_DEPTH_METRIC_FILTERED", p_metric_filtered)
-    add("f2_NORMAL_P3_xyz"); add("f2_NORMAL_P3", p_normal_p3)
-    add("f2_VERTEX_RAW", p_vertex_raw); add("f2_VERTEX_FILTERED", p_vertex_filtered)
-    add("f2_RADIUS", lambda fx: fx["f2_NORMAL_P3"][..., 3])
-    add("f2_CURV1"); add("f2_CURV2"); add("f2_GRADIENT_MAG")
-    add("f2_NORMAL_xyz"); add("f2_NORMAL", p_normal)
+    for pre in ("f2_", "f1_"):            # a frame's pre-processing (frame 1's images are helper arrays: the seed map gathers from them)
+        add(pre + "DEPTH_FILTERED", lambda fx, pre=pre: o_depth_filtered(fx, pre))
+        add(pre + "DEPTH_METRIC", lambda fx, pre=pre: p_metric(fx, pre)); add(pre + "DEPTH_METRIC_FILTERED", lambda fx, pre=pre: p_metric_filtered(fx, pre))
+        add(pre + "NORMAL_P3_xyz", lambda fx, pre=pre: o_normal_p3(fx, pre)); add(pre + "NORMAL_P3", lambda fx, pre=pre: p_normal_p3(fx, pre))
+        if pre == "f2_":
+            add("f2_VERTEX_RAW", p_vertex_raw)
+        add(pre + "VERTEX_FILTERED", lambda fx, pre=pre: p_vertex_filtered(fx, pre))
+        if pre == "f2_":
+            add("f2_RADIUS", lambda fx: fx["f2_NORMAL_P3"][..., 3])
+        add(pre + "CURV1", lambda fx, pre=pre: o_curvature(fx, pre, "CURV1")); add(pre + "CURV2", lambda fx, pre=pre: o_curvature(fx, pre, "CURV2"))
+        if pre == "f2_":
+            add("f2_GRADIENT_MAG", lambda fx: o_curvature(fx, "f2_", "GRADIENT_MAG"))
+        add(pre + "NORMAL_xyz", lambda fx, pre=pre: o_curvature(fx, pre, "NORMAL_xyz")); add(pre + "NORMAL", lambda fx, pre=pre: p_normal(fx, pre))
     add("f2_CONFIDENCE", p_confidence)
-    add("f1_pix"); add("f1_map_rest"); add("f1_map", p_f1_map); add("x_extra"); add("x_old")
+    add("f1_pix"); add("f1_map_rest", p_f1_map_rest); add("f1_map", p_f1_map); add("x_extra"); add("x_old")
     for pre in ("f2_", "x_"):
         add(pre + "a_INDEX")
         add(pre + "a_INDEX_VERTCONF", lambda fx, pre=pre: _index_attr(fx, map_in(fx, pre), fx[pre + "a_INDEX"], "VERTCONF"))
@@ -425,8 +522,8 @@ def plan():
         add("x_p_INDEX_" + k, lambda fx, k=k: _index_attr(fx, ref_final(fx, "x_"), fx["x_p_INDEX"], k))
     add("x_nn_off")
     add("x_PRED_CURV1", lambda fx: p_pred4(fx, None, "INDEX_CURVMAX")); add("x_PRED_CURV2", lambda fx: p_pred4(fx, None, "INDEX_CURVMIN"))
-    add("x_PRED_VERTEX_xyz"); add("x_PRED_VERTEX", lambda fx: p_pred4(fx, "x_PRED_VERTEX", "INDEX_VERTCONF", 3))
-    add("x_PRED_NORMAL_xyz"); add("x_PRED_NORMAL", lambda fx: p_pred4(fx, "x_PRED_NORMAL", "INDEX_NORMRAD", 3))
+    add("x_PRED_VERTEX_xyz", lambda fx: o_prediction(fx, "PRED_VERTEX")); add("x_PRED_VERTEX", lambda fx: p_pred4(fx, "x_PRED_VERTEX", "INDEX_VERTCONF", 3))
+    add("x_PRED_NORMAL_xyz", lambda fx: o_prediction(fx, "PRED_NORMAL")); add("x_PRED_NORMAL", lambda fx: p_pred4(fx, "x_PRED_NORMAL", "INDEX_NORMRAD", 3))
     add("x_PRED_IMAGE", p_pred_image); add("x_PRED_TIME", p_pred_time); add("x_PRED_ICPWEIGHT", p_pred_icpweight)
     for k in ("VERTEX", "NORMAL", "CURV1", "CURV2", "IMAGE", "ICPWEIGHT"):
         add("x_FILL_" + k, lambda fx, k=k: p_fill(fx, k))
@@ -435,14 +532,17 @@ def plan():
 
 
 AUX = ("f2_NORMAL_P3_xyz", "f2_NORMAL_xyz", "x_PRED_VERTEX_xyz", "x_PRED_NORMAL_xyz", "x_nn_off", "f1_pix", "f1_map_rest", "f2_rec_pix",
-       "f2_records_rest", "f2_fused_rec", "x_fused_rec")   # helper arrays of the coding, not passes' outputs
+       "f2_records_rest", "f2_fused_rec", "x_fused_rec",
+       "f1_DEPTH_FILTERED", "f1_DEPTH_METRIC", "f1_DEPTH_METRIC_FILTERED", "f1_NORMAL_P3_xyz", "f1_NORMAL_P3", "f1_VERTEX_FILTERED", "f1_CURV1",
+       "f1_CURV2", "f1_NORMAL_xyz", "f1_NORMAL")   # helper arrays of the coding, not passes' outputs of the fixture
 
 
 def encode(full, path, extra_meta=None):
     """full: {name: array} as make_ref_glsl.run_reference('vga', ...) returns it (which records `tc`, the interpolated texcoords)"""
     full = dict(full)
     full["f2_weighting"] = np.asarray(full["f2_weighting"], f32).reshape(())
-    full["f2_NORMAL_P3_xyz"] = np.ascontiguousarray(full["f2_NORMAL_P3"][..., :3]); full["f2_NORMAL_xyz"] = np.ascontiguousarray(full["f2_NORMAL"][..., :3])
+    for pre in ("f1_", "f2_"):           # (frame 1's images: make_ref_glsl.run_reference(..., keep_frame1=True))
+        full[pre + "NORMAL_P3_xyz"] = np.ascontiguousarray(full[pre + "NORMAL_P3"][..., :3]); full[pre + "NORMAL_xyz"] = np.ascontiguousarray(full[pre + "NORMAL"][..., :3])
     full["x_PRED_VERTEX_xyz"] = np.ascontiguousarray(full["x_PRED_VERTEX"][..., :3]); full["x_PRED_NORMAL_xyz"] = np.ascontiguousarray(full["x_PRED_NORMAL"][..., :3])
     full["x_nn_off"] = nearest_neighbour_offsets(full)
     full["f1_pix"] = f1_pixels(full)
@@ -452,6 +552,7 @@ def encode(full, path, extra_meta=None):
     for pre in ("f2_", "x_"):
         full[pre + "fused_rec"] = fused_records(full, pre)
     store, meta, sizes = {}, {}, {}
+    _release_oracle()
     for key, fn in plan():
         a = np.ascontiguousarray(full[key])
         m = {"dtype": a.dtype.str, "shape": list(a.shape), "crc": zlib.crc32(a.tobytes())}
@@ -470,6 +571,7 @@ def encode(full, path, extra_meta=None):
     meta["_info"] = extra_meta or {}
     store["_meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     np.savez(path, **store)
+    _release_oracle()
     return sizes
 
 
@@ -477,6 +579,7 @@ def decode(path=None):
     z = np.load(path or os.path.join(GOLD, "ref_glsl", "vga.npz"))
     meta = json.loads(z["_meta"].tobytes().decode())
     fx = {}
+    _release_oracle()
     for key, fn in plan():
         m = meta[key]
         if m["kind"] == "raw":
@@ -486,8 +589,11 @@ def decode(path=None):
             a = pred if m["kind"] == "derived" else (_bits(pred) ^ _unpack(z[key], _bits(pred).dtype, m["shape"])).view(np.dtype(m["dtype"]))
         a = np.ascontiguousarray(a).reshape(m["shape"])
         if zlib.crc32(a.tobytes()) != m["crc"]:
-            raise AssertionError("vga fixture: %s does not decode to the recorded bits (predictor %s)" % (key, m["kind"]))
+            _release_oracle()
+            raise AssertionError("vga fixture: %s does not decode to the recorded bits (predictor %s).  If the oracle's filter / PCA / curvature / "
+                                 "prediction arithmetic changed, re-run tests/golden/make_ref_glsl.py --vga-fixture in the build container" % (key, m["kind"]))
         fx[key] = a
+    _release_oracle()
     for k in AUX:
         del fx[k]
     fx["f2_weighting"] = f32(fx["f2_weighting"].ravel()[0])

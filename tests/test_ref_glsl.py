@@ -157,7 +157,7 @@ def _vga_params():
 
 
 def test_vga_fixture_decodes_to_the_recorded_bits_and_covers_every_pass():
-    """tests/ref_glsl_vga.py rebuilds 177 MB of shader outputs from 29 MB (predictors + XOR residuals) and checks a CRC per array"""
+    """tests/ref_glsl_vga.py rebuilds 177 MB of shader outputs from 8.4 MB (numpy and staged-oracle predictors + XOR residuals) and checks a CRC per array"""
     fx = _vga()
     assert "llvmpipe" in fx["_info"]["renderer"]
     assert fx["f2_depth"].shape == (480, 640) and fx["f1_map"].shape[0] > 250000
