@@ -1,0 +1,132 @@
+"""Random COMBINATIONS of the reference's switches (GUI/GlobalStateParam.txt:20-81, the HRBFFusion ctor arguments), HIP path against
+the oracle, bit for bit: tests/test_parity_gpu.py::test_parameter_variants turns the switches one at a time; here every context gets
+a random draw of all of them together (the windowed search WITH the sparse variant WITH frame-to-frame RGB WITHOUT the pyramid ...),
+a random window of the synthetic stream, and now and then a ragged or an empty depth image in the middle.
+
+    python tests/gpu_fuzz_params.py N [seed] [out]     # N contexts of 4-6 frames; appends to gpurun_out/param_fuzz.txt (or `out`)
+
+A mismatch is logged with the draw that produced it (the seed and the index reproduce it) and the run goes on.
+tests/test_parity_gpu.py::test_random_parameter_combinations runs the first 10 draws of seed 1 in the suite.
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        u = a.view(np.uint32).copy(); u[np.isnan(a)] = 0x7FC00000       # NaN sign / payload carry no meaning (tests/test_parity_gpu.bits)
+        return u
+    return a.view(np.uint8)
+
+
+def draw(rng):
+    """one random setting of every switch the path reads; the ranges are what the reference's parameter file documents or uses (the
+    HRBF windows at most the reference's defaults: the library refuses larger ones, DESIGN.md deviations)"""
+    c = lambda *v: v[int(rng.integers(len(v)))]
+    flip = lambda p=0.5: int(rng.random() < p)
+    kw = dict(
+        use_bilateral=flip(0.7), normal_estimation_pca=float(flip(0.7)), so3=flip(0.7), pyramid=flip(0.8), fast_odom=flip(0.3),
+        use_conf_eval=flip(0.3), conf_eval_epsilon=float(c(100.0, 1000.0, 2500.0)), rgb_only=flip(0.1),
+        icp_weight=float(c(1.0, 10.0, 10.0, 25.0, 100.0)), icp_use_corr_search=flip(0.4), icp_search_radius=int(c(1, 2, 2, 3)),
+        use_sparse_icp=flip(0.3), clean_window_multiplier=float(c(1.0, 1.5, 2.0, 2.0, 2.25, 3.0, 4.0)), frame_to_frame_rgb=flip(0.3),
+        rgb_use_grad_weight=flip(0.3), icp_use_weighted=flip(0.7), icp_curv_weight_lambda=float(c(0.0, 5.0, 10.0, 10.0, 30.0)),
+        predict_window_multiplier=float(c(2.0, 2.5, 3.0, 3.0)), predict_min_neighbors=int(c(3, 4, 6, 6, 8)),
+        curv_estimation_window=float(c(2.0, 3.0, 3.0)), curv_valid_threshold=float(c(100.0, 150.0, 300.0, 300.0, 500.0)),
+        confidence_threshold=float(c(1.0, 2.0, 5.0, 5.0, 10.0)), depth_cutoff=float(c(2.0, 2.5, 3.5, 3.5, 5.0)),
+        dense_enough_thresh=float(c(0.5, 0.75, 0.75, 0.99)), predict_conf_threshold=float(c(1.0, 3.0, 3.0, 5.0)),
+        init_radius_multiplier=float(c(2.0, 3.0, 4.0, 4.0, 5.0)), max_depth_processed=float(c(20.0, 20.0, 4.0)))
+    kw["predict_max_neighbors"] = kw["predict_min_neighbors"] + int(c(0, 2, 4, 6))
+    size = c((160, 120), (160, 120), (160, 120), (320, 240))
+    plan = dict(size=size, start=int(rng.integers(0, 400)), step=int(c(1, 1, 2, 3)), frames=int(c(4, 5, 6)), noise=flip(0.7),
+                odd_frame=c(None, None, "ragged", "empty", "far"), odd_at=int(rng.integers(1, 4)))
+    return kw, plan
+
+
+def depth_of(plan, k, d):
+    if plan["odd_frame"] is None or k != plan["odd_at"]:
+        return d
+    if plan["odd_frame"] == "empty":
+        return np.zeros_like(d)
+    if plan["odd_frame"] == "far":
+        return np.full_like(d, 60000)
+    r = d.copy(); r[::3, ::2] = 0; r[:7] = 0; r[:, -5:] = 0
+    return r
+
+
+def run_one(oracle_lib, kw, plan):
+    """None when HIP == oracle on every image, the map and the pose after every frame; else a description of the first difference"""
+    from hrbffusion3d_amd import synth
+    from hrbffusion3d_amd.api import HRBFFusion
+    from hrbffusion3d_amd.params import IMAGES, default_params
+    W, H = plan["size"]
+    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << (17 if W == 160 else 19), **kw)
+    o = g = None
+    try:
+        try:
+            o = oracle_lib.Oracle(p, omp=True)
+        except Exception as e:
+            o, eo = None, e
+        try:
+            g = HRBFFusion(p)
+        except Exception as e:
+            g, eg = None, e
+        if o is None or g is None:
+            return None if (o is None and g is None) else "only one side accepts the parameters (oracle %s, HIP %s)" % (
+                "ok" if o else repr(eo), "ok" if g else repr(eg))
+        for k in range(plan["frames"]):
+            rgb, d, _ = synth.frame(plan["start"] + k * plan["step"], W, H, noise=bool(plan["noise"]))
+            d = depth_of(plan, k, d)
+            o.process_frame(rgb, d); g.process_frame(rgb, d)
+            for name in IMAGES:
+                if not np.array_equal(bits(o.get_image(name)), bits(g.get_image(name))):
+                    return "frame %d: image %s differs in %d values" % (k, name, int((bits(o.get_image(name)) != bits(g.get_image(name))).sum()))
+            if o.surfel_count() != g.surfel_count():
+                return "frame %d: surfel count %d vs %d" % (k, o.surfel_count(), g.surfel_count())
+            if not np.array_equal(bits(o.download_map()), bits(g.download_map())):
+                return "frame %d: map differs" % k
+            if not np.array_equal(bits(o.get_pose()), bits(g.get_pose())):
+                return "frame %d: pose differs" % k
+        return None
+    finally:
+        for x in (o, g):
+            if x is not None:
+                x.close()
+
+
+def main():
+    import oracle_lib
+    n = int(sys.argv[1]); seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "param_fuzz.txt")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    oracle_lib.build()
+    rng = np.random.default_rng(seed)
+    bad = 0
+    t0 = time.time()
+    tally = {}
+    with open(out, "a") as log:
+        log.write("# seed %d, %d draws: every switch drawn at random per context, 4-6 frames, all images + map + pose compared bit for bit\n" % (seed, n))
+        for i in range(n):
+            kw, plan = draw(rng)
+            r = run_one(oracle_lib, kw, plan)
+            for k in ("use_sparse_icp", "icp_use_corr_search", "frame_to_frame_rgb", "rgb_only", "pyramid", "so3", "use_conf_eval"):
+                tally[k] = tally.get(k, 0) + int(kw[k])
+            tally[plan["size"]] = tally.get(plan["size"], 0) + 1
+            tally[plan["odd_frame"]] = tally.get(plan["odd_frame"], 0) + 1
+            if r is not None:
+                bad += 1
+                log.write("MISMATCH draw %d of seed %d: %s\n    %r\n    %r\n" % (i, seed, r, kw, plan))
+            if i % 20 == 19 or i == n - 1:
+                log.write("draw %d: %d mismatches so far, %.0f s\n" % (i + 1, bad, time.time() - t0)); log.flush()
+        log.write("done: %d contexts, %d mismatches; drawn on: %s\n" % (n, bad, ", ".join("%s %d" % (k, v) for k, v in tally.items())))
+    print("param fuzz: %d contexts, %d mismatches" % (n, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -322,6 +322,18 @@ def test_parameter_variants(pair, variant):
         assert_same_state(o, g, "%s frame %d" % (variant, k))
 
 
+def test_random_parameter_combinations(oracle_lib_built, gpu_available):
+    """every switch drawn at random TOGETHER (tests/gpu_fuzz_params.py; the variants above turn one at a time): the first 10 draws
+    of seed 1 — windowed search with the sparse variant without the pyramid, an empty depth image in the middle, ... — HIP == oracle
+    on every image, the map and the pose after every frame.  profiles/r06_param_fuzz.txt holds a run of many hundred draws."""
+    import gpu_fuzz_params as F
+    rng = np.random.default_rng(1)
+    for i in range(10):
+        kw, plan = F.draw(rng)
+        r = F.run_one(oracle_lib_built, kw, plan)
+        assert r is None, (i, r, kw, plan)
+
+
 @pytest.mark.parametrize("size", [(320, 240), (1280, 960)])
 def test_other_resolutions(pair, size):
     """QVGA (BASELINE config 1 geometry) and 1280x960 (config 5 geometry): same kernels, other grid shapes — the
