@@ -518,7 +518,7 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
             confidence = vertconf[gi].w; radius = normrad[gi].w;
             cmx = curvmax[gi]; cmn = curvmin[gi];
             float4 ct = colortime[gi];
-            int ci = (int)ct.x;
+            int ci = hd_f2i(ct.x);
             img = make_uchar4((unsigned char)((ci >> 16) & 0xFF), (unsigned char)((ci >> 8) & 0xFF),
                               (unsigned char)(ci & 0xFF), 255);
             tm = (uint32_t)ct.z;

@@ -47,6 +47,13 @@ HD_FN float hd_sqrtf(float a) { return __builtin_sqrtf(a); }
 HD_FN double hd_sqrt(double a) { return __builtin_sqrt(a); }
 HD_FN float hd_fabsf(float a) { return __builtin_fabsf(a); }
 HD_FN float hd_floorf(float a) { return __builtin_floorf(a); }
+/* float -> int where the operand can be NaN or out of range (the colour word of a surfel merged at total confidence 0: 0 / 0).  C and
+ * GLSL leave that conversion undefined; x86 returns INT_MIN, the GPUs the reference runs on and v_cvt_i32_f32 return 0 for NaN and
+ * saturate.  The contract takes the GPUs' result and states it, so that the host restatement does not inherit the host's. */
+HD_FN int hd_f2i(float a)
+{
+    return a != a ? 0 : (a >= 2147483648.0f ? 2147483647 : (a <= -2147483648.0f ? (-2147483647 - 1) : (int)a));
+}
 
 /* One axis of the shaders' float-stepped window loops, literally (geometry.glsl:198-207 getNormalPCA,
  * depth_curvature_gradient.frag:54-63):

@@ -1,7 +1,9 @@
 """Random COMBINATIONS of the reference's switches (GUI/GlobalStateParam.txt:20-81, the HRBFFusion ctor arguments), HIP path against
 the oracle, bit for bit: tests/test_parity_gpu.py::test_parameter_variants turns the switches one at a time; here every context gets
 a random draw of all of them together (the windowed search WITH the sparse variant WITH frame-to-frame RGB WITHOUT the pyramid ...),
-a random window of the synthetic stream, and now and then a ragged or an empty depth image in the middle.
+a random window of the synthetic stream, now and then a ragged or an empty depth image in the middle, sometimes an uploaded map of the
+scene to track against, a jump of the frame counter, and in half of the contexts' plans the map cut into 2-4 shards (contiguous ranges
+or hash-owned, re-cut in the middle, the registration row-sharded or not).
 
     python tests/gpu_fuzz_params.py N [seed] [out]     # N contexts of 4-6 frames; appends to gpurun_out/param_fuzz.txt (or `out`)
 
@@ -44,7 +46,11 @@ def draw(rng):
     kw["predict_max_neighbors"] = kw["predict_min_neighbors"] + int(c(0, 2, 4, 6))
     size = c((160, 120), (160, 120), (160, 120), (320, 240))
     plan = dict(size=size, start=int(rng.integers(0, 400)), step=int(c(1, 1, 2, 3)), frames=int(c(4, 5, 6)), noise=flip(0.7),
-                odd_frame=c(None, None, "ragged", "empty", "far"), odd_at=int(rng.integers(1, 4)))
+                odd_frame=c(None, None, "ragged", "empty", "far"), odd_at=int(rng.integers(1, 4)),
+                # the sharded map (one process playing G shards), the row-sharded registration, a re-cut of the ranges in the middle
+                shards=int(c(0, 0, 0, 2, 3, 4)), partition=c("ranges", "hash"), row_sharding=flip(), rebalance_at=c(None, 1, 2, 3),
+                # tracking against an uploaded map of the scene instead of an empty one; a jump of the frame counter (stale surfels go)
+                seed_map=int(c(0, 0, 0, 8000, 40000)), tick_jump=c(None, None, None, (2, 40), (3, 400)))
     return kw, plan
 
 
@@ -79,11 +85,29 @@ def run_one(oracle_lib, kw, plan):
         if o is None or g is None:
             return None if (o is None and g is None) else "only one side accepts the parameters (oracle %s, HIP %s)" % (
                 "ok" if o else repr(eo), "ok" if g else repr(eg))
-        for k in range(plan["frames"]):
+        hashed = plan.get("shards", 0) > 1 and plan["partition"] == "hash"
+        if plan.get("shards", 0) > 1:
+            g.comm_init(-1, plan["shards"]); g.map_shard_init(True, partition=plan["partition"])
+            g.set_row_sharding(bool(plan["row_sharding"]))
+        first = 0
+        if plan.get("seed_map", 0):
+            seed = synth.seed_map(plan["seed_map"], width=W)
+            rgb, d, T = synth.frame(plan["start"], W, H, noise=bool(plan["noise"]))
+            for x in (o, g):
+                x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
+            first = 1
+        for k in range(first, plan["frames"] + first):
             rgb, d, _ = synth.frame(plan["start"] + k * plan["step"], W, H, noise=bool(plan["noise"]))
             d = depth_of(plan, k, d)
+            if plan.get("tick_jump") and k == plan["tick_jump"][0]:
+                for x in (o, g):
+                    x.set_tick(x.tick + plan["tick_jump"][1])
             o.process_frame(rgb, d); g.process_frame(rgb, d)
+            if plan.get("shards", 0) > 1 and not hashed and plan.get("rebalance_at") == k:
+                g.map_rebalance()
             for name in IMAGES:
+                if hashed and name == "INDEX":
+                    continue            # ids instead of array positions under hash ownership: names only
                 if not np.array_equal(bits(o.get_image(name)), bits(g.get_image(name))):
                     return "frame %d: image %s differs in %d values" % (k, name, int((bits(o.get_image(name)) != bits(g.get_image(name))).sum()))
             if o.surfel_count() != g.surfel_count():
@@ -118,6 +142,10 @@ def main():
                 tally[k] = tally.get(k, 0) + int(kw[k])
             tally[plan["size"]] = tally.get(plan["size"], 0) + 1
             tally[plan["odd_frame"]] = tally.get(plan["odd_frame"], 0) + 1
+            for k in ("shards", "seed_map"):
+                tally["%s>0" % k] = tally.get("%s>0" % k, 0) + int(plan[k] > 0)
+            tally["hash"] = tally.get("hash", 0) + int(plan["shards"] > 1 and plan["partition"] == "hash")
+            tally["tick_jump"] = tally.get("tick_jump", 0) + int(plan["tick_jump"] is not None)
             if r is not None:
                 bad += 1
                 log.write("MISMATCH draw %d of seed %d: %s\n    %r\n    %r\n" % (i, seed, r, kw, plan))

@@ -69,6 +69,8 @@ def load(omp=False):
     lib.orc_hrbf_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.orc_hrbf_hessian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.orc_expf.restype = C.c_float; lib.orc_expf.argtypes = [C.c_float]
+    lib.orc_f2i.restype = C.c_int; lib.orc_f2i.argtypes = [C.c_float]
+    lib.orc_encode_color.restype = C.c_float; lib.orc_encode_color.argtypes = [C.c_float] * 3
     lib.orc_acosf.restype = C.c_float; lib.orc_acosf.argtypes = [C.c_float]
     lib.orc_atan2f.restype = C.c_float; lib.orc_atan2f.argtypes = [C.c_float, C.c_float]
     lib.orc_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]

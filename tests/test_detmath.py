@@ -23,6 +23,20 @@ def test_expf_accuracy(oracle_lib_built):
     assert math.isinf(lib.orc_expf(100.0))
 
 
+def test_float_to_int_is_defined_for_nan_and_out_of_range(oracle_lib_built):
+    """hd_f2i: what C, GLSL and CUDA leave undefined is stated (NaN -> 0, saturating: the GPUs' conversion, not x86's INT_MIN), and the
+    colour word of a surfel merged at total confidence 0 (every channel 0 / 0) is therefore 0 on both sides (found by
+    tests/gpu_fuzz_params.py, draw 13 of seed 31: the oracle said -2^31, the kernel 0)"""
+    lib = oracle_lib_built.load()
+    nan, inf = float("nan"), float("inf")
+    assert [lib.orc_f2i(x) for x in (nan, -nan, inf, -inf, 3e9, -3e9, 2147483520.0, -2147483648.0)] == \
+        [0, 0, 2147483647, -2147483648, 2147483647, -2147483648, 2147483520, -2147483648]
+    assert [lib.orc_f2i(x) for x in (0.0, -0.0, 2.9, -2.9, 255.0, 16777215.0)] == [0, 0, 2, -2, 255, 16777215]      # truncation, as (int)
+    assert lib.orc_encode_color(nan, nan, nan) == 0.0
+    assert lib.orc_encode_color(1.0, 0.5, 0.0) == float((255 << 16) + (128 << 8))       # rint: 127.5 -> 128 (ties to even)
+    assert lib.orc_encode_color(nan, 1.0, nan) == float(255 << 8)
+
+
 def test_acosf_atan2f_accuracy(oracle_lib_built):
     lib = oracle_lib_built.load()
     xs = np.linspace(-1.0, 1.0, 20001).astype(np.float32)
