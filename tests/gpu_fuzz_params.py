@@ -3,12 +3,13 @@ the oracle, bit for bit: tests/test_parity_gpu.py::test_parameter_variants turns
 a random draw of all of them together (the windowed search WITH the sparse variant WITH frame-to-frame RGB WITHOUT the pyramid ...),
 a random window of the synthetic stream, now and then a ragged or an empty depth image in the middle, sometimes an uploaded map of the
 scene to track against, a jump of the frame counter, and in half of the contexts' plans the map cut into 2-4 shards (contiguous ranges
-or hash-owned, re-cut in the middle, the registration row-sharded or not).
+or hash-owned, re-cut in the middle, the registration row-sharded or not); other image shapes and intrinsics (fx != fy, off-centre, a
+negative fy), millimetre depth, and garbage rows (NaN / inf / negative values) in the uploaded map.
 
     python tests/gpu_fuzz_params.py N [seed] [out]     # N contexts of 4-6 frames; appends to gpurun_out/param_fuzz.txt (or `out`)
 
 A mismatch is logged with the draw that produced it (the seed and the index reproduce it) and the run goes on.
-tests/test_parity_gpu.py::test_random_parameter_combinations runs the first 10 draws of seed 1 in the suite.
+tests/test_parity_gpu.py::test_random_parameter_combinations runs draws 0-9 of seed 1 in the suite, and the one draw that ever differed.
 """
 import os
 import sys
@@ -27,7 +28,13 @@ def bits(a):
     return a.view(np.uint8)
 
 
-def draw(rng):
+def draw(seed, index):
+    """draw `index` of `seed`: its own generator, so a draw does not depend on the ones before it and fields appended later leave
+    the earlier fields of every draw as they were"""
+    return _draw(np.random.default_rng([seed, index]))
+
+
+def _draw(rng):
     """one random setting of every switch the path reads; the ranges are what the reference's parameter file documents or uses (the
     HRBF windows at most the reference's defaults: the library refuses larger ones, DESIGN.md deviations)"""
     c = lambda *v: v[int(rng.integers(len(v)))]
@@ -51,7 +58,42 @@ def draw(rng):
                 shards=int(c(0, 0, 0, 2, 3, 4)), partition=c("ranges", "hash"), row_sharding=flip(), rebalance_at=c(None, 1, 2, 3),
                 # tracking against an uploaded map of the scene instead of an empty one; a jump of the frame counter (stale surfels go)
                 seed_map=int(c(0, 0, 0, 8000, 40000)), tick_jump=c(None, None, None, (2, 40), (3, 400)))
+    # geometry: other image shapes (multiples of 8), fx != fy, an off-centre principal point, now and then the negative fy ICL-NUIM
+    # publishes; raw depth in 1 / 5000 m or in millimetres; some rows of the uploaded map replaced by garbage (NaN / inf positions, zero
+    # normals, negative radii, absurd confidences): whatever the path does with them, both sides must do the same
+    plan["size"] = c(plan["size"], plan["size"], plan["size"], (168, 120), (160, 128), (208, 152), (256, 128))
+    W, H = plan["size"]
+    if flip(0.5):
+        fx = 0.825 * W * float(rng.uniform(0.8, 1.25)); fy = fx * float(rng.uniform(0.9, 1.1)) * (-1.0 if flip(0.1) else 1.0)
+        plan["K"] = (fx, fy, W * float(rng.uniform(0.4, 0.6)), H * float(rng.uniform(0.4, 0.6)))
+    else:
+        plan["K"] = None
+    plan["depth_units"] = float(c(5000.0, 5000.0, 1000.0))
+    plan["garbage_rows"] = int(c(0, 0, 50)) if plan["seed_map"] else 0
+    plan["garbage_seed"] = int(rng.integers(1 << 30))
     return kw, plan
+
+
+def garbage(seed_map, plan):
+    if not plan.get("garbage_rows"):
+        return seed_map
+    rng = np.random.default_rng(plan["garbage_seed"])
+    m = seed_map.copy()
+    rows = rng.choice(m.shape[0], plan["garbage_rows"], replace=False)
+    vals = np.array([np.nan, np.inf, -np.inf, 0.0, -1.0, 1e30, -1e30, 1e-40, 3e9], np.float32)
+    for r in rows:
+        kind = int(rng.integers(5))
+        if kind == 0:
+            m[r, 0:3] = vals[rng.integers(len(vals), size=3)]            # position
+        elif kind == 1:
+            m[r, 8:11] = vals[rng.integers(len(vals), size=3)]           # normal
+        elif kind == 2:
+            m[r, 11] = vals[rng.integers(len(vals))]                     # radius
+        elif kind == 3:
+            m[r, 3] = vals[rng.integers(len(vals))]                      # confidence
+        else:
+            m[r, int(rng.integers(12, 20))] = vals[rng.integers(len(vals))]   # a curvature record
+    return m
 
 
 def depth_of(plan, k, d):
@@ -71,7 +113,8 @@ def run_one(oracle_lib, kw, plan):
     from hrbffusion3d_amd.api import HRBFFusion
     from hrbffusion3d_amd.params import IMAGES, default_params
     W, H = plan["size"]
-    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << (17 if W == 160 else 19), **kw)
+    K, units = plan.get("K"), plan.get("depth_units", 5000.0)
+    p = default_params(W, H, *synth.intrinsics(W, H, K), depth_scale=1.0 / units, max_surfels=1 << (17 if W * H <= 160 * 128 else 19), **kw)
     o = g = None
     try:
         try:
@@ -91,13 +134,13 @@ def run_one(oracle_lib, kw, plan):
             g.set_row_sharding(bool(plan["row_sharding"]))
         first = 0
         if plan.get("seed_map", 0):
-            seed = synth.seed_map(plan["seed_map"], width=W)
-            rgb, d, T = synth.frame(plan["start"], W, H, noise=bool(plan["noise"]))
+            seed = garbage(synth.seed_map(plan["seed_map"], width=W, K=K), plan)
+            rgb, d, T = synth.frame(plan["start"], W, H, noise=bool(plan["noise"]), depth_units=units, K=K)
             for x in (o, g):
                 x.upload_map(seed); x.set_pose(T); x.bootstrap(rgb, d)
             first = 1
         for k in range(first, plan["frames"] + first):
-            rgb, d, _ = synth.frame(plan["start"] + k * plan["step"], W, H, noise=bool(plan["noise"]))
+            rgb, d, _ = synth.frame(plan["start"] + k * plan["step"], W, H, noise=bool(plan["noise"]), depth_units=units, K=K)
             d = depth_of(plan, k, d)
             if plan.get("tick_jump") and k == plan["tick_jump"][0]:
                 for x in (o, g):
@@ -129,23 +172,26 @@ def main():
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "param_fuzz.txt")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     oracle_lib.build()
-    rng = np.random.default_rng(seed)
     bad = 0
     t0 = time.time()
     tally = {}
     with open(out, "a") as log:
         log.write("# seed %d, %d draws: every switch drawn at random per context, 4-6 frames, all images + map + pose compared bit for bit\n" % (seed, n))
         for i in range(n):
-            kw, plan = draw(rng)
+            kw, plan = draw(seed, i)
+            log.write("draw %d\n" % i) if os.environ.get("HRBF_FUZZ_TRACE") else None; log.flush()
             r = run_one(oracle_lib, kw, plan)
             for k in ("use_sparse_icp", "icp_use_corr_search", "frame_to_frame_rgb", "rgb_only", "pyramid", "so3", "use_conf_eval"):
                 tally[k] = tally.get(k, 0) + int(kw[k])
             tally[plan["size"]] = tally.get(plan["size"], 0) + 1
             tally[plan["odd_frame"]] = tally.get(plan["odd_frame"], 0) + 1
-            for k in ("shards", "seed_map"):
+            for k in ("shards", "seed_map", "garbage_rows"):
                 tally["%s>0" % k] = tally.get("%s>0" % k, 0) + int(plan[k] > 0)
             tally["hash"] = tally.get("hash", 0) + int(plan["shards"] > 1 and plan["partition"] == "hash")
             tally["tick_jump"] = tally.get("tick_jump", 0) + int(plan["tick_jump"] is not None)
+            tally["own K"] = tally.get("own K", 0) + int(plan["K"] is not None)
+            tally["fy<0"] = tally.get("fy<0", 0) + int(plan["K"] is not None and plan["K"][1] < 0)
+            tally["mm depth"] = tally.get("mm depth", 0) + int(plan["depth_units"] == 1000.0)
             if r is not None:
                 bad += 1
                 log.write("MISMATCH draw %d of seed %d: %s\n    %r\n    %r\n" % (i, seed, r, kw, plan))
