@@ -75,15 +75,15 @@ __host__ __device__ __forceinline__ float encode_color_bytes(int r, int g, int b
 }
 __host__ __device__ __forceinline__ float encode_color(f3 c)
 {
-    /* hd_f2i: NaN (a merge at total confidence 0) -> 0, the conversion C leaves undefined (hrbf_detmath.h) */
-    int rgb = hd_f2i(hd_rintf(c.x * 255.0f));
-    rgb = (int)((uint32_t)rgb << 8) + hd_f2i(hd_rintf(c.y * 255.0f));
-    rgb = (int)((uint32_t)rgb << 8) + hd_f2i(hd_rintf(c.z * 255.0f));
+    /* hd_cvt_i32: NaN (a merge at total confidence 0) -> 0, the conversion C leaves undefined (hrbf_detmath.h) */
+    int rgb = hd_cvt_i32(hd_rintf(c.x * 255.0f));
+    rgb = (int)((uint32_t)rgb << 8) + hd_cvt_i32(hd_rintf(c.y * 255.0f));
+    rgb = (int)((uint32_t)rgb << 8) + hd_cvt_i32(hd_rintf(c.z * 255.0f));
     return (float)rgb;
 }
 __host__ __device__ __forceinline__ f3 decode_color(float c)
 {
-    int ci = hd_f2i(c);
+    int ci = hd_cvt_i32(c);
     return mk3((float)((ci >> 16) & 0xFF) / 255.0f, (float)((ci >> 8) & 0xFF) / 255.0f, (float)(ci & 0xFF) / 255.0f);
 }
 __host__ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

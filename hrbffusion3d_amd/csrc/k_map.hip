@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_project(Cam cam, const DevPose *__restr
                 item_class[s] = (uint8_t)cl;
             }
             if (submap_active) {   // index_map.vert:41-45: surfels of inactive submaps are not drawn
-                const uint32_t sm = (uint32_t)color_time[s].y;
+                const uint32_t sm = hd_cvt_u32(color_time[s].y);
                 if (sm >= (uint32_t)n_active || submap_active[sm] == 0) continue;
             }
             if (h.z > maxDepth || h.z < 0.0f) continue;
@@ -772,7 +772,7 @@ __device__ __forceinline__ bool clean_window(const CleanParams &cp, const Rigid 
     f3 ln = normalize3(rot_mul(tinv, xyz(vn)));
     bool own_active = true;
     if (cp.submap_active) {
-        const uint32_t sm = (uint32_t)submap;
+        const uint32_t sm = hd_cvt_u32(submap);
         own_active = sm < (uint32_t)cp.n_active && cp.submap_active[sm] != 0;
     }
     const bool nz_ok = hd_fabsf(ln.z) > 0.85f && own_active;
@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_update_model(MapPlanes m, const uint32_
 {
     const uint32_t N = *count;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < N; s += gridDim.x * blockDim.x) {
-        const uint32_t sm = (uint32_t)m.p1[s].y;
+        const uint32_t sm = hd_cvt_u32(m.p1[s].y);
         if (sm >= (uint32_t)n) continue;   // texels the reference never uploaded: left alone (oracle/orc_map.c)
         const float *T = delta + (size_t)sm * 16;
         const float4 p = m.p0[s], nr = m.p2[s];

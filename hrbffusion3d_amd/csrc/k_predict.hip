@@ -518,10 +518,10 @@ __global__ __launch_bounds__(PNT) void k_predict_hrbf(Cam cam, const float4 *__r
             confidence = vertconf[gi].w; radius = normrad[gi].w;
             cmx = curvmax[gi]; cmn = curvmin[gi];
             float4 ct = colortime[gi];
-            int ci = hd_f2i(ct.x);
+            int ci = hd_cvt_i32(ct.x);
             img = make_uchar4((unsigned char)((ci >> 16) & 0xFF), (unsigned char)((ci >> 8) & 0xFF),
                               (unsigned char)(ci & 0xFF), 255);
-            tm = (uint32_t)ct.z;
+            tm = hd_cvt_u32(ct.z);
         }
         float a1 = hd_fabsf(cmx.w), a2 = hd_fabsf(cmn.w);
         float cm = a1 > a2 ? a1 : a2;

@@ -50,9 +50,15 @@ HD_FN float hd_floorf(float a) { return __builtin_floorf(a); }
 /* float -> int where the operand can be NaN or out of range (the colour word of a surfel merged at total confidence 0: 0 / 0).  C and
  * GLSL leave that conversion undefined; x86 returns INT_MIN, the GPUs the reference runs on and v_cvt_i32_f32 return 0 for NaN and
  * saturate.  The contract takes the GPUs' result and states it, so that the host restatement does not inherit the host's. */
-HD_FN int hd_f2i(float a)
+HD_FN int hd_cvt_i32(float a)
 {
     return a != a ? 0 : (a >= 2147483648.0f ? 2147483647 : (a <= -2147483648.0f ? (-2147483647 - 1) : (int)a));
+}
+/* ... and float -> unsigned (GLSL uint(): a surfel's submap id, its init time — index_map.vert:41, predict_hrbf.frag:296): NaN and
+ * negative values -> 0, saturating above (v_cvt_u32_f32; x86 goes through a 64-bit conversion and wraps: -1.0f -> 0xFFFFFFFF) */
+HD_FN unsigned hd_cvt_u32(float a)
+{
+    return !(a > 0.0f) ? 0u : (a >= 4294967296.0f ? 0xFFFFFFFFu : (unsigned)a);
 }
 
 /* One axis of the shaders' float-stepped window loops, literally (geometry.glsl:198-207 getNormalPCA,

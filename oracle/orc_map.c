@@ -75,7 +75,7 @@ void orc_predict_indices(orc_ctx *c)
         /* active-submap mask (index_map.vert:41-45, IndexMap.cpp:222-237): KeyFrameIDMap holds 1 for the ids in
            lActiveKFID and 0 elsewhere.  No mask installed = every submap active (the scoped configs: one submap) */
         if (c->submap_active) {
-            const uint32_t sm = (uint32_t)SURF(m, s, 1).y;
+            const uint32_t sm = hd_cvt_u32(SURF(m, s, 1).y);
             if (sm >= (uint32_t)c->n_submap_active || c->submap_active[sm] == 0) continue;
         }
         if (h.z > maxDepth || h.z < 0.0f) continue;
@@ -237,7 +237,7 @@ static int clean_test(const orc_ctx *c, const float *tinv, f4 vp, f4 *vcol, f4 v
     int count = 0, zCount = 0;
     float active = 1.0f;   /* KeyFrameIDMap lookup of the surfel's own submap (copy_unstable.vert:98-101); no mask = all active */
     if (c->submap_active) {
-        const uint32_t sm = (uint32_t)vcol->y;
+        const uint32_t sm = hd_cvt_u32(vcol->y);
         active = (sm < (uint32_t)c->n_submap_active && c->submap_active[sm]) ? 1.0f : 0.0f;
     }
     if (lp.z < maxDepth && lp.z > 0.0f && x > 0.0f && y > 0.0f && x < (float)W && y < (float)H) {
@@ -312,7 +312,7 @@ void orc_update_model(orc_ctx *c, const float *delta, int n)
 {
     f4 *m = c->map[c->target];
     for (uint32_t s = 0; s < c->count; ++s) {
-        const uint32_t sm = (uint32_t)SURF(m, s, 1).y;
+        const uint32_t sm = hd_cvt_u32(SURF(m, s, 1).y);
         if (sm >= (uint32_t)n) continue;
         const float *T = delta + (size_t)sm * 16;   /* T[col*4 + row] */
         const f4 p = SURF(m, s, 0), nr = SURF(m, s, 2);

@@ -137,10 +137,10 @@ void orc_predict_hrbf(orc_ctx *c)
                     if (dist < dsm) {
                         cmx = cmax[it]; cmn = cmin[it];
                         confidence = vc[it].w; radius = nr[it].w;
-                        int ci = hd_f2i(ct[it].x);
+                        int ci = hd_cvt_i32(ct[it].x);
                         img[0] = (uint8_t)((ci >> 16) & 0xFF); img[1] = (uint8_t)((ci >> 8) & 0xFF);
                         img[2] = (uint8_t)(ci & 0xFF); img[3] = 255;
-                        tm = (uint32_t)ct[it].z;
+                        tm = hd_cvt_u32(ct[it].z);
                         dsm = dist;
                     }
                 }

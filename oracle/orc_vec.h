@@ -64,15 +64,15 @@ static inline void mat4_mul(const float *a, const float *b, float *o) /* o = a*b
 static inline float encode_color_bytes(int r, int g, int b) { return (float)((((r << 8) + g) << 8) + b); }
 static inline float encode_color(f3 c)
 {
-    /* hd_f2i: NaN (a merge at total confidence 0) -> 0, the conversion C leaves undefined (hrbf_detmath.h) */
-    int rgb = hd_f2i(rintf(c.x * 255.0f));
-    rgb = (int)((uint32_t)rgb << 8) + hd_f2i(rintf(c.y * 255.0f));
-    rgb = (int)((uint32_t)rgb << 8) + hd_f2i(rintf(c.z * 255.0f));
+    /* hd_cvt_i32: NaN (a merge at total confidence 0) -> 0, the conversion C leaves undefined (hrbf_detmath.h) */
+    int rgb = hd_cvt_i32(rintf(c.x * 255.0f));
+    rgb = (int)((uint32_t)rgb << 8) + hd_cvt_i32(rintf(c.y * 255.0f));
+    rgb = (int)((uint32_t)rgb << 8) + hd_cvt_i32(rintf(c.z * 255.0f));
     return (float)rgb;
 }
 static inline f3 decode_color(float c)
 {
-    int ci = hd_f2i(c);
+    int ci = hd_cvt_i32(c);
     return v3((float)((ci >> 16) & 0xFF) / 255.0f, (float)((ci >> 8) & 0xFF) / 255.0f, (float)(ci & 0xFF) / 255.0f);
 }
 

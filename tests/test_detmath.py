@@ -24,7 +24,7 @@ def test_expf_accuracy(oracle_lib_built):
 
 
 def test_float_to_int_is_defined_for_nan_and_out_of_range(oracle_lib_built):
-    """hd_f2i: what C, GLSL and CUDA leave undefined is stated (NaN -> 0, saturating: the GPUs' conversion, not x86's INT_MIN), and the
+    """hd_cvt_i32: what C, GLSL and CUDA leave undefined is stated (NaN -> 0, saturating: the GPUs' conversion, not x86's INT_MIN), and the
     colour word of a surfel merged at total confidence 0 (every channel 0 / 0) is therefore 0 on both sides (found by
     tests/gpu_fuzz_params.py, draw 13 of seed 31: the oracle said -2^31, the kernel 0)"""
     lib = oracle_lib_built.load()
@@ -33,6 +33,9 @@ def test_float_to_int_is_defined_for_nan_and_out_of_range(oracle_lib_built):
         [0, 0, 2147483647, -2147483648, 2147483647, -2147483648, 2147483520, -2147483648]
     assert [lib.orc_f2i(x) for x in (0.0, -0.0, 2.9, -2.9, 255.0, 16777215.0)] == [0, 0, 2, -2, 255, 16777215]      # truncation, as (int)
     assert lib.orc_encode_color(nan, nan, nan) == 0.0
+    # uint(): a submap id, an init time (found by tests/gpu_fuzz_stages.py: -1.0 was 0xFFFFFFFF on the host, 1e30 was 0)
+    assert [lib.orc_f2u(x) for x in (nan, -1.0, -0.0, -inf, 0.9, 7.0, 4294967040.0, 4294967296.0, 1e30, inf)] == \
+        [0, 0, 0, 0, 0, 7, 4294967040, 4294967295, 4294967295, 4294967295]
     assert lib.orc_encode_color(1.0, 0.5, 0.0) == float((255 << 16) + (128 << 8))       # rint: 127.5 -> 128 (ties to even)
     assert lib.orc_encode_color(nan, 1.0, nan) == float(255 << 8)
 

@@ -333,7 +333,7 @@ def test_random_parameter_combinations(oracle_lib_built, gpu_available):
         assert r is None, (i, r, kw, plan)
     # the one difference the long runs found (profiles/r06_param_fuzz.txt): a surfel merged at total confidence 0 (confidence evaluation
     # on, every weight 0): position, normal and colour are 0 / 0, and the colour WORD is an int conversion of NaN — undefined in C,
-    # -2^31 on the host, 0 on the device.  Stated since (hd_f2i, hrbf_detmath.h); sharded as drawn and on the single map
+    # -2^31 on the host, 0 on the device.  Stated since (hd_cvt_i32, hrbf_detmath.h); sharded as drawn and on the single map
     kw = {'use_bilateral': 0, 'normal_estimation_pca': 0.0, 'so3': 1, 'pyramid': 0, 'fast_odom': 0, 'use_conf_eval': 1, 'conf_eval_epsilon': 2500.0,
           'rgb_only': 0, 'icp_weight': 25.0, 'icp_use_corr_search': 0, 'icp_search_radius': 2, 'use_sparse_icp': 0, 'clean_window_multiplier': 2.0,
           'frame_to_frame_rgb': 1, 'rgb_use_grad_weight': 0, 'icp_use_weighted': 1, 'icp_curv_weight_lambda': 10.0, 'predict_window_multiplier': 2.0,
@@ -351,6 +351,16 @@ def test_random_parameter_combinations(oracle_lib_built, gpu_available):
     m = o.download_map(); o.close()
     nan = np.isnan(m[:, 0])
     assert nan.sum() >= 1 and (m[nan, 4] == 0).all() and (m[nan, 3] == 0).all()          # the case does occur in this run
+
+
+def test_adversarial_pixels_at_the_stage_seams(oracle_lib_built, gpu_available):
+    """NaN / inf / negative / denormal pixels in the images one stage reads (tests/gpu_fuzz_stages.py): 40 trials of seed 1 and the two
+    trials of seed 3 that differed before uint() of a negative or huge float was stated (hd_cvt_u32) — the init time of a predicted
+    pixel was 0xFFFFFFFF on the host and 0 on the device.  profiles/r06_stage_fuzz.txt: 3 000 trials, 0 mismatches."""
+    import gpu_fuzz_stages as S
+    for seed, i in [(1, k) for k in range(40)] + [(3, 80), (3, 141)]:
+        r = S.trial(oracle_lib_built, seed, i)
+        assert r is None, (seed, i, r)
 
 
 @pytest.mark.parametrize("size", [(320, 240), (1280, 960)])
