@@ -7,6 +7,7 @@ or hash-owned, re-cut in the middle, the registration row-sharded or not); other
 negative fy), millimetre depth, and garbage rows (NaN / inf / negative values) in the uploaded map.
 
     python tests/gpu_fuzz_params.py N [seed] [out]     # N contexts of 4-6 frames; appends to gpurun_out/param_fuzz.txt (or `out`)
+    HRBF_FUZZ_VGA=1 python tests/gpu_fuzz_params.py N ...   # every context at 640 x 480, two thirds of them against a 0.3 M / 1 M map
 
 A mismatch is logged with the draw that produced it (the seed and the index reproduce it) and the run goes on.
 tests/test_parity_gpu.py::test_random_parameter_combinations runs draws 0-9 of seed 1 in the suite, and the one draw that ever differed.
@@ -71,6 +72,11 @@ def _draw(rng):
     plan["depth_units"] = float(c(5000.0, 5000.0, 1000.0))
     plan["garbage_rows"] = int(c(0, 0, 50)) if plan["seed_map"] else 0
     plan["garbage_seed"] = int(rng.integers(1 << 30))
+    if os.environ.get("HRBF_FUZZ_VGA"):       # the benchmark's size: several fuse tiles per workgroup, the 1200-workgroup reduction grids,
+        big = c(0, 300_000, 1_000_000)        # the hipGraph replay from frame 3 on; a map of the benchmark's size to track against
+        plan.update(size=(640, 480), seed_map=int(big), frames=int(c(3, 4, 5)), garbage_rows=int(c(0, 200)) if big else 0)
+        if plan["K"] is not None:
+            plan["K"] = tuple(v * 640.0 / W if i in (0, 2) else v * 480.0 / H for i, v in enumerate(plan["K"]))
     return kw, plan
 
 
@@ -114,7 +120,7 @@ def run_one(oracle_lib, kw, plan):
     from hrbffusion3d_amd.params import IMAGES, default_params
     W, H = plan["size"]
     K, units = plan.get("K"), plan.get("depth_units", 5000.0)
-    p = default_params(W, H, *synth.intrinsics(W, H, K), depth_scale=1.0 / units, max_surfels=1 << (17 if W * H <= 160 * 128 else 19), **kw)
+    p = default_params(W, H, *synth.intrinsics(W, H, K), depth_scale=1.0 / units, max_surfels=(1 << (17 if W * H <= 160 * 128 else 19)) if W < 640 else plan.get("seed_map", 0) + (1 << 20), **kw)
     o = g = None
     try:
         try:
