@@ -148,6 +148,7 @@ struct hrbf_context {
     uint8_t *h_stage[3]; hipEvent_t ev_stage[3]; bool stage_used[3]; uint32_t stage_head;   // pinned input staging ring
     const uint8_t *ride_rgb_src;   // device view of a staged RGB image that the next st_filter uploads (hrbf_process_frame)
     hipEvent_t ev_count; bool ev_pending; uint32_t ub_growth_since;
+    bool inputs_lent;   // the last frame read the caller's device buffers (hrbf_process_frame_device): d_rgb / d_depth hold an OLDER frame
     // ownership by spatial hash: the next free global-order id (the same on every rank: seed size, then + Q per clean pass),
     // 1 / cell size, the device word holding the smallest id alive, scratch of the hashed seeding
     int peer_fallback;          // the ranks agreed to exchange packed records because a rank could not map its peers (hrbf_shard_exchange_mode)
@@ -1226,6 +1227,7 @@ extern "C" int hrbf_upload_frame(hrbf_handle c, const uint8_t *rgb, const uint16
     HIP_CHECK(hipMemcpyAsync(c->d_rgb, rgb, (size_t)c->P * 3, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipMemcpyAsync(c->d_depth, depth, (size_t)c->P * 2, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));   // host buffers are borrowed only for the call
+    c->inputs_lent = false;
     return HRBF_OK;
 }
 
@@ -1253,6 +1255,7 @@ extern "C" int hrbf_process_frame(hrbf_handle c, const uint8_t *rgb, const uint1
     // only the depth image heads the frame; the RGB image is copied by filler workgroups of the first kernel (st_filter)
     launch_copy_inputs(c->stream, dev_view, 0, dev_view + dep_off, ndep, c->d_rgb, (uint8_t *)c->d_depth);
     c->ride_rgb_src = dev_view;
+    c->inputs_lent = false;
     const int r = process_frame_resident(c, wmul);
     HIP_CHECK(hipEventRecord(c->ev_stage[slot], c->stream));   // the slot is free once its readers are through
     c->stage_used[slot] = true;
@@ -1271,6 +1274,7 @@ extern "C" int hrbf_process_frame_device(hrbf_handle c, const void *d_rgb, const
     c->d_rgb = (uint8_t *)d_rgb; c->d_depth = (uint16_t *)d_depth;
     const int r = process_frame_resident(c, wmul);
     c->d_rgb = own_rgb; c->d_depth = own_depth;
+    c->inputs_lent = true;   // the stage seams that read the raw frame would find an older one in the context's own buffers
     return r;
 }
 
@@ -1299,6 +1303,13 @@ extern "C" int hrbf_run_stage(hrbf_handle c, int stage)
 {
     if (!c) return HRBF_ERR_INVALID;
     hipSetDevice(c->device);
+    if (c->inputs_lent && (stage == HRBF_STAGE_FILTER_DEPTH || stage == HRBF_STAGE_METRICISE || stage == HRBF_STAGE_INITIALISE ||
+                           stage == HRBF_STAGE_FUSE || stage == HRBF_STAGE_FILLIN)) {
+        // found by tests/gpu_fuzz_api.py: the stage silently ran on the raw images of the last HOST-pointer frame
+        hrbf_set_error("run_stage: the last frame read the caller's device buffers (hrbf_process_frame_device), which the context does not keep; "
+                       "hrbf_upload_frame() the frame this stage is to run on");
+        return HRBF_ERR_INVALID;
+    }
     switch (stage) {
         case HRBF_STAGE_FILTER_DEPTH: st_filter(c); break;    // also writes both metric images
         case HRBF_STAGE_METRICISE: st_filter(c); break;
@@ -1783,6 +1794,9 @@ extern "C" int hrbf_get_timings(hrbf_handle c, float out[8])
     if (hipEventElapsedTime(&ms, c->ev[5], c->ev[6]) == hipSuccess) out[4] = ms;   // clean/compact/append stream pass
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[9]) == hipSuccess) out[5] = ms;   // whole frame
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) out[6] = ms;   // first projection (+confidence)
+    // a region whose events no frame has recorded yet (timing switched on, nothing run since) fails the query: tolerated above, but the
+    // runtime keeps the error for the next hipGetLastError() — the next launch check would report it as its own (tests/gpu_fuzz_api.py)
+    (void)hipGetLastError();
     return HRBF_OK;
 }
 static int fuse_ring_read(hrbf_context *c, int max_frames, float *merge_ms, float *stream_ms, uint32_t *stats, int nstat)
@@ -1800,6 +1814,7 @@ static int fuse_ring_read(hrbf_context *c, int max_frames, float *merge_ms, floa
         stream_ms[i] = ms; merge_ms[i] = mm;
         memcpy(&stats[i * nstat], &h[slot * 8], sizeof(uint32_t) * (size_t)nstat);
     }
+    (void)hipGetLastError();   // a slot without recorded events reads as -1 above; do not leave the query's error to the next launch check
     free(h);
     return n;
 }

@@ -102,7 +102,8 @@ int hrbf_process_frame(hrbf_handle h, const uint8_t *rgb, const uint16_t *depth,
                        float weight_multiplier);
 /* same, inputs already resident in HBM (device pointers) — what bench.py times.  The call only enqueues and the
  * kernels read d_rgb / d_depth in place (no staging copy): keep both buffers valid and unchanged until
- * hrbf_synchronize() or any blocking getter returns. */
+ * hrbf_synchronize() or any blocking getter returns.  The context does not keep them: a stage seam that reads the raw frame
+ * (hrbf_run_stage FILTER_DEPTH / METRICISE / INITIALISE / FUSE / FILLIN) refuses to run after this entry until hrbf_upload_frame(). */
 int hrbf_process_frame_device(hrbf_handle h, const void *d_rgb, const void *d_depth, int64_t timestamp,
                               float weight_multiplier);
 /* block until all work queued on the context's stream is complete */

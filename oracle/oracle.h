@@ -119,6 +119,7 @@ void orc_set_pose(orc_ctx *c, const float in16[16]);
 int orc_get_tick(orc_ctx *c);
 void orc_set_tick(orc_ctx *c, int t);
 void orc_set_index_submap(orc_ctx *c, int idx);
+void orc_set_switch(orc_ctx *c, int which, float v);   /* the boundary's run-time setters, see orc_ctx.c */
 void orc_set_active_submaps(orc_ctx *c, const uint8_t *active, int n);   /* n = 0: all active */
 /* GlobalModel::updateModel (GlobalModel.cpp:690-767 -> update_delta_trans.vert:41-104) */
 void orc_update_model(orc_ctx *c, const float *delta16_colmajor, int n);

@@ -259,6 +259,22 @@ void orc_set_pose(orc_ctx *c, const float in[16]) { memcpy(c->pose, in, 64); }
 int orc_get_tick(orc_ctx *c) { return c->tick; }
 void orc_set_tick(orc_ctx *c, int t) { c->tick = t; }
 void orc_set_index_submap(orc_ctx *c, int idx) { c->index_submap = idx; }
+/* the run-time switches of the boundary (hrbf_set_rgb_only ... hrbf_set_depth_cutoff, the reference's setters HRBFFusion.h:150-215):
+ * which = 0 rgb_only, 1 icp_weight, 2 pyramid, 3 fast_odom, 4 so3, 5 frame_to_frame_rgb, 6 confidence_threshold, 7 depth_cutoff */
+void orc_set_switch(orc_ctx *c, int which, float v)
+{
+    switch (which) {
+    case 0: c->prm.rgb_only = (int)v; break;
+    case 1: c->prm.icp_weight = v; break;
+    case 2: c->prm.pyramid = (int)v; break;
+    case 3: c->prm.fast_odom = (int)v; break;
+    case 4: c->prm.so3 = (int)v; break;
+    case 5: c->prm.frame_to_frame_rgb = (int)v; break;
+    case 6: c->prm.confidence_threshold = v; break;
+    case 7: c->prm.depth_cutoff = v; break;
+    default: break;
+    }
+}
 void orc_set_active_submaps(orc_ctx *c, const uint8_t *active, int n)
 {
     free(c->submap_active); c->submap_active = NULL; c->n_submap_active = 0;

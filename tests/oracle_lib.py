@@ -44,6 +44,7 @@ def load(omp=False):
     lib.orc_get_odo_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_get_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]; lib.orc_get_pyramid.restype = C.c_size_t
     lib.orc_set_index_submap.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_set_switch.argtypes = [C.c_void_p, C.c_int, C.c_float]
     lib.orc_set_active_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_update_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_so3_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
@@ -180,6 +181,12 @@ class Oracle:
 
     def set_index_submap(self, idx):
         self.lib.orc_set_index_submap(self.h, int(idx))
+
+    SWITCHES = ("rgb_only", "icp_weight", "pyramid", "fast_odom", "so3", "frame_to_frame_rgb", "confidence_threshold", "depth_cutoff")
+
+    def set_switch(self, name, v):
+        """the boundary's run-time setters (HRBFFusion.set_<name> on the library's side)"""
+        self.lib.orc_set_switch(self.h, self.SWITCHES.index(name), float(v))
 
     def set_active_submaps(self, active):
         a = np.ascontiguousarray(np.asarray([] if active is None else active, np.uint8))

@@ -363,6 +363,62 @@ def test_adversarial_pixels_at_the_stage_seams(oracle_lib_built, gpu_available):
         assert r is None, (seed, i, r)
 
 
+def test_random_api_call_sequences(oracle_lib_built, gpu_available):
+    """10-24 random API calls per context (tests/gpu_fuzz_api.py): frames by host and device pointer, pose / tick / weighting / the
+    run-time switches set in between, maps re-uploaded re-ordered or thinned, updateModel, submap masks, stages, images set back
+    unchanged, timing and the shard cut changed on the library's side only — compared with the oracle after every call.  Trials 0-5 of
+    seed 1 and the two trials of seed 5 that found something (below).  profiles/r06_api_fuzz.txt: 600 trials, 0 mismatches."""
+    import gpu_fuzz_api as A
+    for seed, i in [(1, k) for k in range(6)] + [(5, 304), (5, 305)]:
+        r = A.trial(oracle_lib_built, seed, i)
+        assert r is None, (seed, i, r)
+
+
+def test_timings_read_before_any_timed_frame_leave_no_error_behind(pair):
+    """found by the API fuzzer: hrbf_get_timings right after hrbf_enable_timing queries events no frame has recorded; the query's
+    'invalid resource handle' was tolerated but stayed in the runtime's last-error slot, and the NEXT frame's launch check reported
+    it as its own (status -2).  Same for the fuse ring read before a frame."""
+    W, H = 160, 120
+    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 17)
+    o, g = pair(p)
+    g.enable_timing(1)
+    assert np.all(g.timings() == 0)
+    g.fuse_ring_parts(4)
+    for k in range(3):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d); g.process_frame(rgb, d)
+        assert_same_state(o, g, "frame %d" % k)
+    assert g.status() == 0 and g.timings()[5] > 0
+
+
+def test_stage_seams_refuse_raw_images_the_context_does_not_hold(pair):
+    """found by the API fuzzer: after hrbf_process_frame_device (the caller's buffers are read in place and not kept) a stage seam that
+    reads the raw frame ran — silently — on the images of the last HOST-pointer frame.  It now refuses until hrbf_upload_frame()."""
+    import torch
+    from hrbffusion3d_amd.api import HrbfError
+    W, H = 160, 120
+    p = default_params(W, H, *synth.intrinsics(W, H), max_surfels=1 << 17)
+    o, g = pair(p)
+    for k in range(3):
+        rgb, d, _ = synth.frame(k, W, H, noise=True)
+        o.process_frame(rgb, d)
+        if k < 2:
+            g.process_frame(rgb, d)
+        else:
+            tr, td = torch.from_numpy(rgb).cuda(), torch.from_numpy(d.view(np.int16)).cuda()
+            g.process_frame_device(tr.data_ptr(), td.data_ptr(), 0); g.synchronize()
+            del tr, td
+    assert_same_state(o, g, "device-pointer frame")
+    for s in ("FILLIN", "FILTER_DEPTH", "FUSE", "INITIALISE"):
+        with pytest.raises(HrbfError, match="hrbf_upload_frame"):
+            g.run_stage(s)
+    for x in (o, g):
+        x.run_stage("PREDICT_HRBF")             # reads no raw image: runs
+    for x in (o, g):
+        x.upload_frame(rgb, d); x.run_stage("FILLIN")
+    assert_same_state(o, g, "fill-in after the upload")
+
+
 @pytest.mark.parametrize("size", [(320, 240), (1280, 960)])
 def test_other_resolutions(pair, size):
     """QVGA (BASELINE config 1 geometry) and 1280x960 (config 5 geometry): same kernels, other grid shapes — the
