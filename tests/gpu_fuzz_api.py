@@ -14,6 +14,7 @@ wrong.  Each trial draws 10-24 operations:
 After every frame all images, the map and the pose are compared; after every other operation the map, the count and the pose.
 
     python tests/gpu_fuzz_api.py N [seed] [out]       # N trials; appends to gpurun_out/api_fuzz.txt (or `out`)
+    HRBF_FUZZ_INTERLEAVED=1 python tests/gpu_fuzz_api.py N ...   # three contexts alive at once, their calls interleaved at random
 """
 import os
 import sys
@@ -37,7 +38,8 @@ def small_rigid(rng, rot, trans):
     return T.astype(np.float32)
 
 
-def trial(oracle_lib, seed, index, log=None):
+def trial_steps(oracle_lib, seed, index):
+    """generator: one API call per step; returns (StopIteration.value) None or the description of the first difference"""
     from hrbffusion3d_amd import synth
     from hrbffusion3d_amd.api import HRBFFusion
     from hrbffusion3d_amd.params import IMAGES, default_params
@@ -187,11 +189,39 @@ def trial(oracle_lib, seed, index, log=None):
             r = same(full)
             if r:
                 return "after op %d (%s): %s | ops: %s | %r" % (step, ops[-1], r, " ".join(ops), kw)
+            yield
         return None
     except Exception as e:
         return "exception %r after ops: %s | %r" % (e, " ".join(ops), kw)
     finally:
         o.close(); g.close()
+
+
+def trial(oracle_lib, seed, index):
+    it = trial_steps(oracle_lib, seed, index)
+    while True:
+        try:
+            next(it)
+        except StopIteration as e:
+            return e.value
+
+
+def trial_interleaved(oracle_lib, seed, index, n_ctx=3):
+    """n_ctx contexts alive at once on one device, their calls interleaved at random: what one context caches (graphs, function
+    attributes set once, scratch) must not be another's"""
+    rng = np.random.default_rng([seed, index, 77])
+    its = {j: trial_steps(oracle_lib, seed, index * 16 + j) for j in range(n_ctx)}
+    while its:
+        j = list(its)[int(rng.integers(len(its)))]
+        try:
+            next(its[j])
+        except StopIteration as e:
+            del its[j]
+            if e.value is not None:
+                for it in its.values():
+                    it.close()
+                return "context %d of %d interleaved: %s" % (j, n_ctx, e.value)
+    return None
 
 
 def main():
@@ -209,7 +239,7 @@ def main():
         for i in range(n):
             if os.environ.get("HRBF_FUZZ_TRACE"):
                 log.write("trial %d\n" % i); log.flush()
-            r = trial(oracle_lib, seed, i)
+            r = (trial_interleaved if os.environ.get("HRBF_FUZZ_INTERLEAVED") else trial)(oracle_lib, seed, i)
             if r is not None:
                 bad += 1
                 log.write("MISMATCH trial %d of seed %d: %s\n" % (i, seed, r)); log.flush()
