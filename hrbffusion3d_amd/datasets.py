@@ -99,13 +99,17 @@ def associate(first, second, max_dt=0.02, offset=0.0):
     returns index pairs sorted by the first list's stamp"""
     a = np.asarray([s for s, _ in first], np.float64); b = np.asarray([s for s, _ in second], np.float64) + offset
     cand = []
-    j0 = np.searchsorted(b, a - max_dt, "left"); j1 = np.searchsorted(b, a + max_dt, "right")
+    order = np.argsort(b, kind="stable")            # the files are sorted by time; a list that is not is searched through its sorted view
+    bs = b[order]
+    j0 = np.searchsorted(bs, a - max_dt, "left"); j1 = np.searchsorted(bs, a + max_dt, "right")
     for i in range(len(a)):
-        for j in range(j0[i], j1[i]):
+        for jj in range(j0[i], j1[i]):
+            j = int(order[jj])
             d = abs(a[i] - b[j])
             if d < max_dt:
-                cand.append((d, i, j))
+                cand.append((d, a[i], b[j], i, j))       # associate.py sorts (difference, first stamp, second stamp)
     cand.sort()
+    cand = [(d, i, j) for d, _, _, i, j in cand]
     used_a, used_b, pairs = set(), set(), []
     for _, i, j in cand:
         if i not in used_a and j not in used_b:

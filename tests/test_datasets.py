@@ -75,6 +75,33 @@ def test_associate_is_the_benchmark_rule():
     assert ds.associate([(0.0, None)], [(0.02, None)]) == [] and ds.associate([(0.0, None)], [(0.0199, None)]) == [(0, 0)]
 
 
+def test_associate_against_the_benchmarks_dictionary_statement_on_random_lists():
+    """associate.py itself works on the dictionaries' keys: all pairs below the limit, sorted as (difference, first stamp, second stamp),
+    taken greedily while both stamps are still free.  Random lists — sorted or not, with an offset, with stamps on a coarse grid so
+    that equal differences (ties) are common — against that statement, by stamps instead of indices."""
+    from hypothesis import given, settings, strategies as st
+
+    grid = st.integers(0, 400).map(lambda k: k * 0.005)          # 5 ms grid: many equal differences
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(grid, min_size=0, max_size=40, unique=True), st.lists(grid, min_size=0, max_size=40, unique=True),
+           st.sampled_from([0.0, 0.0025, -0.01]), st.sampled_from([0.02, 0.011, 0.0051]), st.booleans())
+    def check(a, b, offset, max_dt, keep_order):
+        if not keep_order:
+            a, b = sorted(a), sorted(b)
+        got = ds.associate([(s, None) for s in a], [(s, None) for s in b], max_dt=max_dt, offset=offset)
+        fa, fb = list(a), list(b)
+        pot = sorted((abs(x - (y + offset)), x, y + offset, y) for x in fa for y in fb if abs(x - (y + offset)) < max_dt)
+        want = []
+        for _, x, _, y in pot:
+            if x in fa and y in fb:
+                fa.remove(x); fb.remove(y); want.append((x, y))
+        assert sorted((a[i], b[j]) for i, j in got) == sorted(want)
+        assert got == sorted(got)
+
+    check()
+
+
 def test_frame_stamp_is_truncated_like_the_references_reader():
     """int64_t(t * 1000000.0) (GUI/src/Tools/RawImageReader.cpp:93): 0.000249 -> 248, not 249"""
     assert ds.reference_frame_stamp(0.000249) == 248 and ds.reference_frame_stamp(1305031102.175304) == 1305031102175304
