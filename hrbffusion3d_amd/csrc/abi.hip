@@ -270,6 +270,23 @@ extern "C" int hrbf_create(const hrbf_params *p, int device, hrbf_handle *out)
         hrbf_set_error("window multipliers above the reference defaults (3/3/8) are not supported");
         return HRBF_ERR_INVALID;
     }
+    {   // every real parameter finite (a NaN multiplier would reach an int conversion on the host), a camera that projects, a depth unit
+        const float reals[] = {p->fx, p->fy, p->cx, p->cy, p->depth_scale, p->confidence_threshold, p->depth_cutoff, p->icp_weight,
+                               p->max_depth_processed, p->init_radius_multiplier, p->curv_estimation_window, p->curv_valid_threshold,
+                               p->normal_estimation_pca, p->conf_eval_epsilon, p->icp_curv_weight_lambda, p->predict_window_multiplier,
+                               p->predict_conf_threshold, p->clean_window_multiplier, p->dense_enough_thresh};
+        for (float v : reals)
+            if (!(v - v == 0.0f)) { hrbf_set_error("a parameter is NaN or infinite"); return HRBF_ERR_INVALID; }
+        if (p->fx == 0.0f || p->fy == 0.0f || !(p->depth_scale > 0.0f)) {
+            hrbf_set_error("fx and fy must not be 0 (fy may be negative), depth_scale must be positive");
+            return HRBF_ERR_INVALID;
+        }
+        if (p->curv_estimation_window < 0.0f || p->predict_window_multiplier < 0.0f || p->clean_window_multiplier < 0.0f || p->icp_search_radius < 0 ||
+            p->max_surfels <= 0) {
+            hrbf_set_error("negative window / search radius, or no room for surfels");
+            return HRBF_ERR_INVALID;
+        }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         hrbf_set_error("no HIP device visible: libhrbf_mi355 has no CPU fallback");
@@ -1839,7 +1856,9 @@ extern "C" int hrbf_so3_step(hrbf_handle c, const uint8_t *last_image, const uin
                              const float image_basis[9], const float kinv[9], const float krlr[9], double A_out[9],
                              double b_out[3], double residual_out[2])
 {
-    if (!c || !last_image || !next_image || rows <= 0 || cols <= 0) return HRBF_ERR_INVALID;
+    if (!c || !last_image || !next_image || rows <= 0 || cols <= 0 || !image_basis || !kinv || !krlr || !A_out || !b_out || !residual_out) {
+        hrbf_set_error("so3_step: null argument or empty image"); return HRBF_ERR_INVALID;
+    }
     hipSetDevice(c->device);
     return run_so3_step(c->stream, last_image, next_image, rows, cols, image_basis, kinv, krlr, A_out, b_out, residual_out);
 }
@@ -1848,7 +1867,10 @@ extern "C" int hrbf_rgb_residual(hrbf_handle c, float min_scale, const int16_t *
                                  const uint8_t *next_image, int rows, int cols, const float kt[3], const float krkinv[9],
                                  int16_t *corres_out, float *diff_out, long long *count, long long *sigma)
 {
-    if (!c || !corres_out || !diff_out || !count || !sigma || rows <= 0 || cols <= 0) return HRBF_ERR_INVALID;
+    if (!c || !corres_out || !diff_out || !count || !sigma || rows <= 0 || cols <= 0 || !dIdx || !dIdy || !last_depth || !next_depth ||
+        !last_image || !next_image || !kt || !krkinv) {
+        hrbf_set_error("rgb_residual: null argument or empty image"); return HRBF_ERR_INVALID;
+    }
     hipSetDevice(c->device);
     return run_rgb_residual(c->stream, min_scale, dIdx, dIdy, last_depth, next_depth, last_image, next_image, rows, cols, kt,
                             krkinv, corres_out, diff_out, count, sigma);
@@ -1858,7 +1880,9 @@ extern "C" int hrbf_rgb_step(hrbf_handle c, const int16_t *corres, const float *
                              int use_grad_weight, int rows, int cols, double A_out[36], double b_out[6],
                              double residual_out[2])
 {
-    if (!c || !corres || !corres_diff || !cloud || rows <= 0 || cols <= 0) return HRBF_ERR_INVALID;
+    if (!c || !corres || !corres_diff || !cloud || rows <= 0 || cols <= 0 || !dIdx || !dIdy || !A_out || !b_out || !residual_out) {
+        hrbf_set_error("rgb_step: null argument or empty image"); return HRBF_ERR_INVALID;
+    }
     hipSetDevice(c->device);
     return run_rgb_step(c->stream, corres, corres_diff, sigma, cloud, fx, fy, dIdx, dIdy, use_grad_weight, rows, cols, A_out,
                         b_out, residual_out);
@@ -1867,7 +1891,7 @@ extern "C" int hrbf_rgb_step(hrbf_handle c, const int16_t *corres, const float *
 // ---- the callers' side of the path: submap bookkeeping and the rigid map correction
 extern "C" int hrbf_set_index_submap(hrbf_handle c, int index)
 {
-    if (!c || index < 0) return HRBF_ERR_INVALID;
+    if (!c || index < 0 || index > (1 << 24)) return HRBF_ERR_INVALID;   // stored in a float32 attribute of the surfel (Vertex.cpp:21-44)
     c->index_submap = index;
     return HRBF_OK;
 }
@@ -1887,7 +1911,9 @@ extern "C" int hrbf_set_active_submaps(hrbf_handle c, const uint8_t *active, int
 }
 extern "C" int hrbf_update_model(hrbf_handle c, const float *delta16_colmajor, int n)
 {
-    if (!c || n < 0 || (n > 0 && !delta16_colmajor)) { hrbf_set_error("update_model: bad arguments"); return HRBF_ERR_INVALID; }
+    // n: one matrix per submap id; the reference keeps them in a 19 200-float texture, 1 200 matrices (GlobalModel.cpp:690-767) — a count
+    // beyond that is a caller's slip (and n x 64 bytes are about to be read from the pointer)
+    if (!c || n < 0 || n > 1200 || (n > 0 && !delta16_colmajor)) { hrbf_set_error("update_model: bad arguments (n = %d; 0 <= n <= 1200)", n); return HRBF_ERR_INVALID; }
     if (n == 0) return HRBF_OK;
     hipSetDevice(c->device);
     if (n > c->delta_cap) {
@@ -2015,7 +2041,11 @@ extern "C" int hrbf_icp_step(hrbf_handle c, const float Rcurr[9], const float tc
                              float dist_thresh, float angle_thresh, int use_weight, double A_out[36], double b_out[6],
                              double residual_out[2])
 {
-    if (!c) return HRBF_ERR_INVALID;
+    // (found by tests/gpu_probe_abi_zero_args.py: this seam read its host matrices without looking at them first)
+    if (!c || !Rcurr || !tcurr || !vmap_curr || !nmap_curr || !ck1_curr || !ck2_curr || !Rprev_inv || !tprev || !vmap_g_prev || !nmap_g_prev ||
+        !ck1_g_prev || !ck2_g_prev || !icp_weight_prev || rows <= 0 || cols <= 0 || !A_out || !b_out || !residual_out) {
+        hrbf_set_error("icp_step: null argument or empty image"); return HRBF_ERR_INVALID;
+    }
     hipSetDevice(c->device);
     return run_icp_step(c->stream, Rcurr, tcurr, vmap_curr, nmap_curr, ck1_curr, ck2_curr, Rprev_inv, tprev, fx, fy, cx,
                         cy, vmap_g_prev, nmap_g_prev, ck1_g_prev, ck2_g_prev, icp_weight_prev, rows, cols, dist_thresh,
@@ -2033,7 +2063,11 @@ extern "C" int hrbf_icp_step_sparse(hrbf_handle c, const float Rcurr[9], const f
                                     float *z_map_out, int32_t *corres_out, double A_out[36], double b_out[6],
                                     double residual_out[2])
 {
-    if (!c || !lambda_map || !z_map_out || !corres_out) return HRBF_ERR_INVALID;
+    if (!c || !lambda_map || !z_map_out || !corres_out || !Rcurr || !tcurr || !vmap_curr || !nmap_curr || !ck1_curr || !ck2_curr || !Rprev_inv ||
+        !tprev || !vmap_g_prev || !nmap_g_prev || !ck1_g_prev || !ck2_g_prev || !icp_weight_prev || rows <= 0 || cols <= 0 || !A_out || !b_out ||
+        !residual_out) {
+        hrbf_set_error("icp_step_sparse: null argument or empty image"); return HRBF_ERR_INVALID;
+    }
     hipSetDevice(c->device);
     return run_icp_step(c->stream, Rcurr, tcurr, vmap_curr, nmap_curr, ck1_curr, ck2_curr, Rprev_inv, tprev, fx, fy, cx,
                         cy, vmap_g_prev, nmap_g_prev, ck1_g_prev, ck2_g_prev, icp_weight_prev, rows, cols, dist_thresh,
@@ -2043,7 +2077,9 @@ extern "C" int hrbf_update_lambda_map(hrbf_handle c, const float Rcurr[9], const
                                       const float Rprev_inv[9], const float tprev[3], const float *vmap_g_prev,
                                       const int32_t *corres, const float *z_map, float *lambda_map, int rows, int cols)
 {
-    if (!c || !corres || !z_map || !lambda_map) return HRBF_ERR_INVALID;
+    if (!c || !corres || !z_map || !lambda_map || !Rcurr || !tcurr || !vmap_curr || !Rprev_inv || !tprev || !vmap_g_prev || rows <= 0 || cols <= 0) {
+        hrbf_set_error("update_lambda_map: null argument or empty image"); return HRBF_ERR_INVALID;
+    }
     hipSetDevice(c->device);
     return run_update_lambda_map(c->stream, Rcurr, tcurr, vmap_curr, Rprev_inv, tprev, vmap_g_prev, corres, z_map, lambda_map,
                                  rows, cols);

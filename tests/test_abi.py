@@ -118,3 +118,29 @@ def test_an_abandoned_peer_rendezvous_can_be_released():
     assert name.startswith("/hrbf_peer_") and os.path.exists("/dev/shm" + name)
     assert HRBFFusion.peer_release_id(uid) and not os.path.exists("/dev/shm" + name)
     assert not HRBFFusion.peer_release_id(uid)
+
+
+def test_every_entry_point_refuses_a_null_handle():
+    """all handle-taking entry points of include/hrbf_mi355.h called with handle = NULL and every other argument zero: HRBF_ERR_INVALID
+    (-1), no signal (the boundary returns a status and never exits).  No device is touched before the check, so this runs
+    without a GPU; in one child process, so that a crash fails the test instead of ending the run."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_probe_abi_zero_args import handle_entry_points
+    eps = handle_entry_points()
+    assert len(eps) >= 70
+    code = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from hrbffusion3d_amd.api import load_library
+lib = load_library()
+for rt, n, nargs in %r:
+    f = getattr(lib, n); f.restype = C.c_int; f.argtypes = None
+    print(n, flush=True)
+    r = f(*([None] + [C.c_void_p(0)] * (nargs - 1)))
+    assert rt != "int" or r == -1, (n, r)
+print("ALL", flush=True)
+""" % (ROOT, eps)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ALL"), (p.returncode, p.stdout.strip().splitlines()[-1:], p.stderr[-400:])

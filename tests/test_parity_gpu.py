@@ -363,6 +363,25 @@ def test_adversarial_pixels_at_the_stage_seams(oracle_lib_built, gpu_available):
         assert r is None, (seed, i, r)
 
 
+def test_no_entry_point_dies_on_zero_arguments(gpu_available):
+    """every handle-taking entry point on a LIVE context (two frames in) with all other arguments zero / NULL, one child process each
+    (tests/gpu_probe_abi_zero_args.py): an error code or a harmless success, never a signal, and the context processes the next frame.
+    hrbf_icp_step read its host matrices unchecked until this survey called it."""
+    import gpu_probe_abi_zero_args as Z
+    eps, bad = Z.survey(warm_states=(1,))
+    assert len(eps) >= 70 and not bad, bad
+
+
+def test_wrong_values_at_the_boundary_are_refused_not_fatal(gpu_available):
+    """tests/gpu_probe_abi_bad_values.py: sizes that do not match, enums out of range, counts beyond the capacity, NaN / zero cameras and
+    units, windows the kernels are not built for — 36 calls on a live context and 21 creations, one child process each: an error status
+    where one is due, never a signal, and the next frame runs.  The first survey found hrbf_update_model reading n x 64 bytes for any n
+    (now 0 <= n <= 1200, the reference's texture) and hrbf_create accepting fx = 0, depth_scale = 0 and NaN parameters."""
+    import gpu_probe_abi_bad_values as B
+    findings = B.survey()
+    assert not findings, findings
+
+
 def test_random_api_call_sequences(oracle_lib_built, gpu_available):
     """10-24 random API calls per context (tests/gpu_fuzz_api.py): frames by host and device pointer, pose / tick / weighting / the
     run-time switches set in between, maps re-uploaded re-ordered or thinned, updateModel, submap masks, stages, images set back
