@@ -60,6 +60,12 @@ HD_FN unsigned hd_cvt_u32(float a)
 {
     return !(a > 0.0f) ? 0u : (a >= 4294967296.0f ? 0xFFFFFFFFu : (unsigned)a);
 }
+/* double -> int64 for the quadrant count of hd_sincos: an angle of 1e20 (a Gauss-Newton step on garbage input) is not an angle any
+ * more, but the conversion must still be the same number on the host and on the device (found by the oracle under UBSan) */
+HD_FN long long hd_cvt_i64(double a)
+{
+    return a != a ? 0 : (a >= 9223372036854775808.0 ? 9223372036854775807LL : (a <= -9223372036854775808.0 ? (-9223372036854775807LL - 1) : (long long)a));
+}
 
 /* One axis of the shaders' float-stepped window loops, literally (geometry.glsl:198-207 getNormalPCA,
  * depth_curvature_gradient.frag:54-63):
@@ -105,7 +111,7 @@ HD_FN float hd_uv_attribute(int p, int n)
 HD_FN float hd_px_attribute(int p, int n) { return hd_uv_attribute(p, n) * (float)n; }
 HD_FN int hd_window_texel(float i, int n)   /* NEAREST filtering, CLAMP_TO_EDGE */
 {
-    int t = (int)hd_floorf(i * (float)n);
+    int t = hd_cvt_i32(hd_floorf(i * (float)n));
     return t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
 }
 
@@ -275,7 +281,7 @@ HD_FN void hd_sincosf(float x, float *s, float *c)
 {
     float ax = hd_fabsf(x);
     float jf = hd_rintf(ax * 0.636619772367581f); /* 2/pi */
-    int j = (int)jf;
+    int j = hd_cvt_i32(jf);   /* saturating beyond the stated range: only j & 3 is used, and it must be the same bits on both sides */
     float r = hd_fmaf(jf, -1.5703125f, ax);
     r = hd_fmaf(jf, -4.837512969970703125e-4f, r);
     r = hd_fmaf(jf, -7.54978995489188216e-8f, r);
@@ -306,7 +312,7 @@ HD_FN void hd_sincos(double x, double *s, double *c)
 {
     double ax = x < 0.0 ? -x : x;
     double jf = hd_rint(ax * 0.63661977236758134308);
-    long long j = (long long)jf;
+    long long j = hd_cvt_i64(jf);
     /* pi/2 in three parts (Cody-Waite) */
     double r = hd_fma(jf, -1.57079632673412561417e+00, ax);
     r = hd_fma(jf, -6.07710050650619224932e-11, r);

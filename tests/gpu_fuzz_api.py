@@ -79,6 +79,8 @@ def trial_steps(oracle_lib, seed, index):
             op = c("frame", "frame", "frame", "frame", "frame", "frame_w", "frame_dev", "set_pose", "set_tick", "set_weighting", "upload_map",
                    "update_model", "index_submap", "active_submaps", "stage", "image_roundtrip", "timing", "ring", "shards", "sync_reads", "switch", "switch") \
                 if step > 1 else "frame"
+            if op == "frame_dev" and os.environ.get("HRBF_FUZZ_NO_DEVICE"):      # tests/oracle_only.py: the oracle on both sides
+                op = "frame"
             ops.append(op)
             full = False
             if op in ("frame", "frame_w", "frame_dev"):

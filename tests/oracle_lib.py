@@ -24,6 +24,9 @@ def load(omp=False):
     # tools/mutation_report.py only: a deliberately MISREAD oracle (oracle/Makefile `mutants`), to show that the metamorphic tests fail on it
     if os.environ.get("HRBF_ORACLE_MUTANT"):
         path = os.path.join(_ODIR, "_build", "liboracle_mutant_%d.so" % int(os.environ["HRBF_ORACLE_MUTANT"]))
+    # tests/test_oracle_sanitized.py only: the ASan + UBSan build (make -C oracle san; the process runs under LD_PRELOAD=libasan)
+    if os.environ.get("HRBF_ORACLE_SAN"):
+        path = os.path.join(_ODIR, "_build", "liboracle_san.so")
     if not os.path.exists(path):
         build()
     lib = C.CDLL(path)
