@@ -8,6 +8,7 @@ negative fy), millimetre depth, and garbage rows (NaN / inf / negative values) i
 
     python tests/gpu_fuzz_params.py N [seed] [out]     # N contexts of 4-6 frames; appends to gpurun_out/param_fuzz.txt (or `out`)
     HRBF_FUZZ_VGA=1 python tests/gpu_fuzz_params.py N ...   # every context at 640 x 480, two thirds of them against a 0.3 M / 1 M map
+    HRBF_FUZZ_SHAPES=tiny|hd python tests/gpu_fuzz_params.py N ...   # 8 x 8 ... 640 x 8 images / 1280 x 960
 
 A mismatch is logged with the draw that produced it (the seed and the index reproduce it) and the run goes on.
 tests/test_parity_gpu.py::test_random_parameter_combinations runs draws 0-9 of seed 1 in the suite, and the one draw that ever differed.
@@ -72,6 +73,17 @@ def _draw(rng):
     plan["depth_units"] = float(c(5000.0, 5000.0, 1000.0))
     plan["garbage_rows"] = int(c(0, 0, 50)) if plan["seed_map"] else 0
     plan["garbage_seed"] = int(rng.integers(1 << 30))
+    shapes = os.environ.get("HRBF_FUZZ_SHAPES")      # tiny: images of a few texels and extreme aspect ratios (one-workgroup grids, pyramids
+    if shapes in ("tiny", "hd"):                     # down to 2 x 2, a thumbnail of no cells); hd: 1280 x 960, BASELINE config 5's geometry
+        W0, H0 = W, H
+        if shapes == "tiny":
+            plan.update(size=c((8, 8), (16, 8), (8, 16), (24, 16), (40, 32), (64, 8), (8, 64), (80, 56), (640, 8), (8, 480), (16, 480), (640, 16)),
+                        seed_map=int(c(0, 0, 2000)), garbage_rows=0)
+        else:
+            plan.update(size=(1280, 960), seed_map=int(c(0, 500_000)), frames=3, garbage_rows=0)
+        if plan["K"] is not None:
+            plan["K"] = tuple(v * plan["size"][0] / W0 if i in (0, 2) else v * plan["size"][1] / H0 for i, v in enumerate(plan["K"]))
+        return kw, plan
     if os.environ.get("HRBF_FUZZ_VGA"):       # the benchmark's size: several fuse tiles per workgroup, the 1200-workgroup reduction grids,
         big = c(0, 300_000, 1_000_000)        # the hipGraph replay from frame 3 on; a map of the benchmark's size to track against
         plan.update(size=(640, 480), seed_map=int(big), frames=int(c(3, 4, 5)), garbage_rows=int(c(0, 200)) if big else 0)
@@ -120,7 +132,7 @@ def run_one(oracle_lib, kw, plan):
     from hrbffusion3d_amd.params import IMAGES, default_params
     W, H = plan["size"]
     K, units = plan.get("K"), plan.get("depth_units", 5000.0)
-    p = default_params(W, H, *synth.intrinsics(W, H, K), depth_scale=1.0 / units, max_surfels=(1 << (17 if W * H <= 160 * 128 else 19)) if W < 640 else plan.get("seed_map", 0) + (1 << 20), **kw)
+    p = default_params(W, H, *synth.intrinsics(W, H, K), depth_scale=1.0 / units, max_surfels=(1 << (17 if W * H <= 160 * 128 else 19)) if W * H < 640 * 480 else plan.get("seed_map", 0) + (1 << (20 if W * H == 640 * 480 else 22)), **kw)
     o = g = None
     try:
         try:
