@@ -215,6 +215,17 @@ def test_two_processes_row_shard_the_registration_bit_identical_to_one(gpu_avail
     _check_comm(two, cfg)
 
 
+def test_random_draws_played_by_real_processes_match_the_oracle(gpu_available, oracle_lib_built):
+    """tests/gpu_fuzz_peers.py: random switch combinations, shapes, ragged / empty frames, uploaded maps with garbage rows, played by 2-3
+    processes over this transport (contiguous ranges, hash ownership or the registration alone sharded) — every rank's pose and the
+    global count after every frame and the ranks' map slices against the ORACLE's single map (the cases above compare with one process
+    of the library).  Trials 0-5 of seed 1; profiles/r06_peer_fuzz.txt holds the long runs."""
+    import gpu_fuzz_peers as PF
+    for i in range(6):
+        r = PF.trial(oracle_lib_built, 1, i)
+        assert r is None, (i, r)
+
+
 def _run_failing_map(rank, world, uid, out):
     sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
     import time
