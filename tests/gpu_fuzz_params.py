@@ -8,6 +8,7 @@ negative fy), millimetre depth, and garbage rows (NaN / inf / negative values) i
 
     python tests/gpu_fuzz_params.py N [seed] [out]     # N contexts of 4-6 frames; appends to gpurun_out/param_fuzz.txt (or `out`)
     HRBF_FUZZ_VGA=1 python tests/gpu_fuzz_params.py N ...   # every context at 640 x 480, two thirds of them against a 0.3 M / 1 M map
+    HRBF_FUZZ_RCCL1=1 python tests/gpu_fuzz_params.py N ...   # sharded draws over a real RCCL communicator of world size 1 instead of virtual shards
     HRBF_FUZZ_SHAPES=tiny|hd python tests/gpu_fuzz_params.py N ...   # 8 x 8 ... 640 x 8 images / 1280 x 960
 
 A mismatch is logged with the draw that produced it (the seed and the index reproduce it) and the run goes on.
@@ -148,7 +149,11 @@ def run_one(oracle_lib, kw, plan):
                 "ok" if o else repr(eo), "ok" if g else repr(eg))
         hashed = plan.get("shards", 0) > 1 and plan["partition"] == "hash"
         if plan.get("shards", 0) > 1:
-            g.comm_init(-1, plan["shards"]); g.map_shard_init(True, partition=plan["partition"])
+            if os.environ.get("HRBF_FUZZ_RCCL1"):      # a real RCCL communicator of world size 1: every collective of the sharded map and of
+                g.comm_init(0, 1, HRBFFusion.comm_unique_id())      # the row-sharded registration is issued through librccl
+            else:
+                g.comm_init(-1, plan["shards"])
+            g.map_shard_init(True, partition=plan["partition"])
             g.set_row_sharding(bool(plan["row_sharding"]))
         first = 0
         if plan.get("seed_map", 0):
