@@ -166,7 +166,7 @@ void orc_hrbf_hessian(const float p[3], const f4 *vc, const f4 *nr, int n, float
 int orc_tap_texel(int c, int n); int orc_window_samples(float t, int n, float win, int *texels);
 int orc_halfpixel_walk_samples(float x, int n, float wm, int *texels); float orc_gl_point_window_coord(float u, float extent, int *clipped);
 float orc_expf(float x); float orc_acosf(float x); float orc_atan2f(float y, float x);
-int orc_f2i(float x); unsigned orc_f2u(float x); float orc_encode_color(float r, float g, float b);   /* hd_cvt_i32 and the colour word built on it */
+int orc_f2i(float x); unsigned orc_f2u(float x); long long orc_d2l(double x); float orc_encode_color(float r, float g, float b);   /* hd_cvt_i32 and the colour word built on it */
 void orc_sincosf(float x, float *s, float *c); void orc_sincos(double x, double *s, double *c);
 double orc_acos(double x);
 void orc_acc_test(const float *v, int n, double *out);

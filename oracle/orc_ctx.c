@@ -381,6 +381,7 @@ float orc_uv_fragment(int p, int n) { return hd_uv_fragment(p, n); }
 float orc_expf(float x) { return hd_expf(x); }
 int orc_f2i(float x) { return hd_cvt_i32(x); }
 unsigned orc_f2u(float x) { return hd_cvt_u32(x); }
+long long orc_d2l(double x) { return hd_cvt_i64(x); }
 float orc_encode_color(float r, float g, float b) { return encode_color(v3(r, g, b)); }
 float orc_acosf(float x) { return hd_acosf(x); }
 float orc_atan2f(float y, float x) { return hd_atan2f(y, x); }

@@ -75,6 +75,7 @@ def load(omp=False):
     lib.orc_expf.restype = C.c_float; lib.orc_expf.argtypes = [C.c_float]
     lib.orc_f2i.restype = C.c_int; lib.orc_f2i.argtypes = [C.c_float]
     lib.orc_f2u.restype = C.c_uint; lib.orc_f2u.argtypes = [C.c_float]
+    lib.orc_d2l.restype = C.c_longlong; lib.orc_d2l.argtypes = [C.c_double]
     lib.orc_encode_color.restype = C.c_float; lib.orc_encode_color.argtypes = [C.c_float] * 3
     lib.orc_acosf.restype = C.c_float; lib.orc_acosf.argtypes = [C.c_float]
     lib.orc_atan2f.restype = C.c_float; lib.orc_atan2f.argtypes = [C.c_float, C.c_float]

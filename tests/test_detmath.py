@@ -33,6 +33,14 @@ def test_float_to_int_is_defined_for_nan_and_out_of_range(oracle_lib_built):
         [0, 0, 2147483647, -2147483648, 2147483647, -2147483648, 2147483520, -2147483648]
     assert [lib.orc_f2i(x) for x in (0.0, -0.0, 2.9, -2.9, 255.0, 16777215.0)] == [0, 0, 2, -2, 255, 16777215]      # truncation, as (int)
     assert lib.orc_encode_color(nan, nan, nan) == 0.0
+    # the quadrant count of hd_sincos (found by the oracle under UBSan: an SE3 step of 1.9e20 rad solved from garbage images)
+    assert [lib.orc_d2l(x) for x in (nan, inf, -inf, 1.9e20, -1.9e20, 9.2233720368547e18, -7.9, 2.0 ** 62)] == \
+        [0, 2 ** 63 - 1, -2 ** 63, 2 ** 63 - 1, -2 ** 63, 9223372036854700032, -7, 2 ** 62]
+    s, c = C.c_double(), C.c_double()
+    for x in (1.9e20, -3e300, 2.0 ** 80):            # no angle any more, but a defined pair of finite numbers, the same on every call
+        lib.orc_sincos(x, C.byref(s), C.byref(c)); first = (s.value, c.value)
+        lib.orc_sincos(x, C.byref(s), C.byref(c))
+        assert (s.value, c.value) == first
     # uint(): a submap id, an init time (found by tests/gpu_fuzz_stages.py: -1.0 was 0xFFFFFFFF on the host, 1e30 was 0)
     assert [lib.orc_f2u(x) for x in (nan, -1.0, -0.0, -inf, 0.9, 7.0, 4294967040.0, 4294967296.0, 1e30, inf)] == \
         [0, 0, 0, 0, 0, 7, 4294967040, 4294967295, 4294967295, 4294967295]
