@@ -102,6 +102,40 @@ def test_associate_against_the_benchmarks_dictionary_statement_on_random_lists()
     check()
 
 
+def test_ate_is_what_the_benchmark_defines_under_any_rigid_motion_of_the_estimate():
+    """evaluate_ate.py aligns with Horn's closed form before it measures: a rigidly moved copy of the ground truth scores 0, the score
+    of a noisy estimate does not change when the whole estimate is moved rigidly, equals the residual of an independent least-squares
+    alignment (scipy's Rotation.align_vectors on the centred points), and a MIRRORED trajectory is not aligned away (proper rotations
+    only — what makes the ICL-NUIM sign convention visible, see the ICL test below)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(17)
+    for trial in range(20):
+        n = int(rng.integers(12, 80))
+        t = 0.1 * np.arange(n) + rng.uniform(0, 0.01, n)          # frames 90-110 ms apart: a 4 ms offset cannot change a pairing
+        G = np.cumsum(rng.normal(0, 0.05, (n, 3)), 0)
+        gp = [np.eye(4) for _ in range(n)]
+        for k in range(n):
+            gp[k][:3, 3] = G[k]
+
+        def moved(P, R, d):
+            out = []
+            for k in range(n):
+                T = np.eye(4); T[:3, 3] = R @ P[k] + d; out.append(T)
+            return out
+        R = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(); d = rng.normal(0, 3, 3)
+        assert ds.evaluate_ate(t, moved(G, R, d), t, gp)["rmse_m"] < 1e-9
+        E = G + rng.normal(0, 0.01, (n, 3))
+        e0 = ds.evaluate_ate(t, moved(E, np.eye(3), np.zeros(3)), t, gp)
+        e1 = ds.evaluate_ate(t + 0.004, moved(E, R, d), t, gp)              # 4 ms off: still the same pairs
+        assert e0["pairs"] == e1["pairs"] == n and abs(e0["rmse_m"] - e1["rmse_m"]) < 1e-9
+        rot, _ = Rotation.align_vectors(G - G.mean(0), E - E.mean(0))
+        want = np.sqrt((((E - E.mean(0)) @ rot.as_matrix().T - (G - G.mean(0))) ** 2).sum(1).mean())
+        assert abs(e0["rmse_m"] - want) < 1e-6
+        M = G * np.array([1.0, -1.0, 1.0])
+        assert ds.evaluate_ate(t, moved(M, np.eye(3), np.zeros(3)), t, gp)["rmse_m"] > 0.02
+    assert ds.evaluate_ate([0.0, 1.0], moved(G, np.eye(3), np.zeros(3))[:2], [0.0, 1.0], gp[:2])["rmse_m"] is None      # fewer than 3 pairs
+
+
 def test_frame_stamp_is_truncated_like_the_references_reader():
     """int64_t(t * 1000000.0) (GUI/src/Tools/RawImageReader.cpp:93): 0.000249 -> 248, not 249"""
     assert ds.reference_frame_stamp(0.000249) == 248 and ds.reference_frame_stamp(1305031102.175304) == 1305031102175304
